@@ -1,0 +1,263 @@
+// opental_amd/csrc/bmp.hip -- BoundaryMaxPooling forward/backward for gfx950 (MI355X).
+//
+// Replaces AFSD/prop_pooling/boundary_max_pooling_kernel.cu:17-145 (1 thread per output,
+// uncoalesced window scans from global memory, atomicAdd backward).  Written for CDNA4 instead:
+//   * a workgroup owns ROWS consecutive (n,c) feature rows -- contiguous in the (B,C,T) layout --
+//     and stages them ONCE into LDS with coalesced loads (algorithmic traffic: every input
+//     element is read from HBM exactly once, every output written once);
+//   * the proposal windows of sample n are decoded (trunc + clamp) once per workgroup into LDS;
+//   * lanes run along k (proposals), so neighbouring lanes scan neighbouring LDS addresses and
+//     the output store is a coalesced row;
+//   * backward is a deterministic gather: each lane owns one input position i and adds the
+//     grad_out of every proposal whose arg-max is i, in ascending k.  No atomics.
+//   * a level table lets ONE launch pool all pyramid levels (packed along T / N).
+// HBM-bound: bytes = 4*(C*T + C*N) + 16*N per sample forward (kernels/bmp).
+#include "common.h"
+
+namespace {
+
+// level lookup with compile-time indices so the table stays in SGPRs
+__device__ __forceinline__ void level_of_n(const LevelTab& lt, int k, int& tb, int& te) {
+    tb = lt.ts[0]; te = lt.ts[1];
+#pragma unroll
+    for (int j = 1; j < OTAL_MAX_LEVELS; ++j)
+        if (j < lt.nlev && k >= lt.ns[j]) { tb = lt.ts[j]; te = lt.ts[j + 1]; }
+}
+__device__ __forceinline__ void level_of_t(const LevelTab& lt, int i, int& kb, int& ke) {
+    kb = lt.ns[0]; ke = lt.ns[1];
+#pragma unroll
+    for (int j = 1; j < OTAL_MAX_LEVELS; ++j)
+        if (j < lt.nlev && i >= lt.ts[j]) { kb = lt.ns[j]; ke = lt.ns[j + 1]; }
+}
+
+// LDS carve (bytes, all 16-aligned)
+struct Carve { int rows, win, g, arg, total; };
+static Carve carve(int ROWS, int T, int N, bool bwd) {
+    auto up = [](int v) { return (v + 15) & ~15; };
+    Carve c;
+    const int Tp = T | 1, Np = N | 1;
+    c.rows = 0;
+    c.win = up(ROWS * Tp * 4);
+    c.g = c.win + up(N * 16);
+    c.arg = c.g + (bwd ? up(ROWS * Np * 4) : 0);
+    c.total = c.arg + (bwd ? up(ROWS * Np * 4) : 0);
+    return c;
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_rows(float* rows, const T* src, int nrows, int len, int lenp,
+                                           int lx, int tid) {
+    // 2-D thread map without integer division: (1 << lx) lanes along the row, the rest across rows
+    const int tx = tid & ((1 << lx) - 1), ty = tid >> lx, ny = 256 >> lx;
+    for (int r = ty; r < nrows; r += ny)
+        for (int i = tx; i < len; i += (1 << lx))
+            rows[r * lenp + i] = ld_f32(src, (size_t)r * len + i);
+}
+
+__device__ __forceinline__ void stage_windows(int* win, const float* seg, int N, const LevelTab& lt, int tid) {
+    for (int k = tid; k < N; k += 256) {
+        int tb, te;
+        level_of_n(lt, k, tb, te);
+        const int hi = te - tb - 1;
+        const float4 s = *reinterpret_cast<const float4*>(seg + (size_t)k * 4);
+        int4 w;
+        w.x = clampi((int)s.x, 0, hi) + tb;
+        w.y = clampi((int)s.y, 0, hi) + tb;
+        w.z = clampi((int)s.z, 0, hi) + tb;
+        w.w = clampi((int)s.w, 0, hi) + tb;
+        *reinterpret_cast<int4*>(win + k * 4) = w;
+    }
+}
+
+template <typename T, int ROWS>
+__global__ __launch_bounds__(256) void bmp_fwd_kernel(const T* __restrict__ in, const float* __restrict__ seg,
+                                                      T* __restrict__ out, int C, int Tt, int Nt,
+                                                      LevelTab lt, int lxT, int lxN, int off_win) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* rows = reinterpret_cast<float*>(smem);
+    int* win = reinterpret_cast<int*>(smem + off_win);
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * ROWS;          // global (n*C + c) row; C % ROWS == 0
+    const int n = row0 / C, c0 = row0 - n * C;
+    const int Tp = Tt | 1;
+    stage_rows(rows, in + (size_t)row0 * Tt, ROWS, Tt, Tp, lxT, tid);
+    stage_windows(win, seg + (size_t)n * Nt * 4, Nt, lt, tid);
+    __syncthreads();
+    const int kx = tid & ((1 << lxN) - 1), ky = tid >> lxN, nky = 256 >> lxN;
+    const int half = C >> 1;
+    for (int r = ky; r < ROWS; r += nky) {
+        const int which = (c0 + r) >= half ? 2 : 0;
+        const float* row = rows + r * Tp;
+        for (int k = kx; k < Nt; k += (1 << lxN)) {
+            const int l = win[k * 4 + which], rr = win[k * 4 + which + 1];
+            float best = row[l];
+            for (int i = l + 1; i <= rr; ++i) {
+                const float v = row[i];
+                if (v > best) best = v;
+            }
+            st_f32(out, (size_t)(row0 + r) * Nt + k, best);
+        }
+    }
+}
+
+template <typename T, int ROWS>
+__global__ __launch_bounds__(256) void bmp_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ in,
+                                                      const float* __restrict__ seg, T* __restrict__ gin,
+                                                      int C, int Tt, int Nt, LevelTab lt, int lxT, int lxN,
+                                                      int off_win, int off_g, int off_arg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* rows = reinterpret_cast<float*>(smem);
+    int* win = reinterpret_cast<int*>(smem + off_win);
+    float* g = reinterpret_cast<float*>(smem + off_g);
+    int* arg = reinterpret_cast<int*>(smem + off_arg);
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * ROWS;
+    const int n = row0 / C, c0 = row0 - n * C;
+    const int Tp = Tt | 1, Np = Nt | 1;
+    stage_rows(rows, in + (size_t)row0 * Tt, ROWS, Tt, Tp, lxT, tid);
+    stage_rows(g, gout + (size_t)row0 * Nt, ROWS, Nt, Np, lxN, tid);
+    stage_windows(win, seg + (size_t)n * Nt * 4, Nt, lt, tid);
+    __syncthreads();
+    {   // phase 1: arg-max per (row, proposal)
+        const int kx = tid & ((1 << lxN) - 1), ky = tid >> lxN, nky = 256 >> lxN;
+        const int half = C >> 1;
+        for (int r = ky; r < ROWS; r += nky) {
+            const int which = (c0 + r) >= half ? 2 : 0;
+            const float* row = rows + r * Tp;
+            for (int k = kx; k < Nt; k += (1 << lxN)) {
+                const int l = win[k * 4 + which], rr = win[k * 4 + which + 1];
+                float best = row[l];
+                int a = l;
+                for (int i = l + 1; i <= rr; ++i) {
+                    const float v = row[i];
+                    if (v > best) { best = v; a = i; }
+                }
+                arg[r * Np + k] = a;
+            }
+        }
+    }
+    __syncthreads();
+    {   // phase 2: gather, ascending k -> deterministic sums
+        const int tx = tid & ((1 << lxT) - 1), ty = tid >> lxT, nty = 256 >> lxT;
+        for (int r = ty; r < ROWS; r += nty) {
+            const int* ar = arg + r * Np;
+            const float* gr = g + r * Np;
+            for (int i = tx; i < Tt; i += (1 << lxT)) {
+                int kb, ke;
+                level_of_t(lt, i, kb, ke);
+                float acc = 0.f;
+                for (int k = kb; k < ke; ++k)
+                    if (ar[k] == i) acc += gr[k];
+                st_f32(gin, (size_t)(row0 + r) * Tt + i, acc);
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_fwd(const T* in, const float* seg, T* out, int B, int C, int Tt, int Nt, const LevelTab& lt, hipStream_t s) {
+    const int lxT = ilog2_ceil(Tt < 256 ? Tt : 256), lxN = ilog2_ceil(Nt < 256 ? Nt : 256);
+    const int cand[4] = {16, 8, 4, 2};
+    for (int ci = 0; ci < 4; ++ci) {
+        const int R = cand[ci];
+        if (C % R) continue;
+        const Carve cv = carve(R, Tt, Nt, false);
+        if (cv.total > 48 * 1024 && R > 2) continue;
+        if (cv.total > 64 * 1024) return OTAL_E_UNSUPPORTED;
+        const dim3 grid((unsigned)((size_t)B * C / R));
+#define OTAL_FWD(RR) hipLaunchKernelGGL((bmp_fwd_kernel<T, RR>), grid, dim3(256), cv.total, s, in, seg, out, C, Tt, Nt, lt, lxT, lxN, cv.win)
+        if (R == 16) OTAL_FWD(16); else if (R == 8) OTAL_FWD(8); else if (R == 4) OTAL_FWD(4); else OTAL_FWD(2);
+#undef OTAL_FWD
+        return otal_launch_status();
+    }
+    return OTAL_E_UNSUPPORTED;
+}
+
+template <typename T>
+int launch_bwd(const T* gout, const T* in, const float* seg, T* gin, int B, int C, int Tt, int Nt,
+               const LevelTab& lt, hipStream_t s) {
+    const int lxT = ilog2_ceil(Tt < 256 ? Tt : 256), lxN = ilog2_ceil(Nt < 256 ? Nt : 256);
+    const int cand[4] = {16, 8, 4, 2};
+    for (int ci = 0; ci < 4; ++ci) {
+        const int R = cand[ci];
+        if (C % R) continue;
+        const Carve cv = carve(R, Tt, Nt, true);
+        if (cv.total > 48 * 1024 && R > 2) continue;
+        if (cv.total > 64 * 1024) return OTAL_E_UNSUPPORTED;
+        const dim3 grid((unsigned)((size_t)B * C / R));
+#define OTAL_BWD(RR) hipLaunchKernelGGL((bmp_bwd_kernel<T, RR>), grid, dim3(256), cv.total, s, gout, in, seg, gin, C, Tt, Nt, lt, lxT, lxN, cv.win, cv.g, cv.arg)
+        if (R == 16) OTAL_BWD(16); else if (R == 8) OTAL_BWD(8); else if (R == 4) OTAL_BWD(4); else OTAL_BWD(2);
+#undef OTAL_BWD
+        return otal_launch_status();
+    }
+    return OTAL_E_UNSUPPORTED;
+}
+
+int check_levels(int nlev, const int* t_start, const int* n_start, LevelTab& lt) {
+    if (nlev < 1 || nlev > OTAL_MAX_LEVELS || !t_start || !n_start) return OTAL_E_LEVELS;
+    if (t_start[0] != 0 || n_start[0] != 0) return OTAL_E_LEVELS;
+    lt.nlev = nlev;
+    for (int i = 0; i <= OTAL_MAX_LEVELS; ++i) {
+        lt.ts[i] = t_start[i <= nlev ? i : nlev];
+        lt.ns[i] = n_start[i <= nlev ? i : nlev];
+        if (i > 0 && i <= nlev && (lt.ts[i] <= lt.ts[i - 1] || lt.ns[i] <= lt.ns[i - 1])) return OTAL_E_LEVELS;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int otal_bmp_fwd_levels(const void* in, const float* seg, void* out, int B, int C, int nlev,
+                                   const int* t_start, const int* n_start, int dtype, void* stream) {
+    if (!in || !seg || !out) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0) return OTAL_E_SHAPE;
+    if (C & 1) return OTAL_E_ODD_C;
+    LevelTab lt;
+    if (int e = check_levels(nlev, t_start, n_start, lt)) return e;
+    const int Tt = lt.ts[nlev], Nt = lt.ns[nlev];
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == OTAL_F32) return launch_fwd<float>((const float*)in, seg, (float*)out, B, C, Tt, Nt, lt, s);
+    if (dtype == OTAL_BF16) return launch_fwd<bf16_t>((const bf16_t*)in, seg, (bf16_t*)out, B, C, Tt, Nt, lt, s);
+    return OTAL_E_DTYPE;
+}
+
+extern "C" int otal_bmp_bwd_levels(const void* gout, const void* in, const float* seg, void* gin, int B, int C,
+                                   int nlev, const int* t_start, const int* n_start, int dtype, void* stream) {
+    if (!gout || !in || !seg || !gin) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0) return OTAL_E_SHAPE;
+    if (C & 1) return OTAL_E_ODD_C;
+    LevelTab lt;
+    if (int e = check_levels(nlev, t_start, n_start, lt)) return e;
+    const int Tt = lt.ts[nlev], Nt = lt.ns[nlev];
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == OTAL_F32) return launch_bwd<float>((const float*)gout, (const float*)in, seg, (float*)gin, B, C, Tt, Nt, lt, s);
+    if (dtype == OTAL_BF16) return launch_bwd<bf16_t>((const bf16_t*)gout, (const bf16_t*)in, seg, (bf16_t*)gin, B, C, Tt, Nt, lt, s);
+    return OTAL_E_DTYPE;
+}
+
+extern "C" int otal_bmp_fwd(const void* in, const float* seg, void* out, int B, int C, int T, int N,
+                            int seg_batch, int dtype, void* stream) {
+    if (T <= 0 || N <= 0) return OTAL_E_SHAPE;
+    if (seg_batch != B) return OTAL_E_BATCH;
+    const int ts[2] = {0, T}, ns[2] = {0, N};
+    return otal_bmp_fwd_levels(in, seg, out, B, C, 1, ts, ns, dtype, stream);
+}
+
+extern "C" int otal_bmp_bwd(const void* gout, const void* in, const float* seg, void* gin, int B, int C, int T,
+                            int N, int seg_batch, int compat_ref_stride, int dtype, void* stream) {
+    if (T <= 0 || N <= 0) return OTAL_E_SHAPE;
+    if (seg_batch != B) return OTAL_E_BATCH;
+    if (!gin) return OTAL_E_NULL;
+    int Teff = T;
+    if (compat_ref_stride && N != T) {
+        // reference launcher: tscale = grad_output.size(2) = N (boundary_max_pooling_kernel.cu:121).
+        // Same kernel over the same buffers viewed as (B*C) rows of N; the tail stays zero.
+        if (N > T) return OTAL_E_SHAPE;   // the reference would write out of bounds here
+        const size_t esz = dtype == OTAL_F32 ? 4 : 2;
+        hipError_t e = hipMemsetAsync(gin, 0, (size_t)B * C * T * esz, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+        Teff = N;
+    }
+    const int ts[2] = {0, Teff}, ns[2] = {0, N};
+    return otal_bmp_bwd_levels(gout, in, seg, gin, B, C, 1, ts, ns, dtype, stream);
+}
