@@ -20,6 +20,7 @@
 #define OPENTAL_HIP_H
 
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -75,6 +76,77 @@ int otal_bmp_fwd_levels(const void* in, const float* seg, void* out,
 int otal_bmp_bwd_levels(const void* grad_out, const void* in, const float* seg, void* grad_in,
                         int B, int C, int nlev, const int* t_start, const int* n_start,
                         int dtype, void* stream);
+
+/* ------------------------------------------------------- implicit-GEMM convolution (MFMA) ----
+ * One kernel family for Conv1d (H=W=1) and Conv3d, fp32 in / fp32 accumulate on
+ * v_mfma_f32_32x32x2_f32.  Replaces, on the hot path, torch.nn.Conv1d inside Unit1D
+ * (AFSD/common/layers.py:178-214), torch.nn.Conv3d inside Unit3D (AFSD/common/i3d_backbone.py:7-87,
+ * AFSD/common/layers.py:106-175) and their autograd backward (cuDNN in the reference).
+ *
+ * geom   : 28 ints  B,Cin,Cout, Ti,Hi,Wi, To,Ho,Wo, kt,kh,kw, st,sh,sw, pt,ph,pw, nlev, lev[0..8]
+ *          (pt/ph/pw = FRONT pad of the reference's SAME rule; out-of-range taps read zero;
+ *          nlev > 1: level-packed stride-1 Conv1d, taps do not cross level boundaries)
+ * strides: 4 int64  x batch stride, x channel stride, y batch stride, y channel stride (elements);
+ *          pointers are pre-offset to the first channel, so channel slices of a concat buffer
+ *          are read / written in place.
+ * ws     : optional split-K workspace (otal_conv_workspace_bytes); a smaller one only lowers the
+ *          split factor.  Split-K partials are reduced in a fixed order (deterministic).
+ * mode   : 0 forward, 1 data gradient, 2 weight gradient. */
+size_t otal_conv_workspace_bytes(const int* geom, int mode);
+
+/* y = act(scale[co] * conv(x, w) + shift[co]); scale/shift nullable (frozen BN folded, or bias). */
+int otal_conv_fwd(const int* geom, const int64_t* strides, const float* x, const float* w,
+                  const float* scale, const float* shift, float* y, int relu,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* dx (+)= conv_transpose(dy', w) with dy' = dy * (ymask > 0) * dscale[co]  (ymask/dscale nullable:
+ * ReLU + frozen-BN backward folded into the loader).  wt_packed = otal_conv_pack_wt(w). */
+int otal_conv_dgrad(const int* geom, const int64_t* strides, const float* dy, const float* wt_packed,
+                    const float* ymask, const float* dscale, float* dx, int accumulate,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* dw (+)= sum_{b,pos} dy'[b,co,pos] * x[b,ci,pos*s + tap - pad] */
+int otal_conv_wgrad(const int* geom, const int64_t* strides, const float* x, const float* dy,
+                    const float* ymask, const float* dscale, float* dw, int accumulate,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* (Cout,Cin,kvol) -> (Cin,Cout,kvol): the A operand of the data-gradient GEMM. */
+int otal_conv_pack_wt(const float* w, float* wt, int Cout, int Cin, int kvol, void* stream);
+
+/* ------------------------------------------------------------------ GroupNorm + ReLU ----
+ * y = relu(GroupNorm_G(x) * gamma + beta) on (B,C,T); statistics per (sample, group, level)
+ * (nlev <= 1 or lev == NULL: one level).  stats: (B,G,nlev,2) {mean, rstd}, kept for backward.
+ * Replaces nn.GroupNorm(32, C) + nn.ReLU after each Unit1D / Unit3D of the pyramid
+ * (AFSD/thumos14/BDNet.py:67-103,:129-203,:274-284). */
+int otal_gn_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                     int B, int C, int T, int G, float eps, int relu, int nlev, const int* lev, void* stream);
+/* dx and per-(sample,channel) partial sums partial[(b*C+c)*3 + {0,1,2}] = {d_gamma, d_beta, sum_t dx}
+ * (sum over b by the caller; sum_t dx is the gradient of the preceding convolution's bias). */
+int otal_gn_relu_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
+                     const float* stats, float* dx, float* partial, int B, int C, int T, int G,
+                     int relu, int nlev, const int* lev, void* stream);
+
+/* ------------------------------------------------------------------ MaxPool3dSamePadding ----
+ * geom: 17 ints B,C, Ti,Hi,Wi, To,Ho,Wo, kt,kh,kw, st,sh,sw, pt,ph,pw (front pads; ZERO padding);
+ * strides as for the convolution.  argtap: (B,C,To,Ho,Wo) uint8 winner tap (255 = padded zero).
+ * Replaces MaxPool3dSamePadding.forward (AFSD/common/layers.py:9-35) and its autograd backward. */
+int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const float* x, float* y,
+                       unsigned char* argtap, void* stream);
+int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const float* dy,
+                       const unsigned char* argtap, float* dx, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ proposal window indices ----
+ * loc (B,Ntot,2) -> level-space windows seg (B,Ntot,4) and frame-space windows frame_seg (B,Ntot,4)
+ * for all levels at once; bit-exact restatement of the no_grad block of CoarsePyramid.forward
+ * (AFSD/thumos14/BDNet.py:355-384).  lev: nlev+1 column starts of the levels inside Ntot. */
+int otal_proposal_windows(const float* loc, float* seg, float* frame_seg, int B, int nlev,
+                          const int* lev, float frame_num, void* stream);
+
+/* ------------------------------------------------------------------ optimizer ----
+ * torch.optim.Adam with L2 weight decay (AFSD/thumos14/train.py:321-323) over one flat fp32
+ * arena; g is multiplied by grad_scale first (1/world_size after a sum all-reduce). */
+int otal_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

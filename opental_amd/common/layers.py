@@ -1,0 +1,153 @@
+"""Layer primitives of the detection path on MI355X, with the reference's constructor signatures
+and state-dict key names (AFSD/common/layers.py): Unit1D (:178-214), Unit3D (:106-175),
+MaxPool3dSamePadding (:9-35).  The arithmetic runs in libopental_hip.so (implicit-GEMM
+convolution on MFMA, fused GroupNorm+ReLU, virtual SAME padding); nn.Conv1d / nn.Conv3d /
+nn.GroupNorm objects are kept only as parameter containers so checkpoints stay interchangeable.
+
+Extra, not in the reference: `levels=` (a level table) runs a stride-1 Unit1D over a packed
+(B,C,sum t_l) pyramid buffer as six independent SAME-padded convolutions in one launch, and
+`ConvGNReLU` fuses the reference's nn.Sequential(Unit, GroupNorm(32,C), ReLU) blocks.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import ops
+
+
+def _tuple3(k):
+    return (k, 1, 1) if isinstance(k, int) else tuple(k)
+
+
+class ConvSameFunction(Function):
+    """y = conv_SAME(x, w) + b for (B,C,T) or (B,C,T,H,W); dx/dw through the MFMA GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, k, s, spatial_valid, levels):
+        ctx.cfg = (_tuple3(k), _tuple3(s), spatial_valid, levels)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return ops.conv_forward(x, w, ctx.cfg[0], ctx.cfg[1], shift=b, spatial_valid=spatial_valid, levels=levels)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        k, s, sv, lev = ctx.cfg
+        dy = dy.contiguous()
+        dx = ops.conv_dgrad(dy, w, x.shape, k, s, spatial_valid=sv, levels=lev) if ctx.needs_input_grad[0] else None
+        dw = ops.conv_wgrad(x, dy, w.shape, k, s, spatial_valid=sv, levels=lev) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=[0] + list(range(2, dy.dim())))
+        return dx, dw, db, None, None, None, None
+
+
+class ConvGNReLUFunction(Function):
+    """relu(GroupNorm_32(conv_SAME(x, w) + b)); the conv output must be 1-D in space (H=W=1 after
+    the convolution), which covers every Unit1D/Unit3D + GroupNorm + ReLU block of BDNet.py."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, k, s, spatial_valid, levels, groups, eps):
+        k, s = _tuple3(k), _tuple3(s)
+        c = ops.conv_forward(x, w, k, s, shift=b, spatial_valid=spatial_valid, levels=levels)
+        c3 = c.view(c.shape[0], c.shape[1], c.shape[2]) if c.dim() == 5 else c
+        y, stats = ops.gn_relu_forward(c3, gamma, beta, groups, eps, True, levels)
+        ctx.cfg = (k, s, spatial_valid, levels, groups)
+        ctx.save_for_backward(x, w, c3, gamma, beta, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, c3, gamma, beta, stats = ctx.saved_tensors
+        k, s, sv, lev, groups = ctx.cfg
+        dc, dgamma, dbeta, dbias = ops.gn_relu_backward(dy.contiguous(), c3, gamma, beta, stats, groups, True, lev)
+        dc5 = dc.view(dc.shape[0], dc.shape[1], dc.shape[2], 1, 1) if x.dim() == 5 else dc
+        dx = ops.conv_dgrad(dc5, w, x.shape, k, s, spatial_valid=sv, levels=lev) if ctx.needs_input_grad[0] else None
+        dw = ops.conv_wgrad(x, dc5, w.shape, k, s, spatial_valid=sv, levels=lev)
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
+
+
+class Unit1D(nn.Module):
+    def __init__(self, in_channels, output_channels, kernel_shape=1, stride=1, padding='same',
+                 activation_fn=F.relu, use_bias=True):
+        super(Unit1D, self).__init__()
+        if padding != 'same':
+            raise NotImplementedError("only padding='same' is used on the hot path")
+        self.conv1d = nn.Conv1d(in_channels, output_channels, kernel_shape, stride, padding=0, bias=use_bias)
+        self._activation_fn = activation_fn
+        self._padding = padding
+        self._stride = stride
+        self._kernel_shape = kernel_shape
+
+    def forward(self, x, levels=None):
+        x = ConvSameFunction.apply(x, self.conv1d.weight, self.conv1d.bias, self._kernel_shape, self._stride,
+                                   False, levels)
+        if self._activation_fn is not None:
+            x = self._activation_fn(x)
+        return x
+
+
+class Unit3D(nn.Module):
+    """Pyramid-projection Unit3D (layers.py:106-175): temporal SAME pad, spatially 'valid'."""
+
+    def __init__(self, in_channels, output_channels, kernel_shape=(1, 1, 1), stride=(1, 1, 1),
+                 padding='spatial_valid', activation_fn=F.relu, use_batch_norm=False, use_bias=False):
+        super(Unit3D, self).__init__()
+        if use_batch_norm:
+            raise NotImplementedError("the pyramid Unit3D never carries BatchNorm (BDNet.py:129-155)")
+        if padding not in ('spatial_valid', 'same'):
+            raise NotImplementedError(padding)
+        self._kernel_shape = tuple(kernel_shape)
+        self._stride = tuple(stride)
+        self._activation_fn = activation_fn
+        self.padding = padding
+        self.conv3d = nn.Conv3d(in_channels, output_channels, self._kernel_shape, self._stride, padding=0,
+                                bias=use_bias)
+
+    def forward(self, x):
+        x = ConvSameFunction.apply(x, self.conv3d.weight, self.conv3d.bias, self._kernel_shape, self._stride,
+                                   self.padding == 'spatial_valid', None)
+        if self._activation_fn is not None:
+            x = self._activation_fn(x)
+        return x
+
+
+class ConvGNReLU(nn.Sequential):
+    """nn.Sequential(Unit1D | Unit3D, nn.GroupNorm(32, C), nn.ReLU) with the reference's child
+    indices (so keys read `<name>.0.conv1d.weight`, `<name>.1.weight`), executed as one fused
+    autograd node: conv (+bias) -> GroupNorm statistics per level -> ReLU."""
+
+    def __init__(self, unit, channels, groups=32):
+        super(ConvGNReLU, self).__init__(unit, nn.GroupNorm(groups, channels), nn.ReLU(inplace=True))
+
+    def forward(self, x, levels=None):
+        unit, gn = self[0], self[1]
+        if isinstance(unit, Unit1D):
+            conv, k, s, sv = unit.conv1d, unit._kernel_shape, unit._stride, False
+        else:
+            conv, k, s, sv = unit.conv3d, unit._kernel_shape, unit._stride, unit.padding == 'spatial_valid'
+        return ConvGNReLUFunction.apply(x, conv.weight, conv.bias, gn.weight, gn.bias, k, s, sv, levels,
+                                        gn.num_groups, gn.eps)
+
+
+class MaxPool3dFunction(Function):
+    @staticmethod
+    def forward(ctx, x, k, s):
+        y, arg = ops.maxpool3d_forward(x, k, s)
+        ctx.cfg = (tuple(k), tuple(s), x.shape)
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        k, s, shape = ctx.cfg
+        return ops.maxpool3d_backward(dy.contiguous(), arg, shape, k, s), None, None
+
+
+class MaxPool3dSamePadding(nn.MaxPool3d):
+    """Zero-padded SAME max-pool (layers.py:9-35) without materialising the padded tensor."""
+
+    def forward(self, x):
+        return MaxPool3dFunction.apply(x, tuple(self.kernel_size), tuple(self.stride))

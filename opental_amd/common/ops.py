@@ -1,0 +1,252 @@
+"""Thin host wrappers over the C ABI (include/opental_hip.h).  torch is used for device memory
+and the current HIP stream only; every numeric step below runs in libopental_hip.so.
+
+Tensors may be channel slices of a larger contiguous buffer (``buf[:, c0:c1]``): batch and
+channel strides are passed to the kernels, which is how Inception concatenation is written
+in place instead of through torch.cat.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib as L
+from .conv_geom import make_geom
+
+_WORKSPACE = {}
+WORKSPACE_BYTES = 192 << 20
+
+
+def workspace(device):
+    """One split-K scratch buffer per device; launches on a stream are serialised, so sharing is safe."""
+    key = (device.type, device.index)
+    ws = _WORKSPACE.get(key)
+    if ws is None:
+        ws = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        _WORKSPACE[key] = ws
+    return ws
+
+
+def _as5(t):
+    if t.dim() == 3:
+        return t.unsqueeze(-1).unsqueeze(-1)
+    if t.dim() != 5:
+        raise RuntimeError("expected a (B,C,T) or (B,C,T,H,W) tensor")
+    return t
+
+
+def _check(t5, name):
+    if not t5.is_cuda:
+        raise RuntimeError(f"{name}: opental_amd ops run on the GPU only (no CPU fallback)")
+    if t5.dtype != torch.float32:
+        raise RuntimeError(f"{name}: float32 expected, got {t5.dtype}")
+    _, _, T, H, W = t5.shape
+    exp = {4: 1, 3: W, 2: H * W}
+    for d, e in exp.items():
+        if t5.shape[d] > 1 and t5.stride(d) != e:
+            raise RuntimeError(f"{name}: spatial dims must be dense (stride {t5.stride()})")
+    if t5.shape[1] > 1 and t5.stride(1) < T * H * W:
+        raise RuntimeError(f"{name}: bad channel stride")
+
+
+def _bs(t5):
+    """(batch stride, channel stride) in elements, tolerant of size-1 dims."""
+    _, C, T, H, W = t5.shape
+    cs = t5.stride(1) if C > 1 else T * H * W
+    bs = t5.stride(0) if t5.shape[0] > 1 else cs * C
+    return bs, cs
+
+
+def _geom_arrays(g, x5, y5):
+    xb, xc = _bs(x5)
+    yb, yc = _bs(y5)
+    return (ctypes.c_int * len(g))(*g), (ctypes.c_int64 * 4)(xb, xc, yb, yc)
+
+
+def _opt(t):
+    return L.ptr(t) if t is not None else None
+
+
+def _k3(k):
+    return (k, 1, 1) if isinstance(k, int) else tuple(k)
+
+
+def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=False, levels=None, out=None):
+    """y = act(scale * conv_SAME(x, w) + shift).  x (B,Cin,T[,H,W]); w (Cout,Cin,*k)."""
+    k, s = _k3(k), _k3(s)
+    x5 = _as5(x)
+    B, Cin, Ti, Hi, Wi = x5.shape
+    Cout = w.shape[0]
+    g, outn = make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
+    if out is None:
+        out = torch.empty((B, Cout) + outn, dtype=x.dtype, device=x.device)
+        if x.dim() == 3:
+            out = out.view(B, Cout, outn[0])
+    y5 = _as5(out)
+    if tuple(y5.shape) != (B, Cout) + outn:
+        raise RuntimeError(f"conv_forward: out has shape {tuple(y5.shape)}, expected {(B, Cout) + outn}")
+    _check(x5, "x"); _check(y5, "y")
+    if not w.is_contiguous():
+        raise RuntimeError("weights must be contiguous")
+    ga, sa = _geom_arrays(g, x5, y5)
+    ws = workspace(x.device)
+    L.check(L.lib().otal_conv_fwd(ga, sa, L.ptr(x5), L.ptr(w), _opt(scale), _opt(shift), L.ptr(y5), int(relu),
+                                  L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()), "otal_conv_fwd")
+    return out
+
+
+def pack_wt(w):
+    """(Cout,Cin,*k) -> (Cin,Cout,kvol) packed A operand of the data-gradient GEMM."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    kvol = w[0, 0].numel()
+    wt = torch.empty((Cin, Cout, kvol), dtype=w.dtype, device=w.device)
+    L.check(L.lib().otal_conv_pack_wt(L.ptr(w), L.ptr(wt), Cout, Cin, kvol, L.stream()), "otal_conv_pack_wt")
+    return wt
+
+
+def conv_dgrad(dy, w, x_shape, k, s, ymask=None, dscale=None, spatial_valid=False, levels=None, out=None,
+               accumulate=False, wt=None):
+    """dx (+)= d conv / d x.  dy/ymask share a layout; `out` may be a channel slice."""
+    k, s = _k3(k), _k3(s)
+    dy5 = _as5(dy)
+    xs5 = tuple(x_shape) + (1, 1) if len(x_shape) == 3 else tuple(x_shape)
+    B, Cin, Ti, Hi, Wi = xs5
+    Cout = w.shape[0]
+    g, outn = make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
+    if out is None:
+        if accumulate:
+            raise RuntimeError("accumulate needs an existing buffer")
+        out = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
+    x5 = _as5(out)
+    _check(x5, "dx"); _check(dy5, "dy")
+    if tuple(dy5.shape) != (B, Cout) + outn:
+        raise RuntimeError(f"conv_dgrad: dy has shape {tuple(dy5.shape)}, expected {(B, Cout) + outn}")
+    if ymask is not None:
+        m5 = _as5(ymask)
+        if m5.stride() != dy5.stride() and tuple(_bs(m5)) != tuple(_bs(dy5)):
+            raise RuntimeError("ymask must share dy's layout")
+    if wt is None:
+        wt = pack_wt(w)
+    ga, sa = _geom_arrays(g, x5, dy5)
+    ws = workspace(dy.device)
+    L.check(L.lib().otal_conv_dgrad(ga, sa, L.ptr(dy5), L.ptr(wt), _opt(ymask), _opt(dscale), L.ptr(x5),
+                                    int(accumulate), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
+            "otal_conv_dgrad")
+    return out
+
+
+def conv_wgrad(x, dy, w_shape, k, s, ymask=None, dscale=None, spatial_valid=False, levels=None, out=None,
+               accumulate=False):
+    """dw (+)= d conv / d w."""
+    k, s = _k3(k), _k3(s)
+    x5, dy5 = _as5(x), _as5(dy)
+    B, Cin, Ti, Hi, Wi = x5.shape
+    Cout = w_shape[0]
+    g, outn = make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
+    if tuple(dy5.shape) != (B, Cout) + outn:
+        raise RuntimeError(f"conv_wgrad: dy has shape {tuple(dy5.shape)}, expected {(B, Cout) + outn}")
+    if out is None:
+        if accumulate:
+            raise RuntimeError("accumulate needs an existing buffer")
+        out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device)
+    if not out.is_contiguous():
+        raise RuntimeError("dw must be contiguous")
+    _check(x5, "x"); _check(dy5, "dy")
+    ga, sa = _geom_arrays(g, x5, dy5)
+    ws = workspace(x.device)
+    L.check(L.lib().otal_conv_wgrad(ga, sa, L.ptr(x5), L.ptr(dy5), _opt(ymask), _opt(dscale), L.ptr(out),
+                                    int(accumulate), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
+            "otal_conv_wgrad")
+    return out
+
+
+# ----------------------------------------------------------------------------- GroupNorm + ReLU
+def _lev_arg(levels):
+    if levels is None or len(levels) <= 2:
+        return 1, None
+    return len(levels) - 1, L.int_array(list(levels))
+
+
+def gn_relu_forward(x, gamma, beta, groups=32, eps=1e-5, relu=True, levels=None):
+    L.require_device(x, gamma, beta)
+    B, C, T = x.shape
+    nlev, lev = _lev_arg(levels)
+    y = torch.empty_like(x)
+    stats = torch.empty((B, groups, nlev, 2), dtype=torch.float32, device=x.device)
+    L.check(L.lib().otal_gn_relu_fwd(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(stats), B, C, T, groups,
+                                     ctypes.c_float(eps), int(relu), nlev, lev, L.stream()), "otal_gn_relu_fwd")
+    return y, stats
+
+
+def gn_relu_backward(dy, x, gamma, beta, stats, groups=32, relu=True, levels=None):
+    L.require_device(dy, x, gamma, beta, stats)
+    B, C, T = x.shape
+    nlev, lev = _lev_arg(levels)
+    dx = torch.empty_like(x)
+    partial = torch.empty((B, C, 3), dtype=torch.float32, device=x.device)
+    L.check(L.lib().otal_gn_relu_bwd(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.ptr(dx),
+                                     L.ptr(partial), B, C, T, groups, int(relu), nlev, lev, L.stream()),
+            "otal_gn_relu_bwd")
+    red = partial.sum(0)            # (C,3): d_gamma, d_beta, d_conv_bias
+    return dx, red[:, 0].contiguous(), red[:, 1].contiguous(), red[:, 2].contiguous()
+
+
+# ----------------------------------------------------------------------------- MaxPool3d (SAME, zero pad)
+def _pool_geom(x5, k, s):
+    from .conv_geom import same_pad
+    B, C, Ti, Hi, Wi = x5.shape
+    pads, outs = [], []
+    for size, kk, ss in zip((Ti, Hi, Wi), k, s):
+        f, o = same_pad(size, kk, ss)
+        pads.append(f)
+        outs.append(o)
+    return [B, C, Ti, Hi, Wi, *outs, *k, *s, *pads], tuple(outs)
+
+
+def maxpool3d_forward(x, k, s, out=None):
+    x5 = _as5(x)
+    g, outn = _pool_geom(x5, k, s)
+    B, C = x5.shape[:2]
+    if out is None:
+        out = torch.empty((B, C) + outn, dtype=x.dtype, device=x.device)
+    arg = torch.empty((B, C) + outn, dtype=torch.uint8, device=x.device)
+    _check(x5, "x"); _check(out, "y")
+    ga, sa = _geom_arrays(g, x5, out)
+    L.check(L.lib().otal_maxpool3d_fwd(ga, sa, L.ptr(x5), L.ptr(out), L.ptr(arg), L.stream()), "otal_maxpool3d_fwd")
+    return out, arg
+
+
+def maxpool3d_backward(dy, arg, x_shape, k, s, out=None, accumulate=False):
+    if out is None:
+        if accumulate:
+            raise RuntimeError("accumulate needs an existing buffer")
+        out = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
+    g, outn = _pool_geom(out, k, s)
+    _check(out, "dx"); _check(dy, "dy")
+    if tuple(dy.shape[2:]) != outn or not arg.is_contiguous():
+        raise RuntimeError("maxpool3d_backward: shape mismatch")
+    ga, sa = _geom_arrays(g, out, dy)
+    L.check(L.lib().otal_maxpool3d_bwd(ga, sa, L.ptr(dy), L.ptr(arg), L.ptr(out), int(accumulate), L.stream()),
+            "otal_maxpool3d_bwd")
+    return out
+
+
+# ----------------------------------------------------------------------------- proposal windows / Adam
+def proposal_windows(loc, levels, frame_num):
+    """loc (B,Ntot,2) -> (segments, frame_segments), both (B,Ntot,4) float32; BDNet.py:355-384."""
+    L.require_device(loc)
+    B, N, _ = loc.shape
+    assert N == levels[-1]
+    seg = torch.empty((B, N, 4), dtype=torch.float32, device=loc.device)
+    fseg = torch.empty_like(seg)
+    L.check(L.lib().otal_proposal_windows(L.ptr(loc), L.ptr(seg), L.ptr(fseg), B, len(levels) - 1,
+                                          L.int_array(list(levels)), ctypes.c_float(frame_num), L.stream()),
+            "otal_proposal_windows")
+    return seg, fseg
+
+
+def adam_flat(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    L.require_device(p, g, m, v)
+    L.check(L.lib().otal_adam_flat(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), ctypes.c_int64(p.numel()),
+                                   ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2),
+                                   ctypes.c_float(eps), ctypes.c_float(weight_decay), int(step),
+                                   ctypes.c_float(grad_scale), L.stream()), "otal_adam_flat")

@@ -1,0 +1,403 @@
+// opental_amd/csrc/conv_gemm.hip -- implicit-GEMM convolution on the gfx950 matrix cores.
+//
+// One kernel family covers every dense convolution of the OpenTAL/AFSD path:
+//   Conv3d of the I3D backbone (AFSD/common/i3d_backbone.py:7-87)      : FWD / DGRAD / WGRAD
+//   Unit3D [1,6,6] / [1,3,3] pyramid projections (thumos14/BDNet.py:129-155)
+//   Unit1D k=1/3, stride 1/2 of the temporal pyramid, towers, ProposalBranch (layers.py:178-214)
+// as a GEMM  C[M][N] = A[M][K] * B[K][N]  with B (and for WGRAD also A) gathered on the fly:
+//   FWD   : M=Cout  N=B*To*Ho*Wo  K=Cin*kvol   A=W          B=im2col(x)      C=y  (+scale/shift/ReLU)
+//   DGRAD : M=Cin   N=B*Ti*Hi*Wi  K=Cout*kvol  A=W^T(packed) B=col2im-gather(dy) C=dx
+//   WGRAD : M=Cout  N=Cin*kvol    K=B*To*Ho*Wo A=dy         B=im2col(x)^T    C=dW
+// fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fma chain), so the
+// result is comparable with the reference at 1e-4 without any reduced-precision step.
+//
+// Tile: BM in {32,64,128} x BN=128, BK=16, 256 threads = 4 wave64.  Global -> registers -> LDS
+// double buffering (one barrier per K step); LDS tiles are stored k-major ([BK][BM+2], [BK][BN+2])
+// so every MFMA operand read is 32 consecutive floats per half-wave (conflict free) and the
+// k-fast global tiles are written with a 2-bank skew (conflict free as well).
+// SAME padding, strides, level-packed pyramids and channel-sliced (concat) tensors are folded
+// into the gather (conv_index.h); ReLU/frozen-BN backward is folded into the dy loader.
+// Split-K writes fp32 slabs that a second kernel reduces in a fixed order (deterministic).
+#include "common.h"
+#include "conv_index.h"
+
+namespace {
+
+constexpr int BN = 128, BK = 16, NT = 256;
+enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
+enum { EPI_RELU = 1, EPI_ACCUM = 2 };
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    ConvGeom g;
+    const float* x;        // FWD/WGRAD: input activations
+    const float* w;        // FWD: W (Cout, Cin*kvol); DGRAD: packed W^T (Cin, Cout*kvol)
+    const float* dy;       // DGRAD/WGRAD: output gradient
+    const float* ymask;    // optional: forward output y (same layout as dy) -> dy *= (y > 0)
+    const float* dscale;   // optional: per-output-channel multiplier applied to dy (frozen BN)
+    float* out;            // FWD: y; DGRAD: dx; WGRAD: dW (Cout, Cin*kvol)
+    const float* scale;    // FWD epilogue: per-Cout scale (nullable -> 1)
+    const float* shift;    // FWD epilogue: per-Cout shift / bias (nullable -> 0)
+    float* slab;           // split-K workspace [splits][M][N] (nullable when splits == 1)
+    int M, N, K;
+    int splits, k_per_split;   // k_per_split is a multiple of BK
+    int flags;
+};
+
+// ---- operand element fetch -------------------------------------------------------------------
+__device__ __forceinline__ float load_dy(const ConvArgs& a, int64_t off, int co) {
+    float v = a.dy[off];
+    if (a.ymask) v = a.ymask[off] > 0.f ? v : 0.f;
+    if (a.dscale) v *= a.dscale[co];
+    return v;
+}
+
+template <int BM, int WM, int WN, int MODE>
+__global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
+    constexpr int LDA = BM + 2, LDB = BN + 2;
+    constexpr int A_PER = BM * BK / NT;     // A elements per thread per K step
+    constexpr int B_PER = BN * BK / NT;     // = 8
+    __shared__ float As[2][BK * LDA];
+    __shared__ float Bs[2][BK * LDB];
+
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int split = blockIdx.z;
+    const int k_begin = split * a.k_per_split;
+    const int k_end = min(a.K, k_begin + a.k_per_split);
+    const int kvol = conv_kvol(g);
+
+    // ---- per-thread invariants of the loaders
+    // A tile is always k-fast: lane&15 -> k, tid>>4 -> m (+16 per step)
+    const int a_k = tid & 15, a_m = tid >> 4;
+    // B tile, n-fast (FWD/DGRAD): tid&127 -> n, (tid>>7)+2j -> k   (k is wave-uniform)
+    // B tile, k-fast (WGRAD)    : tid&15 -> k, (tid>>4)+16j -> n
+    PosDec bpos = {0, 0, 0, 0};
+    bool bpos_ok = false;
+    TapDec wtap[B_PER];                      // WGRAD only: this thread's B_PER fixed columns
+    bool wtap_ok[B_PER];
+    if (MODE == MODE_FWD) {
+        const int n = n0 + (tid & 127);
+        bpos_ok = n < a.N;
+        if (bpos_ok) bpos = dec_pos(n, g.To, g.Ho, g.Wo);
+    } else if (MODE == MODE_DGRAD) {
+        const int n = n0 + (tid & 127);
+        bpos_ok = n < a.N;
+        if (bpos_ok) bpos = dec_pos(n, g.Ti, g.Hi, g.Wi);
+    } else {
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int n = n0 + (tid >> 4) + 16 * j;
+            wtap_ok[j] = n < a.N;
+            wtap[j] = dec_tap(g, wtap_ok[j] ? n : 0);
+        }
+    }
+
+    float ra[A_PER], rb[B_PER];
+
+    auto load_tiles = [&](int k0) {
+        // ---------------- A
+        if (MODE == MODE_WGRAD) {
+            const int k = k0 + a_k;
+            const bool kok = k < k_end;
+            PosDec o = dec_pos(kok ? k : 0, g.To, g.Ho, g.Wo);
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j) {
+                const int m = m0 + a_m + 16 * j;
+                float v = 0.f;
+                if (kok && m < a.M) v = load_dy(a, conv_out_offset(g, o, m), m);
+                ra[j] = v;
+            }
+            // ------------ B (k-fast): same k as A
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) {
+                float v = 0.f;
+                int64_t off;
+                if (kok && wtap_ok[j] && conv_src_of_output(g, o, wtap[j], off)) v = a.x[off];
+                rb[j] = v;
+            }
+        } else {
+            const int k = k0 + a_k;
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j) {
+                const int m = m0 + a_m + 16 * j;
+                ra[j] = (k < k_end && m < a.M) ? a.w[(int64_t)m * a.K + k] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) {
+                const int kk = k0 + __builtin_amdgcn_readfirstlane(tid >> 7) + 2 * j;   // wave-uniform
+                float v = 0.f;
+                if (kk < k_end && bpos_ok) {
+                    const TapDec t = dec_tap(g, kk);
+                    int64_t off;
+                    if (MODE == MODE_FWD) {
+                        if (conv_src_of_output(g, bpos, t, off)) v = a.x[off];
+                    } else {
+                        if (conv_src_of_input(g, bpos, t, off)) v = load_dy(a, off, t.c);
+                    }
+                }
+                rb[j] = v;
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) As[buf][a_k * LDA + a_m + 16 * j] = ra[j];
+        if (MODE == MODE_WGRAD) {
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) Bs[buf][a_k * LDB + (tid >> 4) + 16 * j] = rb[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) Bs[buf][((tid >> 7) + 2 * j) * LDB + (tid & 127)] = rb[j];
+        }
+    };
+
+    // ---- wave tile placement
+    constexpr int WAVES_N = BN / (32 * WN);
+    const int wm0 = (wave / WAVES_N) * (32 * WM);
+    const int wn0 = (wave % WAVES_N) * (32 * WN);
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+    if (nk > 0) {
+        load_tiles(k_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nk) load_tiles(k_begin + (it + 1) * BK);
+        const float* as = As[buf];
+        const float* bs = Bs[buf];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[WM], bv[WN];
+            const int kr = kk + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) av[i] = as[kr * LDA + wm0 + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bv[j] = bs[kr * LDB + wn0 + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + wn0 + j * 32 + (lane & 31);
+        if (n >= a.N) continue;
+        int64_t nbase = 0;
+        if (a.splits == 1) {
+            if (MODE == MODE_FWD) nbase = conv_out_offset(g, dec_pos(n, g.To, g.Ho, g.Wo), 0);
+            else if (MODE == MODE_DGRAD) nbase = conv_in_offset(g, dec_pos(n, g.Ti, g.Hi, g.Wi), 0);
+            else nbase = n;
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= a.M) continue;
+                float v = acc[i][j][r];
+                if (a.splits > 1) {
+                    a.slab[((int64_t)split * a.M + m) * a.N + n] = v;
+                    continue;
+                }
+                int64_t off;
+                if (MODE == MODE_FWD) {
+                    if (a.scale) v *= a.scale[m];
+                    if (a.shift) v += a.shift[m];
+                    if (a.flags & EPI_RELU) v = fmaxf(v, 0.f);
+                    off = nbase + (int64_t)m * g.y_cs;
+                } else if (MODE == MODE_DGRAD) {
+                    off = nbase + (int64_t)m * g.x_cs;
+                } else {
+                    off = (int64_t)m * a.N + nbase;
+                }
+                if (a.flags & EPI_ACCUM) v += a.out[off];
+                a.out[off] = v;
+            }
+    }
+}
+
+// fixed-order reduction of the split-K slabs + the same epilogue
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
+    const ConvGeom& g = a.g;
+    const int64_t total = (int64_t)a.M * a.N;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int m = (int)(idx / a.N), n = (int)(idx - (int64_t)m * a.N);
+        float v = 0.f;
+        for (int s = 0; s < a.splits; ++s) v += a.slab[(int64_t)s * total + idx];
+        int64_t off;
+        if (MODE == MODE_FWD) {
+            if (a.scale) v *= a.scale[m];
+            if (a.shift) v += a.shift[m];
+            if (a.flags & EPI_RELU) v = fmaxf(v, 0.f);
+            off = conv_out_offset(g, dec_pos(n, g.To, g.Ho, g.Wo), m);
+        } else if (MODE == MODE_DGRAD) {
+            off = conv_in_offset(g, dec_pos(n, g.Ti, g.Hi, g.Wi), m);
+        } else {
+            off = idx;
+        }
+        if (a.flags & EPI_ACCUM) v += a.out[off];
+        a.out[off] = v;
+    }
+}
+
+// W (Cout, Cin, kvol) -> W^T packed (Cin, Cout, kvol): the A operand of DGRAD
+__global__ __launch_bounds__(256) void pack_wt_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                      int Cout, int Cin, int kvol) {
+    const int64_t total = (int64_t)Cout * Cin * kvol;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int r = (int)(idx % kvol);
+        const int64_t q = idx / kvol;
+        const int co = (int)(q % Cout), ci = (int)(q / Cout);
+        wt[idx] = w[((int64_t)co * Cin + ci) * kvol + r];
+    }
+}
+
+int fill_geom(ConvGeom& g, const int* d) {
+    // d: B,Cin,Cout, Ti,Hi,Wi, To,Ho,Wo, kt,kh,kw, st,sh,sw, pt,ph,pw, nlev, lev[0..8]
+    g.B = d[0]; g.Cin = d[1]; g.Cout = d[2];
+    g.Ti = d[3]; g.Hi = d[4]; g.Wi = d[5];
+    g.To = d[6]; g.Ho = d[7]; g.Wo = d[8];
+    g.kt = d[9]; g.kh = d[10]; g.kw = d[11];
+    g.st = d[12]; g.sh = d[13]; g.sw = d[14];
+    g.pt = d[15]; g.ph = d[16]; g.pw = d[17];
+    g.nlev = d[18];
+    for (int i = 0; i <= OTAL_CONV_MAX_LEVELS; ++i) g.lev[i] = d[19 + i];
+    const int v[] = {g.B, g.Cin, g.Cout, g.Ti, g.Hi, g.Wi, g.To, g.Ho, g.Wo, g.kt, g.kh, g.kw, g.st, g.sh, g.sw};
+    for (int x : v) if (x <= 0) return OTAL_E_SHAPE;
+    if (g.pt < 0 || g.ph < 0 || g.pw < 0) return OTAL_E_SHAPE;
+    if (g.nlev > 1) {
+        if (g.nlev > OTAL_CONV_MAX_LEVELS || g.Hi != 1 || g.Wi != 1 || g.st != 1 || g.Ti != g.To) return OTAL_E_LEVELS;
+        if (g.lev[0] != 0 || g.lev[g.nlev] != g.Ti) return OTAL_E_LEVELS;
+        for (int i = 0; i < g.nlev; ++i) if (g.lev[i + 1] <= g.lev[i]) return OTAL_E_LEVELS;
+    }
+    if ((int64_t)g.B * g.To * g.Ho * g.Wo >= (1LL << 31) || (int64_t)g.B * g.Ti * g.Hi * g.Wi >= (1LL << 31) ||
+        (int64_t)g.Cin * g.kt * g.kh * g.kw * (int64_t)(g.Cout > g.Cin ? 1 : 1) >= (1LL << 31)) return OTAL_E_SHAPE;
+    return 0;
+}
+
+// choose split-K so that the grid fills the chip (256 CUs) without shredding K
+int choose_splits(int tiles, int K) {
+    if (tiles >= 384) return 1;
+    int want = (768 + tiles - 1) / tiles;
+    int maxs = K / (4 * BK);              // at least 4 K-steps per split
+    if (maxs < 1) maxs = 1;
+    int s = want < maxs ? want : maxs;
+    return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+
+template <int MODE>
+int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int BMsel = a.M <= 32 ? 32 : (a.M <= 64 ? 64 : 128);
+    const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + BN - 1) / BN;
+    int splits = choose_splits(tm * tn, a.K);
+    if (splits > 1) {
+        const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
+        if (!ws || ws_bytes < need) {       // shrink to what the workspace allows
+            splits = ws ? (int)(ws_bytes / ((size_t)a.M * a.N * sizeof(float))) : 1;
+            if (splits < 2) splits = 1;
+        }
+    }
+    int kps = ((a.K + splits - 1) / splits + BK - 1) / BK * BK;
+    splits = (a.K + kps - 1) / kps;
+    a.splits = splits;
+    a.k_per_split = kps;
+    a.slab = splits > 1 ? (float*)ws : nullptr;
+    const dim3 grid(tn, tm, splits);
+    if (BMsel == 128) hipLaunchKernelGGL((conv_gemm_kernel<128, 2, 2, MODE>), grid, dim3(NT), 0, st, a);
+    else if (BMsel == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 2, 1, MODE>), grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<32, 1, 1, MODE>), grid, dim3(NT), 0, st, a);
+    if (int e = otal_launch_status()) return e;
+    if (splits > 1) {
+        const int64_t total = (int64_t)a.M * a.N;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL((splitk_reduce_kernel<MODE>), dim3(blocks), dim3(256), 0, st, a);
+        return otal_launch_status();
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
+    ConvGeom g;
+    if (!geom || fill_geom(g, geom)) return 0;
+    const int kvol = conv_kvol(g);
+    int64_t M, N, K;
+    if (mode == MODE_FWD) { M = g.Cout; N = (int64_t)g.B * conv_out_positions(g); K = (int64_t)g.Cin * kvol; }
+    else if (mode == MODE_DGRAD) { M = g.Cin; N = (int64_t)g.B * conv_in_positions(g); K = (int64_t)g.Cout * kvol; }
+    else { M = g.Cout; N = (int64_t)g.Cin * kvol; K = (int64_t)g.B * conv_out_positions(g); }
+    const int BMsel = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
+    const int tiles = (int)(((M + BMsel - 1) / BMsel) * ((N + BN - 1) / BN));
+    const int s = choose_splits(tiles, (int)K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+extern "C" int otal_conv_fwd(const int* geom, const int64_t* strides, const float* x, const float* w,
+                             const float* scale, const float* shift, float* y, int relu,
+                             void* ws, size_t ws_bytes, void* stream) {
+    if (!geom || !strides || !x || !w || !y) return OTAL_E_NULL;
+    ConvArgs a = {};
+    if (int e = fill_geom(a.g, geom)) return e;
+    a.g.x_bs = strides[0]; a.g.x_cs = strides[1]; a.g.y_bs = strides[2]; a.g.y_cs = strides[3];
+    a.x = x; a.w = w; a.out = y; a.scale = scale; a.shift = shift;
+    a.M = a.g.Cout; a.N = a.g.B * conv_out_positions(a.g); a.K = a.g.Cin * conv_kvol(a.g);
+    a.flags = relu ? EPI_RELU : 0;
+    return launch_mode<MODE_FWD>(a, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int otal_conv_dgrad(const int* geom, const int64_t* strides, const float* dy, const float* wt_packed,
+                               const float* ymask, const float* dscale, float* dx, int accumulate,
+                               void* ws, size_t ws_bytes, void* stream) {
+    if (!geom || !strides || !dy || !wt_packed || !dx) return OTAL_E_NULL;
+    ConvArgs a = {};
+    if (int e = fill_geom(a.g, geom)) return e;
+    a.g.x_bs = strides[0]; a.g.x_cs = strides[1]; a.g.y_bs = strides[2]; a.g.y_cs = strides[3];
+    a.dy = dy; a.w = wt_packed; a.out = dx; a.ymask = ymask; a.dscale = dscale;
+    a.M = a.g.Cin; a.N = a.g.B * conv_in_positions(a.g); a.K = a.g.Cout * conv_kvol(a.g);
+    a.flags = accumulate ? EPI_ACCUM : 0;
+    return launch_mode<MODE_DGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int otal_conv_wgrad(const int* geom, const int64_t* strides, const float* x, const float* dy,
+                               const float* ymask, const float* dscale, float* dw, int accumulate,
+                               void* ws, size_t ws_bytes, void* stream) {
+    if (!geom || !strides || !x || !dy || !dw) return OTAL_E_NULL;
+    ConvArgs a = {};
+    if (int e = fill_geom(a.g, geom)) return e;
+    a.g.x_bs = strides[0]; a.g.x_cs = strides[1]; a.g.y_bs = strides[2]; a.g.y_cs = strides[3];
+    a.x = x; a.dy = dy; a.out = dw; a.ymask = ymask; a.dscale = dscale;
+    a.M = a.g.Cout; a.N = a.g.Cin * conv_kvol(a.g); a.K = a.g.B * conv_out_positions(a.g);
+    a.flags = accumulate ? EPI_ACCUM : 0;
+    return launch_mode<MODE_WGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int otal_conv_pack_wt(const float* w, float* wt, int Cout, int Cin, int kvol, void* stream) {
+    if (!w || !wt) return OTAL_E_NULL;
+    if (Cout <= 0 || Cin <= 0 || kvol <= 0) return OTAL_E_SHAPE;
+    const int64_t total = (int64_t)Cout * Cin * kvol;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pack_wt_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, Cout, Cin, kvol);
+    return otal_launch_status();
+}

@@ -1,0 +1,177 @@
+// opental_amd/csrc/gn.hip -- GroupNorm(G, C) + ReLU, forward and backward, for (B,C,T) maps.
+//
+// Replaces nn.GroupNorm(32, C) + nn.ReLU after every Unit1D/Unit3D of the pyramid
+// (AFSD/thumos14/BDNet.py:67-103,:129-203,:274-284): 2 ATen launches per block in the reference.
+// HBM-bound.  A workgroup owns one (sample, group): its cpg*T floats are contiguous in the
+// (B,C,T) layout, are read from HBM once with coalesced loads, kept in LDS for the two-pass
+// statistics (mean, then centred variance -- no E[x^2]-E[x]^2 cancellation), normalised, and
+// written once.  A level table gives each packed pyramid level its own statistics, so one
+// launch normalises all six levels of a level-batched tower.
+// Backward also emits, per (sample, channel), the partial sums of d_gamma, d_beta and of the
+// gradient w.r.t. the convolution bias (= sum_t dx); the tiny reduction over the batch is done by
+// the caller.  Everything is computed in a fixed order (deterministic).
+#include "common.h"
+
+namespace {
+
+struct GnLevels { int nlev; int lev[OTAL_MAX_LEVELS + 1]; };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// block-wide sum of a per-thread value; result broadcast to all threads.  red: 8 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// x,y: (B,C,T); stats out: (B,G,nlev,2) = {mean, rstd}
+__global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          float* __restrict__ stats, int C, int T, int G,
+                                                          float eps, int relu, GnLevels L) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* buf = reinterpret_cast<float*>(smem);
+    float* red = buf + (size_t)(C / G) * T;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int cpg = C / G;
+    const int64_t base = ((int64_t)b * C + (int64_t)g * cpg) * T;
+    const int n = cpg * T;
+    for (int i = tid; i < n; i += 256) buf[i] = x[base + i];
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 0; l < L.nlev; ++l) {
+        const int lo = L.lev[l], len = L.lev[l + 1] - lo;
+        const int cnt = cpg * len;
+        float s = 0.f;
+        for (int i = tid; i < cnt; i += 256) { const int c = i / len, t = i - c * len; s += buf[c * T + lo + t]; }
+        const float mean = block_sum(s, red, tid) / (float)cnt;
+        float q = 0.f;
+        for (int i = tid; i < cnt; i += 256) { const int c = i / len, t = i - c * len; const float d = buf[c * T + lo + t] - mean; q += d * d; }
+        const float var = block_sum(q, red, tid) / (float)cnt;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        if (tid == 0) {
+            stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 0] = mean;
+            stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 1] = rstd;
+        }
+        for (int i = tid; i < cnt; i += 256) {
+            const int c = i / len, t = i - c * len;
+            const int ch = g * cpg + c;
+            float v = (buf[c * T + lo + t] - mean) * rstd * gamma[ch] + beta[ch];
+            if (relu) v = fmaxf(v, 0.f);
+            y[base + (int64_t)c * T + lo + t] = v;
+        }
+    }
+}
+
+// dx: (B,C,T); partial: (B,C,3) = {sum dyh*xhat, sum dyh, sum dx}
+__global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ stats, float* __restrict__ dx,
+                                                          float* __restrict__ partial, int C, int T, int G, int relu,
+                                                          GnLevels L) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cpg = C / G;
+    float* xb = reinterpret_cast<float*>(smem);          // x, later xhat
+    float* gb = xb + (size_t)cpg * T;                    // dy masked (dyh), later dx
+    float* red = gb + (size_t)cpg * T;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int64_t base = ((int64_t)b * C + (int64_t)g * cpg) * T;
+    const int n = cpg * T;
+    for (int i = tid; i < n; i += 256) { xb[i] = x[base + i]; gb[i] = dy[base + i]; }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 0; l < L.nlev; ++l) {
+        const int lo = L.lev[l], len = L.lev[l + 1] - lo;
+        const int cnt = cpg * len;
+        const float mean = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 0];
+        const float rstd = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 1];
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = tid; i < cnt; i += 256) {
+            const int c = i / len, t = i - c * len, ch = g * cpg + c, p = c * T + lo + t;
+            const float xh = (xb[p] - mean) * rstd;
+            float d = gb[p];
+            if (relu && !(xh * gamma[ch] + beta[ch] > 0.f)) d = 0.f;
+            xb[p] = xh;
+            gb[p] = d;
+            const float dg = d * gamma[ch];
+            s1 += dg;
+            s2 += dg * xh;
+        }
+        const float m1 = block_sum(s1, red, tid) / (float)cnt;
+        const float m2 = block_sum(s2, red, tid) / (float)cnt;
+        // block_sum's barriers also make every thread's xb/gb writes visible
+        for (int i = tid; i < cnt; i += 256) {
+            const int c = i / len, t = i - c * len, ch = g * cpg + c, p = c * T + lo + t;
+            const float v = rstd * (gb[p] * gamma[ch] - m1 - xb[p] * m2);
+            dx[base + (int64_t)c * T + lo + t] = v;
+            // keep dyh in gb for the per-channel sums below; stash dx in the (now free) dy slot? no:
+            // per-channel sums need dyh, xhat and dx -> recompute dx there.
+        }
+        __syncthreads();
+    }
+    // per-channel sums over all t (all levels), fixed order: one wave per channel, lanes stride t
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int c = wave; c < cpg; c += 4) {
+        const int ch = g * cpg + c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int t = lane; t < T; t += 64) {
+            const float d = gb[c * T + t], xh = xb[c * T + t];
+            a0 += d * xh;
+            a1 += d;
+            a2 += dx[base + (int64_t)c * T + t];
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if (lane == 0) {
+            float* p = partial + ((int64_t)b * C + ch) * 3;
+            p[0] = a0; p[1] = a1; p[2] = a2;
+        }
+    }
+}
+
+int fill_levels(GnLevels& L, int T, int nlev, const int* lev) {
+    if (nlev <= 1 || !lev) { L.nlev = 1; L.lev[0] = 0; for (int i = 1; i <= OTAL_MAX_LEVELS; ++i) L.lev[i] = T; return 0; }
+    if (nlev > OTAL_MAX_LEVELS || lev[0] != 0 || lev[nlev] != T) return OTAL_E_LEVELS;
+    L.nlev = nlev;
+    for (int i = 0; i <= OTAL_MAX_LEVELS; ++i) L.lev[i] = lev[i <= nlev ? i : nlev];
+    for (int i = 0; i < nlev; ++i) if (L.lev[i + 1] <= L.lev[i]) return OTAL_E_LEVELS;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int otal_gn_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                                int B, int C, int T, int G, float eps, int relu, int nlev, const int* lev,
+                                void* stream) {
+    if (!x || !gamma || !beta || !y || !stats) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G) return OTAL_E_SHAPE;
+    GnLevels L;
+    if (int e = fill_levels(L, T, nlev, lev)) return e;
+    const size_t lds = (size_t)(C / G) * T * 4 + 64;
+    if (lds > 64 * 1024) return OTAL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G), dim3(256), lds, (hipStream_t)stream,
+                       x, gamma, beta, y, stats, C, T, G, eps, relu, L);
+    return otal_launch_status();
+}
+
+extern "C" int otal_gn_relu_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
+                                const float* stats, float* dx, float* partial, int B, int C, int T, int G,
+                                int relu, int nlev, const int* lev, void* stream) {
+    if (!dy || !x || !gamma || !beta || !stats || !dx || !partial) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G) return OTAL_E_SHAPE;
+    GnLevels L;
+    if (int e = fill_levels(L, T, nlev, lev)) return e;
+    const size_t lds = (size_t)(C / G) * T * 8 + 64;
+    if (lds > 64 * 1024) return OTAL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(256), lds, (hipStream_t)stream,
+                       dy, x, gamma, beta, stats, dx, partial, C, T, G, relu, L);
+    return otal_launch_status();
+}

@@ -1,0 +1,93 @@
+// opental_amd/csrc/misc.hip -- small fused kernels of the detection path: proposal-window index
+// math (bit-exact), flat Adam.
+#include "common.h"
+
+namespace {
+
+struct Levels { int nlev; int lev[OTAL_MAX_LEVELS + 1]; };
+
+// Restates the no_grad block of CoarsePyramid.forward (AFSD/thumos14/BDNet.py:355-384) in ONE launch
+// for all levels (the reference issues ~25 tiny elementwise kernels per level).  The operation
+// order of the reference is kept literally and the file is compiled with -ffp-contract=off, so
+// the rounded window indices are bit-identical: torch.round == rintf (half to even), `/` is the
+// correctly rounded fp32 division, the prior centre (c + 0.5) / t is formed in double and
+// rounded once to float exactly as torch.Tensor([...]) does.
+__global__ __launch_bounds__(256) void proposal_windows_kernel(const float* __restrict__ loc, float* __restrict__ seg,
+                                                               float* __restrict__ fseg, int B, int Ntot,
+                                                               float frame_num, Levels L) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * Ntot) return;
+    const int k = idx % Ntot;
+    int lo = L.lev[0], hi = L.lev[1];
+#pragma unroll
+    for (int j = 1; j < OTAL_MAX_LEVELS; ++j)
+        if (j < L.nlev && k >= L.lev[j]) { lo = L.lev[j]; hi = L.lev[j + 1]; }
+    const int t = hi - lo, c = k - lo;
+    const float tf = (float)t;
+    const float prior = (float)(((double)c + 0.5) / (double)t);
+    const float l0 = loc[(size_t)idx * 2], l1 = loc[(size_t)idx * 2 + 1];
+    // level space
+    const float s0 = l0 / frame_num * tf, s1 = l1 / frame_num * tf;
+    const float centre = rintf(prior * tf - 0.5f);
+    float plen = s0 + s1;
+    float inner = fmaxf(plen / 4.0f, 1.0f), outer = fmaxf(plen / 10.0f, 1.0f);
+    const float left = centre - s0, right = centre + s1;
+    float4 w;
+    w.x = rintf(left - outer); w.y = rintf(left + inner); w.z = rintf(right - inner); w.w = rintf(right + outer);
+    *reinterpret_cast<float4*>(seg + (size_t)idx * 4) = w;
+    // frame space
+    const float d0 = prior * frame_num - l0, d1 = prior * frame_num + l1;
+    plen = d1 - d0 + 1.0f;
+    inner = fmaxf(plen / 4.0f, 1.0f); outer = fmaxf(plen / 10.0f, 1.0f);
+    w.x = rintf(d0 - outer); w.y = rintf(d0 + inner); w.z = rintf(d1 - inner); w.w = rintf(d1 + outer);
+    *reinterpret_cast<float4*>(fseg + (size_t)idx * 4) = w;
+}
+
+// torch.optim.Adam (L2 weight decay folded into the gradient, reference AFSD/thumos14/train.py:321-323)
+// over ONE flat parameter arena: p, g, m, v are parallel fp32 arrays of n elements.
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                        float lr, float b1, float b2, float eps, float wd,
+                                                        float bc1, float bc2_sqrt, float grad_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gi = g[i] * grad_scale;
+        const float pi = p[i];
+        gi = gi + wd * pi;
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);             // lerp form used by torch
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int otal_proposal_windows(const float* loc, float* seg, float* frame_seg, int B, int nlev,
+                                     const int* lev, float frame_num, void* stream) {
+    if (!loc || !seg || !frame_seg || !lev) return OTAL_E_NULL;
+    if (B <= 0 || nlev < 1 || nlev > OTAL_MAX_LEVELS || lev[0] != 0) return OTAL_E_LEVELS;
+    Levels L;
+    L.nlev = nlev;
+    for (int i = 0; i <= OTAL_MAX_LEVELS; ++i) L.lev[i] = lev[i <= nlev ? i : nlev];
+    for (int i = 0; i < nlev; ++i) if (L.lev[i + 1] <= L.lev[i]) return OTAL_E_LEVELS;
+    const int Ntot = L.lev[nlev];
+    const int total = B * Ntot;
+    hipLaunchKernelGGL(proposal_windows_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       loc, seg, frame_seg, B, Ntot, frame_num, L);
+    return otal_launch_status();
+}
+
+extern "C" int otal_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v) return OTAL_E_NULL;
+    if (n <= 0 || step < 1) return OTAL_E_SHAPE;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int64_t blocks64 = (n + 255) / 256;
+    const int blocks = (int)(blocks64 < 4096 ? blocks64 : 4096);
+    hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    return otal_launch_status();
+}

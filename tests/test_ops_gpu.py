@@ -1,0 +1,234 @@
+"""GPU parity of the dense ops (through the C ABI) against the CPU oracle / torch-CPU fp32:
+implicit-GEMM conv (fwd, dgrad, wgrad; SAME pads, strides, split-K, channel slices, level packing,
+fused epilogues), GroupNorm+ReLU, MaxPool3dSamePadding, proposal windows (bit-exact), Adam."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import afsd_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=1e-4)   # north_star: 1e-4 fp32
+
+
+def close(a, b, scale=None, tol=1e-4):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    s = float(b.abs().max()) if scale is None else scale
+    err = float((a - b).abs().max())
+    assert err <= tol * max(s, 1e-6), f"max err {err:.3e} vs scale {s:.3e}"
+
+
+def ref_conv(x, w, b, k, s, spatial_valid=False):
+    if x.dim() == 3:
+        return O.unit1d(x, w, b, s if isinstance(s, int) else s[0])
+    pads = []
+    for d in (2, 1, 0):
+        f, bk = (0, 0) if (spatial_valid and d > 0) else O.same_pad(x.shape[2 + d], k[d], s[d])
+        pads += [f, bk]
+    return F.conv3d(F.pad(x, pads), w, b, stride=s)
+
+
+CONV_CASES = [
+    # (x shape, Cout, k, s, spatial_valid)
+    ((1, 3, 16, 24, 24), 64, (7, 7, 7), (2, 2, 2), False),
+    ((1, 3, 9, 13, 13), 64, (7, 7, 7), (2, 2, 2), False),
+    ((1, 64, 6, 12, 12), 192, (3, 3, 3), (1, 1, 1), False),
+    ((2, 192, 4, 6, 6), 16, (1, 1, 1), (1, 1, 1), False),
+    ((1, 96, 4, 6, 6), 208, (3, 3, 3), (1, 1, 1), False),
+    ((2, 480, 4, 3, 3), 112, (1, 1, 1), (1, 1, 1), False),
+    ((2, 832, 8, 6, 6), 512, (1, 6, 6), (1, 1, 1), True),
+    ((2, 1024, 4, 3, 3), 512, (1, 3, 3), (1, 1, 1), True),
+    ((2, 512, 64), 512, 3, 1, False),
+    ((2, 512, 32), 512, 3, 2, False),
+    ((1, 512, 2), 512, 3, 2, False),
+    ((2, 512, 64), 1024, 1, 1, False),
+    ((1, 2048, 64), 512, 1, 1, False),
+    ((2, 512, 64), 2, 3, 1, False),
+    ((2, 512, 16), 15, 3, 1, False),
+    ((8, 512, 256), 1, 3, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_backward(case):
+    from opental_amd.common.layers import ConvSameFunction
+    shape, cout, k, s, sv = case
+    rs = np.random.RandomState(abs(hash(str(case))) % 10000)
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32))
+    kk = (k,) if isinstance(k, int) else k
+    w = torch.from_numpy((rs.randn(cout, shape[1], *kk) / np.sqrt(shape[1] * np.prod(kk))).astype(np.float32))
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = ref_conv(xr, wr, br, k, s, sv)
+    dy = torch.from_numpy(rs.randn(*yr.shape).astype(np.float32))
+    yr.backward(dy)
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ConvSameFunction.apply(xd, wd, bd, k, s, sv, None)
+    assert y.shape == yr.shape
+    y.backward(dy.cuda())
+    close(y, yr)
+    close(xd.grad, xr.grad)
+    close(wd.grad, wr.grad)
+    close(bd.grad, br.grad)
+
+
+def test_conv_epilogue_mask_slices_accumulate():
+    from opental_amd.common import ops
+    rs = np.random.RandomState(4)
+    B, Cin, Cout, T, H, W = 2, 24, 40, 4, 6, 6
+    x = torch.from_numpy(rs.randn(B, Cin, T, H, W).astype(np.float32))
+    w = torch.from_numpy((rs.randn(Cout, Cin, 3, 3, 3) / 25).astype(np.float32))
+    sc = torch.from_numpy(rs.uniform(0.5, 1.5, Cout).astype(np.float32))
+    sh = torch.from_numpy(rs.uniform(-0.3, 0.3, Cout).astype(np.float32))
+    ref = F.relu(F.conv3d(F.pad(x, [1] * 6), w) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1))
+    # input and output are channel slices of wider buffers
+    xb = torch.zeros(B, Cin + 5, T, H, W, device="cuda")
+    xb[:, 3:3 + Cin] = x.cuda()
+    yb = torch.full((B, Cout + 7, T, H, W), 9.0, device="cuda")
+    ops.conv_forward(xb[:, 3:3 + Cin], w.cuda(), (3, 3, 3), (1, 1, 1), scale=sc.cuda(), shift=sh.cuda(), relu=True,
+                     out=yb[:, 2:2 + Cout])
+    close(yb[:, 2:2 + Cout], ref)
+    assert bool((yb[:, :2] == 9).all()) and bool((yb[:, 2 + Cout:] == 9).all())
+    # backward with ReLU mask + BN scale folded into the loaders, accumulating into an existing dx slice
+    dy = torch.from_numpy(rs.randn(*ref.shape).astype(np.float32))
+    dz = dy * (ref > 0) * sc.view(1, -1, 1, 1, 1)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    F.conv3d(F.pad(xr, [1] * 6), wr).backward(dz)
+    dyb = torch.zeros_like(yb)
+    dyb[:, 2:2 + Cout] = dy.cuda()
+    dxb = torch.full((B, Cin + 5, T, H, W), 1.0, device="cuda")
+    ops.conv_dgrad(dyb[:, 2:2 + Cout], w.cuda(), (B, Cin, T, H, W), (3, 3, 3), (1, 1, 1), ymask=yb[:, 2:2 + Cout],
+                   dscale=sc.cuda(), out=dxb[:, 3:3 + Cin], accumulate=True)
+    close(dxb[:, 3:3 + Cin] - 1.0, xr.grad)
+    assert bool((dxb[:, :3] == 1).all())
+    dw = ops.conv_wgrad(xb[:, 3:3 + Cin], dyb[:, 2:2 + Cout], w.shape, (3, 3, 3), (1, 1, 1), ymask=yb[:, 2:2 + Cout],
+                        dscale=sc.cuda())
+    close(dw, wr.grad)
+    dw2 = ops.conv_wgrad(xb[:, 3:3 + Cin], dyb[:, 2:2 + Cout], w.shape, (3, 3, 3), (1, 1, 1), ymask=yb[:, 2:2 + Cout],
+                         dscale=sc.cuda(), out=dw.clone(), accumulate=True)
+    close(dw2, 2 * wr.grad)
+
+
+def test_wgrad_long_k_split():
+    """weight gradient with a long reduction (split-K slabs) -- Conv3d_2c-like."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(8)
+    x = torch.from_numpy(rs.randn(1, 16, 16, 24, 24).astype(np.float32))
+    w = torch.zeros(24, 16, 3, 3, 3)
+    dy = torch.from_numpy(rs.randn(1, 24, 16, 24, 24).astype(np.float32))
+    wr = w.clone().requires_grad_(True)
+    F.conv3d(F.pad(x, [1] * 6), wr).backward(dy)
+    dw = ops.conv_wgrad(x.cuda(), dy.cuda(), w.shape, (3, 3, 3), (1, 1, 1))
+    close(dw, wr.grad)
+
+
+LEV = [0, 64, 96, 112, 120, 124, 126]
+
+
+def test_level_packed_conv_gn_block():
+    from opental_amd.common.layers import ConvGNReLUFunction
+    rs = np.random.RandomState(6)
+    B, C = 2, 512
+    x = torch.from_numpy(rs.randn(B, C, 126).astype(np.float32))
+    w = torch.from_numpy((rs.randn(C, C, 3) / 40).astype(np.float32))
+    b = torch.from_numpy(rs.randn(C).astype(np.float32) * 0.1)
+    ga = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32))
+    be = torch.from_numpy(rs.uniform(-0.2, 0.2, C).astype(np.float32))
+    leaves = [t.clone().requires_grad_(True) for t in (x, w, b, ga, be)]
+    outs = []
+    for i in range(6):
+        seg = leaves[0][:, :, LEV[i]:LEV[i + 1]]
+        outs.append(O.gn_relu(O.unit1d(seg, leaves[1], leaves[2]), leaves[3], leaves[4]))
+    yr = torch.cat(outs, 2)
+    dy = torch.from_numpy(rs.randn(*yr.shape).astype(np.float32))
+    yr.backward(dy)
+    dl = [t.cuda().requires_grad_(True) for t in (x, w, b, ga, be)]
+    y = ConvGNReLUFunction.apply(dl[0], dl[1], dl[2], dl[3], dl[4], 3, 1, False, tuple(LEV), 32, 1e-5)
+    y.backward(dy.cuda())
+    close(y, yr)
+    for got, ref in zip(dl, leaves):
+        close(got.grad, ref.grad)
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 64), (1, 1024, 32), (2, 512, 256), (3, 64, 2)])
+def test_groupnorm_relu(shape):
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape))
+    x = torch.from_numpy((rs.randn(*shape) * 2 + 0.5).astype(np.float32))
+    ga = torch.from_numpy(rs.uniform(0.5, 1.5, shape[1]).astype(np.float32))
+    be = torch.from_numpy(rs.uniform(-0.5, 0.5, shape[1]).astype(np.float32))
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, ga, be))
+    yr = O.gn_relu(xr, gr, br)
+    dy = torch.from_numpy(rs.randn(*shape).astype(np.float32))
+    yr.backward(dy)
+    y, stats = ops.gn_relu_forward(x.cuda(), ga.cuda(), be.cuda())
+    close(y, yr)
+    dx, dg, db, dbias = ops.gn_relu_backward(dy.cuda(), x.cuda(), ga.cuda(), be.cuda(), stats)
+    close(dx, xr.grad)
+    close(dg, gr.grad)
+    close(db, br.grad)
+    close(dbias, xr.grad.sum((0, 2)), scale=float(xr.grad.abs().sum((0, 2)).max()))
+
+
+POOLS = [((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (1, 1, 1)), ((3, 3, 3), (2, 2, 2)), ((2, 2, 2), (2, 2, 2))]
+
+
+@pytest.mark.parametrize("ks", POOLS)
+@pytest.mark.parametrize("relu_input", [False, True])
+def test_maxpool3d_same(ks, relu_input):
+    from opental_amd.common.layers import MaxPool3dFunction
+    k, s = ks
+    rs = np.random.RandomState(11)
+    for shape in ((2, 5, 8, 12, 12), (1, 3, 7, 9, 11), (1, 4, 4, 6, 6)):
+        x = torch.from_numpy(rs.randn(*shape).astype(np.float32))
+        if relu_input:
+            x = x.clamp(min=0) - 0.0   # exact zeros tie with the zero padding and with each other
+        xr = x.clone().requires_grad_(True)
+        yr = O.maxpool3d_same(xr, k, s)
+        dy = torch.from_numpy(rs.randn(*yr.shape).astype(np.float32))
+        yr.backward(dy)
+        xd = x.cuda().requires_grad_(True)
+        y = MaxPool3dFunction.apply(xd, k, s)
+        y.backward(dy.cuda())
+        assert torch.equal(y.cpu(), yr.detach())
+        if relu_input:   # gradient routed to a zero input is killed by the preceding ReLU anyway
+            m = (x > 0)
+            assert torch.equal(xd.grad.cpu()[m], xr.grad[m])
+        else:
+            assert torch.equal(xd.grad.cpu(), xr.grad)
+
+
+def test_proposal_windows_bit_exact():
+    from opental_amd.common import ops
+    rs = np.random.RandomState(3)
+    for lens, frames in (([64, 32, 16, 8, 4, 2], 256.0), ([96, 48, 24, 12, 6, 3], 768.0)):
+        lev = [0]
+        for t in lens:
+            lev.append(lev[-1] + t)
+        for B in (1, 3):
+            loc = torch.from_numpy(np.exp(rs.uniform(-1, 5.5, size=(B, lev[-1], 2))).astype(np.float32))
+            seg, fseg = ops.proposal_windows(loc.cuda(), lev, frames)
+            for i, t in enumerate(lens):
+                s_ref, f_ref = O.proposal_windows(loc[:, lev[i]:lev[i + 1]], t, frames)
+                assert torch.equal(seg[:, lev[i]:lev[i + 1]].cpu(), s_ref), (lens, i)
+                assert torch.equal(fseg[:, lev[i]:lev[i + 1]].cpu(), f_ref), (lens, i)
+
+
+def test_adam_flat_matches_torch():
+    from opental_amd.common import ops
+    rs = np.random.RandomState(9)
+    n = 100003
+    p0 = torch.from_numpy(rs.randn(n).astype(np.float32))
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3, weight_decay=1e-3)
+    p = p0.cuda(); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for step in range(1, 4):
+        g = torch.from_numpy(rs.randn(n).astype(np.float32))
+        pr.grad = g.clone()
+        opt.step()
+        ops.adam_flat(p, g.cuda(), m, v, step, 1e-3, weight_decay=1e-3)
+    close(p, pr, tol=1e-6)
+    mo, vo = torch.zeros(n), torch.zeros(n)
+    pp = p0.clone()
+    O.adam_step(pp, g, mo, vo, 1, 1e-3, 1e-3)   # the oracle's own Adam agrees with torch for one step
