@@ -1,0 +1,272 @@
+"""Inception-v1 I3D feature extractor on MI355X.
+
+Same module tree / state-dict keys / `extract_features` contract as the reference
+(AFSD/common/i3d_backbone.py: Unit3D :7-87, InceptionModule :90-121, InceptionI3d :124-342), but the
+execution is MI355X-first:
+
+  * the whole backbone is ONE autograd node (`I3DFeaturesFunction`) with an explicit tape, instead
+    of ~190 ATen nodes (50+ conv3d, BN, ReLU, pad, pool, cat);
+  * every Unit3D = SAME-pad + Conv3d + frozen BatchNorm3d(eps 1e-3) + ReLU is one implicit-GEMM
+    launch on the matrix cores: padding is virtual, BN is a per-channel scale/shift epilogue;
+  * Inception concatenation is written in place (each branch's GEMM stores straight into its
+    channel slice of the module output) -- no torch.cat copies;
+  * backward folds the ReLU mask and the BN scale into the dy loaders of the dgrad/wgrad GEMMs and
+    accumulates the four branch gradients into one buffer -- no elementwise passes over the
+    (up to 600 MB) activation maps;
+  * max-pools keep a uint8 winner tap; their backward is a gather (no atomics).
+
+BatchNorm is supported in the configuration the reference trains with: frozen statistics and frozen
+affine (configs/thumos14_opental_final.yaml: freeze_bn / freeze_bn_affine; BDNet.py:39-49).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import ops
+from .layers import MaxPool3dSamePadding
+
+ONE, THREE = (1, 1, 1), (3, 3, 3)
+BN_EPS = 1e-3
+
+
+class Unit3D(nn.Module):
+    """Parameter container with the reference's signature (i3d_backbone.py:9-44)."""
+
+    def __init__(self, in_channels, output_channels, kernel_shape=(1, 1, 1), stride=(1, 1, 1), padding=0,
+                 activation_fn=F.relu, use_batch_norm=True, use_bias=False, padding_valid_spatial=False,
+                 name='unit_3d'):
+        super(Unit3D, self).__init__()
+        if not use_batch_norm or use_bias or activation_fn is not F.relu or padding_valid_spatial or padding == -1:
+            raise NotImplementedError("backbone Unit3D is conv(no bias) + BN + ReLU with SAME padding")
+        self._output_channels = output_channels
+        self._kernel_shape = tuple(kernel_shape)
+        self._stride = tuple(stride)
+        self.name = name
+        self.conv3d = nn.Conv3d(in_channels, output_channels, self._kernel_shape, self._stride, padding=0, bias=False)
+        self.bn = nn.BatchNorm3d(output_channels, eps=BN_EPS, momentum=0.01)
+
+    def folded_bn(self):
+        """frozen BN as y = scale * conv + shift."""
+        bn = self.bn
+        scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+        return scale, bn.bias.detach() - bn.running_mean * scale
+
+    def forward(self, x):
+        scale, shift = self.folded_bn()
+        return I3DFeaturesFunction.apply(x, [("conv", 0, self._kernel_shape, self._stride)], ("out",), scale, shift,
+                                         [0, scale.numel()], self.conv3d.weight)[0]
+
+
+class InceptionModule(nn.Module):
+    def __init__(self, in_channels, out_channels, name):
+        super(InceptionModule, self).__init__()
+        oc = out_channels
+        self.b0 = Unit3D(in_channels, oc[0], ONE, name=name + '/Branch_0/Conv3d_0a_1x1')
+        self.b1a = Unit3D(in_channels, oc[1], ONE, name=name + '/Branch_1/Conv3d_0a_1x1')
+        self.b1b = Unit3D(oc[1], oc[2], THREE, name=name + '/Branch_1/Conv3d_0b_3x3')
+        self.b2a = Unit3D(in_channels, oc[3], ONE, name=name + '/Branch_2/Conv3d_0a_1x1')
+        self.b2b = Unit3D(oc[3], oc[4], THREE, name=name + '/Branch_2/Conv3d_0b_3x3')
+        self.b3a = MaxPool3dSamePadding(kernel_size=[3, 3, 3], stride=(1, 1, 1), padding=0)
+        self.b3b = Unit3D(in_channels, oc[5], ONE, name=name + '/Branch_3/Conv3d_0b_1x1')
+        self.name = name
+        self.out_channels = tuple(oc)
+
+    def units(self):
+        return [self.b0, self.b1a, self.b1b, self.b2a, self.b2b, self.b3b]
+
+
+# endpoint table (i3d_backbone.py:194-296)
+_ENDPOINTS = (
+    ('Conv3d_1a_7x7', 'conv', (None, 64, (7, 7, 7), (2, 2, 2))),
+    ('MaxPool3d_2a_3x3', 'pool', ((1, 3, 3), (1, 2, 2))),
+    ('Conv3d_2b_1x1', 'conv', (64, 64, ONE, ONE)),
+    ('Conv3d_2c_3x3', 'conv', (64, 192, THREE, ONE)),
+    ('MaxPool3d_3a_3x3', 'pool', ((1, 3, 3), (1, 2, 2))),
+    ('Mixed_3b', 'mixed', (192, (64, 96, 128, 16, 32, 32))),
+    ('Mixed_3c', 'mixed', (256, (128, 128, 192, 32, 96, 64))),
+    ('MaxPool3d_4a_3x3', 'pool', (THREE, (2, 2, 2))),
+    ('Mixed_4b', 'mixed', (480, (192, 96, 208, 16, 48, 64))),
+    ('Mixed_4c', 'mixed', (512, (160, 112, 224, 24, 64, 64))),
+    ('Mixed_4d', 'mixed', (512, (128, 128, 256, 24, 64, 64))),
+    ('Mixed_4e', 'mixed', (512, (112, 144, 288, 32, 64, 64))),
+    ('Mixed_4f', 'mixed', (528, (256, 160, 320, 32, 128, 128))),
+    ('MaxPool3d_5a_2x2', 'pool', ((2, 2, 2), (2, 2, 2))),
+    ('Mixed_5b', 'mixed', (832, (256, 160, 320, 32, 128, 128))),
+    ('Mixed_5c', 'mixed', (832, (384, 192, 384, 48, 128, 128))),
+)
+
+
+class InceptionI3d(nn.Module):
+    VALID_ENDPOINTS = tuple(n for n, _, _ in _ENDPOINTS) + ('Logits', 'Predictions')
+
+    def __init__(self, num_classes=400, spatial_squeeze=True, final_endpoint='Mixed_5c', name='inception_i3d',
+                 in_channels=3, dropout_keep_prob=0.5):
+        super(InceptionI3d, self).__init__()
+        if final_endpoint not in self.VALID_ENDPOINTS:
+            raise ValueError('Unknown final endpoint %s' % final_endpoint)
+        if final_endpoint in ('Logits', 'Predictions'):
+            raise NotImplementedError("the detection path stops at Mixed_5c (BDNet.py:27)")
+        self._final_endpoint = final_endpoint
+        self.end_points = {}
+        for ep, kind, args in _ENDPOINTS:
+            if kind == 'conv':
+                cin, cout, k, s = args
+                self.end_points[ep] = Unit3D(in_channels if cin is None else cin, cout, k, s, name=name + ep)
+            elif kind == 'pool':
+                self.end_points[ep] = MaxPool3dSamePadding(kernel_size=list(args[0]), stride=args[1], padding=0)
+            else:
+                self.end_points[ep] = InceptionModule(args[0], list(args[1]), name + ep)
+            if ep == final_endpoint:
+                break
+        self._plan = None
+
+    def build(self):
+        for k in self.end_points.keys():
+            self.add_module(k, self.end_points[k])
+
+    def _make_plan(self):
+        """Flatten the module tree into the launch plan of I3DFeaturesFunction."""
+        plan, units = [], []
+        for ep, kind, args in _ENDPOINTS:
+            if ep not in self.end_points:
+                break
+            mod = self.end_points[ep]
+            if kind == 'conv':
+                plan.append(("conv", len(units), mod._kernel_shape, mod._stride))
+                units.append(mod)
+            elif kind == 'pool':
+                plan.append(("pool", tuple(mod.kernel_size), tuple(mod.stride)))
+            else:
+                plan.append(("mixed", len(units), mod.out_channels))
+                units += mod.units()
+            plan[-1] = plan[-1] + (ep,)
+        return plan, units
+
+    def extract_features(self, x, endpoints=('Mixed_4f', 'Mixed_5c')):
+        """dict endpoint -> tensor.  The reference returns all 16 endpoints (i3d_backbone.py:335-342)
+        but only Mixed_4f / Mixed_5c are consumed (BDNet.py:307-308); pass `endpoints` for others."""
+        if self._plan is None:
+            self._plan = self._make_plan()
+        plan, units = self._plan
+        for u in units:
+            if u.bn.training or u.bn.weight.requires_grad:
+                raise NotImplementedError("I3D BatchNorm must be frozen (freeze_bn + freeze_bn_affine, BDNet.py:39-49)")
+        folded = [u.folded_bn() for u in units]
+        offs = [0]
+        for sc, _ in folded:
+            offs.append(offs[-1] + sc.numel())
+        scale = torch.cat([sc for sc, _ in folded])
+        shift = torch.cat([sh for _, sh in folded])
+        outs = I3DFeaturesFunction.apply(x, plan, tuple(endpoints), scale, shift, offs,
+                                         *[u.conv3d.weight for u in units])
+        return dict(zip(endpoints, outs))
+
+    def forward(self, x):
+        raise NotImplementedError("classification logits are not part of the detection path; use extract_features")
+
+
+class I3DFeaturesFunction(Function):
+    @staticmethod
+    def forward(ctx, x, plan, endpoints, scale, shift, offs, *weights):
+        x = x.contiguous()
+        sc = lambda i: scale[offs[i]:offs[i + 1]]
+        sh = lambda i: shift[offs[i]:offs[i + 1]]
+        tape, found = [], {}
+        cur = x
+        for step in plan:
+            kind, name = step[0], step[-1]
+            if kind == "conv":
+                _, wi, k, s, _ = step
+                y = ops.conv_forward(cur, weights[wi], k, s, scale=sc(wi), shift=sh(wi), relu=True)
+                tape.append(("conv", wi, k, s, cur, y))
+                cur = y
+            elif kind == "pool":
+                _, k, s, _ = step
+                y, arg = ops.maxpool3d_forward(cur, k, s)
+                tape.append(("pool", k, s, cur.shape, arg))
+                cur = y
+            else:
+                _, w0, oc, _ = step
+                B, _, T, H, W = cur.shape
+                ctot = oc[0] + oc[2] + oc[4] + oc[5]
+                Y = torch.empty((B, ctot, T, H, W), dtype=cur.dtype, device=cur.device)
+                c1, c2, c3 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
+                ops.conv_forward(cur, weights[w0], ONE, ONE, scale=sc(w0), shift=sh(w0), relu=True, out=Y[:, :c1])
+                h1 = ops.conv_forward(cur, weights[w0 + 1], ONE, ONE, scale=sc(w0 + 1), shift=sh(w0 + 1), relu=True)
+                ops.conv_forward(h1, weights[w0 + 2], THREE, ONE, scale=sc(w0 + 2), shift=sh(w0 + 2), relu=True,
+                                 out=Y[:, c1:c2])
+                h2 = ops.conv_forward(cur, weights[w0 + 3], ONE, ONE, scale=sc(w0 + 3), shift=sh(w0 + 3), relu=True)
+                ops.conv_forward(h2, weights[w0 + 4], THREE, ONE, scale=sc(w0 + 4), shift=sh(w0 + 4), relu=True,
+                                 out=Y[:, c2:c3])
+                pm, argm = ops.maxpool3d_forward(cur, THREE, ONE)
+                ops.conv_forward(pm, weights[w0 + 5], ONE, ONE, scale=sc(w0 + 5), shift=sh(w0 + 5), relu=True,
+                                 out=Y[:, c3:])
+                tape.append(("mixed", w0, (c1, c2, c3), cur, h1, h2, pm, argm, Y))
+                cur = Y
+            if name in endpoints:
+                found[name] = (cur, len(tape))
+        missing = [e for e in endpoints if e not in found]
+        if missing:
+            raise RuntimeError(f"unknown endpoints {missing}")
+        ctx.tape = tape
+        ctx.meta = (scale, offs, [found[e][1] for e in endpoints], len(weights), x.requires_grad)
+        ctx.weights = weights
+        return tuple(found[e][0] for e in endpoints)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        tape, weights = ctx.tape, ctx.weights
+        scale, offs, out_pos, nw, need_dx = ctx.meta
+        sc = lambda i: scale[offs[i]:offs[i + 1]]
+        dws = [None] * nw
+        # gradient arriving at the output of tape step (pos-1)
+        pending = {}
+        for pos, g in zip(out_pos, douts):
+            if g is not None:
+                g = g.contiguous()
+                pending[pos] = pending[pos] + g if pos in pending else g
+        dcur = None
+        for pos in range(len(tape), 0, -1):
+            if pos in pending:
+                ext = pending.pop(pos)
+                if dcur is None:
+                    dcur = ext.clone() if any(ext is d for d in douts) else ext
+                else:
+                    dcur.add_(ext)
+            if dcur is None:
+                continue
+            step = tape[pos - 1]
+            first = pos == 1
+            if step[0] == "conv":
+                _, wi, k, s, xin, y = step
+                dws[wi] = ops.conv_wgrad(xin, dcur, weights[wi].shape, k, s, ymask=y, dscale=sc(wi))
+                if first and not need_dx:
+                    dcur = None
+                else:
+                    dcur = ops.conv_dgrad(dcur, weights[wi], xin.shape, k, s, ymask=y, dscale=sc(wi))
+            elif step[0] == "pool":
+                _, k, s, shape, arg = step
+                dcur = ops.maxpool3d_backward(dcur, arg, shape, k, s)
+            else:
+                _, w0, (c1, c2, c3), xin, h1, h2, pm, argm, Y = step
+                dY = dcur
+                dX = torch.empty_like(xin)
+                sl = (slice(0, c1), slice(c1, c2), slice(c2, c3), slice(c3, Y.shape[1]))
+                g0, y0 = dY[:, sl[0]], Y[:, sl[0]]
+                dws[w0] = ops.conv_wgrad(xin, g0, weights[w0].shape, ONE, ONE, ymask=y0, dscale=sc(w0))
+                ops.conv_dgrad(g0, weights[w0], xin.shape, ONE, ONE, ymask=y0, dscale=sc(w0), out=dX)
+                for a, b, hid, sli in ((w0 + 1, w0 + 2, h1, sl[1]), (w0 + 3, w0 + 4, h2, sl[2])):
+                    g, yb = dY[:, sli], Y[:, sli]
+                    dws[b] = ops.conv_wgrad(hid, g, weights[b].shape, THREE, ONE, ymask=yb, dscale=sc(b))
+                    dh = ops.conv_dgrad(g, weights[b], hid.shape, THREE, ONE, ymask=yb, dscale=sc(b))
+                    dws[a] = ops.conv_wgrad(xin, dh, weights[a].shape, ONE, ONE, ymask=hid, dscale=sc(a))
+                    ops.conv_dgrad(dh, weights[a], xin.shape, ONE, ONE, ymask=hid, dscale=sc(a), out=dX, accumulate=True)
+                g3, y3 = dY[:, sl[3]], Y[:, sl[3]]
+                dws[w0 + 5] = ops.conv_wgrad(pm, g3, weights[w0 + 5].shape, ONE, ONE, ymask=y3, dscale=sc(w0 + 5))
+                dpm = ops.conv_dgrad(g3, weights[w0 + 5], pm.shape, ONE, ONE, ymask=y3, dscale=sc(w0 + 5))
+                ops.maxpool3d_backward(dpm, argm, xin.shape, THREE, ONE, out=dX, accumulate=True)
+                dcur = dX
+        ctx.tape = None
+        dx = dcur if need_dx else None
+        return (dx, None, None, None, None, None) + tuple(dws)

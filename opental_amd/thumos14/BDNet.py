@@ -1,0 +1,333 @@
+"""OpenTAL / AFSD THUMOS14 detector on MI355X.
+
+Same constructor, forward signature, output dict and state-dict keys as the reference's
+AFSD/thumos14/BDNet.py (I3D_BackBone :25-52, ScaleExp :55-61, ProposalBranch :64-113,
+CoarsePyramid :116-432, BDNet :435-535, DirichletLayer :538-561).  What differs is HOW it runs:
+
+  * level batching -- towers, heads and both ProposalBranches share their weights across the six
+    pyramid levels (BDNet.py:333-412), so the levels are packed side by side into one
+    (B,512,126) buffer and every shared layer runs ONCE with a level table (taps, GroupNorm
+    statistics and pooling windows never cross a level boundary) instead of six times;
+  * every Conv + GroupNorm + ReLU block is one fused autograd node (layers.ConvGNReLU);
+  * the ~150 tiny elementwise launches of the proposal index math (BDNet.py:355-384) are one
+    bit-exact kernel; the 24 BoundaryMaxPooling calls become 4 (2 level-batched, 2 frame-level
+    with all 126 proposals).
+
+Known reference hazards handled explicitly: the ssl/triplet branch only works for
+batch 1 in the reference (H3) -- sample 0 is used; BatchNorm must be frozen.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..common import ops
+from ..common.i3d_backbone import InceptionI3d
+from ..common.layers import ConvGNReLU, Unit1D, Unit3D
+from ..prop_pooling.boundary_pooling_op import (BoundaryMaxPooling, BoundaryMaxPoolingFunction,
+                                                BoundaryMaxPoolingLevelsFunction)
+
+layer_num = 6
+conv_channels = 512
+feat_t = 256 // 4
+
+DEFAULT_MODEL_CFG = dict(num_classes=16, freeze_bn=True, freeze_bn_affine=True, evidence='exp', dropout=0.0,
+                         os_head=True)
+
+
+def model_cfg_from(config=None):
+    """The keys BDNet.py:12-18 reads from the global config at import time."""
+    cfg = dict(DEFAULT_MODEL_CFG)
+    if config is not None:
+        cfg['num_classes'] = config['dataset']['num_classes']
+        for k in ('freeze_bn', 'freeze_bn_affine', 'evidence', 'dropout', 'os_head'):
+            if k in config['model']:
+                cfg[k] = config['model'][k]
+        if config['model'].get('transformer', False) or config['model'].get('use_rpl', False):
+            raise NotImplementedError("TransformerHead / RPLHead baselines are outside the OpenTAL hot path")
+    return cfg
+
+
+class I3D_BackBone(nn.Module):
+    def __init__(self, final_endpoint='Mixed_5c', name='inception_i3d', in_channels=3, freeze_bn=True,
+                 freeze_bn_affine=True):
+        super(I3D_BackBone, self).__init__()
+        self._model = InceptionI3d(final_endpoint=final_endpoint, name=name, in_channels=in_channels)
+        self._model.build()
+        self._freeze_bn = freeze_bn
+        self._freeze_bn_affine = freeze_bn_affine
+
+    def load_pretrained_weight(self, model_path='models/i3d_models/rgb_imagenet.pt'):
+        self._model.load_state_dict(torch.load(model_path), strict=False)
+
+    def train(self, mode=True):
+        super(I3D_BackBone, self).train(mode)
+        if self._freeze_bn and mode:
+            for m in self._model.modules():
+                if isinstance(m, nn.BatchNorm3d):
+                    m.eval()
+                    if self._freeze_bn_affine:
+                        m.weight.requires_grad_(False)
+                        m.bias.requires_grad_(False)
+        return self
+
+    def forward(self, x):
+        return self._model.extract_features(x)
+
+
+class ScaleExp(nn.Module):
+    def __init__(self, init_value=1.0):
+        super(ScaleExp, self).__init__()
+        self.scale = nn.Parameter(torch.FloatTensor([init_value]))
+
+    def forward(self, input):
+        return torch.exp(input * self.scale)
+
+
+def _block(cin, cout, k, stride=1):
+    return ConvGNReLU(Unit1D(cin, cout, k, stride=stride, use_bias=True, activation_fn=None), cout)
+
+
+class ProposalBranch(nn.Module):
+    def __init__(self, in_channels, proposal_channels):
+        super(ProposalBranch, self).__init__()
+        self.cur_point_conv = _block(in_channels, proposal_channels, 1)
+        self.lr_conv = _block(in_channels, proposal_channels * 2, 1)
+        self.boundary_max_pooling = BoundaryMaxPooling()
+        self.roi_conv = _block(proposal_channels, proposal_channels, 1)
+        self.proposal_conv = _block(proposal_channels * 4, in_channels, 1)
+
+    def forward(self, feature, frame_level_feature, segments, frame_segments, levels=None):
+        """`levels` None: one pyramid level, as the reference calls it (BDNet.py:105-113);
+        a level table: all levels packed along the last axis."""
+        fm_short = self.cur_point_conv(feature, levels)
+        feature = self.lr_conv(feature, levels)
+        if levels is None:
+            prop_feature = self.boundary_max_pooling(feature, segments)
+        else:
+            prop_feature = BoundaryMaxPoolingLevelsFunction.apply(feature, segments, levels, levels)
+        prop_roi_feature = self.boundary_max_pooling(frame_level_feature, frame_segments)
+        prop_roi_feature = self.roi_conv(prop_roi_feature, levels)
+        prop_feature = torch.cat([prop_roi_feature, prop_feature, fm_short], dim=1)
+        prop_feature = self.proposal_conv(prop_feature, levels)
+        return prop_feature, feature
+
+
+class CoarsePyramid(nn.Module):
+    def __init__(self, feat_channels, num_cls, frame_num=256, use_rpl=False, dropout=0.0, os_head=True):
+        super(CoarsePyramid, self).__init__()
+        if use_rpl:
+            raise NotImplementedError("RPL baseline head is outside the OpenTAL hot path")
+        C = conv_channels
+        self.frame_num = frame_num
+        self.layer_num = layer_num
+        self.dropout = dropout
+        self.num_classes = num_cls
+        self.os_head = os_head
+        self.pyramids = nn.ModuleList()
+        self.loc_heads = nn.ModuleList()
+        for fc, kk in zip(feat_channels, ([1, 6, 6], [1, 3, 3])):
+            self.pyramids.append(ConvGNReLU(Unit3D(fc, C, kernel_shape=kk, padding='spatial_valid',
+                                                   use_batch_norm=False, use_bias=True, activation_fn=None), C))
+        for _ in range(2, layer_num):
+            self.pyramids.append(_block(C, C, 3, stride=2))
+        self.loc_tower = nn.Sequential(_block(C, C, 3), _block(C, C, 3))
+        self.conf_tower = nn.Sequential(_block(C, C, 3), _block(C, C, 3))
+        head = lambda co, k: Unit1D(C, co, kernel_shape=k, stride=1, use_bias=True, activation_fn=None)
+        self.loc_head = head(2, 3)
+        self.conf_head = head(num_cls, 3)
+        if self.os_head:
+            self.actionness_head = head(1, 3)
+        self.loc_proposal_branch = ProposalBranch(C, 512)
+        self.conf_proposal_branch = ProposalBranch(C, 512)
+        self.prop_loc_head = head(2, 1)
+        self.prop_conf_head = head(num_cls, 1)
+        if self.os_head:
+            self.prop_actionness_head = head(1, 1)
+        self.center_head = head(1, 3)
+        dec = []
+        for k in (3, 3, 1):
+            dec += [Unit1D(C, C, k, activation_fn=None), nn.GroupNorm(32, C), nn.ReLU(inplace=True)]
+        self.deconv = nn.Sequential(*dec)
+        self.priors = []
+        self.level_lengths = []
+        t = feat_t
+        for _ in range(layer_num):
+            self.loc_heads.append(ScaleExp())
+            self.priors.append(torch.Tensor([[(c + 0.5) / t] for c in range(t)]).view(-1, 1))
+            self.level_lengths.append(t)
+            t = t // 2
+        self.levels = tuple(int(v) for v in np.concatenate([[0], np.cumsum(self.level_lengths)]))
+
+    # ------------------------------------------------------------------ pieces
+    def _deconv(self, x):
+        for i in (0, 3, 6):
+            unit, gn = self.deconv[i], self.deconv[i + 1]
+            from ..common.layers import ConvGNReLUFunction
+            x = ConvGNReLUFunction.apply(x, unit.conv1d.weight, unit.conv1d.bias, gn.weight, gn.bias,
+                                         unit._kernel_shape, unit._stride, False, None, gn.num_groups, gn.eps)
+        return x
+
+    def _pyramid(self, feat_dict):
+        x1, x2 = feat_dict['Mixed_4f'], feat_dict['Mixed_5c']
+        p0 = self.pyramids[0](x1)
+        p1 = self.pyramids[1](x2)
+        p0 = p0 + F.interpolate(p1, p0.size()[2:], mode='nearest')          # BDNet.py:316-319
+        feats = [p0, p1]
+        x = p1
+        for i in range(2, self.layer_num):
+            x = self.pyramids[i](x)
+            feats.append(x)
+        frame = F.interpolate(p0.unsqueeze(-1), [self.frame_num, 1]).squeeze(-1)   # BDNet.py:324-325
+        return feats, self._deconv(frame)
+
+    def _drop(self, x):
+        return F.dropout(x, p=self.dropout) if self.dropout > 0 else x
+
+    def forward(self, feat_dict, ssl=False, get_feat=False):
+        tr = lambda y: y.permute(0, 2, 1).contiguous()
+        feats, frame_level_feat = self._pyramid(feat_dict)
+        batch_num = feats[0].size(0)
+        if ssl:   # triplet branch: level 0 only (BDNet.py:392-398)
+            loc_feat = self.loc_tower[1](self.loc_tower[0](feats[0]))
+            conf_feat = self.conf_tower[1](self.conf_tower[0](feats[0]))
+            return [frame_level_feat, self.loc_proposal_branch.lr_conv(loc_feat),
+                    self.conf_proposal_branch.lr_conv(conf_feat)]
+        lev = self.levels
+        packed = torch.cat(feats, dim=2)                                    # (B,512,126)
+        loc_feat = self.loc_tower[1](self.loc_tower[0](packed, lev), lev)
+        conf_feat = self.conf_tower[1](self.conf_tower[0](packed, lev), lev)
+        scale_cols = torch.cat([self.loc_heads[i].scale.expand(t) for i, t in enumerate(self.level_lengths)])
+        loc = tr(torch.exp(self.loc_head(loc_feat, lev) * scale_cols))      # ScaleExp per level
+        conf = tr(self.conf_head(self._drop(conf_feat), lev))
+        act = tr(self.actionness_head(conf_feat, lev)) if self.os_head else None
+        with torch.no_grad():
+            segments, frame_segments = ops.proposal_windows(loc.detach(), lev, float(self.frame_num))
+        loc_prop_feat, loc_lr = self.loc_proposal_branch(loc_feat, frame_level_feat, segments, frame_segments, lev)
+        conf_prop_feat, conf_lr = self.conf_proposal_branch(conf_feat, frame_level_feat, segments, frame_segments, lev)
+        half = frame_level_feat.size(1) // 2
+        start, end = tr(frame_level_feat[:, :half]), tr(frame_level_feat[:, half:])
+        t0 = self.level_lengths[0]
+        ndim = loc_lr.size(1) // 2
+        start_loc_prop, end_loc_prop = tr(loc_lr[:, :ndim, :t0]), tr(loc_lr[:, ndim:, :t0])
+        start_conf_prop, end_conf_prop = tr(conf_lr[:, :ndim, :t0]), tr(conf_lr[:, ndim:, :t0])
+        prop_loc = tr(self.prop_loc_head(loc_prop_feat))
+        prop_conf = tr(self.prop_conf_head(self._drop(conf_prop_feat)))
+        prop_act = tr(self.prop_actionness_head(conf_prop_feat)) if self.os_head else None
+        center = tr(self.center_head(loc_prop_feat, lev))
+        priors = torch.cat(self.priors, 0).to(loc.device)
+        outs = (loc, conf, prop_loc, prop_conf, center, priors, start, end,
+                start_loc_prop, end_loc_prop, start_conf_prop, end_conf_prop, act, prop_act)
+        ctr_feat = prop_ctr_feat = None
+        if get_feat:
+            ctr_feat, prop_ctr_feat = tr(conf_feat), tr(conf_prop_feat)
+        self._last_windows = (segments, frame_segments)
+        return outs + (ctr_feat, prop_ctr_feat)
+
+
+class BDNet(nn.Module):
+    def __init__(self, in_channels=3, backbone_model=None, training=True, use_edl=False, use_rpl=False, cfg=None):
+        super(BDNet, self).__init__()
+        if use_rpl:
+            raise NotImplementedError("RPL baseline is outside the OpenTAL hot path")
+        if cfg is None:
+            try:
+                from ..common import config as _c
+                cfg = model_cfg_from(_c._config) if _c._config is not None else dict(DEFAULT_MODEL_CFG)
+            except Exception:
+                cfg = dict(DEFAULT_MODEL_CFG)
+        self.cfg = cfg
+        self.os_head = cfg['os_head']
+        self.num_classes = cfg['num_classes'] - 1 if self.os_head else cfg['num_classes']
+        self.coarse_pyramid_detection = CoarsePyramid([832, 1024], self.num_classes, use_rpl=use_rpl,
+                                                      dropout=cfg['dropout'], os_head=self.os_head)
+        self.reset_params()
+        self.backbone = I3D_BackBone(in_channels=in_channels, freeze_bn=cfg['freeze_bn'],
+                                     freeze_bn_affine=cfg['freeze_bn_affine'])
+        self.boundary_max_pooling = BoundaryMaxPooling()
+        self._training = training
+        if self._training:
+            if backbone_model is None:
+                self.backbone.load_pretrained_weight()
+            else:
+                self.backbone.load_pretrained_weight(backbone_model)
+        self.scales = [1, 4, 4]
+        self.use_edl = use_edl
+        self.evidence = cfg['evidence']
+        if self.use_edl:
+            self.out_layer = DirichletLayer(self.evidence, dim=-1)
+        self.use_rpl = use_rpl
+
+    @staticmethod
+    def weight_init(m):
+        """glorot-uniform of BDNet.py:460-473: limit = sqrt(3 / max(1, (fan_in + fan_out) / 2))."""
+        if isinstance(m, (nn.Conv1d, nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d)):
+            fan_in, fan_out = nn.init._calculate_fan_in_and_fan_out(m.weight)
+            limit = float(np.sqrt(3.0 / max(1.0, (fan_in + fan_out) / 2.0)))
+            with torch.no_grad():
+                m.weight.uniform_(-limit, limit)
+                if m.bias is not None:
+                    m.bias.zero_()
+
+    def reset_params(self):
+        for m in self.modules():
+            self.weight_init(m)
+
+    def forward(self, x, proposals=None, ssl=False, get_feat=False):
+        feat_dict = self.backbone(x)
+        if ssl:
+            top_feat = self.coarse_pyramid_detection(feat_dict, ssl)
+            d = proposals[0].unsqueeze(0)
+            plen = d[:, :, 1:] - d[:, :, :1] + 1.0
+            in_plen = torch.clamp(plen / 4.0, min=1.0)
+            out_plen = torch.clamp(plen / 10.0, min=1.0)
+            frame_segments = torch.cat([torch.round(d[:, :, :1] - out_plen), torch.round(d[:, :, :1] + in_plen),
+                                        torch.round(d[:, :, 1:] - in_plen), torch.round(d[:, :, 1:] + out_plen)], -1)
+            anchor, positive, negative = [], [], []
+            for i in range(3):
+                # the reference passes batch-1 segments with batch-b features (out of bounds for b > 1,
+                # SURVEY H3); sample 0 is the defined behaviour here
+                seg = (frame_segments / self.scales[i]).contiguous()
+                bound_feat = self.boundary_max_pooling(top_feat[i][:1].contiguous(), seg)
+                ndim = bound_feat.size(1) // 2
+                anchor.append(bound_feat[:, ndim:, 0])
+                positive.append(bound_feat[:, :ndim, 1])
+                negative.append(bound_feat[:, :ndim, 2])
+            return anchor, positive, negative
+        loc, conf, prop_loc, prop_conf, center, priors, start, end, start_loc_prop, end_loc_prop, \
+            start_conf_prop, end_conf_prop, act, prop_act, ctr_feat, prop_ctr_feat = \
+            self.coarse_pyramid_detection(feat_dict, get_feat=get_feat)
+        out_dict = {'loc': loc, 'conf': conf, 'priors': priors, 'prop_loc': prop_loc, 'prop_conf': prop_conf,
+                    'center': center, 'start': start, 'end': end, 'start_loc_prop': start_loc_prop,
+                    'end_loc_prop': end_loc_prop, 'start_conf_prop': start_conf_prop,
+                    'end_conf_prop': end_conf_prop, 'act': act, 'prop_act': prop_act}
+        if self.use_edl:
+            out_dict.update({'unct': self.out_layer.compute_uncertainty(conf),
+                             'prop_unct': self.out_layer.compute_uncertainty(prop_conf)})
+        if get_feat and not self.training:
+            out_dict.update({'conf_feat': ctr_feat, 'prop_conf_feat': prop_ctr_feat})
+        return out_dict
+
+
+class DirichletLayer(nn.Module):
+    def __init__(self, evidence='exp', dim=-1):
+        super(DirichletLayer, self).__init__()
+        self.evidence = evidence
+        self.dim = dim
+
+    def evidence_func(self, logit):
+        if self.evidence == 'relu':
+            return F.relu(logit)
+        if self.evidence == 'exp':
+            return torch.exp(torch.clamp(logit, -10, 10))
+        if self.evidence == 'softplus':
+            return F.softplus(logit)
+        raise NotImplementedError(self.evidence)
+
+    def compute_uncertainty(self, logit):
+        alpha = self.evidence_func(logit) + 1
+        return logit.size(-1) / alpha.sum(-1)
+
+    def forward(self, logit):
+        alpha = self.evidence_func(logit) + 1
+        return alpha / alpha.sum(dim=self.dim, keepdim=True)
