@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- clips/sec of one OpenTAL THUMOS14 training step on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward (I3D + temporal pyramid + heads) + MultiSegmentLoss (EDL/IBM + actionness + tIoU
+quality + boundary BCE) + backward + bucketed gradient all-reduce (RCCL, overlapped) + Adam, on a
+batch of synthetic 256x3x96x96 clips already resident in HBM.  `value` = world_size * batch /
+max-over-ranks step time.  Rank 0 prints ONE JSON line with `roofline` (the implicit-GEMM
+convolution, the kernel that dominates the step) and `cpu_baseline` (the CPU oracle timed on the
+host cores of this box on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+EDL = dict(evidence='exp', loss_type='log', iou_aware=True, with_focal=False, alpha=0.25, gamma=2, with_ibm=True,
+           ibm_start=10, momentum=0.99, num_bins=50)
+ACT = dict(margin=1.0, weight=0)
+W = dict(lw=1.0, cw=10.0, ctw=1.0, actw=1.0, ssl=0.001)   # experiments/opental/train_opental_final.sh
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
+
+
+def synth_batch(batch, seed, device):
+    """Synthetic clips / targets of the THUMOS14 shape (no dataset in the container)."""
+    rs = np.random.RandomState(seed)
+    g = torch.Generator(device=device).manual_seed(seed)
+    clips = torch.randint(0, 256, (batch, 3, 256, 96, 96), device=device, generator=g, dtype=torch.uint8)
+    clips = (clips.float() / 255.0) * 2.0 - 1.0
+    targets, scores = [], np.zeros((batch, 2, 256), np.float32)
+    for i in range(batch):
+        rows = []
+        for _ in range(rs.randint(1, 4)):
+            length = rs.uniform(8.0 / 256, 0.6)
+            start = rs.uniform(0.0, 1.0 - length)
+            rows.append([start, start + length, float(rs.randint(1, 16))])
+            s_f, e_f = start * 256, (start + length) * 256
+            d = max((e_f - s_f) / 10.0, 2.0)
+            for ch, c in ((0, s_f), (1, e_f)):
+                lo = int(np.clip(int(round(c - d / 2)), 0, 255)); hi = int(np.clip(int(round(c + d / 2)), 0, 255)) + 1
+                scores[i, ch, lo:hi] = 1.0
+        targets.append(torch.tensor(rows, dtype=torch.float32, device=device))
+    return clips, targets, torch.from_numpy(scores).to(device)
+
+
+def build_trainer(device, seed=2020):
+    from opental_amd.thumos14.BDNet import BDNet
+    from opental_amd.thumos14.multisegment_loss import MultiSegmentLoss
+    from opental_amd.thumos14.train import DetectorTrainer
+    torch.manual_seed(seed)
+    net = BDNet(in_channels=3, training=False, use_edl=True)      # no pretrained file in the container
+    net.backbone._model.apply(BDNet.weight_init)                  # random-init weights of the architecture
+    net = net.to(device).train()
+    crit = MultiSegmentLoss(15, 0.5, 1.0, cls_loss_type='edl', edl_config=EDL, os_head=True, act_config=ACT).to(device)
+    crit.cls_loss.epoch = 12            # past ibm_start: the IBM re-weighting runs inside the timed step
+    return DetectorTrainer(net, crit, W, lr=1e-5, weight_decay=1e-3)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (oracle/afsd_oracle.py: the restatement pinned against the imported reference)
+    doing the same training step -- forward, loss, backward, Adam -- at batch 1 on this box's host
+    cores.  Bounded: 1 warm-up + as many timed steps as fit the budget (at least 1)."""
+    from oracle import afsd_oracle as O, arch
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    P = O.to_torch(arch.make_params(2020), requires_grad=True)
+    train = [k for k, v in P.items() if v.requires_grad]
+    m = {k: torch.zeros_like(P[k]) for k in train}
+    v = {k: torch.zeros_like(P[k]) for k in train}
+    x = torch.from_numpy(arch.make_clip(3, 1))
+    tg = [torch.from_numpy(t) for t in arch.make_targets(5, 1)]
+    sc = torch.from_numpy(arch.make_scores(arch.make_targets(5, 1)))
+    st = O.EvidenceState()
+    st.epoch = 12
+
+    def one(step):
+        for k in train:
+            P[k].grad = None
+        out = O.bdnet_forward(P, x)
+        cost, _ = O.train_cost(out, tg, sc, state=st)
+        cost.backward()
+        with torch.no_grad():
+            for k in train:
+                O.adam_step(P[k], P[k].grad, m[k], v[k], step, 1e-5, 1e-3)
+    one(1)
+    n, t0 = 0, time.time()
+    while True:
+        one(n + 2)
+        n += 1
+        if time.time() - t0 > seconds_budget or n >= 8:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": 1.0 / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full training steps (fwd+loss+bwd+Adam) at batch 1, 256x3x96x96, fp32, after 1 warm-up; "
+                      f"CPU oracle (torch-CPU restatement pinned to the reference), {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU (configs[2]: batch 8/GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+    trainer = build_trainer(device)
+    clips, targets, scores = synth_batch(args.batch, 1000 + rank, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(clips, targets, scores)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(clips, targets, scores)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        from opental_amd.common import ops
+        ops.CONV_PROFILE = []
+        for _ in range(2):
+            trainer.step(clips, targets, scores)
+        torch.cuda.synchronize()
+        prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+        by = {}
+        for mode, flops, a, b in prof:
+            e = by.setdefault(mode, [0.0, 0.0, 0])
+            e[0] += flops; e[1] += a.elapsed_time(b) * 1e-3; e[2] += 1
+        tot_f = sum(e[0] for e in by.values()); tot_t = sum(e[1] for e in by.values()); tot_n = sum(e[2] for e in by.values())
+        ach = tot_f / tot_t / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad, f32 MFMA)",
+                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": tot_n // 2, "avg_launch_us": round(tot_t / tot_n * 1e6, 1),
+                    "conv_time_ms_per_step": round(tot_t / 2 * 1e3, 2),
+                    "by_mode_TFLOPs": {k: round(e[0] / e[1] / 1e12, 2) for k, e in by.items()}}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "clips/sec training step, 256-frame THUMOS14 clips", "value": round(value, 3),
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "OpenTAL THUMOS14 split_0 training step (configs/thumos14_opental_final.yaml, "
+                                   "EDL+IBM loss, ssl branch off), 256x3x96x96 clips, random-init weights",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "grad_allreduce": "RCCL, flat-arena buckets overlapped with backward"},
+            "roofline": roofline, "cpu_baseline": cpu}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

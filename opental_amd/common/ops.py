@@ -15,6 +15,29 @@ from .conv_geom import make_geom
 _WORKSPACE = {}
 WORKSPACE_BYTES = 192 << 20
 
+# Optional per-launch timing of the implicit-GEMM kernels (bench.py's roofline leg): when a list is
+# installed here, every conv launch is bracketed by HIP events recorded on the launch stream
+# (torch's current stream IS the stream the C ABI launches on) and tagged with its algorithmic FLOPs.
+CONV_PROFILE = None
+
+
+def _prof_begin():
+    if CONV_PROFILE is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _prof_end(ev, mode, g):
+    if ev is None:
+        return
+    end = torch.cuda.Event(enable_timing=True)
+    end.record()
+    B, Cin, Cout = g[0], g[1], g[2]
+    flops = 2.0 * B * Cout * g[6] * g[7] * g[8] * Cin * g[9] * g[10] * g[11]
+    CONV_PROFILE.append((mode, flops, ev, end))
+
 
 def workspace(device):
     """One split-K scratch buffer per device; launches on a stream are serialised, so sharing is safe."""
@@ -89,8 +112,10 @@ def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=F
         raise RuntimeError("weights must be contiguous")
     ga, sa = _geom_arrays(g, x5, y5)
     ws = workspace(x.device)
+    ev = _prof_begin()
     L.check(L.lib().otal_conv_fwd(ga, sa, L.ptr(x5), L.ptr(w), _opt(scale), _opt(shift), L.ptr(y5), int(relu),
                                   L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()), "otal_conv_fwd")
+    _prof_end(ev, "fwd", g)
     return out
 
 
@@ -128,9 +153,11 @@ def conv_dgrad(dy, w, x_shape, k, s, ymask=None, dscale=None, spatial_valid=Fals
         wt = pack_wt(w)
     ga, sa = _geom_arrays(g, x5, dy5)
     ws = workspace(dy.device)
+    ev = _prof_begin()
     L.check(L.lib().otal_conv_dgrad(ga, sa, L.ptr(dy5), L.ptr(wt), _opt(ymask), _opt(dscale), L.ptr(x5),
                                     int(accumulate), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
             "otal_conv_dgrad")
+    _prof_end(ev, "dgrad", g)
     return out
 
 
@@ -153,9 +180,11 @@ def conv_wgrad(x, dy, w_shape, k, s, ymask=None, dscale=None, spatial_valid=Fals
     _check(x5, "x"); _check(dy5, "dy")
     ga, sa = _geom_arrays(g, x5, dy5)
     ws = workspace(x.device)
+    ev = _prof_begin()
     L.check(L.lib().otal_conv_wgrad(ga, sa, L.ptr(x5), L.ptr(dy5), _opt(ymask), _opt(dscale), L.ptr(out),
                                     int(accumulate), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
             "otal_conv_wgrad")
+    _prof_end(ev, "wgrad", g)
     return out
 
 

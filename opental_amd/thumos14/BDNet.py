@@ -106,7 +106,15 @@ class ProposalBranch(nn.Module):
             prop_feature = self.boundary_max_pooling(feature, segments)
         else:
             prop_feature = BoundaryMaxPoolingLevelsFunction.apply(feature, segments, levels, levels)
-        prop_roi_feature = self.boundary_max_pooling(frame_level_feature, frame_segments)
+        from ..prop_pooling import boundary_pooling_op as _bp
+        if levels is not None and _bp.COMPAT_REFERENCE_BWD:
+            # gradient-parity mode: the reference's backward addresses rows with stride N = t_l of each
+            # per-level call (boundary_max_pooling_kernel.cu:121), so pool level by level here
+            prop_roi_feature = torch.cat([
+                self.boundary_max_pooling(frame_level_feature, frame_segments[:, levels[i]:levels[i + 1]].contiguous())
+                for i in range(len(levels) - 1)], dim=2)
+        else:
+            prop_roi_feature = self.boundary_max_pooling(frame_level_feature, frame_segments)
         prop_roi_feature = self.roi_conv(prop_roi_feature, levels)
         prop_feature = torch.cat([prop_roi_feature, prop_feature, fm_short], dim=1)
         prop_feature = self.proposal_conv(prop_feature, levels)

@@ -97,12 +97,12 @@ class _BMPFn(torch.autograd.Function):
     def forward(ctx, x, seg, compat):
         ctx.save_for_backward(x, seg)
         ctx.compat = compat
-        return bmp_forward(x, seg)
+        return bmp_forward(x, seg).to(x.dtype)
 
     @staticmethod
     def backward(ctx, g):
         x, seg = ctx.saved_tensors
-        return bmp_backward(g, x, seg, ctx.compat), None, None
+        return bmp_backward(g, x, seg, ctx.compat).to(x.dtype), None, None
 
 
 def boundary_max_pool(x, seg, compat_reference_bwd=False):

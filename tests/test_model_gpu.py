@@ -111,24 +111,33 @@ def test_training_cost_and_gradients(run, compat):
         cost.backward()
     finally:
         bp.COMPAT_REFERENCE_BWD = False
-    assert abs(float(cost) - float(fx["cost_edl0"])) < 1e-4 * abs(float(fx["cost_edl0"]))
+    assert abs(float(cost.detach()) - float(fx["cost_edl0"])) < 1e-4 * abs(float(fx["cost_edl0"]))
     grads = dict((k, p.grad) for k, p in net.named_parameters() if p.grad is not None)
     names = [str(n) for n in fx["grad_names"]]
     assert sorted(grads) == names
-    want = fx["gradnorm_compat" if compat else "gradnorm_correct"]
+    # Yardstick: the fp64 run of the restatement.  fp32 gradients of this network are conditioned to
+    # ~3e-5 (median) .. 5e-3 (first conv) -- that is how far the reference's own CPU fp32 gradients
+    # sit from fp64 (grad32dist_*, measured when the fixture was written).  The HIP path must be
+    # as close to fp64 as that, within a factor 5: its rounding errors are an independent draw of the
+    # same size (MFMA k-ordered chains vs blocked CPU sums), and the worst of 161 tensors is tested.
+    mode = "compat" if compat else "correct"
+    d32 = fx[f"grad32dist_{mode}"]
+    n64 = fx[f"grad64norm_{mode}"]
     got = np.array([float(grads[n].double().norm()) for n in names])
-    tot = float(np.sqrt((want ** 2).sum()))
-    worst = np.abs(got - want) / (want + 1e-3 * tot)
-    assert worst.max() < 2e-3, (names[int(worst.argmax())], float(worst.max()))
-    if compat:   # the reference's own gradients (its launcher addresses rows with stride N)
-        ref = fx["gradnorm_reference"]
-        assert (np.abs(got - ref) / (ref + 1e-3 * tot)).max() < 2e-3
-    key = "gradprobe_compat/" if compat else "gradprobe_correct/"
+    allowed = 5.0 * d32 + 1e-4
+    worst = np.abs(got - n64) / (n64 + 1e-30) / allowed
+    assert worst.max() < 1.0, (names[int(worst.argmax())], float(worst.max()))
+    key = f"grad64probe_{mode}/"
     for k in fx.files:
         if k.startswith(key):
             name = k[len(key):]
-            probe = strided(grads[name], 512)
-            assert rel_err(probe, fx[k]) < 2e-3, name
+            probe = strided(grads[name], 512).astype(np.float64)
+            dist = float(np.linalg.norm(probe - fx[k]) / np.linalg.norm(fx[k]))
+            tol = 5.0 * float(d32[names.index(name)]) + 1e-4
+            assert dist < tol, (name, dist, tol)
+    if compat:   # and against the reference's own fp32 gradients (its launcher addresses rows with stride N)
+        ref = fx["gradnorm_reference"]
+        assert (np.abs(got - ref) / (ref + 1e-30) / (2 * allowed)).max() < 1.0
 
 
 def test_eval_mode_inference_matches_train_mode_forward(run):
@@ -152,5 +161,5 @@ def test_ssl_triplet_branch(golden_dir):
     with torch.no_grad():
         a, p, n = O.ssl_triplets(P, xh, props)
         ref = float(O.triplet_cost(a, p, n, 1.0))
-        got = float(forward_one_epoch(net, None, xh.cuda(), [t.cuda() for t in props], training=False and True, ssl=True))
+        got = float(forward_one_epoch(net, None, xh.cuda(), [t.cuda() for t in props], training=True, ssl=True))
     assert abs(got - ref) < 1e-4 * max(1.0, abs(ref))
