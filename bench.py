@@ -67,13 +67,15 @@ def build_trainer(device, seed=2020):
     return DetectorTrainer(net, crit, W, lr=1e-5, weight_decay=1e-3)
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=20.0, threads=32):
     """The CPU oracle (oracle/afsd_oracle.py: the restatement pinned against the imported reference)
     doing the same training step -- forward, loss, backward, Adam -- at batch 1 on this box's host
-    cores.  Bounded: 1 warm-up + as many timed steps as fit the budget (at least 1)."""
+    cores.  Bounded: the first step doubles as warm-up and is the sample if it alone exceeds the
+    budget; otherwise further steps are timed until the budget is spent.  torch-CPU conv3d does not
+    scale past a few dozen threads (256 threads measured 392 s/step on the EPYC 9575F box), so the
+    thread count is capped and reported as `cores`."""
     from oracle import afsd_oracle as O, arch
-    cores = os.cpu_count()
-    torch.set_num_threads(cores)
+    torch.set_num_threads(min(threads, os.cpu_count()))
     P = O.to_torch(arch.make_params(2020), requires_grad=True)
     train = [k for k, v in P.items() if v.requires_grad]
     m = {k: torch.zeros_like(P[k]) for k in train}
@@ -85,6 +87,7 @@ def cpu_baseline(seconds_budget=25.0):
     st.epoch = 12
 
     def one(step):
+        t0 = time.time()
         for k in train:
             P[k].grad = None
         out = O.bdnet_forward(P, x)
@@ -93,17 +96,17 @@ def cpu_baseline(seconds_budget=25.0):
         with torch.no_grad():
             for k in train:
                 O.adam_step(P[k], P[k].grad, m[k], v[k], step, 1e-5, 1e-3)
-    one(1)
-    n, t0 = 0, time.time()
-    while True:
-        one(n + 2)
-        n += 1
-        if time.time() - t0 > seconds_budget or n >= 8:
-            break
-    dt = (time.time() - t0) / n
-    return {"value": 1.0 / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full training steps (fwd+loss+bwd+Adam) at batch 1, 256x3x96x96, fp32, after 1 warm-up; "
-                      f"CPU oracle (torch-CPU restatement pinned to the reference), {dt:.2f} s/step"}
+        return time.time() - t0
+    first = one(1)
+    times, spent = [], first
+    while spent < seconds_budget and len(times) < 5:
+        times.append(one(len(times) + 2))
+        spent += times[-1]
+    dt = float(np.median(times)) if times else first
+    what = f"median of {len(times)} steps after 1 warm-up" if times else "1 cold step (it alone exceeded the budget)"
+    return {"value": round(1.0 / dt, 5), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"full training step (fwd+loss+bwd+Adam) at batch 1, 256x3x96x96, fp32, {what}; "
+                      f"CPU oracle = torch-CPU restatement pinned to the reference; {dt:.2f} s/step"}
 
 
 def main():
