@@ -1,0 +1,113 @@
+"""CPU, world_size 2, gloo: the data-parallel machinery of opental_amd.thumos14.train --
+flat parameter/gradient arena, bucket assignment, hook-driven asynchronous all-reduce, the
+"bucket never completed" path, EvidenceLoss state averaging -- on a small CPU module (the HIP
+kernels are not involved; the optimizer update is overridden with the oracle's Adam)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 16)
+        self.b = nn.Linear(16, 16)
+        self.unused = nn.Linear(4, 4)       # never receives a gradient: its bucket must still be reduced
+        self.c = nn.Linear(16, 1)
+
+    def forward(self, x):
+        return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+
+
+def _make_trainer(world_aware):
+    from opental_amd.thumos14.train import DetectorTrainer
+    from oracle import afsd_oracle as O
+
+    class CpuTrainer(DetectorTrainer):
+        def compute_cost(self, clips, targets, scores, ssl_clips=None, ssl_targets=None):
+            out = self.net(clips)
+            cost = ((out - targets) ** 2).mean()
+            return cost, (cost,)
+
+        def optimizer_update(self):
+            a = self.arena
+            with torch.no_grad():
+                O.adam_step(a.flat, a.grad / self.world, a.m, a.v, self.step_count, self.lr, self.wd)
+
+    torch.manual_seed(0)
+    net = Toy()
+    crit = nn.Module()
+    return CpuTrainer(net, crit, {}, lr=1e-2, weight_decay=1e-3, bucket_mb=0, distributed=world_aware), net
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tr, net = _make_trainer(True)
+        assert len(tr.arena.buckets) >= 4          # bucket_mb=0 -> one bucket per tensor
+        g = torch.Generator().manual_seed(100)
+        xs = torch.randn(world, 3, 5, 8, generator=g)
+        ys = torch.randn(world, 3, 5, 1, generator=g)
+        for step in range(3):
+            tr.step(xs[rank, step], ys[rank, step], None)
+        q.put((rank, tr.arena.flat.clone(), tr.arena.grad.clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process_on_the_global_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # all ranks hold identical parameters and identical (summed) gradients
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    # single process, mean of the two per-rank losses == what DP optimises
+    tr, net = _make_trainer(False)
+    g = torch.Generator().manual_seed(100)
+    xs = torch.randn(world, 3, 5, 8, generator=g)
+    ys = torch.randn(world, 3, 5, 1, generator=g)
+
+    class Both(type(tr)):
+        pass
+    for step in range(3):
+        tr.arena.grad.zero_()
+        tr._pending = list(tr.arena.bucket_size)
+        cost = sum(((net(xs[r, step]) - ys[r, step]) ** 2).mean() for r in range(world)) / world
+        cost.backward()
+        tr.step_count += 1
+        tr.optimizer_update()
+    assert torch.allclose(tr.arena.flat, res[0][1], rtol=1e-5, atol=1e-6)
+
+
+def test_arena_views_alias_parameters():
+    tr, net = _make_trainer(False)
+    a = tr.arena
+    assert a.numel == sum(p.numel() for p in net.parameters())
+    for p, off in zip(a.params, a.offsets):
+        assert p.data_ptr() == a.flat.data_ptr() + 4 * off
+        assert p.grad.data_ptr() == a.grad.data_ptr() + 4 * off
+    covered = sorted(a.buckets)
+    assert covered[0][0] == 0 and covered[-1][1] == a.numel
+    assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
