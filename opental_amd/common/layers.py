@@ -35,7 +35,10 @@ class ConvSameFunction(Function):
         x, w = ctx.saved_tensors
         k, s, sv, lev = ctx.cfg
         dy = dy.contiguous()
-        dx = ops.conv_dgrad(dy, w, x.shape, k, s, spatial_valid=sv, levels=lev) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (ops.conv_dgrad_collapse(dy, w, x.shape) if ops.is_full_collapse(x.shape, k, s, sv)
+                  else ops.conv_dgrad(dy, w, x.shape, k, s, spatial_valid=sv, levels=lev))
         dw = ops.conv_wgrad(x, dy, w.shape, k, s, spatial_valid=sv, levels=lev) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -63,7 +66,10 @@ class ConvGNReLUFunction(Function):
         k, s, sv, lev, groups = ctx.cfg
         dc, dgamma, dbeta, dbias = ops.gn_relu_backward(dy.contiguous(), c3, gamma, beta, stats, groups, True, lev)
         dc5 = dc.view(dc.shape[0], dc.shape[1], dc.shape[2], 1, 1) if x.dim() == 5 else dc
-        dx = ops.conv_dgrad(dc5, w, x.shape, k, s, spatial_valid=sv, levels=lev) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (ops.conv_dgrad_collapse(dc5, w, x.shape) if ops.is_full_collapse(x.shape, k, s, sv)
+                  else ops.conv_dgrad(dc5, w, x.shape, k, s, spatial_valid=sv, levels=lev))
         dw = ops.conv_wgrad(x, dc5, w.shape, k, s, spatial_valid=sv, levels=lev)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 

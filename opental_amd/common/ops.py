@@ -161,6 +161,27 @@ def conv_dgrad(dy, w, x_shape, k, s, ymask=None, dscale=None, spatial_valid=Fals
     return out
 
 
+def is_full_collapse(x_shape, k, s, spatial_valid):
+    """Unit3D 'spatial_valid' projection whose kernel covers the whole H x W plane (BDNet.py:129-155)."""
+    return (spatial_valid and len(x_shape) == 5 and tuple(x_shape[3:]) == tuple(k[1:]) and k[0] == 1
+            and tuple(s) == (1, 1, 1))
+
+
+def conv_dgrad_collapse(dy, w, x_shape):
+    """Data gradient of a full-collapse projection as ONE plain GEMM.
+
+    Every input element (ci, t, h, w) is reached by exactly one tap, so the generic data-gradient
+    gather would visit kh*kw taps to find it (36x redundant work for the [1,6,6] projection).
+    Instead: dx[b, (ci,hw), t] = sum_co W[co, (ci,hw)] * dy[b, co, t] -- a forward-mode 1x1 GEMM
+    with M = Cin*kh*kw, K = Cout on the transposed weights, then (ci,hw,t) -> (ci,t,hw)."""
+    B, Cin, T, H, W = x_shape
+    Cout = w.shape[0]
+    wt = w.reshape(Cout, Cin * H * W).t().contiguous().view(Cin * H * W, Cout, 1)
+    dy3 = dy.reshape(B, Cout, T)
+    dxp = conv_forward(dy3, wt, 1, 1)                                   # (B, Cin*H*W, T)
+    return dxp.view(B, Cin, H * W, T).permute(0, 1, 3, 2).contiguous().view(B, Cin, T, H, W)
+
+
 def conv_wgrad(x, dy, w_shape, k, s, ymask=None, dscale=None, spatial_valid=False, levels=None, out=None,
                accumulate=False):
     """dw (+)= d conv / d w."""

@@ -31,6 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct ConvArgs {
     ConvGeom g;
+    ConvFastDiv fd;        // host-built exact fast-division constants (no runtime integer divides)
     const float* x;        // FWD/WGRAD: input activations
     const float* w;        // FWD: W (Cout, Cin*kvol); DGRAD: packed W^T (Cin, Cout*kvol)
     const float* dy;       // DGRAD/WGRAD: output gradient
@@ -43,6 +44,7 @@ struct ConvArgs {
     int M, N, K;
     int splits, k_per_split;   // k_per_split is a multiple of BK
     int flags;
+    int a_vec4;            // A rows are 16-byte aligned and K % 4 == 0 -> float4 weight loads
 };
 
 // ---- operand element fetch -------------------------------------------------------------------
@@ -53,15 +55,35 @@ __device__ __forceinline__ float load_dy(const ConvArgs& a, int64_t off, int co)
     return v;
 }
 
+// per-thread gather anchor of an OUTPUT position (FWD, WGRAD): everything that does not depend on the tap
+struct OutAnchor {
+    int64_t base;          // b*x_bs + ((to*st-pt)*Hi + (ho*sh-ph))*Wi + (wo*sw-pw)
+    int t0, h0, w0;        // input coordinate of tap (0,0,0)
+    int lo, up;            // temporal bounds (level-aware)
+};
+__device__ __forceinline__ OutAnchor make_out_anchor(const ConvGeom& g, const PosDec& o) {
+    OutAnchor r;
+    r.t0 = o.t * g.st - g.pt; r.h0 = o.h * g.sh - g.ph; r.w0 = o.w * g.sw - g.pw;
+    r.base = (int64_t)o.b * g.x_bs + ((int64_t)r.t0 * g.Hi + r.h0) * g.Wi + r.w0;
+    level_bounds(g, o.t, g.Ti, r.lo, r.up);
+    return r;
+}
+__device__ __forceinline__ float gather_x(const ConvArgs& a, const OutAnchor& r, int64_t koff, int dt, int dh, int dw) {
+    const int ti = r.t0 + dt, hi = r.h0 + dh, wi = r.w0 + dw;
+    const bool ok = ti >= r.lo && ti < r.up && (unsigned)hi < (unsigned)a.g.Hi && (unsigned)wi < (unsigned)a.g.Wi;
+    return ok ? a.x[r.base + koff] : 0.f;
+}
+
 template <int BM, int WM, int WN, int MODE>
 __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int LDA = BM + 2, LDB = BN + 2;
-    constexpr int A_PER = BM * BK / NT;     // A elements per thread per K step
+    constexpr int A_PER = BM * BK / NT;     // A elements per thread per K step (2, 4 or 8)
     constexpr int B_PER = BN * BK / NT;     // = 8
     __shared__ float As[2][BK * LDA];
     __shared__ float Bs[2][BK * LDB];
 
     const ConvGeom& g = a.g;
+    const ConvFastDiv& fd = a.fd;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,75 +92,110 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     const int split = blockIdx.z;
     const int k_begin = split * a.k_per_split;
     const int k_end = min(a.K, k_begin + a.k_per_split);
-    const int kvol = conv_kvol(g);
+    const int HWi = g.Hi * g.Wi;
 
     // ---- per-thread invariants of the loaders
-    // A tile is always k-fast: lane&15 -> k, tid>>4 -> m (+16 per step)
-    const int a_k = tid & 15, a_m = tid >> 4;
+    // A tile, scalar map : lane&15 -> k, tid>>4 -> m (+16 per step)
+    // A tile, float4 map : (tid&3)*4 -> k, tid>>2 -> m (+64 per step)
     // B tile, n-fast (FWD/DGRAD): tid&127 -> n, (tid>>7)+2j -> k   (k is wave-uniform)
     // B tile, k-fast (WGRAD)    : tid&15 -> k, (tid>>4)+16j -> n
-    PosDec bpos = {0, 0, 0, 0};
-    bool bpos_ok = false;
-    TapDec wtap[B_PER];                      // WGRAD only: this thread's B_PER fixed columns
-    bool wtap_ok[B_PER];
-    if (MODE == MODE_FWD) {
+    const int a_k = tid & 15, a_m = tid >> 4;
+    const int v_k = (tid & 3) * 4, v_m = tid >> 2;
+    bool n_ok = false;
+    OutAnchor anchor = {};                   // FWD: this thread's output column
+    PosDec ipos = {0, 0, 0, 0};              // DGRAD: this thread's input position
+    int64_t ibase = 0;
+    int ilo = 0, iup = 0;
+    int64_t wcoff[B_PER];                    // WGRAD: this thread's B_PER fixed (ci, tap) columns
+    int wtap[B_PER];                         //        packed dt | dh << 8 | dw << 16, -1 = out of range
+    if constexpr (MODE == MODE_FWD) {
         const int n = n0 + (tid & 127);
-        bpos_ok = n < a.N;
-        if (bpos_ok) bpos = dec_pos(n, g.To, g.Ho, g.Wo);
-    } else if (MODE == MODE_DGRAD) {
+        n_ok = n < a.N;
+        if (n_ok) anchor = make_out_anchor(g, dec_pos_fd(n, fd.To, fd.Ho, fd.Wo));
+    } else if constexpr (MODE == MODE_DGRAD) {
         const int n = n0 + (tid & 127);
-        bpos_ok = n < a.N;
-        if (bpos_ok) bpos = dec_pos(n, g.Ti, g.Hi, g.Wi);
+        n_ok = n < a.N;
+        if (n_ok) {
+            ipos = dec_pos_fd(n, fd.Ti, fd.Hi, fd.Wi);
+            ibase = (int64_t)ipos.b * g.y_bs;
+            level_bounds(g, ipos.t, g.Ti, ilo, iup);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
             const int n = n0 + (tid >> 4) + 16 * j;
-            wtap_ok[j] = n < a.N;
-            wtap[j] = dec_tap(g, wtap_ok[j] ? n : 0);
+            if (n < a.N) {
+                const TapDec t = dec_tap_fd(fd, n);
+                wcoff[j] = (int64_t)t.c * g.x_cs + (int64_t)t.dt * HWi + t.dh * g.Wi + t.dw;
+                wtap[j] = t.dt | (t.dh << 8) | (t.dw << 16);
+            } else {
+                wcoff[j] = 0;
+                wtap[j] = -1;
+            }
         }
     }
 
     float ra[A_PER], rb[B_PER];
 
     auto load_tiles = [&](int k0) {
-        // ---------------- A
-        if (MODE == MODE_WGRAD) {
+        if constexpr (MODE == MODE_WGRAD) {
             const int k = k0 + a_k;
             const bool kok = k < k_end;
-            PosDec o = dec_pos(kok ? k : 0, g.To, g.Ho, g.Wo);
+            const PosDec o = dec_pos_fd(kok ? k : 0, fd.To, fd.Ho, fd.Wo);
+            const int64_t dyoff = (int64_t)o.b * g.y_bs + ((int64_t)o.t * g.Ho + o.h) * g.Wo + o.w;
 #pragma unroll
             for (int j = 0; j < A_PER; ++j) {
                 const int m = m0 + a_m + 16 * j;
-                float v = 0.f;
-                if (kok && m < a.M) v = load_dy(a, conv_out_offset(g, o, m), m);
-                ra[j] = v;
+                ra[j] = (kok && m < a.M) ? load_dy(a, dyoff + (int64_t)m * g.y_cs, m) : 0.f;
             }
-            // ------------ B (k-fast): same k as A
+            const OutAnchor r = make_out_anchor(g, o);
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) {
-                float v = 0.f;
-                int64_t off;
-                if (kok && wtap_ok[j] && conv_src_of_output(g, o, wtap[j], off)) v = a.x[off];
-                rb[j] = v;
+                const int tp = wtap[j];
+                rb[j] = (kok && tp >= 0) ? gather_x(a, r, wcoff[j], tp & 255, (tp >> 8) & 255, tp >> 16) : 0.f;
             }
         } else {
-            const int k = k0 + a_k;
+            // ---------------- A: weights, row-major [M][K]
+            bool a_done = false;
+            if constexpr (BM >= 64) {
+                if (a.a_vec4) {     // K % 4 == 0 and 16-byte aligned rows: one float4 per 4 k
+                    constexpr int PASSES = BM / 64;
 #pragma unroll
-            for (int j = 0; j < A_PER; ++j) {
-                const int m = m0 + a_m + 16 * j;
-                ra[j] = (k < k_end && m < a.M) ? a.w[(int64_t)m * a.K + k] : 0.f;
+                    for (int j = 0; j < PASSES; ++j) {
+                        const int m = m0 + v_m + 64 * j;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (m < a.M && k0 + v_k < k_end)
+                            v = *reinterpret_cast<const float4*>(a.w + (int64_t)m * a.K + k0 + v_k);
+                        ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
+                    }
+                    a_done = true;
+                }
             }
+            if (!a_done) {
+                const int k = k0 + a_k;
+#pragma unroll
+                for (int j = 0; j < A_PER; ++j) {
+                    const int m = m0 + a_m + 16 * j;
+                    ra[j] = (k < k_end && m < a.M) ? a.w[(int64_t)m * a.K + k] : 0.f;
+                }
+            }
+            // ---------------- B: gathered activations, n-fast
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) {
                 const int kk = k0 + __builtin_amdgcn_readfirstlane(tid >> 7) + 2 * j;   // wave-uniform
                 float v = 0.f;
-                if (kk < k_end && bpos_ok) {
-                    const TapDec t = dec_tap(g, kk);
-                    int64_t off;
-                    if (MODE == MODE_FWD) {
-                        if (conv_src_of_output(g, bpos, t, off)) v = a.x[off];
+                if (kk < k_end && n_ok) {
+                    const TapDec t = dec_tap_fd(fd, kk);
+                    if constexpr (MODE == MODE_FWD) {
+                        const int64_t koff = (int64_t)t.c * g.x_cs + (int64_t)t.dt * HWi + t.dh * g.Wi + t.dw;
+                        v = gather_x(a, anchor, koff, t.dt, t.dh, t.dw);
                     } else {
-                        if (conv_src_of_input(g, bpos, t, off)) v = load_dy(a, off, t.c);
+                        int to, ho, wo;
+                        bool ok = div_stride(ipos.t + g.pt - t.dt, g.st, g.To, to);
+                        ok = ok && div_stride(ipos.h + g.ph - t.dh, g.sh, g.Ho, ho);
+                        ok = ok && div_stride(ipos.w + g.pw - t.dw, g.sw, g.Wo, wo);
+                        if (g.nlev > 1) ok = ok && to >= ilo && to < iup;
+                        if (ok) v = load_dy(a, ibase + (int64_t)t.c * g.y_cs + ((int64_t)to * g.Ho + ho) * g.Wo + wo, t.c);
                     }
                 }
                 rb[j] = v;
@@ -146,12 +203,27 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
         }
     };
     auto store_tiles = [&](int buf) {
+        if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
-        for (int j = 0; j < A_PER; ++j) As[buf][a_k * LDA + a_m + 16 * j] = ra[j];
-        if (MODE == MODE_WGRAD) {
+            for (int j = 0; j < A_PER; ++j) As[buf][a_k * LDA + a_m + 16 * j] = ra[j];
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) Bs[buf][a_k * LDB + (tid >> 4) + 16 * j] = rb[j];
         } else {
+            bool a_done = false;
+            if constexpr (BM >= 64) {
+                if (a.a_vec4) {
+                    constexpr int PASSES = BM / 64;
+#pragma unroll
+                    for (int j = 0; j < PASSES; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) As[buf][(v_k + i) * LDA + v_m + 64 * j] = ra[4 * j + i];
+                    a_done = true;
+                }
+            }
+            if (!a_done) {
+#pragma unroll
+                for (int j = 0; j < A_PER; ++j) As[buf][a_k * LDA + a_m + 16 * j] = ra[j];
+            }
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) Bs[buf][((tid >> 7) + 2 * j) * LDB + (tid & 127)] = rb[j];
         }
@@ -205,8 +277,8 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
         if (n >= a.N) continue;
         int64_t nbase = 0;
         if (a.splits == 1) {
-            if (MODE == MODE_FWD) nbase = conv_out_offset(g, dec_pos(n, g.To, g.Ho, g.Wo), 0);
-            else if (MODE == MODE_DGRAD) nbase = conv_in_offset(g, dec_pos(n, g.Ti, g.Hi, g.Wi), 0);
+            if constexpr (MODE == MODE_FWD) nbase = conv_out_offset(g, dec_pos_fd(n, fd.To, fd.Ho, fd.Wo), 0);
+            else if constexpr (MODE == MODE_DGRAD) nbase = conv_in_offset(g, dec_pos_fd(n, fd.Ti, fd.Hi, fd.Wi), 0);
             else nbase = n;
         }
 #pragma unroll
@@ -221,12 +293,12 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
                     continue;
                 }
                 int64_t off;
-                if (MODE == MODE_FWD) {
+                if constexpr (MODE == MODE_FWD) {
                     if (a.scale) v *= a.scale[m];
                     if (a.shift) v += a.shift[m];
                     if (a.flags & EPI_RELU) v = fmaxf(v, 0.f);
                     off = nbase + (int64_t)m * g.y_cs;
-                } else if (MODE == MODE_DGRAD) {
+                } else if constexpr (MODE == MODE_DGRAD) {
                     off = nbase + (int64_t)m * g.x_cs;
                 } else {
                     off = (int64_t)m * a.N + nbase;
@@ -251,9 +323,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
             if (a.scale) v *= a.scale[m];
             if (a.shift) v += a.shift[m];
             if (a.flags & EPI_RELU) v = fmaxf(v, 0.f);
-            off = conv_out_offset(g, dec_pos(n, g.To, g.Ho, g.Wo), m);
+            off = conv_out_offset(g, dec_pos_fd(n, a.fd.To, a.fd.Ho, a.fd.Wo), m);
         } else if (MODE == MODE_DGRAD) {
-            off = conv_in_offset(g, dec_pos(n, g.Ti, g.Hi, g.Wi), m);
+            off = conv_in_offset(g, dec_pos_fd(n, a.fd.Ti, a.fd.Hi, a.fd.Wi), m);
         } else {
             off = idx;
         }
@@ -293,7 +365,7 @@ int fill_geom(ConvGeom& g, const int* d) {
         for (int i = 0; i < g.nlev; ++i) if (g.lev[i + 1] <= g.lev[i]) return OTAL_E_LEVELS;
     }
     if ((int64_t)g.B * g.To * g.Ho * g.Wo >= (1LL << 31) || (int64_t)g.B * g.Ti * g.Hi * g.Wi >= (1LL << 31) ||
-        (int64_t)g.Cin * g.kt * g.kh * g.kw * (int64_t)(g.Cout > g.Cin ? 1 : 1) >= (1LL << 31)) return OTAL_E_SHAPE;
+        (int64_t)g.Cin * g.kt * g.kh * g.kw >= (1LL << 31) || (int64_t)g.Cout * g.kt * g.kh * g.kw >= (1LL << 31)) return OTAL_E_SHAPE;
     return 0;
 }
 
@@ -311,6 +383,8 @@ template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int BMsel = a.M <= 32 ? 32 : (a.M <= 64 ? 64 : 128);
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + BN - 1) / BN;
+    a.fd = make_conv_fastdiv(a.g);
+    a.a_vec4 = (MODE != MODE_WGRAD) && (a.K % 4 == 0) && (((uintptr_t)a.w & 15) == 0) && BMsel >= 64;
     int splits = choose_splits(tm * tn, a.K);
     if (splits > 1) {
         const size_t need = (size_t)splits * a.M * a.N * sizeof(float);

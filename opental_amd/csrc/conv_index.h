@@ -31,6 +31,34 @@ struct ConvGeom {
     int lev[OTAL_CONV_MAX_LEVELS + 1];
 };
 
+// Division by a launch-invariant divisor without the ~40-instruction runtime divide: round-up
+// multiplier method (Granlund-Montgomery), exact for every 32-bit numerator.  Built on the host.
+struct FastDiv {
+    uint32_t d, mul, sh;   // sh == 32 marks d == 1
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) { f.mul = 0; f.sh = 32; return f; }
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;                       // s = ceil(log2 d), 1..32
+    f.mul = (uint32_t)((((1ull << s) - d) << 32) / d + 1);
+    f.sh = s - 1;
+    return f;
+}
+OTAL_HD uint32_t otal_umulhi(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+OTAL_HD uint32_t fd_div(const FastDiv& f, uint32_t n) {
+    if (f.sh == 32) return n;
+    const uint32_t t = otal_umulhi(f.mul, n);
+    return (t + ((n - t) >> 1)) >> f.sh;
+}
+
 struct PosDec { int b, t, h, w; };          // a decomposed spatial position
 struct TapDec { int c, dt, dh, dw; };       // channel + kernel tap
 
@@ -50,6 +78,29 @@ OTAL_HD TapDec dec_tap(const ConvGeom& g, int k) {     // k = ((c*kt + dt)*kh + 
     d.dw = k % g.kw; k /= g.kw;
     d.dh = k % g.kh; k /= g.kh;
     d.dt = k % g.kt; d.c = k / g.kt;
+    return d;
+}
+
+struct ConvFastDiv { FastDiv kw, kh, kt, Wo, Ho, To, Wi, Hi, Ti; };
+inline ConvFastDiv make_conv_fastdiv(const ConvGeom& g) {
+    ConvFastDiv f;
+    f.kw = make_fastdiv(g.kw); f.kh = make_fastdiv(g.kh); f.kt = make_fastdiv(g.kt);
+    f.Wo = make_fastdiv(g.Wo); f.Ho = make_fastdiv(g.Ho); f.To = make_fastdiv(g.To);
+    f.Wi = make_fastdiv(g.Wi); f.Hi = make_fastdiv(g.Hi); f.Ti = make_fastdiv(g.Ti);
+    return f;
+}
+OTAL_HD PosDec dec_pos_fd(uint32_t n, const FastDiv& T, const FastDiv& H, const FastDiv& W) {
+    PosDec p;
+    uint32_t q = fd_div(W, n); p.w = (int)(n - q * W.d); n = q;
+    q = fd_div(H, n); p.h = (int)(n - q * H.d); n = q;
+    q = fd_div(T, n); p.t = (int)(n - q * T.d); p.b = (int)q;
+    return p;
+}
+OTAL_HD TapDec dec_tap_fd(const ConvFastDiv& f, uint32_t k) {
+    TapDec d;
+    uint32_t q = fd_div(f.kw, k); d.dw = (int)(k - q * f.kw.d); k = q;
+    q = fd_div(f.kh, k); d.dh = (int)(k - q * f.kh.d); k = q;
+    q = fd_div(f.kt, k); d.dt = (int)(k - q * f.kt.d); d.c = (int)q;
     return d;
 }
 

@@ -9,90 +9,116 @@
 // order, as aten::max_pool3d does.  HBM-bound: each element is read / written once.
 #include "common.h"
 
+#include "conv_index.h"
+
 namespace {
 
 struct PoolGeom {
     int B, C, Ti, Hi, Wi, To, Ho, Wo;
     int kt, kh, kw, st, sh, sw, pt, ph, pw;
     int64_t x_bs, x_cs, y_bs, y_cs;
+    FastDiv fWo, fHo, fWi, fHi;
 };
 
+// KT..SW > 0: compile-time kernel / stride (the four pools of I3D); 0: read them from the geometry.
+template <int KT, int KH, int KW, int ST, int SH, int SW>
+struct PoolShape {
+    __device__ __forceinline__ static int kt(const PoolGeom& g) { return KT ? KT : g.kt; }
+    __device__ __forceinline__ static int kh(const PoolGeom& g) { return KT ? KH : g.kh; }
+    __device__ __forceinline__ static int kw(const PoolGeom& g) { return KT ? KW : g.kw; }
+    __device__ __forceinline__ static int st(const PoolGeom& g) { return KT ? ST : g.st; }
+    __device__ __forceinline__ static int sh(const PoolGeom& g) { return KT ? SH : g.sh; }
+    __device__ __forceinline__ static int sw(const PoolGeom& g) { return KT ? SW : g.sw; }
+};
+
+// grid: x over output positions of one (b,c) plane, y = b*C + c
+template <int KT, int KH, int KW, int ST, int SH, int SW>
 __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             unsigned char* __restrict__ arg, PoolGeom g) {
-    const int64_t P = (int64_t)g.To * g.Ho * g.Wo;
-    const int64_t total = (int64_t)g.B * g.C * P;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        int64_t r = idx;
-        const int wo = (int)(r % g.Wo); r /= g.Wo;
-        const int ho = (int)(r % g.Ho); r /= g.Ho;
-        const int to = (int)(r % g.To); r /= g.To;
-        const int c = (int)(r % g.C);
-        const int b = (int)(r / g.C);
-        const float* xb = x + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs;
-        float best = 0.f;
-        int win = 255;
-        bool first = true;
-        for (int dt = 0; dt < g.kt; ++dt) {
-            const int ti = to * g.st + dt - g.pt;
-            for (int dh = 0; dh < g.kh; ++dh) {
-                const int hi = ho * g.sh + dh - g.ph;
-                for (int dw = 0; dw < g.kw; ++dw) {
-                    const int wi = wo * g.sw + dw - g.pw;
-                    const bool in = (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
-                    const float v = in ? xb[((int64_t)ti * g.Hi + hi) * g.Wi + wi] : 0.f;
-                    if (first || v > best || v != v) {
-                        best = v;
-                        win = in ? (dt * g.kh + dh) * g.kw + dw : 255;
-                        first = false;
-                    }
+    using S = PoolShape<KT, KH, KW, ST, SH, SW>;
+    const int P = g.To * g.Ho * g.Wo;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    uint32_t q = fd_div(g.fWo, p);
+    const int wo = p - q * g.Wo;
+    const uint32_t q2 = fd_div(g.fHo, q);
+    const int ho = q - q2 * g.Ho, to = (int)q2;
+    const float* xb = x + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs;
+    const int kt = S::kt(g), kh = S::kh(g), kw = S::kw(g);
+    float best = 0.f;
+    int win = 255;
+    bool first = true;
+#pragma unroll
+    for (int dt = 0; dt < kt; ++dt) {
+        const int ti = to * S::st(g) + dt - g.pt;
+#pragma unroll
+        for (int dh = 0; dh < kh; ++dh) {
+            const int hi = ho * S::sh(g) + dh - g.ph;
+#pragma unroll
+            for (int dw = 0; dw < kw; ++dw) {
+                const int wi = wo * S::sw(g) + dw - g.pw;
+                const bool in = (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+                const float v = in ? xb[((int64_t)ti * g.Hi + hi) * g.Wi + wi] : 0.f;
+                if (first || v > best || v != v) {
+                    best = v;
+                    win = in ? (dt * kh + dh) * kw + dw : 255;
+                    first = false;
                 }
             }
         }
-        y[(int64_t)b * g.y_bs + (int64_t)c * g.y_cs + ((int64_t)to * g.Ho + ho) * g.Wo + wo] = best;
-        arg[idx] = (unsigned char)win;
     }
+    y[(int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p] = best;
+    arg[(int64_t)bc * P + p] = (unsigned char)win;
 }
 
 // dx[b,c,i] (+)= sum over outputs o whose recorded winner is i of dy[b,c,o]; fixed (dt,dh,dw) order
+template <int KT, int KH, int KW, int ST, int SH, int SW>
 __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restrict__ dy,
                                                             const unsigned char* __restrict__ arg,
                                                             float* __restrict__ dx, PoolGeom g, int accumulate) {
-    const int64_t Pi = (int64_t)g.Ti * g.Hi * g.Wi;
-    const int64_t Po = (int64_t)g.To * g.Ho * g.Wo;
-    const int64_t total = (int64_t)g.B * g.C * Pi;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        int64_t r = idx;
-        const int wi = (int)(r % g.Wi); r /= g.Wi;
-        const int hi = (int)(r % g.Hi); r /= g.Hi;
-        const int ti = (int)(r % g.Ti); r /= g.Ti;
-        const int c = (int)(r % g.C);
-        const int b = (int)(r / g.C);
-        const float* dyb = dy + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs;
-        const unsigned char* ab = arg + ((int64_t)b * g.C + c) * Po;
-        float acc = 0.f;
-        for (int dt = 0; dt < g.kt; ++dt) {
-            const int tn = ti + g.pt - dt;
-            if (tn < 0 || tn % g.st) continue;
-            const int to = tn / g.st;
-            if (to >= g.To) continue;
-            for (int dh = 0; dh < g.kh; ++dh) {
-                const int hn = hi + g.ph - dh;
-                if (hn < 0 || hn % g.sh) continue;
-                const int ho = hn / g.sh;
-                if (ho >= g.Ho) continue;
-                for (int dw = 0; dw < g.kw; ++dw) {
-                    const int wn = wi + g.pw - dw;
-                    if (wn < 0 || wn % g.sw) continue;
-                    const int wo = wn / g.sw;
-                    if (wo >= g.Wo) continue;
-                    const int64_t o = ((int64_t)to * g.Ho + ho) * g.Wo + wo;
-                    if (ab[o] == (dt * g.kh + dh) * g.kw + dw) acc += dyb[o];
-                }
+    using S = PoolShape<KT, KH, KW, ST, SH, SW>;
+    const int Pi = g.Ti * g.Hi * g.Wi;
+    const int Po = g.To * g.Ho * g.Wo;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= Pi) return;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    uint32_t q = fd_div(g.fWi, p);
+    const int wi = p - q * g.Wi;
+    const uint32_t q2 = fd_div(g.fHi, q);
+    const int hi = q - q2 * g.Hi, ti = (int)q2;
+    const float* dyb = dy + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs;
+    const unsigned char* ab = arg + (int64_t)bc * Po;
+    const int kt = S::kt(g), kh = S::kh(g), kw = S::kw(g);
+    const int st = S::st(g), sh = S::sh(g), sw = S::sw(g);
+    float acc = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < kt; ++dt) {
+        const int tn = ti + g.pt - dt;
+        if (tn < 0 || tn % st) continue;
+        const int to = tn / st;
+        if (to >= g.To) continue;
+#pragma unroll
+        for (int dh = 0; dh < kh; ++dh) {
+            const int hn = hi + g.ph - dh;
+            if (hn < 0 || hn % sh) continue;
+            const int ho = hn / sh;
+            if (ho >= g.Ho) continue;
+#pragma unroll
+            for (int dw = 0; dw < kw; ++dw) {
+                const int wn = wi + g.pw - dw;
+                if (wn < 0 || wn % sw) continue;
+                const int wo = wn / sw;
+                if (wo >= g.Wo) continue;
+                const int o = (to * g.Ho + ho) * g.Wo + wo;
+                if (ab[o] == (dt * kh + dh) * kw + dw) acc += dyb[o];
             }
         }
-        const int64_t off = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)ti * g.Hi + hi) * g.Wi + wi;
-        dx[off] = accumulate ? dx[off] + acc : acc;
     }
+    const int64_t off = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + p;
+    dx[off] = accumulate ? dx[off] + acc : acc;
 }
 
 int fill(PoolGeom& g, const int* d, const int64_t* s) {
@@ -102,9 +128,22 @@ int fill(PoolGeom& g, const int* d, const int64_t* s) {
     g.pt = d[14]; g.ph = d[15]; g.pw = d[16];
     for (int i = 0; i < 14; ++i) if (d[i] <= 0) return OTAL_E_SHAPE;
     if (g.kt * g.kh * g.kw > 254) return OTAL_E_UNSUPPORTED;
+    if ((int64_t)g.B * g.C > 65535) return OTAL_E_UNSUPPORTED;
+    if ((int64_t)g.Ti * g.Hi * g.Wi >= (1LL << 31)) return OTAL_E_SHAPE;
     g.x_bs = s[0]; g.x_cs = s[1]; g.y_bs = s[2]; g.y_cs = s[3];
+    g.fWo = make_fastdiv(g.Wo); g.fHo = make_fastdiv(g.Ho); g.fWi = make_fastdiv(g.Wi); g.fHi = make_fastdiv(g.Hi);
     return 0;
 }
+
+#define OTAL_POOL_DISPATCH(KERNEL, GRID, ...)                                                                   \
+    do {                                                                                                         \
+        const int kk = g.kt * 100 + g.kh * 10 + g.kw, ss = g.st * 100 + g.sh * 10 + g.sw;                        \
+        if (kk == 133 && ss == 122) hipLaunchKernelGGL((KERNEL<1, 3, 3, 1, 2, 2>), GRID, dim3(256), 0, st_, __VA_ARGS__); \
+        else if (kk == 333 && ss == 111) hipLaunchKernelGGL((KERNEL<3, 3, 3, 1, 1, 1>), GRID, dim3(256), 0, st_, __VA_ARGS__); \
+        else if (kk == 333 && ss == 222) hipLaunchKernelGGL((KERNEL<3, 3, 3, 2, 2, 2>), GRID, dim3(256), 0, st_, __VA_ARGS__); \
+        else if (kk == 222 && ss == 222) hipLaunchKernelGGL((KERNEL<2, 2, 2, 2, 2, 2>), GRID, dim3(256), 0, st_, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<0, 0, 0, 0, 0, 0>), GRID, dim3(256), 0, st_, __VA_ARGS__);              \
+    } while (0)
 
 }  // namespace
 
@@ -113,9 +152,9 @@ extern "C" int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const
     if (!geom || !strides || !x || !y || !argtap) return OTAL_E_NULL;
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
-    const int64_t total = (int64_t)g.B * g.C * g.To * g.Ho * g.Wo;
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(maxpool3d_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, argtap, g);
+    hipStream_t st_ = (hipStream_t)stream;
+    const dim3 grid((g.To * g.Ho * g.Wo + 255) / 256, g.B * g.C);
+    OTAL_POOL_DISPATCH(maxpool3d_fwd_kernel, grid, x, y, argtap, g);
     return otal_launch_status();
 }
 
@@ -124,8 +163,8 @@ extern "C" int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const
     if (!geom || !strides || !dy || !dx || !argtap) return OTAL_E_NULL;
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
-    const int64_t total = (int64_t)g.B * g.C * g.Ti * g.Hi * g.Wi;
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(maxpool3d_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, argtap, dx, g, accumulate);
+    hipStream_t st_ = (hipStream_t)stream;
+    const dim3 grid((g.Ti * g.Hi * g.Wi + 255) / 256, g.B * g.C);
+    OTAL_POOL_DISPATCH(maxpool3d_bwd_kernel, grid, dy, argtap, dx, g, accumulate);
     return otal_launch_status();
 }

@@ -64,3 +64,26 @@ extern "C" void cpu_conv_wgrad(const int* d, const int64_t* s, const float* x, c
 }
 
 extern "C" void cpu_same_pad(int size, int k, int s, int* front, int* out) { same_pad(size, k, s, *front, *out); }
+
+// fast division == true division (exhaustive over small divisors, sampled numerators up to 2^32-1)
+extern "C" int cpu_fastdiv_check(void) {
+    const uint32_t ds[] = {1, 2, 3, 4, 5, 6, 7, 9, 12, 24, 27, 36, 48, 64, 96, 126, 128, 343, 1029, 18432, 65537, 1u << 20, 2147483647u};
+    for (uint32_t d : ds) {
+        FastDiv f = make_fastdiv(d);
+        for (uint64_t n = 0; n < (1ull << 32); n += (n < 100000 ? 1 : 65521)) {
+            if (fd_div(f, (uint32_t)n) != (uint32_t)n / d) return (int)d;
+        }
+        const uint32_t edge[] = {0xffffffffu, 0xfffffffeu, 0x80000000u, 0x7fffffffu, d - 1, d, d + 1, 2 * d - 1, 2 * d};
+        for (uint32_t n : edge) if (fd_div(f, n) != n / d) return -(int)d;
+    }
+    return 0;
+}
+extern "C" int cpu_dec_fd_check(const int* d, const int64_t* s) {
+    ConvGeom g; fill(g, d, s);
+    ConvFastDiv f = make_conv_fastdiv(g);
+    const int K = g.Cin * conv_kvol(g), N = g.B * conv_out_positions(g), Ni = g.B * conv_in_positions(g);
+    for (int k = 0; k < K; ++k) { TapDec a = dec_tap(g, k), b = dec_tap_fd(f, k); if (a.c != b.c || a.dt != b.dt || a.dh != b.dh || a.dw != b.dw) return 1; }
+    for (int n = 0; n < N; ++n) { PosDec a = dec_pos(n, g.To, g.Ho, g.Wo), b = dec_pos_fd(n, f.To, f.Ho, f.Wo); if (a.b != b.b || a.t != b.t || a.h != b.h || a.w != b.w) return 2; }
+    for (int n = 0; n < Ni; ++n) { PosDec a = dec_pos(n, g.Ti, g.Hi, g.Wi), b = dec_pos_fd(n, f.Ti, f.Hi, f.Wi); if (a.b != b.b || a.t != b.t || a.h != b.h || a.w != b.w) return 3; }
+    return 0;
+}

@@ -123,3 +123,13 @@ def test_same_pad_rule_matches_oracle(lib):
                 lib.cpu_same_pad(size, k, s, ctypes.byref(f), ctypes.byref(o))
                 fo, bo = O.same_pad(size, k, s)
                 assert f.value == fo and o.value == (size + fo + bo - k) // s + 1
+
+
+def test_fast_division_is_exact(lib):
+    assert lib.cpu_fastdiv_check() == 0
+    from opental_amd.common.conv_geom import make_geom
+    for case in CASES:
+        g, _ = make_geom(*case)
+        garr = (ctypes.c_int * len(g))(*g)
+        st = (ctypes.c_int64 * 4)(1, 1, 1, 1)
+        assert lib.cpu_dec_fd_check(garr, st) == 0, case
