@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 1
+#define OTAL_ABI_VERSION 2
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -99,10 +99,13 @@ int otal_conv_fwd(const int* geom, const int64_t* strides, const float* x, const
                   const float* scale, const float* shift, float* y, int relu,
                   void* ws, size_t ws_bytes, void* stream);
 
-/* dx (+)= conv_transpose(dy', w) with dy' = dy * (ymask > 0) * dscale[co]  (ymask/dscale nullable:
- * ReLU + frozen-BN backward folded into the loader).  wt_packed = otal_conv_pack_wt(w). */
+/* dx (+)= m * conv_transpose(dy', w) with dy' = dy * (ymask > 0) * dscale[co]  (ymask/dscale nullable:
+ * ReLU + frozen-BN backward of THIS layer folded into the loader) and, when out_mask/out_scale are
+ * given, m = (out_mask[dx offset] > 0) * out_scale[ci]: the ReLU + frozen-BN backward of the layer
+ * that PRODUCED x, folded into the store (out_mask has dx's layout).  wt_packed = otal_conv_pack_wt(w). */
 int otal_conv_dgrad(const int* geom, const int64_t* strides, const float* dy, const float* wt_packed,
                     const float* ymask, const float* dscale, float* dx, int accumulate,
+                    const float* out_mask, const float* out_scale,
                     void* ws, size_t ws_bytes, void* stream);
 
 /* dw (+)= sum_{b,pos} dy'[b,co,pos] * x[b,ci,pos*s + tap - pad] */
@@ -132,8 +135,10 @@ int otal_gn_relu_bwd(const float* dy, const float* x, const float* gamma, const 
  * Replaces MaxPool3dSamePadding.forward (AFSD/common/layers.py:9-35) and its autograd backward. */
 int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const float* x, float* y,
                        unsigned char* argtap, void* stream);
+/* out_mask/out_scale (nullable pair): dx contribution *= (out_mask[dx offset] > 0) * out_scale[c]. */
 int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const float* dy,
-                       const unsigned char* argtap, float* dx, int accumulate, void* stream);
+                       const unsigned char* argtap, float* dx, int accumulate,
+                       const float* out_mask, const float* out_scale, void* stream);
 
 /* ------------------------------------------------------------------ proposal window indices ----
  * loc (B,Ntot,2) -> level-space windows seg (B,Ntot,4) and frame-space windows frame_seg (B,Ntot,4)

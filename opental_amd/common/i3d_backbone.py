@@ -167,6 +167,14 @@ class InceptionI3d(nn.Module):
 
 
 class I3DFeaturesFunction(Function):
+    """Forward + hand-written backward tape of the whole backbone.
+
+    Gradient convention inside the tape: the gradient held for the output Z of a conv / Inception
+    step is already multiplied by (Z > 0) * bn_scale[channel] ("dz"), because every kernel that
+    contributes to it (the consumers' dgrad GEMMs, max-pool backward) applies that factor in its
+    store epilogue.  The producer's wgrad / dgrad GEMMs therefore read ONE tensor per operand
+    instead of gradient + activation.  Gradients of pool outputs are raw."""
+
     @staticmethod
     def forward(ctx, x, plan, endpoints, scale, shift, offs, *weights):
         x = x.contiguous()
@@ -174,18 +182,19 @@ class I3DFeaturesFunction(Function):
         sh = lambda i: shift[offs[i]:offs[i + 1]]
         tape, found = [], {}
         cur = x
+        cur_scale = None            # bn scale vector of the tensor `cur` when it is a conv/mixed output
         for step in plan:
             kind, name = step[0], step[-1]
             if kind == "conv":
                 _, wi, k, s, _ = step
                 y = ops.conv_forward(cur, weights[wi], k, s, scale=sc(wi), shift=sh(wi), relu=True)
-                tape.append(("conv", wi, k, s, cur, y))
-                cur = y
+                tape.append(("conv", wi, k, s, cur, y, cur_scale, sc(wi)))
+                cur, cur_scale = y, sc(wi)
             elif kind == "pool":
                 _, k, s, _ = step
                 y, arg = ops.maxpool3d_forward(cur, k, s)
-                tape.append(("pool", k, s, cur.shape, arg))
-                cur = y
+                tape.append(("pool", k, s, cur, arg, cur_scale, None))
+                cur, cur_scale = y, None
             else:
                 _, w0, oc, _ = step
                 B, _, T, H, W = cur.shape
@@ -202,8 +211,9 @@ class I3DFeaturesFunction(Function):
                 pm, argm = ops.maxpool3d_forward(cur, THREE, ONE)
                 ops.conv_forward(pm, weights[w0 + 5], ONE, ONE, scale=sc(w0 + 5), shift=sh(w0 + 5), relu=True,
                                  out=Y[:, c3:])
-                tape.append(("mixed", w0, (c1, c2, c3), cur, h1, h2, pm, argm, Y))
-                cur = Y
+                out_scale = torch.cat([sc(w0), sc(w0 + 2), sc(w0 + 4), sc(w0 + 5)])
+                tape.append(("mixed", w0, (c1, c2, c3), cur, h1, h2, pm, argm, Y, cur_scale, out_scale))
+                cur, cur_scale = Y, out_scale
             if name in endpoints:
                 found[name] = (cur, len(tape))
         missing = [e for e in endpoints if e not in found]
@@ -212,7 +222,8 @@ class I3DFeaturesFunction(Function):
         ctx.tape = tape
         ctx.meta = (scale, offs, [found[e][1] for e in endpoints], len(weights), x.requires_grad)
         ctx.weights = weights
-        return tuple(found[e][0] for e in endpoints)
+        ctx.outs = [found[e][0] for e in endpoints]
+        return tuple(ctx.outs)
 
     @staticmethod
     def backward(ctx, *douts):
@@ -220,53 +231,62 @@ class I3DFeaturesFunction(Function):
         scale, offs, out_pos, nw, need_dx = ctx.meta
         sc = lambda i: scale[offs[i]:offs[i + 1]]
         dws = [None] * nw
-        # gradient arriving at the output of tape step (pos-1)
+        # external gradients arrive raw at the output of tape step (pos-1): apply that output's
+        # ReLU mask and BN scale once, here (these are the small Mixed_4f / Mixed_5c maps)
         pending = {}
-        for pos, g in zip(out_pos, douts):
-            if g is not None:
-                g = g.contiguous()
-                pending[pos] = pending[pos] + g if pos in pending else g
+        for pos, g, z in zip(out_pos, douts, ctx.outs):
+            if g is None:
+                continue
+            zs = tape[pos - 1][-1]
+            if zs is not None:
+                g = g * (z > 0) * zs.view(1, -1, 1, 1, 1)
+            else:
+                g = g.contiguous().clone()
+            pending[pos] = pending[pos] + g if pos in pending else g
         dcur = None
         for pos in range(len(tape), 0, -1):
             if pos in pending:
                 ext = pending.pop(pos)
-                if dcur is None:
-                    dcur = ext.clone() if any(ext is d for d in douts) else ext
-                else:
-                    dcur.add_(ext)
+                dcur = ext if dcur is None else dcur.add_(ext)
             if dcur is None:
                 continue
             step = tape[pos - 1]
             first = pos == 1
             if step[0] == "conv":
-                _, wi, k, s, xin, y = step
-                dws[wi] = ops.conv_wgrad(xin, dcur, weights[wi].shape, k, s, ymask=y, dscale=sc(wi))
+                _, wi, k, s, xin, y, in_scale, _ = step
+                dws[wi] = ops.conv_wgrad(xin, dcur, weights[wi].shape, k, s)
                 if first and not need_dx:
                     dcur = None
                 else:
-                    dcur = ops.conv_dgrad(dcur, weights[wi], xin.shape, k, s, ymask=y, dscale=sc(wi))
+                    dcur = ops.conv_dgrad(dcur, weights[wi], xin.shape, k, s,
+                                          out_mask=xin if in_scale is not None else None, out_scale=in_scale)
             elif step[0] == "pool":
-                _, k, s, shape, arg = step
-                dcur = ops.maxpool3d_backward(dcur, arg, shape, k, s)
+                _, k, s, xin, arg, in_scale, _ = step
+                dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s,
+                                              out_mask=xin if in_scale is not None else None, out_scale=in_scale)
             else:
-                _, w0, (c1, c2, c3), xin, h1, h2, pm, argm, Y = step
+                _, w0, (c1, c2, c3), xin, h1, h2, pm, argm, Y, in_scale, _ = step
                 dY = dcur
                 dX = torch.empty_like(xin)
+                xm = xin if in_scale is not None else None
                 sl = (slice(0, c1), slice(c1, c2), slice(c2, c3), slice(c3, Y.shape[1]))
-                g0, y0 = dY[:, sl[0]], Y[:, sl[0]]
-                dws[w0] = ops.conv_wgrad(xin, g0, weights[w0].shape, ONE, ONE, ymask=y0, dscale=sc(w0))
-                ops.conv_dgrad(g0, weights[w0], xin.shape, ONE, ONE, ymask=y0, dscale=sc(w0), out=dX)
+                g0 = dY[:, sl[0]]
+                dws[w0] = ops.conv_wgrad(xin, g0, weights[w0].shape, ONE, ONE)
+                ops.conv_dgrad(g0, weights[w0], xin.shape, ONE, ONE, out=dX, out_mask=xm, out_scale=in_scale)
                 for a, b, hid, sli in ((w0 + 1, w0 + 2, h1, sl[1]), (w0 + 3, w0 + 4, h2, sl[2])):
-                    g, yb = dY[:, sli], Y[:, sli]
-                    dws[b] = ops.conv_wgrad(hid, g, weights[b].shape, THREE, ONE, ymask=yb, dscale=sc(b))
-                    dh = ops.conv_dgrad(g, weights[b], hid.shape, THREE, ONE, ymask=yb, dscale=sc(b))
-                    dws[a] = ops.conv_wgrad(xin, dh, weights[a].shape, ONE, ONE, ymask=hid, dscale=sc(a))
-                    ops.conv_dgrad(dh, weights[a], xin.shape, ONE, ONE, ymask=hid, dscale=sc(a), out=dX, accumulate=True)
-                g3, y3 = dY[:, sl[3]], Y[:, sl[3]]
-                dws[w0 + 5] = ops.conv_wgrad(pm, g3, weights[w0 + 5].shape, ONE, ONE, ymask=y3, dscale=sc(w0 + 5))
-                dpm = ops.conv_dgrad(g3, weights[w0 + 5], pm.shape, ONE, ONE, ymask=y3, dscale=sc(w0 + 5))
-                ops.maxpool3d_backward(dpm, argm, xin.shape, THREE, ONE, out=dX, accumulate=True)
+                    g = dY[:, sli]
+                    dws[b] = ops.conv_wgrad(hid, g, weights[b].shape, THREE, ONE)
+                    dh = ops.conv_dgrad(g, weights[b], hid.shape, THREE, ONE, out_mask=hid, out_scale=sc(a))
+                    dws[a] = ops.conv_wgrad(xin, dh, weights[a].shape, ONE, ONE)
+                    ops.conv_dgrad(dh, weights[a], xin.shape, ONE, ONE, out=dX, accumulate=True,
+                                   out_mask=xm, out_scale=in_scale)
+                g3 = dY[:, sl[3]]
+                dws[w0 + 5] = ops.conv_wgrad(pm, g3, weights[w0 + 5].shape, ONE, ONE)
+                dpm = ops.conv_dgrad(g3, weights[w0 + 5], pm.shape, ONE, ONE)
+                ops.maxpool3d_backward(dpm, argm, xin.shape, THREE, ONE, out=dX, accumulate=True,
+                                       out_mask=xm, out_scale=in_scale)
                 dcur = dX
         ctx.tape = None
+        ctx.outs = None
         dx = dcur if need_dx else None
         return (dx, None, None, None, None, None) + tuple(dws)

@@ -129,8 +129,10 @@ def pack_wt(w):
 
 
 def conv_dgrad(dy, w, x_shape, k, s, ymask=None, dscale=None, spatial_valid=False, levels=None, out=None,
-               accumulate=False, wt=None):
-    """dx (+)= d conv / d x.  dy/ymask share a layout; `out` may be a channel slice."""
+               accumulate=False, wt=None, out_mask=None, out_scale=None):
+    """dx (+)= d conv / d x.  dy/ymask share a layout; `out` may be a channel slice.
+    out_mask/out_scale: multiply this contribution by (out_mask > 0) * out_scale[ci] in the store
+    (ReLU + frozen-BN backward of the layer that produced x; out_mask has dx's layout)."""
     k, s = _k3(k), _k3(s)
     dy5 = _as5(dy)
     xs5 = tuple(x_shape) + (1, 1) if len(x_shape) == 3 else tuple(x_shape)
@@ -154,8 +156,13 @@ def conv_dgrad(dy, w, x_shape, k, s, ymask=None, dscale=None, spatial_valid=Fals
     ga, sa = _geom_arrays(g, x5, dy5)
     ws = workspace(dy.device)
     ev = _prof_begin()
+    if out_mask is not None:
+        m5 = _as5(out_mask)
+        if tuple(m5.shape) != tuple(x5.shape) or tuple(_bs(m5)) != tuple(_bs(x5)):
+            raise RuntimeError("out_mask must share dx's shape and layout")
     L.check(L.lib().otal_conv_dgrad(ga, sa, L.ptr(dy5), L.ptr(wt), _opt(ymask), _opt(dscale), L.ptr(x5),
-                                    int(accumulate), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
+                                    int(accumulate), _opt(out_mask), _opt(out_scale),
+                                    L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
             "otal_conv_dgrad")
     _prof_end(ev, "dgrad", g)
     return out
@@ -265,7 +272,7 @@ def maxpool3d_forward(x, k, s, out=None):
     return out, arg
 
 
-def maxpool3d_backward(dy, arg, x_shape, k, s, out=None, accumulate=False):
+def maxpool3d_backward(dy, arg, x_shape, k, s, out=None, accumulate=False, out_mask=None, out_scale=None):
     if out is None:
         if accumulate:
             raise RuntimeError("accumulate needs an existing buffer")
@@ -275,8 +282,10 @@ def maxpool3d_backward(dy, arg, x_shape, k, s, out=None, accumulate=False):
     if tuple(dy.shape[2:]) != outn or not arg.is_contiguous():
         raise RuntimeError("maxpool3d_backward: shape mismatch")
     ga, sa = _geom_arrays(g, out, dy)
-    L.check(L.lib().otal_maxpool3d_bwd(ga, sa, L.ptr(dy), L.ptr(arg), L.ptr(out), int(accumulate), L.stream()),
-            "otal_maxpool3d_bwd")
+    if out_mask is not None and (tuple(out_mask.shape) != tuple(out.shape) or out_mask.stride() != out.stride()):
+        raise RuntimeError("out_mask must share dx's shape and layout")
+    L.check(L.lib().otal_maxpool3d_bwd(ga, sa, L.ptr(dy), L.ptr(arg), L.ptr(out), int(accumulate),
+                                       _opt(out_mask), _opt(out_scale), L.stream()), "otal_maxpool3d_bwd")
     return out
 
 

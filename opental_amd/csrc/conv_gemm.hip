@@ -41,6 +41,8 @@ struct ConvArgs {
     const float* scale;    // FWD epilogue: per-Cout scale (nullable -> 1)
     const float* shift;    // FWD epilogue: per-Cout shift / bias (nullable -> 0)
     float* slab;           // split-K workspace [splits][M][N] (nullable when splits == 1)
+    const float* emask;    // DGRAD epilogue (nullable): dx *= (emask[off] > 0) * escale[ci]  -- the ReLU/BN
+    const float* escale;   //   backward of the layer that PRODUCED this conv's input, fused into the store
     int M, N, K;
     int splits, k_per_split;   // k_per_split is a multiple of BK
     int flags;
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
         }
     }
 
-    float ra[A_PER], rb[B_PER];
+    constexpr int A_VPASS = (BM + 63) / 64;
+    float ra[(A_PER > 4 * A_VPASS) ? A_PER : 4 * A_VPASS], rb[B_PER];
 
     auto load_tiles = [&](int k0) {
         if constexpr (MODE == MODE_WGRAD) {
@@ -159,12 +162,11 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
             bool a_done = false;
             if constexpr (BM >= 64) {
                 if (a.a_vec4) {     // K % 4 == 0 and 16-byte aligned rows: one float4 per 4 k
-                    constexpr int PASSES = BM / 64;
 #pragma unroll
-                    for (int j = 0; j < PASSES; ++j) {
+                    for (int j = 0; j < A_VPASS; ++j) {
                         const int m = m0 + v_m + 64 * j;
                         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (m < a.M && k0 + v_k < k_end)
+                        if (v_m + 64 * j < BM && m < a.M && k0 + v_k < k_end)
                             v = *reinterpret_cast<const float4*>(a.w + (int64_t)m * a.K + k0 + v_k);
                         ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
                     }
@@ -212,11 +214,12 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
             bool a_done = false;
             if constexpr (BM >= 64) {
                 if (a.a_vec4) {
-                    constexpr int PASSES = BM / 64;
 #pragma unroll
-                    for (int j = 0; j < PASSES; ++j)
+                    for (int j = 0; j < A_VPASS; ++j)
+                        if (v_m + 64 * j < BM) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) As[buf][(v_k + i) * LDA + v_m + 64 * j] = ra[4 * j + i];
+                            for (int i = 0; i < 4; ++i) As[buf][(v_k + i) * LDA + v_m + 64 * j] = ra[4 * j + i];
+                        }
                     a_done = true;
                 }
             }
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
                     off = nbase + (int64_t)m * g.y_cs;
                 } else if constexpr (MODE == MODE_DGRAD) {
                     off = nbase + (int64_t)m * g.x_cs;
+                    if (a.emask) v = a.emask[off] > 0.f ? v * a.escale[m] : 0.f;
                 } else {
                     off = (int64_t)m * a.N + nbase;
                 }
@@ -326,6 +330,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
             off = conv_out_offset(g, dec_pos_fd(n, a.fd.To, a.fd.Ho, a.fd.Wo), m);
         } else if (MODE == MODE_DGRAD) {
             off = conv_in_offset(g, dec_pos_fd(n, a.fd.Ti, a.fd.Hi, a.fd.Wi), m);
+            if (a.emask) v = a.emask[off] > 0.f ? v * a.escale[m] : 0.f;
         } else {
             off = idx;
         }
@@ -369,6 +374,19 @@ int fill_geom(ConvGeom& g, const int* d) {
     return 0;
 }
 
+// tile height: least padded M, with a small penalty for the lower arithmetic intensity of short tiles
+int choose_bm(int M) {
+    const int cand[4] = {128, 96, 64, 32};
+    const double pen[4] = {1.00, 1.03, 1.10, 1.30};
+    int best = 128;
+    double bc = 1e30;
+    for (int i = 0; i < 4; ++i) {
+        const double c = (double)((M + cand[i] - 1) / cand[i] * cand[i]) * pen[i];
+        if (c < bc) { bc = c; best = cand[i]; }
+    }
+    return best;
+}
+
 // choose split-K so that the grid fills the chip (256 CUs) without shredding K
 int choose_splits(int tiles, int K) {
     if (tiles >= 384) return 1;
@@ -381,7 +399,7 @@ int choose_splits(int tiles, int K) {
 
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
-    const int BMsel = a.M <= 32 ? 32 : (a.M <= 64 ? 64 : 128);
+    const int BMsel = choose_bm(a.M);
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + BN - 1) / BN;
     a.fd = make_conv_fastdiv(a.g);
     a.a_vec4 = (MODE != MODE_WGRAD) && (a.K % 4 == 0) && (((uintptr_t)a.w & 15) == 0) && BMsel >= 64;
@@ -400,6 +418,7 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     a.slab = splits > 1 ? (float*)ws : nullptr;
     const dim3 grid(tn, tm, splits);
     if (BMsel == 128) hipLaunchKernelGGL((conv_gemm_kernel<128, 2, 2, MODE>), grid, dim3(NT), 0, st, a);
+    else if (BMsel == 96) hipLaunchKernelGGL((conv_gemm_kernel<96, 3, 1, MODE>), grid, dim3(NT), 0, st, a);
     else if (BMsel == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 2, 1, MODE>), grid, dim3(NT), 0, st, a);
     else hipLaunchKernelGGL((conv_gemm_kernel<32, 1, 1, MODE>), grid, dim3(NT), 0, st, a);
     if (int e = otal_launch_status()) return e;
@@ -422,7 +441,7 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
     if (mode == MODE_FWD) { M = g.Cout; N = (int64_t)g.B * conv_out_positions(g); K = (int64_t)g.Cin * kvol; }
     else if (mode == MODE_DGRAD) { M = g.Cin; N = (int64_t)g.B * conv_in_positions(g); K = (int64_t)g.Cout * kvol; }
     else { M = g.Cout; N = (int64_t)g.Cin * kvol; K = (int64_t)g.B * conv_out_positions(g); }
-    const int BMsel = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
+    const int BMsel = choose_bm((int)M);
     const int tiles = (int)(((M + BMsel - 1) / BMsel) * ((N + BN - 1) / BN));
     const int s = choose_splits(tiles, (int)K);
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
@@ -443,12 +462,15 @@ extern "C" int otal_conv_fwd(const int* geom, const int64_t* strides, const floa
 
 extern "C" int otal_conv_dgrad(const int* geom, const int64_t* strides, const float* dy, const float* wt_packed,
                                const float* ymask, const float* dscale, float* dx, int accumulate,
+                               const float* out_mask, const float* out_scale,
                                void* ws, size_t ws_bytes, void* stream) {
     if (!geom || !strides || !dy || !wt_packed || !dx) return OTAL_E_NULL;
+    if ((out_mask == nullptr) != (out_scale == nullptr)) return OTAL_E_NULL;
     ConvArgs a = {};
     if (int e = fill_geom(a.g, geom)) return e;
     a.g.x_bs = strides[0]; a.g.x_cs = strides[1]; a.g.y_bs = strides[2]; a.g.y_cs = strides[3];
     a.dy = dy; a.w = wt_packed; a.out = dx; a.ymask = ymask; a.dscale = dscale;
+    a.emask = out_mask; a.escale = out_scale;
     a.M = a.g.Cin; a.N = a.g.B * conv_in_positions(a.g); a.K = a.g.Cout * conv_kvol(a.g);
     a.flags = accumulate ? EPI_ACCUM : 0;
     return launch_mode<MODE_DGRAD>(a, ws, ws_bytes, (hipStream_t)stream);

@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(const float* __restr
 template <int KT, int KH, int KW, int ST, int SH, int SW>
 __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restrict__ dy,
                                                             const unsigned char* __restrict__ arg,
-                                                            float* __restrict__ dx, PoolGeom g, int accumulate) {
+                                                            float* __restrict__ dx, PoolGeom g, int accumulate,
+                                                            const float* __restrict__ emask,
+                                                            const float* __restrict__ escale) {
     using S = PoolShape<KT, KH, KW, ST, SH, SW>;
     const int Pi = g.Ti * g.Hi * g.Wi;
     const int Po = g.To * g.Ho * g.Wo;
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restr
         }
     }
     const int64_t off = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + p;
+    if (emask) acc = emask[off] > 0.f ? acc * escale[c] : 0.f;   // ReLU/BN backward of the pooled layer
     dx[off] = accumulate ? dx[off] + acc : acc;
 }
 
@@ -159,12 +162,14 @@ extern "C" int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const
 }
 
 extern "C" int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const float* dy,
-                                  const unsigned char* argtap, float* dx, int accumulate, void* stream) {
+                                  const unsigned char* argtap, float* dx, int accumulate,
+                                  const float* out_mask, const float* out_scale, void* stream) {
     if (!geom || !strides || !dy || !dx || !argtap) return OTAL_E_NULL;
+    if ((out_mask == nullptr) != (out_scale == nullptr)) return OTAL_E_NULL;
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
     const dim3 grid((g.Ti * g.Hi * g.Wi + 255) / 256, g.B * g.C);
-    OTAL_POOL_DISPATCH(maxpool3d_bwd_kernel, grid, dy, argtap, dx, g, accumulate);
+    OTAL_POOL_DISPATCH(maxpool3d_bwd_kernel, grid, dy, argtap, dx, g, accumulate, out_mask, out_scale);
     return otal_launch_status();
 }

@@ -108,6 +108,21 @@ def test_conv_epilogue_mask_slices_accumulate():
     dw2 = ops.conv_wgrad(xb[:, 3:3 + Cin], dyb[:, 2:2 + Cout], w.shape, (3, 3, 3), (1, 1, 1), ymask=yb[:, 2:2 + Cout],
                          dscale=sc.cuda(), out=dw.clone(), accumulate=True)
     close(dw2, 2 * wr.grad)
+    # producer-side masking in the store epilogue: dx * (x > 0) * in_scale[ci], accumulated
+    isc = torch.from_numpy(rs.uniform(0.5, 1.5, Cin).astype(np.float32))
+    dxb2 = torch.full((B, Cin + 5, T, H, W), 1.0, device="cuda")
+    ops.conv_dgrad(dyb[:, 2:2 + Cout], w.cuda(), (B, Cin, T, H, W), (3, 3, 3), (1, 1, 1), ymask=yb[:, 2:2 + Cout],
+                   dscale=sc.cuda(), out=dxb2[:, 3:3 + Cin], accumulate=True, out_mask=xb[:, 3:3 + Cin],
+                   out_scale=isc.cuda())
+    close(dxb2[:, 3:3 + Cin] - 1.0, xr.grad * (x > 0) * isc.view(1, -1, 1, 1, 1))
+    from oracle import afsd_oracle as O
+    xp = x.clone().requires_grad_(True)
+    yp = O.maxpool3d_same(xp, (3, 3, 3), (1, 1, 1))
+    gp = torch.from_numpy(rs.randn(*yp.shape).astype(np.float32))
+    yp.backward(gp)
+    yq, arg = ops.maxpool3d_forward(x.cuda(), (3, 3, 3), (1, 1, 1))
+    dq = ops.maxpool3d_backward(gp.cuda(), arg, x.shape, (3, 3, 3), (1, 1, 1), out_mask=x.cuda(), out_scale=isc.cuda())
+    close(dq, xp.grad * (x > 0) * isc.view(1, -1, 1, 1, 1))
 
 
 def test_wgrad_long_k_split():
