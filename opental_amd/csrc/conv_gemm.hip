@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int BN = 128, BK = 16, NT = 256;
+constexpr int BK = 16, NT = 256;
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 enum { EPI_RELU = 1, EPI_ACCUM = 2 };
 
@@ -76,11 +76,13 @@ __device__ __forceinline__ float gather_x(const ConvArgs& a, const OutAnchor& r,
     return ok ? a.x[r.base + koff] : 0.f;
 }
 
-template <int BM, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int LDA = BM + 2, LDB = BN + 2;
-    constexpr int A_PER = BM * BK / NT;     // A elements per thread per K step (2, 4 or 8)
-    constexpr int B_PER = BN * BK / NT;     // = 8
+    constexpr int A_PER = BM * BK / NT;     // A elements per thread per K step (2, 4, 6 or 8)
+    constexpr int B_PER = BN * BK / NT;     // 8 (BN = 128) or 16 (BN = 256)
+    constexpr int B_ROWS = NT / BN;         // k rows covered per pass of the n-fast B loader (2 or 1)
+    static_assert(BN == 128 || BN == 256, "BN");
     __shared__ float As[2][BK * LDA];
     __shared__ float Bs[2][BK * LDB];
 
@@ -99,8 +101,10 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     // ---- per-thread invariants of the loaders
     // A tile, scalar map : lane&15 -> k, tid>>4 -> m (+16 per step)
     // A tile, float4 map : (tid&3)*4 -> k, tid>>2 -> m (+64 per step)
-    // B tile, n-fast (FWD/DGRAD): tid&127 -> n, (tid>>7)+2j -> k   (k is wave-uniform)
+    // B tile, n-fast (FWD/DGRAD): tid % BN -> n, tid / BN + B_ROWS*j -> k   (k is wave-uniform)
     // B tile, k-fast (WGRAD)    : tid&15 -> k, (tid>>4)+16j -> n
+    const int b_n = tid & (BN - 1);
+    const int b_k0 = __builtin_amdgcn_readfirstlane(tid / BN);
     const int a_k = tid & 15, a_m = tid >> 4;
     const int v_k = (tid & 3) * 4, v_m = tid >> 2;
     bool n_ok = false;
@@ -111,11 +115,11 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     int64_t wcoff[B_PER];                    // WGRAD: this thread's B_PER fixed (ci, tap) columns
     int wtap[B_PER];                         //        packed dt | dh << 8 | dw << 16, -1 = out of range
     if constexpr (MODE == MODE_FWD) {
-        const int n = n0 + (tid & 127);
+        const int n = n0 + b_n;
         n_ok = n < a.N;
         if (n_ok) anchor = make_out_anchor(g, dec_pos_fd(n, fd.To, fd.Ho, fd.Wo));
     } else if constexpr (MODE == MODE_DGRAD) {
-        const int n = n0 + (tid & 127);
+        const int n = n0 + b_n;
         n_ok = n < a.N;
         if (n_ok) {
             ipos = dec_pos_fd(n, fd.Ti, fd.Hi, fd.Wi);
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
             // ---------------- B: gathered activations, n-fast
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) {
-                const int kk = k0 + __builtin_amdgcn_readfirstlane(tid >> 7) + 2 * j;   // wave-uniform
+                const int kk = k0 + b_k0 + B_ROWS * j;   // wave-uniform
                 float v = 0.f;
                 if (kk < k_end && n_ok) {
                     const TapDec t = dec_tap_fd(fd, kk);
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
                 for (int j = 0; j < A_PER; ++j) As[buf][a_k * LDA + a_m + 16 * j] = ra[j];
             }
 #pragma unroll
-            for (int j = 0; j < B_PER; ++j) Bs[buf][((tid >> 7) + 2 * j) * LDB + (tid & 127)] = rb[j];
+            for (int j = 0; j < B_PER; ++j) Bs[buf][(b_k0 + B_ROWS * j) * LDB + b_n] = rb[j];
         }
     };
 
@@ -400,6 +404,7 @@ int choose_splits(int tiles, int K) {
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int BMsel = choose_bm(a.M);
+    const int BN = BMsel <= 64 ? 256 : 128;      // short tiles get a wide N so each wave still owns 4 MFMA tiles
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + BN - 1) / BN;
     a.fd = make_conv_fastdiv(a.g);
     a.a_vec4 = (MODE != MODE_WGRAD) && (a.K % 4 == 0) && (((uintptr_t)a.w & 15) == 0) && BMsel >= 64;
@@ -417,10 +422,10 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     a.k_per_split = kps;
     a.slab = splits > 1 ? (float*)ws : nullptr;
     const dim3 grid(tn, tm, splits);
-    if (BMsel == 128) hipLaunchKernelGGL((conv_gemm_kernel<128, 2, 2, MODE>), grid, dim3(NT), 0, st, a);
-    else if (BMsel == 96) hipLaunchKernelGGL((conv_gemm_kernel<96, 3, 1, MODE>), grid, dim3(NT), 0, st, a);
-    else if (BMsel == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 2, 1, MODE>), grid, dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<32, 1, 1, MODE>), grid, dim3(NT), 0, st, a);
+    if (BMsel == 128) hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 2, 2, MODE>), grid, dim3(NT), 0, st, a);
+    else if (BMsel == 96) hipLaunchKernelGGL((conv_gemm_kernel<96, 128, 3, 1, MODE>), grid, dim3(NT), 0, st, a);
+    else if (BMsel == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 256, 2, 2, MODE>), grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<32, 256, 1, 2, MODE>), grid, dim3(NT), 0, st, a);
     if (int e = otal_launch_status()) return e;
     if (splits > 1) {
         const int64_t total = (int64_t)a.M * a.N;
@@ -442,6 +447,7 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
     else if (mode == MODE_DGRAD) { M = g.Cin; N = (int64_t)g.B * conv_in_positions(g); K = (int64_t)g.Cout * kvol; }
     else { M = g.Cout; N = (int64_t)g.Cin * kvol; K = (int64_t)g.B * conv_out_positions(g); }
     const int BMsel = choose_bm((int)M);
+    const int BN = BMsel <= 64 ? 256 : 128;
     const int tiles = (int)(((M + BMsel - 1) / BMsel) * ((N + BN - 1) / BN));
     const int s = choose_splits(tiles, (int)K);
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
