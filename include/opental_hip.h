@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 2
+#define OTAL_ABI_VERSION 3
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -99,19 +99,17 @@ int otal_conv_fwd(const int* geom, const int64_t* strides, const float* x, const
                   const float* scale, const float* shift, float* y, int relu,
                   void* ws, size_t ws_bytes, void* stream);
 
-/* dx (+)= m * conv_transpose(dy', w) with dy' = dy * (ymask > 0) * dscale[co]  (ymask/dscale nullable:
- * ReLU + frozen-BN backward of THIS layer folded into the loader) and, when out_mask/out_scale are
- * given, m = (out_mask[dx offset] > 0) * out_scale[ci]: the ReLU + frozen-BN backward of the layer
- * that PRODUCED x, folded into the store (out_mask has dx's layout).  wt_packed = otal_conv_pack_wt(w). */
+/* dx (+)= m * conv_transpose(dy, w); when out_mask/out_scale are given,
+ * m = (out_mask[dx offset] > 0) * out_scale[ci]: the ReLU + frozen-BN backward of the layer that
+ * PRODUCED x, folded into the store (out_mask has dx's layout), so the gradient handed to that layer
+ * is already the gradient w.r.t. its convolution output.  wt_packed = otal_conv_pack_wt(w). */
 int otal_conv_dgrad(const int* geom, const int64_t* strides, const float* dy, const float* wt_packed,
-                    const float* ymask, const float* dscale, float* dx, int accumulate,
-                    const float* out_mask, const float* out_scale,
+                    float* dx, int accumulate, const float* out_mask, const float* out_scale,
                     void* ws, size_t ws_bytes, void* stream);
 
-/* dw (+)= sum_{b,pos} dy'[b,co,pos] * x[b,ci,pos*s + tap - pad] */
+/* dw (+)= sum_{b,pos} dy[b,co,pos] * x[b,ci,pos*s + tap - pad] */
 int otal_conv_wgrad(const int* geom, const int64_t* strides, const float* x, const float* dy,
-                    const float* ymask, const float* dscale, float* dw, int accumulate,
-                    void* ws, size_t ws_bytes, void* stream);
+                    float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* (Cout,Cin,kvol) -> (Cin,Cout,kvol): the A operand of the data-gradient GEMM. */
 int otal_conv_pack_wt(const float* w, float* wt, int Cout, int Cin, int kvol, void* stream);

@@ -128,9 +128,9 @@ def pack_wt(w):
     return wt
 
 
-def conv_dgrad(dy, w, x_shape, k, s, ymask=None, dscale=None, spatial_valid=False, levels=None, out=None,
+def conv_dgrad(dy, w, x_shape, k, s, spatial_valid=False, levels=None, out=None,
                accumulate=False, wt=None, out_mask=None, out_scale=None):
-    """dx (+)= d conv / d x.  dy/ymask share a layout; `out` may be a channel slice.
+    """dx (+)= d conv / d x.  `out` may be a channel slice.
     out_mask/out_scale: multiply this contribution by (out_mask > 0) * out_scale[ci] in the store
     (ReLU + frozen-BN backward of the layer that produced x; out_mask has dx's layout)."""
     k, s = _k3(k), _k3(s)
@@ -147,10 +147,6 @@ def conv_dgrad(dy, w, x_shape, k, s, ymask=None, dscale=None, spatial_valid=Fals
     _check(x5, "dx"); _check(dy5, "dy")
     if tuple(dy5.shape) != (B, Cout) + outn:
         raise RuntimeError(f"conv_dgrad: dy has shape {tuple(dy5.shape)}, expected {(B, Cout) + outn}")
-    if ymask is not None:
-        m5 = _as5(ymask)
-        if m5.stride() != dy5.stride() and tuple(_bs(m5)) != tuple(_bs(dy5)):
-            raise RuntimeError("ymask must share dy's layout")
     if wt is None:
         wt = pack_wt(w)
     ga, sa = _geom_arrays(g, x5, dy5)
@@ -160,7 +156,7 @@ def conv_dgrad(dy, w, x_shape, k, s, ymask=None, dscale=None, spatial_valid=Fals
         m5 = _as5(out_mask)
         if tuple(m5.shape) != tuple(x5.shape) or tuple(_bs(m5)) != tuple(_bs(x5)):
             raise RuntimeError("out_mask must share dx's shape and layout")
-    L.check(L.lib().otal_conv_dgrad(ga, sa, L.ptr(dy5), L.ptr(wt), _opt(ymask), _opt(dscale), L.ptr(x5),
+    L.check(L.lib().otal_conv_dgrad(ga, sa, L.ptr(dy5), L.ptr(wt), L.ptr(x5),
                                     int(accumulate), _opt(out_mask), _opt(out_scale),
                                     L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
             "otal_conv_dgrad")
@@ -189,8 +185,7 @@ def conv_dgrad_collapse(dy, w, x_shape):
     return dxp.view(B, Cin, H * W, T).permute(0, 1, 3, 2).contiguous().view(B, Cin, T, H, W)
 
 
-def conv_wgrad(x, dy, w_shape, k, s, ymask=None, dscale=None, spatial_valid=False, levels=None, out=None,
-               accumulate=False):
+def conv_wgrad(x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None, accumulate=False):
     """dw (+)= d conv / d w."""
     k, s = _k3(k), _k3(s)
     x5, dy5 = _as5(x), _as5(dy)
@@ -209,7 +204,7 @@ def conv_wgrad(x, dy, w_shape, k, s, ymask=None, dscale=None, spatial_valid=Fals
     ga, sa = _geom_arrays(g, x5, dy5)
     ws = workspace(x.device)
     ev = _prof_begin()
-    L.check(L.lib().otal_conv_wgrad(ga, sa, L.ptr(x5), L.ptr(dy5), _opt(ymask), _opt(dscale), L.ptr(out),
+    L.check(L.lib().otal_conv_wgrad(ga, sa, L.ptr(x5), L.ptr(dy5), L.ptr(out),
                                     int(accumulate), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
             "otal_conv_wgrad")
     _prof_end(ev, "wgrad", g)

@@ -16,7 +16,8 @@
 // so every MFMA operand read is 32 consecutive floats per half-wave (conflict free) and the
 // k-fast global tiles are written with a 2-bank skew (conflict free as well).
 // SAME padding, strides, level-packed pyramids and channel-sliced (concat) tensors are folded
-// into the gather (conv_index.h); ReLU/frozen-BN backward is folded into the dy loader.
+// into the gather (conv_index.h); the ReLU/frozen-BN backward of the PRODUCING layer is folded
+// into the DGRAD store epilogue (out_mask/out_scale), so loaders read one tensor per operand.
 // Split-K writes fp32 slabs that a second kernel reduces in a fixed order (deterministic).
 #include "common.h"
 #include "conv_index.h"
@@ -35,8 +36,6 @@ struct ConvArgs {
     const float* x;        // FWD/WGRAD: input activations
     const float* w;        // FWD: W (Cout, Cin*kvol); DGRAD: packed W^T (Cin, Cout*kvol)
     const float* dy;       // DGRAD/WGRAD: output gradient
-    const float* ymask;    // optional: forward output y (same layout as dy) -> dy *= (y > 0)
-    const float* dscale;   // optional: per-output-channel multiplier applied to dy (frozen BN)
     float* out;            // FWD: y; DGRAD: dx; WGRAD: dW (Cout, Cin*kvol)
     const float* scale;    // FWD epilogue: per-Cout scale (nullable -> 1)
     const float* shift;    // FWD epilogue: per-Cout shift / bias (nullable -> 0)
@@ -50,11 +49,16 @@ struct ConvArgs {
 };
 
 // ---- operand element fetch -------------------------------------------------------------------
-__device__ __forceinline__ float load_dy(const ConvArgs& a, int64_t off, int co) {
-    float v = a.dy[off];
-    if (a.ymask) v = a.ymask[off] > 0.f ? v : 0.f;
-    if (a.dscale) v *= a.dscale[co];
-    return v;
+// Every gather loads UNCONDITIONALLY: an out-of-range element reads a device zero word instead of
+// being guarded.  A guarded load (`ok ? p[off] : 0`) makes hipcc branch around each load and wait
+// vmcnt(0) inside the branch (the 16 loads of a K step serialise), and even a select AFTER the load
+// pins the wait in front of the MFMA block.  Selecting the POINTER leaves the loaded registers
+// untouched until the LDS store behind the MFMAs, so HBM/L2 latency hides under the matrix work.
+__device__ __attribute__((aligned(16))) float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ float ld_or_zero(const float* base, int64_t off, bool ok) {
+    const float* p = ok ? base + off : g_zero4;
+    return *p;
 }
 
 // per-thread gather anchor of an OUTPUT position (FWD, WGRAD): everything that does not depend on the tap
@@ -70,10 +74,11 @@ __device__ __forceinline__ OutAnchor make_out_anchor(const ConvGeom& g, const Po
     level_bounds(g, o.t, g.Ti, r.lo, r.up);
     return r;
 }
-__device__ __forceinline__ float gather_x(const ConvArgs& a, const OutAnchor& r, int64_t koff, int dt, int dh, int dw) {
+__device__ __forceinline__ float gather_x(const ConvArgs& a, const OutAnchor& r, int64_t koff, int dt, int dh, int dw,
+                                          bool live) {
     const int ti = r.t0 + dt, hi = r.h0 + dh, wi = r.w0 + dw;
-    const bool ok = ti >= r.lo && ti < r.up && (unsigned)hi < (unsigned)a.g.Hi && (unsigned)wi < (unsigned)a.g.Wi;
-    return ok ? a.x[r.base + koff] : 0.f;
+    const bool ok = live && ti >= r.lo && ti < r.up && (unsigned)hi < (unsigned)a.g.Hi && (unsigned)wi < (unsigned)a.g.Wi;
+    return ld_or_zero(a.x, r.base + koff, ok);
 }
 
 template <int BM, int BN, int WM, int WN, int MODE>
@@ -124,7 +129,8 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
         if (n_ok) {
             ipos = dec_pos_fd(n, fd.Ti, fd.Hi, fd.Wi);
             ibase = (int64_t)ipos.b * g.y_bs;
-            level_bounds(g, ipos.t, g.Ti, ilo, iup);
+            level_bounds(g, ipos.t, g.Ti, ilo, iup);      // stride 1 when packed; else [0, Ti) -- widen to To
+            if (g.nlev <= 1) { ilo = 0; iup = g.To; }
         }
     } else {
 #pragma unroll
@@ -153,13 +159,13 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < A_PER; ++j) {
                 const int m = m0 + a_m + 16 * j;
-                ra[j] = (kok && m < a.M) ? load_dy(a, dyoff + (int64_t)m * g.y_cs, m) : 0.f;
+                ra[j] = ld_or_zero(a.dy, dyoff + (int64_t)m * g.y_cs, kok && m < a.M);
             }
             const OutAnchor r = make_out_anchor(g, o);
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) {
                 const int tp = wtap[j];
-                rb[j] = (kok && tp >= 0) ? gather_x(a, r, wcoff[j], tp & 255, (tp >> 8) & 255, tp >> 16) : 0.f;
+                rb[j] = gather_x(a, r, wcoff[j], tp & 255, (tp >> 8) & 255, (tp >> 16) & 255, kok && tp >= 0);
             }
         } else {
             // ---------------- A: weights, row-major [M][K]
@@ -169,9 +175,9 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < A_VPASS; ++j) {
                         const int m = m0 + v_m + 64 * j;
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (v_m + 64 * j < BM && m < a.M && k0 + v_k < k_end)
-                            v = *reinterpret_cast<const float4*>(a.w + (int64_t)m * a.K + k0 + v_k);
+                        const bool ok = v_m + 64 * j < BM && m < a.M && k0 + v_k < k_end;
+                        const float* ap = ok ? a.w + (int64_t)m * a.K + k0 + v_k : g_zero4;
+                        const float4 v = *reinterpret_cast<const float4*>(ap);
                         ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
                     }
                     a_done = true;
@@ -182,27 +188,26 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < A_PER; ++j) {
                     const int m = m0 + a_m + 16 * j;
-                    ra[j] = (k < k_end && m < a.M) ? a.w[(int64_t)m * a.K + k] : 0.f;
+                    ra[j] = ld_or_zero(a.w, (int64_t)m * a.K + k, k < k_end && m < a.M);
                 }
             }
             // ---------------- B: gathered activations, n-fast
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) {
                 const int kk = k0 + b_k0 + B_ROWS * j;   // wave-uniform
-                float v = 0.f;
-                if (kk < k_end && n_ok) {
-                    const TapDec t = dec_tap_fd(fd, kk);
-                    if constexpr (MODE == MODE_FWD) {
-                        const int64_t koff = (int64_t)t.c * g.x_cs + (int64_t)t.dt * HWi + t.dh * g.Wi + t.dw;
-                        v = gather_x(a, anchor, koff, t.dt, t.dh, t.dw);
-                    } else {
-                        int to, ho, wo;
-                        bool ok = div_stride(ipos.t + g.pt - t.dt, g.st, g.To, to);
-                        ok = ok && div_stride(ipos.h + g.ph - t.dh, g.sh, g.Ho, ho);
-                        ok = ok && div_stride(ipos.w + g.pw - t.dw, g.sw, g.Wo, wo);
-                        if (g.nlev > 1) ok = ok && to >= ilo && to < iup;
-                        if (ok) v = load_dy(a, ibase + (int64_t)t.c * g.y_cs + ((int64_t)to * g.Ho + ho) * g.Wo + wo, t.c);
-                    }
+                const bool live = kk < k_end && n_ok;
+                const TapDec t = dec_tap_fd(fd, live ? kk : 0);
+                float v;
+                if constexpr (MODE == MODE_FWD) {
+                    const int64_t koff = (int64_t)t.c * g.x_cs + (int64_t)t.dt * HWi + t.dh * g.Wi + t.dw;
+                    v = gather_x(a, anchor, koff, t.dt, t.dh, t.dw, live);
+                } else {
+                    int to = 0, ho = 0, wo = 0;
+                    bool ok = live & div_stride12(ipos.t + g.pt - t.dt, g.st, g.To, to);
+                    ok = ok & div_stride12(ipos.h + g.ph - t.dh, g.sh, g.Ho, ho);
+                    ok = ok & div_stride12(ipos.w + g.pw - t.dw, g.sw, g.Wo, wo);
+                    ok = ok & (to >= ilo) & (to < iup);
+                    v = ld_or_zero(a.dy, ibase + (int64_t)t.c * g.y_cs + ((int64_t)to * g.Ho + ho) * g.Wo + wo, ok);
                 }
                 rb[j] = v;
             }
@@ -404,7 +409,7 @@ int choose_splits(int tiles, int K) {
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int BMsel = choose_bm(a.M);
-    const int BN = BMsel <= 64 ? 256 : 128;      // short tiles get a wide N so each wave still owns 4 MFMA tiles
+    const int BN = 128;
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + BN - 1) / BN;
     a.fd = make_conv_fastdiv(a.g);
     a.a_vec4 = (MODE != MODE_WGRAD) && (a.K % 4 == 0) && (((uintptr_t)a.w & 15) == 0) && BMsel >= 64;
@@ -424,8 +429,8 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const dim3 grid(tn, tm, splits);
     if (BMsel == 128) hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 2, 2, MODE>), grid, dim3(NT), 0, st, a);
     else if (BMsel == 96) hipLaunchKernelGGL((conv_gemm_kernel<96, 128, 3, 1, MODE>), grid, dim3(NT), 0, st, a);
-    else if (BMsel == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 256, 2, 2, MODE>), grid, dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<32, 256, 1, 2, MODE>), grid, dim3(NT), 0, st, a);
+    else if (BMsel == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 128, 2, 1, MODE>), grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<32, 128, 1, 1, MODE>), grid, dim3(NT), 0, st, a);
     if (int e = otal_launch_status()) return e;
     if (splits > 1) {
         const int64_t total = (int64_t)a.M * a.N;
@@ -447,7 +452,7 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
     else if (mode == MODE_DGRAD) { M = g.Cin; N = (int64_t)g.B * conv_in_positions(g); K = (int64_t)g.Cout * kvol; }
     else { M = g.Cout; N = (int64_t)g.Cin * kvol; K = (int64_t)g.B * conv_out_positions(g); }
     const int BMsel = choose_bm((int)M);
-    const int BN = BMsel <= 64 ? 256 : 128;
+    const int BN = 128;
     const int tiles = (int)(((M + BMsel - 1) / BMsel) * ((N + BN - 1) / BN));
     const int s = choose_splits(tiles, (int)K);
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
@@ -467,15 +472,15 @@ extern "C" int otal_conv_fwd(const int* geom, const int64_t* strides, const floa
 }
 
 extern "C" int otal_conv_dgrad(const int* geom, const int64_t* strides, const float* dy, const float* wt_packed,
-                               const float* ymask, const float* dscale, float* dx, int accumulate,
-                               const float* out_mask, const float* out_scale,
+                               float* dx, int accumulate, const float* out_mask, const float* out_scale,
                                void* ws, size_t ws_bytes, void* stream) {
     if (!geom || !strides || !dy || !wt_packed || !dx) return OTAL_E_NULL;
     if ((out_mask == nullptr) != (out_scale == nullptr)) return OTAL_E_NULL;
     ConvArgs a = {};
     if (int e = fill_geom(a.g, geom)) return e;
     a.g.x_bs = strides[0]; a.g.x_cs = strides[1]; a.g.y_bs = strides[2]; a.g.y_cs = strides[3];
-    a.dy = dy; a.w = wt_packed; a.out = dx; a.ymask = ymask; a.dscale = dscale;
+    a.dy = dy; a.w = wt_packed; a.out = dx;
+    if (a.g.st > 2 || a.g.sh > 2 || a.g.sw > 2) return OTAL_E_UNSUPPORTED;   // gather is specialised for strides 1, 2
     a.emask = out_mask; a.escale = out_scale;
     a.M = a.g.Cin; a.N = a.g.B * conv_in_positions(a.g); a.K = a.g.Cout * conv_kvol(a.g);
     a.flags = accumulate ? EPI_ACCUM : 0;
@@ -483,13 +488,13 @@ extern "C" int otal_conv_dgrad(const int* geom, const int64_t* strides, const fl
 }
 
 extern "C" int otal_conv_wgrad(const int* geom, const int64_t* strides, const float* x, const float* dy,
-                               const float* ymask, const float* dscale, float* dw, int accumulate,
+                               float* dw, int accumulate,
                                void* ws, size_t ws_bytes, void* stream) {
     if (!geom || !strides || !x || !dy || !dw) return OTAL_E_NULL;
     ConvArgs a = {};
     if (int e = fill_geom(a.g, geom)) return e;
     a.g.x_bs = strides[0]; a.g.x_cs = strides[1]; a.g.y_bs = strides[2]; a.g.y_cs = strides[3];
-    a.x = x; a.dy = dy; a.out = dw; a.ymask = ymask; a.dscale = dscale;
+    a.x = x; a.dy = dy; a.out = dw;
     a.M = a.g.Cout; a.N = a.g.Cin * conv_kvol(a.g); a.K = a.g.B * conv_out_positions(a.g);
     a.flags = accumulate ? EPI_ACCUM : 0;
     return launch_mode<MODE_WGRAD>(a, ws, ws_bytes, (hipStream_t)stream);

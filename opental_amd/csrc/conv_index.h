@@ -34,12 +34,13 @@ struct ConvGeom {
 // Division by a launch-invariant divisor without the ~40-instruction runtime divide: round-up
 // multiplier method (Granlund-Montgomery), exact for every 32-bit numerator.  Built on the host.
 struct FastDiv {
-    uint32_t d, mul, sh;   // sh == 32 marks d == 1
+    uint32_t d, mul, sh, one;   // one = 0xffffffff marks d == 1 (identity), else 0; branch-free at run time
 };
 inline FastDiv make_fastdiv(uint32_t d) {
     FastDiv f;
     f.d = d;
-    if (d <= 1) { f.mul = 0; f.sh = 32; return f; }
+    f.one = 0;
+    if (d <= 1) { f.d = 1; f.mul = 0; f.sh = 0; f.one = 0xffffffffu; return f; }
     uint32_t s = 0;
     while ((1ull << s) < d) ++s;                       // s = ceil(log2 d), 1..32
     f.mul = (uint32_t)((((1ull << s) - d) << 32) / d + 1);
@@ -54,9 +55,9 @@ OTAL_HD uint32_t otal_umulhi(uint32_t a, uint32_t b) {
 #endif
 }
 OTAL_HD uint32_t fd_div(const FastDiv& f, uint32_t n) {
-    if (f.sh == 32) return n;
     const uint32_t t = otal_umulhi(f.mul, n);
-    return (t + ((n - t) >> 1)) >> f.sh;
+    const uint32_t q = (t + ((n - t) >> 1)) >> f.sh;
+    return (q & ~f.one) | (n & f.one);
 }
 
 struct PosDec { int b, t, h, w; };          // a decomposed spatial position
@@ -134,6 +135,13 @@ OTAL_HD bool div_stride(int num, int s, int extent, int& q) {
     else if (s == 2) { if (num & 1) return false; q = num >> 1; }
     else { if (num % s) return false; q = num / s; }
     return q < extent;
+}
+
+// branch-free form for strides 1 and 2 (all the model has): num = q * s exactly, 0 <= q < extent
+OTAL_HD bool div_stride12(int num, int s, int extent, int& q) {
+    const int sm1 = s - 1;                   // 0 or 1
+    q = num >> sm1;
+    return (num >= 0) & ((num & sm1) == 0) & (q < extent);
 }
 
 // data-gradient gather: which output-gradient element reaches input position `i` through tap `k`

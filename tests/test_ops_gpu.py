@@ -90,30 +90,28 @@ def test_conv_epilogue_mask_slices_accumulate():
                      out=yb[:, 2:2 + Cout])
     close(yb[:, 2:2 + Cout], ref)
     assert bool((yb[:, :2] == 9).all()) and bool((yb[:, 2 + Cout:] == 9).all())
-    # backward with ReLU mask + BN scale folded into the loaders, accumulating into an existing dx slice
+    # backward on a pre-masked gradient (dz = dy * (y > 0) * scale), accumulating into an existing dx slice
     dy = torch.from_numpy(rs.randn(*ref.shape).astype(np.float32))
     dz = dy * (ref > 0) * sc.view(1, -1, 1, 1, 1)
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     F.conv3d(F.pad(xr, [1] * 6), wr).backward(dz)
-    dyb = torch.zeros_like(yb)
-    dyb[:, 2:2 + Cout] = dy.cuda()
+    dzb = torch.zeros_like(yb)
+    dzb[:, 2:2 + Cout] = dz.cuda()
     dxb = torch.full((B, Cin + 5, T, H, W), 1.0, device="cuda")
-    ops.conv_dgrad(dyb[:, 2:2 + Cout], w.cuda(), (B, Cin, T, H, W), (3, 3, 3), (1, 1, 1), ymask=yb[:, 2:2 + Cout],
-                   dscale=sc.cuda(), out=dxb[:, 3:3 + Cin], accumulate=True)
+    ops.conv_dgrad(dzb[:, 2:2 + Cout], w.cuda(), (B, Cin, T, H, W), (3, 3, 3), (1, 1, 1), out=dxb[:, 3:3 + Cin],
+                   accumulate=True)
     close(dxb[:, 3:3 + Cin] - 1.0, xr.grad)
     assert bool((dxb[:, :3] == 1).all())
-    dw = ops.conv_wgrad(xb[:, 3:3 + Cin], dyb[:, 2:2 + Cout], w.shape, (3, 3, 3), (1, 1, 1), ymask=yb[:, 2:2 + Cout],
-                        dscale=sc.cuda())
+    dw = ops.conv_wgrad(xb[:, 3:3 + Cin], dzb[:, 2:2 + Cout], w.shape, (3, 3, 3), (1, 1, 1))
     close(dw, wr.grad)
-    dw2 = ops.conv_wgrad(xb[:, 3:3 + Cin], dyb[:, 2:2 + Cout], w.shape, (3, 3, 3), (1, 1, 1), ymask=yb[:, 2:2 + Cout],
-                         dscale=sc.cuda(), out=dw.clone(), accumulate=True)
+    dw2 = ops.conv_wgrad(xb[:, 3:3 + Cin], dzb[:, 2:2 + Cout], w.shape, (3, 3, 3), (1, 1, 1), out=dw.clone(),
+                         accumulate=True)
     close(dw2, 2 * wr.grad)
     # producer-side masking in the store epilogue: dx * (x > 0) * in_scale[ci], accumulated
     isc = torch.from_numpy(rs.uniform(0.5, 1.5, Cin).astype(np.float32))
     dxb2 = torch.full((B, Cin + 5, T, H, W), 1.0, device="cuda")
-    ops.conv_dgrad(dyb[:, 2:2 + Cout], w.cuda(), (B, Cin, T, H, W), (3, 3, 3), (1, 1, 1), ymask=yb[:, 2:2 + Cout],
-                   dscale=sc.cuda(), out=dxb2[:, 3:3 + Cin], accumulate=True, out_mask=xb[:, 3:3 + Cin],
-                   out_scale=isc.cuda())
+    ops.conv_dgrad(dzb[:, 2:2 + Cout], w.cuda(), (B, Cin, T, H, W), (3, 3, 3), (1, 1, 1), out=dxb2[:, 3:3 + Cin],
+                   accumulate=True, out_mask=xb[:, 3:3 + Cin], out_scale=isc.cuda())
     close(dxb2[:, 3:3 + Cin] - 1.0, xr.grad * (x > 0) * isc.view(1, -1, 1, 1, 1))
     from oracle import afsd_oracle as O
     xp = x.clone().requires_grad_(True)
