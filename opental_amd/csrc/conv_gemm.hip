@@ -81,7 +81,7 @@ __device__ __forceinline__ float gather_x(const ConvArgs& a, const OutAnchor& r,
     return ld_or_zero(a.x, r.base + koff, ok);
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, bool AVEC>
 __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int LDA = BM + 2, LDB = BN + 2;
     constexpr int A_PER = BM * BK / NT;     // A elements per thread per K step (2, 4, 6 or 8)
@@ -147,69 +147,61 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
         }
     }
 
-    constexpr int A_VPASS = (BM + 63) / 64;
-    float ra[(A_PER > 4 * A_VPASS) ? A_PER : 4 * A_VPASS], rb[B_PER];
+    constexpr int A_VPASS = (BM + 63) / 64;                 // float4 passes of the A tile (AVEC)
+    constexpr int A_LOADS = AVEC ? A_VPASS : A_PER;         // A load instructions per thread per K step
+    constexpr int A_REGS = AVEC ? 4 * A_VPASS : A_PER;
+    constexpr int NCH = BK / 2;                             // one chunk per MFMA k-pair
+    constexpr int B_PER_CH = B_PER / NCH;
+    static_assert(A_LOADS <= NCH && B_PER % NCH == 0, "chunking");
+    float ra[A_REGS], rb[B_PER];
+    OutAnchor wanchor = {};                  // WGRAD: anchor of this thread's k (an output position), per K step
+    int64_t wdyoff = 0;
+    bool wkok = false;
 
-    auto load_tiles = [&](int k0) {
+    // ---- next-tile loaders, one element (or float4) at a time so that they can be spread between the
+    // MFMAs of the current tile.  `live` false (no next tile / out of range) reads the device zero word.
+    auto prep = [&](int k0, bool live) {
         if constexpr (MODE == MODE_WGRAD) {
             const int k = k0 + a_k;
-            const bool kok = k < k_end;
-            const PosDec o = dec_pos_fd(kok ? k : 0, fd.To, fd.Ho, fd.Wo);
-            const int64_t dyoff = (int64_t)o.b * g.y_bs + ((int64_t)o.t * g.Ho + o.h) * g.Wo + o.w;
-#pragma unroll
-            for (int j = 0; j < A_PER; ++j) {
-                const int m = m0 + a_m + 16 * j;
-                ra[j] = ld_or_zero(a.dy, dyoff + (int64_t)m * g.y_cs, kok && m < a.M);
-            }
-            const OutAnchor r = make_out_anchor(g, o);
-#pragma unroll
-            for (int j = 0; j < B_PER; ++j) {
-                const int tp = wtap[j];
-                rb[j] = gather_x(a, r, wcoff[j], tp & 255, (tp >> 8) & 255, (tp >> 16) & 255, kok && tp >= 0);
-            }
+            wkok = live && k < k_end;
+            const PosDec o = dec_pos_fd(wkok ? k : 0, fd.To, fd.Ho, fd.Wo);
+            wdyoff = (int64_t)o.b * g.y_bs + ((int64_t)o.t * g.Ho + o.h) * g.Wo + o.w;
+            wanchor = make_out_anchor(g, o);
+        }
+    };
+    auto loadA = [&](int j, int k0, bool live) {
+        if constexpr (MODE == MODE_WGRAD) {
+            const int m = m0 + a_m + 16 * j;
+            ra[j] = ld_or_zero(a.dy, wdyoff + (int64_t)m * g.y_cs, wkok && m < a.M);
+        } else if constexpr (AVEC) {            // weights [M][K], K % 4 == 0, 16-byte aligned rows
+            const int m = m0 + v_m + 64 * j;
+            const bool ok = live && v_m + 64 * j < BM && m < a.M && k0 + v_k < k_end;
+            const float* ap = ok ? a.w + (int64_t)m * a.K + k0 + v_k : g_zero4;
+            const float4 v = *reinterpret_cast<const float4*>(ap);
+            ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
         } else {
-            // ---------------- A: weights, row-major [M][K]
-            bool a_done = false;
-            if constexpr (BM >= 64) {
-                if (a.a_vec4) {     // K % 4 == 0 and 16-byte aligned rows: one float4 per 4 k
-#pragma unroll
-                    for (int j = 0; j < A_VPASS; ++j) {
-                        const int m = m0 + v_m + 64 * j;
-                        const bool ok = v_m + 64 * j < BM && m < a.M && k0 + v_k < k_end;
-                        const float* ap = ok ? a.w + (int64_t)m * a.K + k0 + v_k : g_zero4;
-                        const float4 v = *reinterpret_cast<const float4*>(ap);
-                        ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
-                    }
-                    a_done = true;
-                }
-            }
-            if (!a_done) {
-                const int k = k0 + a_k;
-#pragma unroll
-                for (int j = 0; j < A_PER; ++j) {
-                    const int m = m0 + a_m + 16 * j;
-                    ra[j] = ld_or_zero(a.w, (int64_t)m * a.K + k, k < k_end && m < a.M);
-                }
-            }
-            // ---------------- B: gathered activations, n-fast
-#pragma unroll
-            for (int j = 0; j < B_PER; ++j) {
-                const int kk = k0 + b_k0 + B_ROWS * j;   // wave-uniform
-                const bool live = kk < k_end && n_ok;
-                const TapDec t = dec_tap_fd(fd, live ? kk : 0);
-                float v;
-                if constexpr (MODE == MODE_FWD) {
-                    const int64_t koff = (int64_t)t.c * g.x_cs + (int64_t)t.dt * HWi + t.dh * g.Wi + t.dw;
-                    v = gather_x(a, anchor, koff, t.dt, t.dh, t.dw, live);
-                } else {
-                    int to = 0, ho = 0, wo = 0;
-                    bool ok = live & div_stride12(ipos.t + g.pt - t.dt, g.st, g.To, to);
-                    ok = ok & div_stride12(ipos.h + g.ph - t.dh, g.sh, g.Ho, ho);
-                    ok = ok & div_stride12(ipos.w + g.pw - t.dw, g.sw, g.Wo, wo);
-                    ok = ok & (to >= ilo) & (to < iup);
-                    v = ld_or_zero(a.dy, ibase + (int64_t)t.c * g.y_cs + ((int64_t)to * g.Ho + ho) * g.Wo + wo, ok);
-                }
-                rb[j] = v;
+            const int k = k0 + a_k, m = m0 + a_m + 16 * j;
+            ra[j] = ld_or_zero(a.w, (int64_t)m * a.K + k, live && k < k_end && m < a.M);
+        }
+    };
+    auto loadB = [&](int j, int k0, bool live) {
+        if constexpr (MODE == MODE_WGRAD) {
+            const int tp = wtap[j];
+            rb[j] = gather_x(a, wanchor, wcoff[j], tp & 255, (tp >> 8) & 255, (tp >> 16) & 255, wkok && tp >= 0);
+        } else {
+            const int kk = k0 + b_k0 + B_ROWS * j;              // wave-uniform
+            const bool ok0 = live && kk < k_end && n_ok;
+            const TapDec t = dec_tap_fd(fd, ok0 ? kk : 0);
+            if constexpr (MODE == MODE_FWD) {
+                const int64_t koff = (int64_t)t.c * g.x_cs + (int64_t)t.dt * HWi + t.dh * g.Wi + t.dw;
+                rb[j] = gather_x(a, anchor, koff, t.dt, t.dh, t.dw, ok0);
+            } else {
+                int to = 0, ho = 0, wo = 0;
+                bool ok = ok0 & div_stride12(ipos.t + g.pt - t.dt, g.st, g.To, to);
+                ok = ok & div_stride12(ipos.h + g.ph - t.dh, g.sh, g.Ho, ho);
+                ok = ok & div_stride12(ipos.w + g.pw - t.dw, g.sw, g.Wo, wo);
+                ok = ok & (to >= ilo) & (to < iup);
+                rb[j] = ld_or_zero(a.dy, ibase + (int64_t)t.c * g.y_cs + ((int64_t)to * g.Ho + ho) * g.Wo + wo, ok);
             }
         }
     };
@@ -220,19 +212,14 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) Bs[buf][a_k * LDB + (tid >> 4) + 16 * j] = rb[j];
         } else {
-            bool a_done = false;
-            if constexpr (BM >= 64) {
-                if (a.a_vec4) {
+            if constexpr (AVEC) {
 #pragma unroll
-                    for (int j = 0; j < A_VPASS; ++j)
-                        if (v_m + 64 * j < BM) {
+                for (int j = 0; j < A_VPASS; ++j)
+                    if (v_m + 64 * j < BM) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) As[buf][(v_k + i) * LDA + v_m + 64 * j] = ra[4 * j + i];
-                        }
-                    a_done = true;
-                }
-            }
-            if (!a_done) {
+                        for (int i = 0; i < 4; ++i) As[buf][(v_k + i) * LDA + v_m + 64 * j] = ra[4 * j + i];
+                    }
+            } else {
 #pragma unroll
                 for (int j = 0; j < A_PER; ++j) As[buf][a_k * LDA + a_m + 16 * j] = ra[j];
             }
@@ -254,20 +241,31 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (k_end - k_begin + BK - 1) / BK;
-    if (nk > 0) {
-        load_tiles(k_begin);
-        store_tiles(0);
-    }
+    prep(k_begin, nk > 0);
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) loadA(j, k_begin, nk > 0);
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) loadB(j, k_begin, nk > 0);
+    store_tiles(0);
     __syncthreads();
+    // Main loop, software-pipelined INSIDE the wave: the address math + global loads of tile it+1 are
+    // issued in NCH slices between the MFMA groups of tile it (an MFMA occupies the matrix pipe for 64
+    // cycles while the wave keeps issuing VALU/VMEM), the loaded registers are only touched by the LDS
+    // store after the last MFMA, and one barrier per K step flips the LDS buffers.
     for (int it = 0; it < nk; ++it) {
         const int buf = it & 1;
-        if (it + 1 < nk) load_tiles(k_begin + (it + 1) * BK);
+        const bool has_next = it + 1 < nk;
+        const int kn = k_begin + (it + 1) * BK;
         const float* as = As[buf];
         const float* bs = Bs[buf];
+        prep(kn, has_next);
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
+        for (int c = 0; c < NCH; ++c) {
+            if (c < A_LOADS) loadA(c, kn, has_next);
+#pragma unroll
+            for (int q = 0; q < B_PER_CH; ++q) loadB(c * B_PER_CH + q, kn, has_next);
             float av[WM], bv[WN];
-            const int kr = kk + (lane >> 5);
+            const int kr = 2 * c + (lane >> 5);
 #pragma unroll
             for (int i = 0; i < WM; ++i) av[i] = as[kr * LDA + wm0 + i * 32 + (lane & 31)];
 #pragma unroll
@@ -277,8 +275,9 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);      // keep the slices where they are
         }
-        if (it + 1 < nk) store_tiles(buf ^ 1);
+        store_tiles(buf ^ 1);                       // harmless on the last step (buffer is never read)
         __syncthreads();
     }
 
@@ -427,10 +426,21 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     a.k_per_split = kps;
     a.slab = splits > 1 ? (float*)ws : nullptr;
     const dim3 grid(tn, tm, splits);
-    if (BMsel == 128) hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 2, 2, MODE>), grid, dim3(NT), 0, st, a);
-    else if (BMsel == 96) hipLaunchKernelGGL((conv_gemm_kernel<96, 128, 3, 1, MODE>), grid, dim3(NT), 0, st, a);
-    else if (BMsel == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 128, 2, 1, MODE>), grid, dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<32, 128, 1, 1, MODE>), grid, dim3(NT), 0, st, a);
+#define OTAL_LAUNCH(BM_, WM_, WN_, AV_) \
+    hipLaunchKernelGGL((conv_gemm_kernel<BM_, 128, WM_, WN_, MODE, AV_>), grid, dim3(NT), 0, st, a)
+    const bool av = a.a_vec4 != 0;
+    if constexpr (MODE == MODE_WGRAD) {
+        if (BMsel == 128) OTAL_LAUNCH(128, 2, 2, false);
+        else if (BMsel == 96) OTAL_LAUNCH(96, 3, 1, false);
+        else if (BMsel == 64) OTAL_LAUNCH(64, 2, 1, false);
+        else OTAL_LAUNCH(32, 1, 1, false);
+    } else {
+        if (BMsel == 128) { if (av) OTAL_LAUNCH(128, 2, 2, true); else OTAL_LAUNCH(128, 2, 2, false); }
+        else if (BMsel == 96) { if (av) OTAL_LAUNCH(96, 3, 1, true); else OTAL_LAUNCH(96, 3, 1, false); }
+        else if (BMsel == 64) { if (av) OTAL_LAUNCH(64, 2, 1, true); else OTAL_LAUNCH(64, 2, 1, false); }
+        else OTAL_LAUNCH(32, 1, 1, false);
+    }
+#undef OTAL_LAUNCH
     if (int e = otal_launch_status()) return e;
     if (splits > 1) {
         const int64_t total = (int64_t)a.M * a.N;
