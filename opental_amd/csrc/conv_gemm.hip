@@ -21,12 +21,13 @@
 // Split-K writes fp32 slabs that a second kernel reduces in a fixed order (deterministic).
 #include "common.h"
 #include "conv_index.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int BK = 16, NT = 256;
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
-enum { EPI_RELU = 1, EPI_ACCUM = 2 };
+enum { EPI_RELU = 1, EPI_ACCUM = 2, DBG_NOLOAD = 4, DBG_NOSTORE = 8, DBG_NOBARRIER = 16 };   // DBG_*: ablation only (OTAL_CONV_DEBUG)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -61,24 +62,59 @@ __device__ __forceinline__ float ld_or_zero(const float* base, int64_t off, bool
     return *p;
 }
 
-// per-thread gather anchor of an OUTPUT position (FWD, WGRAD): everything that does not depend on the tap
-struct OutAnchor {
-    int64_t base;          // b*x_bs + ((to*st-pt)*Hi + (ho*sh-ph))*Wi + (wo*sw-pw)
-    int t0, h0, w0;        // input coordinate of tap (0,0,0)
-    int lo, up;            // temporal bounds (level-aware)
+// Per-thread gather anchor.  Everything that depends only on the thread's own position is folded,
+// ONCE, into (a) a base pointer and (b) a 24-bit validity mask: bit dt says tap dt is inside the
+// (level-aware) temporal range, bit 8+dh / 16+dw the same for h / w (kernels up to 8 per axis).  A tap
+// is then checked with three shifts and two ANDs and addressed with `base + uniform offset`, where the
+// uniform offset (channel stride, tap displacement) is computed on the scalar unit.
+struct Anchor {
+    const float* base;
+    unsigned mask;
 };
-__device__ __forceinline__ OutAnchor make_out_anchor(const ConvGeom& g, const PosDec& o) {
-    OutAnchor r;
-    r.t0 = o.t * g.st - g.pt; r.h0 = o.h * g.sh - g.ph; r.w0 = o.w * g.sw - g.pw;
-    r.base = (int64_t)o.b * g.x_bs + ((int64_t)r.t0 * g.Hi + r.h0) * g.Wi + r.w0;
-    level_bounds(g, o.t, g.Ti, r.lo, r.up);
+// an OUTPUT position o reads input (o*s - p + tap): FWD and WGRAD
+__device__ __forceinline__ Anchor anchor_of_output(const ConvGeom& g, const float* x, const PosDec& o, bool live) {
+    const int t0 = o.t * g.st - g.pt, h0 = o.h * g.sh - g.ph, w0 = o.w * g.sw - g.pw;
+    int lo, up;
+    level_bounds(g, o.t, g.Ti, lo, up);
+    unsigned m = 0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        m |= (unsigned)(d < g.kt && t0 + d >= lo && t0 + d < up) << d;
+        m |= (unsigned)(d < g.kh && (unsigned)(h0 + d) < (unsigned)g.Hi) << (8 + d);
+        m |= (unsigned)(d < g.kw && (unsigned)(w0 + d) < (unsigned)g.Wi) << (16 + d);
+    }
+    Anchor r;
+    r.base = x + ((int64_t)o.b * g.x_bs + ((int64_t)t0 * g.Hi + h0) * g.Wi + w0);
+    r.mask = live ? m : 0u;
     return r;
 }
-__device__ __forceinline__ float gather_x(const ConvArgs& a, const OutAnchor& r, int64_t koff, int dt, int dh, int dw,
-                                          bool live) {
-    const int ti = r.t0 + dt, hi = r.h0 + dh, wi = r.w0 + dw;
-    const bool ok = live && ti >= r.lo && ti < r.up && (unsigned)hi < (unsigned)a.g.Hi && (unsigned)wi < (unsigned)a.g.Wi;
-    return ld_or_zero(a.x, r.base + koff, ok);
+// an INPUT position i is reached from output ((i + p - tap) / s) when that division is exact: DGRAD.
+// Strides are 1 or 2, so (i + p - tap) / s == ((i + p) >> (s-1)) - (tap >> (s-1)) whenever it is exact.
+__device__ __forceinline__ Anchor anchor_of_input(const ConvGeom& g, const float* dy, const PosDec& i, bool live) {
+    const int tn = i.t + g.pt, hn = i.h + g.ph, wn = i.w + g.pw;
+    const int st1 = g.st - 1, sh1 = g.sh - 1, sw1 = g.sw - 1;
+    int lo, up;
+    level_bounds(g, i.t, g.Ti, lo, up);
+    if (g.nlev <= 1) { lo = 0; up = g.To; }
+    unsigned m = 0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const int vt = tn - d, vh = hn - d, vw = wn - d;
+        m |= (unsigned)(d < g.kt && vt >= 0 && (vt & st1) == 0 && (vt >> st1) >= lo && (vt >> st1) < up) << d;
+        m |= (unsigned)(d < g.kh && vh >= 0 && (vh & sh1) == 0 && (vh >> sh1) < g.Ho) << (8 + d);
+        m |= (unsigned)(d < g.kw && vw >= 0 && (vw & sw1) == 0 && (vw >> sw1) < g.Wo) << (16 + d);
+    }
+    Anchor r;
+    r.base = dy + ((int64_t)i.b * g.y_bs + ((int64_t)(tn >> st1) * g.Ho + (hn >> sh1)) * g.Wo + (wn >> sw1));
+    r.mask = live ? m : 0u;
+    return r;
+}
+__device__ __forceinline__ bool tap_ok(unsigned mask, int dt, int dh, int dw) {
+    return ((mask >> dt) & (mask >> (8 + dh)) & (mask >> (16 + dw)) & 1u) != 0;
+}
+__device__ __forceinline__ float ld_sel(const float* p, bool ok) {
+    const float* q = ok ? p : g_zero4;
+    return *q;
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, bool AVEC>
@@ -112,38 +148,42 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     const int b_k0 = __builtin_amdgcn_readfirstlane(tid / BN);
     const int a_k = tid & 15, a_m = tid >> 4;
     const int v_k = (tid & 3) * 4, v_m = tid >> 2;
-    bool n_ok = false;
-    OutAnchor anchor = {};                   // FWD: this thread's output column
-    PosDec ipos = {0, 0, 0, 0};              // DGRAD: this thread's input position
-    int64_t ibase = 0;
-    int ilo = 0, iup = 0;
-    int64_t wcoff[B_PER];                    // WGRAD: this thread's B_PER fixed (ci, tap) columns
-    int wtap[B_PER];                         //        packed dt | dh << 8 | dw << 16, -1 = out of range
+    Anchor anchor = {g_zero4, 0u};           // FWD: this thread's output column; DGRAD: its input position
+    int wcoff[B_PER];                        // WGRAD: this thread's B_PER fixed (ci, tap) columns: element offset
+    int wtap[B_PER];                         //        dt | (8+dh) << 8 | (16+dw) << 16, or -1 when out of range
     if constexpr (MODE == MODE_FWD) {
         const int n = n0 + b_n;
-        n_ok = n < a.N;
-        if (n_ok) anchor = make_out_anchor(g, dec_pos_fd(n, fd.To, fd.Ho, fd.Wo));
+        anchor = anchor_of_output(g, a.x, dec_pos_fd(n < a.N ? n : 0, fd.To, fd.Ho, fd.Wo), n < a.N);
     } else if constexpr (MODE == MODE_DGRAD) {
         const int n = n0 + b_n;
-        n_ok = n < a.N;
-        if (n_ok) {
-            ipos = dec_pos_fd(n, fd.Ti, fd.Hi, fd.Wi);
-            ibase = (int64_t)ipos.b * g.y_bs;
-            level_bounds(g, ipos.t, g.Ti, ilo, iup);      // stride 1 when packed; else [0, Ti) -- widen to To
-            if (g.nlev <= 1) { ilo = 0; iup = g.To; }
-        }
+        anchor = anchor_of_input(g, a.dy, dec_pos_fd(n < a.N ? n : 0, fd.Ti, fd.Hi, fd.Wi), n < a.N);
     } else {
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
             const int n = n0 + (tid >> 4) + 16 * j;
-            if (n < a.N) {
-                const TapDec t = dec_tap_fd(fd, n);
-                wcoff[j] = (int64_t)t.c * g.x_cs + (int64_t)t.dt * HWi + t.dh * g.Wi + t.dw;
-                wtap[j] = t.dt | (t.dh << 8) | (t.dw << 16);
-            } else {
-                wcoff[j] = 0;
-                wtap[j] = -1;
-            }
+            const TapDec t = dec_tap_fd(fd, n < a.N ? n : 0);
+            wcoff[j] = t.c * (int)g.x_cs + t.dt * HWi + t.dh * g.Wi + t.dw;
+            wtap[j] = n < a.N ? (t.dt | ((8 + t.dh) << 8) | ((16 + t.dw) << 16)) : -1;
+        }
+    }
+    // A operand rows of this thread: weights (FWD/DGRAD) or dy rows (WGRAD), as element offsets
+    constexpr int A_VPASS_ = (BM + 63) / 64;
+    int64_t arow[AVEC ? A_VPASS_ : A_PER];
+    bool arow_ok[AVEC ? A_VPASS_ : A_PER];
+#pragma unroll
+    for (int j = 0; j < (AVEC ? A_VPASS_ : A_PER); ++j) {
+        if constexpr (MODE == MODE_WGRAD) {
+            const int m = m0 + a_m + 16 * j;
+            arow_ok[j] = m < a.M;
+            arow[j] = (int64_t)m * g.y_cs;
+        } else if constexpr (AVEC) {
+            const int m = m0 + v_m + 64 * j;
+            arow_ok[j] = v_m + 64 * j < BM && m < a.M;
+            arow[j] = (int64_t)m * a.K + v_k;
+        } else {
+            const int m = m0 + a_m + 16 * j;
+            arow_ok[j] = m < a.M;
+            arow[j] = (int64_t)m * a.K + a_k;
         }
     }
 
@@ -154,55 +194,51 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int B_PER_CH = B_PER / NCH;
     static_assert(A_LOADS <= NCH && B_PER % NCH == 0, "chunking");
     float ra[A_REGS], rb[B_PER];
-    OutAnchor wanchor = {};                  // WGRAD: anchor of this thread's k (an output position), per K step
-    int64_t wdyoff = 0;
+    Anchor wanchor = {g_zero4, 0u};          // WGRAD: anchor of this thread's k (an output position), per K step
+    const float* wdyp = g_zero4;
     bool wkok = false;
 
     // ---- next-tile loaders, one element (or float4) at a time so that they can be spread between the
-    // MFMAs of the current tile.  `live` false (no next tile / out of range) reads the device zero word.
+    // MFMAs of the current tile.  Out-of-range elements read the device zero word (pointer select).
     auto prep = [&](int k0, bool live) {
         if constexpr (MODE == MODE_WGRAD) {
             const int k = k0 + a_k;
-            wkok = live && k < k_end;
-            const PosDec o = dec_pos_fd(wkok ? k : 0, fd.To, fd.Ho, fd.Wo);
-            wdyoff = (int64_t)o.b * g.y_bs + ((int64_t)o.t * g.Ho + o.h) * g.Wo + o.w;
-            wanchor = make_out_anchor(g, o);
+            const bool kok = live && k < k_end;
+            const PosDec o = dec_pos_fd(kok ? k : 0, fd.To, fd.Ho, fd.Wo);
+            wdyp = a.dy + ((int64_t)o.b * g.y_bs + ((int64_t)o.t * g.Ho + o.h) * g.Wo + o.w);
+            wanchor = anchor_of_output(g, a.x, o, kok);
+            wkok = kok;
         }
     };
     auto loadA = [&](int j, int k0, bool live) {
         if constexpr (MODE == MODE_WGRAD) {
-            const int m = m0 + a_m + 16 * j;
-            ra[j] = ld_or_zero(a.dy, wdyoff + (int64_t)m * g.y_cs, wkok && m < a.M);
+            ra[j] = ld_sel(wdyp + arow[j], wkok && arow_ok[j]);
         } else if constexpr (AVEC) {            // weights [M][K], K % 4 == 0, 16-byte aligned rows
-            const int m = m0 + v_m + 64 * j;
-            const bool ok = live && v_m + 64 * j < BM && m < a.M && k0 + v_k < k_end;
-            const float* ap = ok ? a.w + (int64_t)m * a.K + k0 + v_k : g_zero4;
+            const bool ok = live && arow_ok[j] && k0 + v_k < k_end;
+            const float* ap = ok ? a.w + arow[j] + k0 : g_zero4;
             const float4 v = *reinterpret_cast<const float4*>(ap);
             ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
         } else {
-            const int k = k0 + a_k, m = m0 + a_m + 16 * j;
-            ra[j] = ld_or_zero(a.w, (int64_t)m * a.K + k, live && k < k_end && m < a.M);
+            ra[j] = ld_sel(a.w + arow[j] + k0, live && arow_ok[j] && k0 + a_k < k_end);
         }
     };
     auto loadB = [&](int j, int k0, bool live) {
         if constexpr (MODE == MODE_WGRAD) {
             const int tp = wtap[j];
-            rb[j] = gather_x(a, wanchor, wcoff[j], tp & 255, (tp >> 8) & 255, (tp >> 16) & 255, wkok && tp >= 0);
+            const bool ok = tp >= 0 && tap_ok(wanchor.mask, tp & 255, (tp >> 8) & 255, (tp >> 16) & 255);
+            rb[j] = ld_sel(wanchor.base + wcoff[j], ok);
         } else {
-            const int kk = k0 + b_k0 + B_ROWS * j;              // wave-uniform
-            const bool ok0 = live && kk < k_end && n_ok;
-            const TapDec t = dec_tap_fd(fd, ok0 ? kk : 0);
+            const int kk = k0 + b_k0 + B_ROWS * j;                  // wave-uniform: tap math runs on the scalar unit
+            const bool ulive = live && kk < k_end;
+            const TapDec t = dec_tap_fd(fd, (uint32_t)kk);
+            int64_t koff;
             if constexpr (MODE == MODE_FWD) {
-                const int64_t koff = (int64_t)t.c * g.x_cs + (int64_t)t.dt * HWi + t.dh * g.Wi + t.dw;
-                rb[j] = gather_x(a, anchor, koff, t.dt, t.dh, t.dw, ok0);
+                koff = (int64_t)t.c * g.x_cs + (int64_t)t.dt * HWi + t.dh * g.Wi + t.dw;
             } else {
-                int to = 0, ho = 0, wo = 0;
-                bool ok = ok0 & div_stride12(ipos.t + g.pt - t.dt, g.st, g.To, to);
-                ok = ok & div_stride12(ipos.h + g.ph - t.dh, g.sh, g.Ho, ho);
-                ok = ok & div_stride12(ipos.w + g.pw - t.dw, g.sw, g.Wo, wo);
-                ok = ok & (to >= ilo) & (to < iup);
-                rb[j] = ld_or_zero(a.dy, ibase + (int64_t)t.c * g.y_cs + ((int64_t)to * g.Ho + ho) * g.Wo + wo, ok);
+                koff = (int64_t)t.c * g.y_cs -
+                       (((int64_t)(t.dt >> (g.st - 1)) * g.Ho + (t.dh >> (g.sh - 1))) * g.Wo + (t.dw >> (g.sw - 1)));
             }
+            rb[j] = ld_sel(anchor.base + koff, ulive && tap_ok(anchor.mask, t.dt, t.dh, t.dw));
         }
     };
     auto store_tiles = [&](int buf) {
@@ -241,6 +277,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (k_end - k_begin + BK - 1) / BK;
+    const bool dbg_load = !(a.flags & DBG_NOLOAD);
     prep(k_begin, nk > 0);
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) loadA(j, k_begin, nk > 0);
@@ -254,7 +291,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     // store after the last MFMA, and one barrier per K step flips the LDS buffers.
     for (int it = 0; it < nk; ++it) {
         const int buf = it & 1;
-        const bool has_next = it + 1 < nk;
+        const bool has_next = (it + 1 < nk) && dbg_load;
         const int kn = k_begin + (it + 1) * BK;
         const float* as = As[buf];
         const float* bs = Bs[buf];
@@ -277,8 +314,8 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);      // keep the slices where they are
         }
-        store_tiles(buf ^ 1);                       // harmless on the last step (buffer is never read)
-        __syncthreads();
+        if (!(a.flags & DBG_NOSTORE)) store_tiles(buf ^ 1);   // harmless on the last step (buffer is never read)
+        if (!(a.flags & DBG_NOBARRIER)) __syncthreads();
     }
 
     // ---- epilogue.  C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -372,6 +409,8 @@ int fill_geom(ConvGeom& g, const int* d) {
     const int v[] = {g.B, g.Cin, g.Cout, g.Ti, g.Hi, g.Wi, g.To, g.Ho, g.Wo, g.kt, g.kh, g.kw, g.st, g.sh, g.sw};
     for (int x : v) if (x <= 0) return OTAL_E_SHAPE;
     if (g.pt < 0 || g.ph < 0 || g.pw < 0) return OTAL_E_SHAPE;
+    if (g.kt > 8 || g.kh > 8 || g.kw > 8) return OTAL_E_UNSUPPORTED;      // 8-bit validity masks per axis
+    if (g.st > 2 || g.sh > 2 || g.sw > 2) return OTAL_E_UNSUPPORTED;      // gathers are specialised for strides 1, 2
     if (g.nlev > 1) {
         if (g.nlev > OTAL_CONV_MAX_LEVELS || g.Hi != 1 || g.Wi != 1 || g.st != 1 || g.Ti != g.To) return OTAL_E_LEVELS;
         if (g.lev[0] != 0 || g.lev[g.nlev] != g.Ti) return OTAL_E_LEVELS;
@@ -407,6 +446,7 @@ int choose_splits(int tiles, int K) {
 
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (const char* d = getenv("OTAL_CONV_DEBUG")) a.flags |= (atoi(d) & (DBG_NOLOAD | DBG_NOSTORE | DBG_NOBARRIER));
     const int BMsel = choose_bm(a.M);
     const int BN = 128;
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + BN - 1) / BN;
