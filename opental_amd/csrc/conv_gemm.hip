@@ -150,7 +150,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     const int v_k = (tid & 3) * 4, v_m = tid >> 2;
     Anchor anchor = {g_zero4, 0u};           // FWD: this thread's output column; DGRAD: its input position
     int wcoff[B_PER];                        // WGRAD: this thread's B_PER fixed (ci, tap) columns: element offset
-    int wtap[B_PER];                         //        dt | (8+dh) << 8 | (16+dw) << 16, or -1 when out of range
+    int wtap[B_PER];                         //        dt | dh << 8 | dw << 16, or -1 when out of range
     if constexpr (MODE == MODE_FWD) {
         const int n = n0 + b_n;
         anchor = anchor_of_output(g, a.x, dec_pos_fd(n < a.N ? n : 0, fd.To, fd.Ho, fd.Wo), n < a.N);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
             const int n = n0 + (tid >> 4) + 16 * j;
             const TapDec t = dec_tap_fd(fd, n < a.N ? n : 0);
             wcoff[j] = t.c * (int)g.x_cs + t.dt * HWi + t.dh * g.Wi + t.dw;
-            wtap[j] = n < a.N ? (t.dt | ((8 + t.dh) << 8) | ((16 + t.dw) << 16)) : -1;
+            wtap[j] = n < a.N ? (t.dt | (t.dh << 8) | (t.dw << 16)) : -1;
         }
     }
     // A operand rows of this thread: weights (FWD/DGRAD) or dy rows (WGRAD), as element offsets
