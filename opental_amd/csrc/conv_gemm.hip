@@ -166,24 +166,21 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
             wtap[j] = n < a.N ? (t.dt | (t.dh << 8) | (t.dw << 16)) : -1;
         }
     }
-    // A operand rows of this thread: weights (FWD/DGRAD) or dy rows (WGRAD), as element offsets
+    // A operand rows of this thread: weights (FWD/DGRAD) or dy rows (WGRAD), as 32-bit element offsets
+    // (weight numel and per-sample sizes are < 2^31, checked on the host); -1 = row out of range
     constexpr int A_VPASS_ = (BM + 63) / 64;
-    int64_t arow[AVEC ? A_VPASS_ : A_PER];
-    bool arow_ok[AVEC ? A_VPASS_ : A_PER];
+    int arow[AVEC ? A_VPASS_ : A_PER];
 #pragma unroll
     for (int j = 0; j < (AVEC ? A_VPASS_ : A_PER); ++j) {
         if constexpr (MODE == MODE_WGRAD) {
             const int m = m0 + a_m + 16 * j;
-            arow_ok[j] = m < a.M;
-            arow[j] = (int64_t)m * g.y_cs;
+            arow[j] = m < a.M ? m * (int)g.y_cs : -1;
         } else if constexpr (AVEC) {
             const int m = m0 + v_m + 64 * j;
-            arow_ok[j] = v_m + 64 * j < BM && m < a.M;
-            arow[j] = (int64_t)m * a.K + v_k;
+            arow[j] = (v_m + 64 * j < BM && m < a.M) ? m * a.K + v_k : -1;
         } else {
             const int m = m0 + a_m + 16 * j;
-            arow_ok[j] = m < a.M;
-            arow[j] = (int64_t)m * a.K + a_k;
+            arow[j] = m < a.M ? m * a.K + a_k : -1;
         }
     }
 
@@ -194,9 +191,11 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int B_PER_CH = B_PER / NCH;
     static_assert(A_LOADS <= NCH && B_PER % NCH == 0, "chunking");
     float ra[A_REGS], rb[B_PER];
-    Anchor wanchor = {g_zero4, 0u};          // WGRAD: anchor of this thread's k (an output position), per K step
-    const float* wdyp = g_zero4;
-    bool wkok = false;
+    // WGRAD: per K step this thread's k is one output position; its taps are per-lane (fixed per column)
+    const float* wxp = g_zero4;              // a.x + b*x_bs + ((to*st-pt)*Hi + (ho*sh-ph))*Wi + (wo*sw-pw)
+    const float* wdyp = g_zero4;             // a.dy + b*y_bs + pos
+    int wt0 = 0, wh0 = 0, ww0 = 0;           // input coordinate of tap (0,0,0), t relative to the level start
+    unsigned wtr = 0;                        // temporal extent of the level (0 when k is out of range)
 
     // ---- next-tile loaders, one element (or float4) at a time so that they can be spread between the
     // MFMAs of the current tile.  Out-of-range elements read the device zero word (pointer select).
@@ -205,28 +204,36 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
             const int k = k0 + a_k;
             const bool kok = live && k < k_end;
             const PosDec o = dec_pos_fd(kok ? k : 0, fd.To, fd.Ho, fd.Wo);
+            int lo, up;
+            level_bounds(g, o.t, g.Ti, lo, up);
+            const int t0 = o.t * g.st - g.pt;
+            wh0 = o.h * g.sh - g.ph;
+            ww0 = o.w * g.sw - g.pw;
+            wt0 = t0 - lo;
+            wtr = kok ? (unsigned)(up - lo) : 0u;
             wdyp = a.dy + ((int64_t)o.b * g.y_bs + ((int64_t)o.t * g.Ho + o.h) * g.Wo + o.w);
-            wanchor = anchor_of_output(g, a.x, o, kok);
-            wkok = kok;
+            wxp = a.x + ((int64_t)o.b * g.x_bs + ((int64_t)t0 * g.Hi + wh0) * g.Wi + ww0);
         }
     };
     auto loadA = [&](int j, int k0, bool live) {
         if constexpr (MODE == MODE_WGRAD) {
-            ra[j] = ld_sel(wdyp + arow[j], wkok && arow_ok[j]);
+            ra[j] = ld_sel(wdyp + arow[j], wtr != 0u && arow[j] >= 0);
         } else if constexpr (AVEC) {            // weights [M][K], K % 4 == 0, 16-byte aligned rows
-            const bool ok = live && arow_ok[j] && k0 + v_k < k_end;
+            const bool ok = live && arow[j] >= 0 && k0 + v_k < k_end;
             const float* ap = ok ? a.w + arow[j] + k0 : g_zero4;
             const float4 v = *reinterpret_cast<const float4*>(ap);
             ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
         } else {
-            ra[j] = ld_sel(a.w + arow[j] + k0, live && arow_ok[j] && k0 + a_k < k_end);
+            ra[j] = ld_sel(a.w + arow[j] + k0, live && arow[j] >= 0 && k0 + a_k < k_end);
         }
     };
     auto loadB = [&](int j, int k0, bool live) {
         if constexpr (MODE == MODE_WGRAD) {
             const int tp = wtap[j];
-            const bool ok = tp >= 0 && tap_ok(wanchor.mask, tp & 255, (tp >> 8) & 255, (tp >> 16) & 255);
-            rb[j] = ld_sel(wanchor.base + wcoff[j], ok);
+            const bool ok = (tp >= 0) & ((unsigned)(wt0 + (tp & 255)) < wtr) &
+                            ((unsigned)(wh0 + ((tp >> 8) & 255)) < (unsigned)g.Hi) &
+                            ((unsigned)(ww0 + ((tp >> 16) & 255)) < (unsigned)g.Wi);
+            rb[j] = ld_sel(wxp + wcoff[j], ok);
         } else {
             const int kk = k0 + b_k0 + B_ROWS * j;                  // wave-uniform: tap math runs on the scalar unit
             const bool ulive = live && kk < k_end;
@@ -416,6 +423,8 @@ int fill_geom(ConvGeom& g, const int* d) {
         if (g.lev[0] != 0 || g.lev[g.nlev] != g.Ti) return OTAL_E_LEVELS;
         for (int i = 0; i < g.nlev; ++i) if (g.lev[i + 1] <= g.lev[i]) return OTAL_E_LEVELS;
     }
+    if ((int64_t)g.Cin * g.Ti * g.Hi * g.Wi >= (1LL << 31) || (int64_t)g.Cout * g.To * g.Ho * g.Wo >= (1LL << 31) ||
+        (int64_t)g.Cout * g.Cin * g.kt * g.kh * g.kw >= (1LL << 31)) return OTAL_E_SHAPE;   // 32-bit row offsets
     if ((int64_t)g.B * g.To * g.Ho * g.Wo >= (1LL << 31) || (int64_t)g.B * g.Ti * g.Hi * g.Wi >= (1LL << 31) ||
         (int64_t)g.Cin * g.kt * g.kh * g.kw >= (1LL << 31) || (int64_t)g.Cout * g.kt * g.kh * g.kw >= (1LL << 31)) return OTAL_E_SHAPE;
     return 0;
@@ -441,7 +450,7 @@ int choose_splits(int tiles, int K) {
     int maxs = K / (4 * BK);              // at least 4 K-steps per split
     if (maxs < 1) maxs = 1;
     int s = want < maxs ? want : maxs;
-    return s < 1 ? 1 : (s > 64 ? 64 : s);
+    return s < 1 ? 1 : (s > 384 ? 384 : s);
 }
 
 template <int MODE>
