@@ -145,6 +145,28 @@ int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const float* dy,
 int otal_proposal_windows(const float* loc, float* seg, float* frame_seg, int B, int nlev,
                           const int* lev, float frame_num, void* stream);
 
+/* ------------------------------------------------------------------ inference post-processing ----
+ * otal_decode_clips: parse_output + decode_predictions + the threshold test of filtering
+ * (AFSD/thumos14/test.py:79-162) for `nclips` clips in one launch.  Inputs are the model outputs
+ * (nclips,A,.) as the reference lays them out; offsets/fps: per-clip frame offset and sampling rate.
+ * Outputs: seg (nclips,A,2) seconds, score (nclips,K,A), unct/actn (nclips,A), flag (nclips,K,A) uint8
+ * = score > conf_thresh && actionness > 0.5. */
+int otal_decode_clips(const float* loc, const float* prop_loc, const float* priors, const float* conf,
+                      const float* prop_conf, const float* center, const float* act, const float* prop_act,
+                      const float* offsets, const float* fps, float* seg, float* score, float* unct,
+                      float* actn, unsigned char* flag, int nclips, int A, int K, float clip_length,
+                      float conf_thresh, void* stream);
+/* otal_softnms_classes: for every (video, class) gather the flagged candidates of the video's clips
+ * [clip_start[v], clip_start[v+1]) in clip-major / anchor-minor order and run softnms_v2
+ * (AFSD/common/segment_utils.py:128-162; get_video_detections, test.py:165-200).
+ * out: (nvideos*K, top_k, out_cols) rows [start,end,decayed score,unct,actionness] in original index
+ * order; counts: (nvideos*K); out_index (nullable): (nvideos*K, top_k) source row = clip*A + anchor,
+ * relative to the video's first clip.  max_clips bounds the clips of one video. */
+int otal_softnms_classes(const float* seg, const float* score, const float* unct, const float* actn,
+                         const unsigned char* flag, const int* clip_start, int nvideos, int max_clips,
+                         int A, int K, float sigma, int top_k, float score_threshold, float* out,
+                         int* counts, int* out_index, int out_cols, void* stream);
+
 /* ------------------------------------------------------------------ optimizer ----
  * torch.optim.Adam with L2 weight decay (AFSD/thumos14/train.py:321-323) over one flat fp32
  * arena; g is multiplied by grad_scale first (1/world_size after a sum all-reduce). */

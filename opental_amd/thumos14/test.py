@@ -1,0 +1,134 @@
+"""Inference path of OpenTAL/AFSD on MI355X, with the reference's function names
+(AFSD/thumos14/test.py): get_offsets (:48-56), prepare_clip (:67-76), parse_output (:79-109),
+decode_predictions (:112-140), filtering (:143-162), get_video_detections (:165-200).
+
+`detect_batch` is the MI355X-first entry point: all sliding windows of a batch of videos go through
+the network in large batches (the reference runs b=1, test.py:227-235), then TWO launches do the
+rest -- otal_decode_clips (decode + per-class threshold for every clip) and otal_softnms_classes
+(gather + Soft-NMS for every (video, class)) -- with no host synchronisation until the final copy.
+Multi-GPU: shard the video list across ranks (as the reference's unused AFSD/anet/test.py:248-273
+sketches); there is no collective on this path.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib as L
+
+
+def get_offsets(sample_count, clip_length, stride):
+    """test.py:48-56 with the video's sample count passed in."""
+    if sample_count < clip_length:
+        return [0]
+    out = list(range(0, sample_count - clip_length + 1, stride))
+    if (sample_count - clip_length) % stride:
+        out += [sample_count - clip_length]
+    return out
+
+
+def prepare_clip(data, offset, clip_length):
+    """uint8 (C,T,H,W) device tensor -> (1,C,clip_length,H,W) float in [-1,1], zero padded (test.py:67-76)."""
+    clip = data[:, offset: offset + clip_length].float()
+    clip = (clip / 255.0) * 2.0 - 1.0
+    if clip.size(1) < clip_length:
+        pad = torch.zeros([clip.size(0), clip_length - clip.size(1), clip.size(2), clip.size(3)], device=clip.device)
+        clip = torch.cat([clip, pad], dim=1)
+    return clip.unsqueeze(0)
+
+
+def decode_clips(output_dict, offsets, fps, clip_length=256, conf_thresh=0.01):
+    """Batched parse_output + decode_predictions + threshold masks.  output_dict: model outputs for
+    `n` clips; offsets/fps: per-clip tensors or lists.  Returns dict(seg, score, unct, actn, flag)."""
+    loc = output_dict['loc'].contiguous()
+    n, A, _ = loc.shape
+    K = output_dict['conf'].shape[-1]
+    dev = loc.device
+    offs = torch.as_tensor(offsets, dtype=torch.float32, device=dev).contiguous()
+    fpst = torch.as_tensor(fps, dtype=torch.float32, device=dev).contiguous()
+    if fpst.numel() == 1:
+        fpst = fpst.expand(n).contiguous()
+    seg = torch.empty((n, A, 2), device=dev)
+    score = torch.empty((n, K, A), device=dev)
+    unct = torch.empty((n, A), device=dev)
+    actn = torch.empty((n, A), device=dev)
+    flag = torch.empty((n, K, A), dtype=torch.uint8, device=dev)
+    t = lambda k: output_dict[k].contiguous()
+    L.check(L.lib().otal_decode_clips(L.ptr(loc), L.ptr(t('prop_loc')), L.ptr(output_dict['priors'].contiguous()),
+                                      L.ptr(t('conf')), L.ptr(t('prop_conf')), L.ptr(t('center')), L.ptr(t('act')),
+                                      L.ptr(t('prop_act')), L.ptr(offs), L.ptr(fpst), L.ptr(seg), L.ptr(score),
+                                      L.ptr(unct), L.ptr(actn), L.ptr(flag), n, A, K, ctypes.c_float(clip_length),
+                                      ctypes.c_float(conf_thresh), L.stream()), "otal_decode_clips")
+    return dict(seg=seg, score=score, unct=unct, actn=actn, flag=flag)
+
+
+def decode_predictions(output_dict, idx, offset, sample_fps, clip_length=256):
+    """Single-clip view with the reference's return values (test.py:112-140):
+    decoded_segments (A,2), conf_scores (K,A), uncertainty (A,), actionness (A,)."""
+    one = {k: (v[idx:idx + 1] if (v is not None and k != 'priors') else v) for k, v in output_dict.items()}
+    d = decode_clips(one, [float(offset)], [float(sample_fps)], clip_length)
+    return d['seg'][0], d['score'][0], d['unct'][0], d['actn'][0]
+
+
+def filtering(decoded_segments, conf_score_cls, uncertainty, actionness, conf_thresh, use_edl=True, os_head=True):
+    """test.py:143-162 for one class: (n,5) rows [start,end,score,unct,act] or None."""
+    m = (conf_score_cls > conf_thresh) & (actionness > 0.5)
+    if int(m.sum()) == 0:
+        return None
+    return torch.cat([decoded_segments[m], conf_score_cls[m, None], uncertainty[m, None], actionness[m, None]], -1)
+
+
+def softnms_classes(dec, clip_start, top_k=5000, sigma=0.5, score_threshold=0.001):
+    """All (video, class) Soft-NMS problems in one launch.  clip_start: per-video clip ranges (V+1).
+    Returns rows (V,K,top_k,5), counts (V,K), index (V,K,top_k)."""
+    n, K, A = dec['score'].shape
+    dev = dec['score'].device
+    cs = torch.as_tensor(clip_start, dtype=torch.int32, device=dev).contiguous()
+    V = cs.numel() - 1
+    starts = [int(v) for v in clip_start]
+    max_clips = max(b - a for a, b in zip(starts[:-1], starts[1:]))
+    tk = min(int(top_k), max_clips * A)
+    out = torch.zeros((V, K, tk, 5), device=dev)
+    counts = torch.zeros((V, K), dtype=torch.int32, device=dev)
+    index = torch.zeros((V, K, tk), dtype=torch.int32, device=dev)
+    L.check(L.lib().otal_softnms_classes(L.ptr(dec['seg']), L.ptr(dec['score']), L.ptr(dec['unct']),
+                                         L.ptr(dec['actn']), L.ptr(dec['flag']), L.ptr(cs), V, max_clips, A, K,
+                                         ctypes.c_float(sigma), tk, ctypes.c_float(score_threshold), L.ptr(out),
+                                         L.ptr(counts), L.ptr(index), 5, L.stream()), "otal_softnms_classes")
+    return out, counts, index
+
+
+def get_video_detections(rows, counts, idx_to_class=None, top_k=5000):
+    """test.py:165-200: per-video proposal list from the suppressed rows of one video (K,top_k,5)."""
+    rows, counts = rows.cpu().numpy(), counts.cpu().numpy()
+    proposal_list = []
+    for cl in range(rows.shape[0]):
+        name = idx_to_class[cl + 1] if idx_to_class is not None else cl + 1
+        for i in range(int(counts[cl])):
+            r = rows[cl, i]
+            if r[2] > 0:
+                proposal_list.append({'label': name, 'score': float(r[2]), 'segment': [float(r[0]), float(r[1])],
+                                      'uncertainty': float(r[3]), 'actionness': float(r[4])})
+    return proposal_list
+
+
+@torch.no_grad()
+def detect_batch(net, videos, sample_fps, clip_length=256, stride=128, conf_thresh=0.01, top_k=5000, nms_sigma=0.5,
+                 batch_clips=16):
+    """videos: list of uint8 (C,T,96,96) device tensors (already centre-cropped).  Returns the
+    per-video rows/counts of Soft-NMS.  test.py:203-252 without the JSON dump."""
+    clips, offsets, fps, clip_start = [], [], [], [0]
+    for v, data in enumerate(videos):
+        offs = get_offsets(data.shape[1], clip_length, stride)
+        for o in offs:
+            clips.append((v, o))
+        offsets += [float(o) for o in offs]
+        fps += [float(sample_fps[v] if hasattr(sample_fps, '__len__') else sample_fps)] * len(offs)
+        clip_start.append(clip_start[-1] + len(offs))
+    outs = []
+    for i in range(0, len(clips), batch_clips):
+        batch = torch.cat([prepare_clip(videos[v], o, clip_length) for v, o in clips[i:i + batch_clips]], 0)
+        outs.append(net(batch))
+    merged = {k: (torch.cat([o[k] for o in outs], 0) if k != 'priors' else outs[0][k])
+              for k in ('loc', 'conf', 'prop_loc', 'prop_conf', 'center', 'act', 'prop_act', 'priors')}
+    dec = decode_clips(merged, offsets, fps, clip_length, conf_thresh)
+    return softnms_classes(dec, clip_start, top_k, nms_sigma) + (dec,)

@@ -1,0 +1,127 @@
+"""GPU parity of the inference post-processing (decode + filter + Soft-NMS) through the C ABI against
+the golden vectors produced by the imported reference (tests/golden/decode_b2.npz, softnms.npz) and the
+CPU oracle.  Kept index sets are compared exactly; values within fp32 tolerance (exp last-ulp)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import afsd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_softnms_v2_golden_vectors(golden_dir):
+    from opental_amd.common.segment_utils import softnms_v2
+    fx = np.load(os.path.join(golden_dir, "softnms.npz"))
+    for n in (0, 1, 2, 50, 400, 2000):
+        seg = torch.from_numpy(fx[f"in_{n}"]).cuda()
+        rows, count, mask = softnms_v2(seg, sigma=0.5, top_k=5000, score_threshold=0.001, use_edl=True, os_head=True,
+                                       get_mask=True)
+        assert np.array_equal(mask.cpu().numpy(), fx[f"mask_{n}"]), n
+        assert int(count) == int(fx[f"mask_{n}"].sum())
+        if int(count):
+            np.testing.assert_allclose(rows.cpu().numpy(), fx[f"rows_{n}"], rtol=2e-6, atol=1e-7)
+    rows, count, mask = softnms_v2(torch.from_numpy(fx["in_400"]).cuda(), top_k=20, use_edl=True, os_head=True,
+                                   get_mask=True)
+    assert int(count) == 20 and np.array_equal(mask.cpu().numpy(), fx["mask_400_top20"])
+    np.testing.assert_allclose(rows.cpu().numpy(), fx["rows_400_top20"], rtol=2e-6, atol=1e-7)
+
+
+def test_softnms_quirks():
+    from opental_amd.common.segment_utils import softnms_v2
+    one = torch.tensor([[0., 1., 0.9, 0.1, 0.9]]).cuda()
+    assert int(softnms_v2(one, use_edl=True, os_head=True)[1]) == 0          # last survivor never kept
+    three = torch.tensor([[0., 1., 0.2, 0, 0], [5., 6., 0.9, 0, 0], [10., 11., 0.5, 0, 0]]).cuda()
+    rows, cnt, mask = softnms_v2(three, use_edl=True, os_head=True, get_mask=True)
+    assert int(cnt) == 2 and mask.tolist() == [False, True, True]             # original index order
+    assert rows[0, 2].item() == pytest.approx(0.9) and rows[1, 2].item() == pytest.approx(0.5)
+    ties = torch.tensor([[0., 1., 0.5, 0, 0], [0.2, 1.2, 0.5, 0, 0], [9., 10., 0.5, 0, 0], [20., 21., 0.4, 0, 0]]).cuda()
+    r_ref, c_ref, m_ref = O.softnms_v2(ties.cpu())
+    r, c, m = softnms_v2(ties, use_edl=True, os_head=True, get_mask=True)
+    assert int(c) == c_ref and m.cpu().tolist() == m_ref.tolist()             # first maximum wins ties
+
+
+def _fixture_outputs(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "thumos_b2.npz"))
+    out = {k: torch.from_numpy(fx["out_" + k]).cuda() for k in
+           ("loc", "conf", "prop_loc", "prop_conf", "center", "act", "prop_act")}
+    out["priors"] = O.priors_all().cuda()
+    return out
+
+
+def test_decode_and_filter_golden(golden_dir):
+    from opental_amd.thumos14 import test as T
+    dfx = np.load(os.path.join(golden_dir, "decode_b2.npz"))
+    out = _fixture_outputs(golden_dir)
+    dec = T.decode_clips(out, [0.0, 384.0], [10.0, 10.0], 256, 0.01)
+    for idx in (0, 1):
+        np.testing.assert_allclose(dec["seg"][idx].cpu().numpy(), dfx[f"seg_{idx}"], rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(dec["score"][idx].cpu().numpy(), dfx[f"score_{idx}"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(dec["unct"][idx].cpu().numpy(), dfx[f"unct_{idx}"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(dec["actn"][idx].cpu().numpy(), dfx[f"act_{idx}"], rtol=1e-5, atol=1e-7)
+        seg, score, unct, actn = T.decode_predictions(out, idx, (0.0, 384.0)[idx], 10.0, 256)
+        for cl in (0, 7, 14):
+            got = T.filtering(seg, score[cl], unct, actn, 0.01)
+            key = f"filtered_{idx}_{cl}"
+            assert (got is None) == (key not in dfx.files)
+            if got is not None:
+                assert got.shape == dfx[key].shape            # same kept anchors, same order
+                np.testing.assert_allclose(got.cpu().numpy(), dfx[key], rtol=1e-5, atol=1e-6)
+                flagged = dec["flag"][idx, cl].bool().cpu().numpy()
+                ref_mask = (dfx[f"score_{idx}"][cl] > 0.01) & (dfx[f"act_{idx}"] > 0.5)
+                assert np.array_equal(flagged, ref_mask)
+
+
+def test_batched_gather_and_nms_matches_per_class_oracle():
+    from opental_amd.thumos14 import test as T
+    rs = np.random.RandomState(4)
+    A, K = 126, 15
+    clips_per_video = [3, 1, 7]
+    clip_start = np.concatenate([[0], np.cumsum(clips_per_video)]).tolist()
+    n = clip_start[-1]
+    centres = rs.uniform(5, 90, size=(n, 6))
+    c = centres[np.arange(n)[:, None], rs.randint(0, 6, size=(n, A))] + rs.normal(0, 2.0, size=(n, A))
+    w = np.abs(rs.normal(6, 3, size=(n, A))) + 0.5
+    seg = np.stack([c - w / 2, c + w / 2], -1).astype(np.float32)
+    score = rs.beta(0.5, 2.0, size=(n, K, A)).astype(np.float32)
+    unct = rs.uniform(0, 1, size=(n, A)).astype(np.float32)
+    actn = rs.uniform(0.3, 1, size=(n, A)).astype(np.float32)
+    flag = ((score > 0.2) & (actn[:, None, :] > 0.5)).astype(np.uint8)
+    flag[1] = 0                                            # a clip without any candidate
+    dec = {k: torch.from_numpy(v).cuda() for k, v in dict(seg=seg, score=score, unct=unct, actn=actn, flag=flag).items()}
+    rows, counts, index = T.softnms_classes(dec, clip_start, top_k=5000, sigma=0.5)
+    for v in range(3):
+        for k in (0, 4, 14):
+            sel = []
+            for cidx in range(clip_start[v], clip_start[v + 1]):
+                m = flag[cidx, k].astype(bool)
+                sel.append(np.concatenate([seg[cidx][m], score[cidx, k][m, None], unct[cidx][m, None], actn[cidx][m, None]], -1))
+            cand = torch.from_numpy(np.concatenate(sel, 0))
+            r_ref, c_ref, m_ref = O.softnms_v2_c(cand) if len(cand) else (cand, 0, None)
+            assert int(counts[v, k]) == c_ref, (v, k)
+            if c_ref:
+                np.testing.assert_allclose(rows[v, k, :c_ref].cpu().numpy(), r_ref.numpy(), rtol=2e-6, atol=1e-7)
+
+
+def test_full_size_properties():
+    """THUMOS-scale: 32 videos x 30 clips x 15 classes in one launch; size-independent invariants."""
+    from opental_amd.thumos14 import test as T
+    g = torch.Generator(device="cuda").manual_seed(0)
+    V, C, A, K = 32, 30, 126, 15
+    n = V * C
+    ctr = torch.rand(n, A, device="cuda", generator=g) * 400
+    w = torch.rand(n, A, device="cuda", generator=g) * 10 + 0.5
+    dec = dict(seg=torch.stack([ctr - w / 2, ctr + w / 2], -1).contiguous(),
+               score=torch.rand(n, K, A, device="cuda", generator=g) ** 3,
+               unct=torch.rand(n, A, device="cuda", generator=g), actn=torch.rand(n, A, device="cuda", generator=g))
+    dec["flag"] = ((dec["score"] > 0.3) & (dec["actn"][:, None, :] > 0.5)).to(torch.uint8)
+    rows, counts, index = T.softnms_classes(dec, list(range(0, n + 1, C)), top_k=5000, sigma=0.5)
+    nflag = dec["flag"].view(V, C, K, A).sum((1, 3)).cpu()
+    assert bool((counts.cpu() <= torch.clamp(nflag - 1, min=0)).all())        # the last survivor is never kept
+    kept = torch.arange(rows.shape[2], device="cuda")[None, None, :] < counts[..., None]
+    assert bool((rows[..., 2][kept] >= 0.001).all()) and bool((rows[..., 2][kept] <= 1.0).all())
+    idx = index.long()
+    inc = (idx[..., 1:] > idx[..., :-1]) | ~kept[..., 1:]
+    assert bool(inc.all())                                                     # original index order
