@@ -150,7 +150,7 @@ class InceptionI3d(nn.Module):
             self._plan = self._make_plan()
         plan, units = self._plan
         for u in units:
-            if u.bn.training or u.bn.weight.requires_grad:
+            if u.bn.training or (torch.is_grad_enabled() and u.bn.weight.requires_grad):
                 raise NotImplementedError("I3D BatchNorm must be frozen (freeze_bn + freeze_bn_affine, BDNet.py:39-49)")
         folded = [u.folded_bn() for u in units]
         offs = [0]

@@ -95,25 +95,18 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restr
     const unsigned char* ab = arg + (int64_t)bc * Po;
     const int kt = S::kt(g), kh = S::kh(g), kw = S::kw(g);
     const int st = S::st(g), sh = S::sh(g), sw = S::sw(g);
+    // only the windows that actually cover (ti,hi,wi): to in [ceil((ti+pt-kt+1)/st), floor((ti+pt)/st)], etc.
+    // (4 candidates for the stride-2 pools instead of 9/27 divisibility tests)
+    const int tn = ti + g.pt, hn = hi + g.ph, wn = wi + g.pw;
+    const int to_hi = min(tn / st, g.To - 1), ho_hi = min(hn / sh, g.Ho - 1), wo_hi = min(wn / sw, g.Wo - 1);
+    const int to_lo = max((tn - kt + st) / st, 0), ho_lo = max((hn - kh + sh) / sh, 0), wo_lo = max((wn - kw + sw) / sw, 0);
     float acc = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < kt; ++dt) {
-        const int tn = ti + g.pt - dt;
-        if (tn < 0 || tn % st) continue;
-        const int to = tn / st;
-        if (to >= g.To) continue;
-#pragma unroll
-        for (int dh = 0; dh < kh; ++dh) {
-            const int hn = hi + g.ph - dh;
-            if (hn < 0 || hn % sh) continue;
-            const int ho = hn / sh;
-            if (ho >= g.Ho) continue;
-#pragma unroll
-            for (int dw = 0; dw < kw; ++dw) {
-                const int wn = wi + g.pw - dw;
-                if (wn < 0 || wn % sw) continue;
-                const int wo = wn / sw;
-                if (wo >= g.Wo) continue;
+    for (int to = to_hi; to >= to_lo; --to) {            // descending output index == ascending tap (fixed order)
+        const int dt = tn - to * st;
+        for (int ho = ho_hi; ho >= ho_lo; --ho) {
+            const int dh = hn - ho * sh;
+            for (int wo = wo_hi; wo >= wo_lo; --wo) {
+                const int dw = wn - wo * sw;
                 const int o = (to * g.Ho + ho) * g.Wo + wo;
                 if (ab[o] == (dt * kh + dh) * kw + dw) acc += dyb[o];
             }
