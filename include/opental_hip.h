@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 3
+#define OTAL_ABI_VERSION 4
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -91,12 +91,15 @@ int otal_bmp_bwd_levels(const void* grad_out, const void* in, const float* seg, 
  *          are read / written in place.
  * ws     : optional split-K workspace (otal_conv_workspace_bytes); a smaller one only lowers the
  *          split factor.  Split-K partials are reduced in a fixed order (deterministic).
- * mode   : 0 forward, 1 data gradient, 2 weight gradient. */
+ * mode   : 0 forward, 1 data gradient, 2 weight gradient.
+ * precision: 0 = fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32, the parity path);
+ *            1 = operands rounded to bf16 when staged into LDS, v_mfma_f32_32x32x16_bf16, fp32
+ *                accumulation and fp32 tensors in HBM (the throughput path). */
 size_t otal_conv_workspace_bytes(const int* geom, int mode);
 
 /* y = act(scale[co] * conv(x, w) + shift[co]); scale/shift nullable (frozen BN folded, or bias). */
 int otal_conv_fwd(const int* geom, const int64_t* strides, const float* x, const float* w,
-                  const float* scale, const float* shift, float* y, int relu,
+                  const float* scale, const float* shift, float* y, int relu, int precision,
                   void* ws, size_t ws_bytes, void* stream);
 
 /* dx (+)= m * conv_transpose(dy, w); when out_mask/out_scale are given,
@@ -105,11 +108,11 @@ int otal_conv_fwd(const int* geom, const int64_t* strides, const float* x, const
  * is already the gradient w.r.t. its convolution output.  wt_packed = otal_conv_pack_wt(w). */
 int otal_conv_dgrad(const int* geom, const int64_t* strides, const float* dy, const float* wt_packed,
                     float* dx, int accumulate, const float* out_mask, const float* out_scale,
-                    void* ws, size_t ws_bytes, void* stream);
+                    int precision, void* ws, size_t ws_bytes, void* stream);
 
 /* dw (+)= sum_{b,pos} dy[b,co,pos] * x[b,ci,pos*s + tap - pad] */
 int otal_conv_wgrad(const int* geom, const int64_t* strides, const float* x, const float* dy,
-                    float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream);
+                    float* dw, int accumulate, int precision, void* ws, size_t ws_bytes, void* stream);
 
 /* (Cout,Cin,kvol) -> (Cin,Cout,kvol): the A operand of the data-gradient GEMM. */
 int otal_conv_pack_wt(const float* w, float* wt, int Cout, int Cin, int kvol, void* stream);

@@ -20,6 +20,10 @@ WORKSPACE_BYTES = 192 << 20
 # (torch's current stream IS the stream the C ABI launches on) and tagged with its algorithmic FLOPs.
 CONV_PROFILE = None
 
+# 0: fp32 MFMA (bit-for-bit an fp32 fma chain; the parity path).  1: bf16 MFMA operands with fp32
+# accumulation (BASELINE.json's benchmark dtype; tensors stay fp32 in HBM).  Set by bench.py --dtype.
+CONV_PRECISION = 0
+
 
 def _prof_begin():
     if CONV_PROFILE is None:
@@ -114,7 +118,7 @@ def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=F
     ws = workspace(x.device)
     ev = _prof_begin()
     L.check(L.lib().otal_conv_fwd(ga, sa, L.ptr(x5), L.ptr(w), _opt(scale), _opt(shift), L.ptr(y5), int(relu),
-                                  L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()), "otal_conv_fwd")
+                                  int(CONV_PRECISION), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()), "otal_conv_fwd")
     _prof_end(ev, "fwd", g)
     return out
 
@@ -157,7 +161,7 @@ def conv_dgrad(dy, w, x_shape, k, s, spatial_valid=False, levels=None, out=None,
         if tuple(m5.shape) != tuple(x5.shape) or tuple(_bs(m5)) != tuple(_bs(x5)):
             raise RuntimeError("out_mask must share dx's shape and layout")
     L.check(L.lib().otal_conv_dgrad(ga, sa, L.ptr(dy5), L.ptr(wt), L.ptr(x5),
-                                    int(accumulate), _opt(out_mask), _opt(out_scale),
+                                    int(accumulate), _opt(out_mask), _opt(out_scale), int(CONV_PRECISION),
                                     L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
             "otal_conv_dgrad")
     _prof_end(ev, "dgrad", g)
@@ -205,7 +209,7 @@ def conv_wgrad(x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None,
     ws = workspace(x.device)
     ev = _prof_begin()
     L.check(L.lib().otal_conv_wgrad(ga, sa, L.ptr(x5), L.ptr(dy5), L.ptr(out),
-                                    int(accumulate), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
+                                    int(accumulate), int(CONV_PRECISION), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
             "otal_conv_wgrad")
     _prof_end(ev, "wgrad", g)
     return out

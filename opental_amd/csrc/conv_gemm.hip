@@ -25,7 +25,7 @@
 
 namespace {
 
-constexpr int BK = 16, NT = 256;
+constexpr int NT = 256, BK_MIN = 16;
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 enum { EPI_RELU = 1, EPI_ACCUM = 2, DBG_NOLOAD = 4, DBG_NOSTORE = 8, DBG_NOBARRIER = 16 };   // DBG_*: ablation only (OTAL_CONV_DEBUG)
 
@@ -47,6 +47,7 @@ struct ConvArgs {
     int splits, k_per_split;   // k_per_split is a multiple of BK
     int flags;
     int a_vec4;            // A rows are 16-byte aligned and K % 4 == 0 -> float4 weight loads
+    int prec;              // 0: fp32 MFMA (exact), 1: bf16 MFMA operands, fp32 accumulate
 };
 
 // ---- operand element fetch -------------------------------------------------------------------
@@ -117,15 +118,29 @@ __device__ __forceinline__ float ld_sel(const float* p, bool ok) {
     return *q;
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, bool AVEC>
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {     // round to nearest even, lo in bits 0..15
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
+// PREC 0: fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32; BK = 16, LDS tiles k-major [k][m]).
+// PREC 1: operands rounded to bf16 while they are staged into LDS, v_mfma_f32_32x32x16_bf16 with fp32
+//         accumulation (16x the matrix rate; BK = 32, LDS tiles k-contiguous [m][k] with an 80-byte row
+//         pitch so that every ds_read_b128 operand fetch is bank-conflict free).  Tensors stay fp32 in HBM.
+template <int BM, int BN, int WM, int WN, int MODE, bool AVEC, int PREC>
 __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
-    constexpr int LDA = BM + 2, LDB = BN + 2;
-    constexpr int A_PER = BM * BK / NT;     // A elements per thread per K step (2, 4, 6 or 8)
-    constexpr int B_PER = BN * BK / NT;     // 8 (BN = 128) or 16 (BN = 256)
-    constexpr int B_ROWS = NT / BN;         // k rows covered per pass of the n-fast B loader (2 or 1)
-    static_assert(BN == 128 || BN == 256, "BN");
-    __shared__ float As[2][BK * LDA];
-    __shared__ float Bs[2][BK * LDB];
+    constexpr int BK = PREC ? 32 : 16;
+    constexpr int KP = 40;                                  // bf16 row pitch (elements): 32 + 8 pad = 80 bytes
+    constexpr int LDA = BM + 2, LDB = BN + 2;               // fp32 k-major pitches
+    constexpr int A_BYTES = PREC ? BM * KP * 2 : BK * LDA * 4;
+    constexpr int B_BYTES = PREC ? BN * KP * 2 : BK * LDB * 4;
+    __shared__ __attribute__((aligned(16))) char smemA[2][A_BYTES];
+    __shared__ __attribute__((aligned(16))) char smemB[2][B_BYTES];
+    static_assert(BN == 128, "BN");
 
     const ConvGeom& g = a.g;
     const ConvFastDiv& fd = a.fd;
@@ -139,18 +154,29 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     const int k_end = min(a.K, k_begin + a.k_per_split);
     const int HWi = g.Hi * g.Wi;
 
-    // ---- per-thread invariants of the loaders
-    // A tile, scalar map : lane&15 -> k, tid>>4 -> m (+16 per step)
-    // A tile, float4 map : (tid&3)*4 -> k, tid>>2 -> m (+64 per step)
-    // B tile, n-fast (FWD/DGRAD): tid % BN -> n, tid / BN + B_ROWS*j -> k   (k is wave-uniform)
-    // B tile, k-fast (WGRAD)    : tid&15 -> k, (tid>>4)+16j -> n
+    // ---- thread -> tile element maps
+    // B, n-fast (FWD/DGRAD): n = tid & 127; this thread owns BK/2 CONSECUTIVE k rows: k = (tid >> 7) * BK/2 + j
+    //                         (consecutive so that the bf16 path can pack them into ds_write_b128; wave-uniform)
+    // A, weights AVEC       : float4 along k: k = (tid % (BK/4)) * 4, m = tid / (BK/4) + (NT*4/BK) * j
+    // A, weights scalar     : k = tid % BK, m = tid / BK + (NT/BK) * j
+    // WGRAD (k-fast, both operands): k = (tid & 15) + 16 * p (p < BK/16), rows/cols = (tid >> 4) + 16 * j
+    constexpr int B_PER = BK / 2;                           // B elements per thread per K step (n-fast)
+    constexpr int AV_TPR = BK / 4;                          // threads per A row (float4 path)
+    constexpr int AV_ROWS = NT / AV_TPR;                    // rows per pass: 64 (fp32) / 32 (bf16)
+    constexpr int AV_PASS = (BM + AV_ROWS - 1) / AV_ROWS;
+    constexpr int AS_ROWS = NT / BK;                        // scalar path rows per pass: 16 / 8
+    constexpr int AS_PER = BM / AS_ROWS;
+    constexpr int KSUB = BK / 16;                           // WGRAD k sub-steps per K step
+    constexpr int WA_PER = BM / 16, WB_PER = BN / 16;       // WGRAD rows / cols per thread
     const int b_n = tid & (BN - 1);
-    const int b_k0 = __builtin_amdgcn_readfirstlane(tid / BN);
-    const int a_k = tid & 15, a_m = tid >> 4;
-    const int v_k = (tid & 3) * 4, v_m = tid >> 2;
+    const int b_kq = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int v_k = (tid % AV_TPR) * 4, v_m = tid / AV_TPR;
+    const int s_k = tid % BK, s_m = tid / BK;
+    const int w_k = tid & 15, w_r = tid >> 4;
+
     Anchor anchor = {g_zero4, 0u};           // FWD: this thread's output column; DGRAD: its input position
-    int wcoff[B_PER];                        // WGRAD: this thread's B_PER fixed (ci, tap) columns: element offset
-    int wtap[B_PER];                         //        dt | dh << 8 | dw << 16, or -1 when out of range
+    int wcoff[MODE == MODE_WGRAD ? WB_PER : 1];             // WGRAD: fixed (ci, tap) columns: element offset
+    int wtap[MODE == MODE_WGRAD ? WB_PER : 1];              //        dt | dh << 8 | dw << 16, or -1
     if constexpr (MODE == MODE_FWD) {
         const int n = n0 + b_n;
         anchor = anchor_of_output(g, a.x, dec_pos_fd(n < a.N ? n : 0, fd.To, fd.Ho, fd.Wo), n < a.N);
@@ -159,83 +185,86 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
         anchor = anchor_of_input(g, a.dy, dec_pos_fd(n < a.N ? n : 0, fd.Ti, fd.Hi, fd.Wi), n < a.N);
     } else {
 #pragma unroll
-        for (int j = 0; j < B_PER; ++j) {
-            const int n = n0 + (tid >> 4) + 16 * j;
+        for (int j = 0; j < WB_PER; ++j) {
+            const int n = n0 + w_r + 16 * j;
             const TapDec t = dec_tap_fd(fd, n < a.N ? n : 0);
             wcoff[j] = t.c * (int)g.x_cs + t.dt * HWi + t.dh * g.Wi + t.dw;
             wtap[j] = n < a.N ? (t.dt | (t.dh << 8) | (t.dw << 16)) : -1;
         }
     }
-    // A operand rows of this thread: weights (FWD/DGRAD) or dy rows (WGRAD), as 32-bit element offsets
-    // (weight numel and per-sample sizes are < 2^31, checked on the host); -1 = row out of range
-    constexpr int A_VPASS_ = (BM + 63) / 64;
-    int arow[AVEC ? A_VPASS_ : A_PER];
+    // A rows of this thread as 32-bit element offsets (-1 = out of range)
+    constexpr int A_ROWSN = MODE == MODE_WGRAD ? WA_PER : (AVEC ? AV_PASS : AS_PER);
+    int arow[A_ROWSN];
 #pragma unroll
-    for (int j = 0; j < (AVEC ? A_VPASS_ : A_PER); ++j) {
+    for (int j = 0; j < A_ROWSN; ++j) {
         if constexpr (MODE == MODE_WGRAD) {
-            const int m = m0 + a_m + 16 * j;
+            const int m = m0 + w_r + 16 * j;
             arow[j] = m < a.M ? m * (int)g.y_cs : -1;
         } else if constexpr (AVEC) {
-            const int m = m0 + v_m + 64 * j;
-            arow[j] = (v_m + 64 * j < BM && m < a.M) ? m * a.K + v_k : -1;
+            const int m = m0 + v_m + AV_ROWS * j;
+            arow[j] = (v_m + AV_ROWS * j < BM && m < a.M) ? m * a.K + v_k : -1;
         } else {
-            const int m = m0 + a_m + 16 * j;
-            arow[j] = m < a.M ? m * a.K + a_k : -1;
+            const int m = m0 + s_m + AS_ROWS * j;
+            arow[j] = m < a.M ? m * a.K + s_k : -1;
         }
     }
 
-    constexpr int A_VPASS = (BM + 63) / 64;                 // float4 passes of the A tile (AVEC)
-    constexpr int A_LOADS = AVEC ? A_VPASS : A_PER;         // A load instructions per thread per K step
-    constexpr int A_REGS = AVEC ? 4 * A_VPASS : A_PER;
-    constexpr int NCH = BK / 2;                             // one chunk per MFMA k-pair
-    constexpr int B_PER_CH = B_PER / NCH;
-    static_assert(A_LOADS <= NCH && B_PER % NCH == 0, "chunking");
-    float ra[A_REGS], rb[B_PER];
-    // WGRAD: per K step this thread's k is one output position; its taps are per-lane (fixed per column)
-    const float* wxp = g_zero4;              // a.x + b*x_bs + ((to*st-pt)*Hi + (ho*sh-ph))*Wi + (wo*sw-pw)
-    const float* wdyp = g_zero4;             // a.dy + b*y_bs + pos
-    int wt0 = 0, wh0 = 0, ww0 = 0;           // input coordinate of tap (0,0,0), t relative to the level start
-    unsigned wtr = 0;                        // temporal extent of the level (0 when k is out of range)
+    // ---- staging registers
+    constexpr int A_REGS = MODE == MODE_WGRAD ? WA_PER * KSUB : (AVEC ? 4 * AV_PASS : AS_PER);
+    constexpr int B_REGS = MODE == MODE_WGRAD ? WB_PER * KSUB : B_PER;
+    constexpr int A_LOADS = MODE == MODE_WGRAD ? WA_PER * KSUB : (AVEC ? AV_PASS : AS_PER);
+    constexpr int B_LOADS = B_REGS;
+    float ra[A_REGS], rb[B_REGS];
+    // WGRAD per-(K step, sub-step) position state
+    const float* wxp[KSUB];
+    const float* wdyp[KSUB];
+    int wt0[KSUB], wh0[KSUB], ww0[KSUB];
+    unsigned wtr[KSUB];
+#pragma unroll
+    for (int p = 0; p < KSUB; ++p) { wxp[p] = g_zero4; wdyp[p] = g_zero4; wt0[p] = wh0[p] = ww0[p] = 0; wtr[p] = 0u; }
 
-    // ---- next-tile loaders, one element (or float4) at a time so that they can be spread between the
-    // MFMAs of the current tile.  Out-of-range elements read the device zero word (pointer select).
     auto prep = [&](int k0, bool live) {
         if constexpr (MODE == MODE_WGRAD) {
-            const int k = k0 + a_k;
-            const bool kok = live && k < k_end;
-            const PosDec o = dec_pos_fd(kok ? k : 0, fd.To, fd.Ho, fd.Wo);
-            int lo, up;
-            level_bounds(g, o.t, g.Ti, lo, up);
-            const int t0 = o.t * g.st - g.pt;
-            wh0 = o.h * g.sh - g.ph;
-            ww0 = o.w * g.sw - g.pw;
-            wt0 = t0 - lo;
-            wtr = kok ? (unsigned)(up - lo) : 0u;
-            wdyp = a.dy + ((int64_t)o.b * g.y_bs + ((int64_t)o.t * g.Ho + o.h) * g.Wo + o.w);
-            wxp = a.x + ((int64_t)o.b * g.x_bs + ((int64_t)t0 * g.Hi + wh0) * g.Wi + ww0);
+#pragma unroll
+            for (int p = 0; p < KSUB; ++p) {
+                const int k = k0 + 16 * p + w_k;
+                const bool kok = live && k < k_end;
+                const PosDec o = dec_pos_fd(kok ? k : 0, fd.To, fd.Ho, fd.Wo);
+                int lo, up;
+                level_bounds(g, o.t, g.Ti, lo, up);
+                const int t0 = o.t * g.st - g.pt;
+                wh0[p] = o.h * g.sh - g.ph;
+                ww0[p] = o.w * g.sw - g.pw;
+                wt0[p] = t0 - lo;
+                wtr[p] = kok ? (unsigned)(up - lo) : 0u;
+                wdyp[p] = a.dy + ((int64_t)o.b * g.y_bs + ((int64_t)o.t * g.Ho + o.h) * g.Wo + o.w);
+                wxp[p] = a.x + ((int64_t)o.b * g.x_bs + ((int64_t)t0 * g.Hi + wh0[p]) * g.Wi + ww0[p]);
+            }
         }
     };
-    auto loadA = [&](int j, int k0, bool live) {
+    auto loadA = [&](int q, int k0, bool live) {         // q-th A load of the K step
         if constexpr (MODE == MODE_WGRAD) {
-            ra[j] = ld_sel(wdyp + arow[j], wtr != 0u && arow[j] >= 0);
-        } else if constexpr (AVEC) {            // weights [M][K], K % 4 == 0, 16-byte aligned rows
-            const bool ok = live && arow[j] >= 0 && k0 + v_k < k_end;
-            const float* ap = ok ? a.w + arow[j] + k0 : g_zero4;
+            const int p = q / WA_PER, j = q % WA_PER;
+            ra[q] = ld_sel(wdyp[p] + arow[j], wtr[p] != 0u && arow[j] >= 0);
+        } else if constexpr (AVEC) {
+            const bool ok = live && arow[q] >= 0 && k0 + v_k < k_end;
+            const float* ap = ok ? a.w + arow[q] + k0 : g_zero4;
             const float4 v = *reinterpret_cast<const float4*>(ap);
-            ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
+            ra[4 * q] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
         } else {
-            ra[j] = ld_sel(a.w + arow[j] + k0, live && arow[j] >= 0 && k0 + a_k < k_end);
+            ra[q] = ld_sel(a.w + arow[q] + k0, live && arow[q] >= 0 && k0 + s_k < k_end);
         }
     };
-    auto loadB = [&](int j, int k0, bool live) {
+    auto loadB = [&](int q, int k0, bool live) {         // q-th B load of the K step
         if constexpr (MODE == MODE_WGRAD) {
+            const int p = q / WB_PER, j = q % WB_PER;
             const int tp = wtap[j];
-            const bool ok = (tp >= 0) & ((unsigned)(wt0 + (tp & 255)) < wtr) &
-                            ((unsigned)(wh0 + ((tp >> 8) & 255)) < (unsigned)g.Hi) &
-                            ((unsigned)(ww0 + ((tp >> 16) & 255)) < (unsigned)g.Wi);
-            rb[j] = ld_sel(wxp + wcoff[j], ok);
+            const bool ok = (tp >= 0) & ((unsigned)(wt0[p] + (tp & 255)) < wtr[p]) &
+                            ((unsigned)(wh0[p] + ((tp >> 8) & 255)) < (unsigned)g.Hi) &
+                            ((unsigned)(ww0[p] + ((tp >> 16) & 255)) < (unsigned)g.Wi);
+            rb[q] = ld_sel(wxp[p] + wcoff[j], ok);
         } else {
-            const int kk = k0 + b_k0 + B_ROWS * j;                  // wave-uniform: tap math runs on the scalar unit
+            const int kk = k0 + b_kq * B_PER + q;                   // wave-uniform: tap math on the scalar unit
             const bool ulive = live && kk < k_end;
             const TapDec t = dec_tap_fd(fd, (uint32_t)kk);
             int64_t koff;
@@ -245,29 +274,68 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
                 koff = (int64_t)t.c * g.y_cs -
                        (((int64_t)(t.dt >> (g.st - 1)) * g.Ho + (t.dh >> (g.sh - 1))) * g.Wo + (t.dw >> (g.sw - 1)));
             }
-            rb[j] = ld_sel(anchor.base + koff, ulive && tap_ok(anchor.mask, t.dt, t.dh, t.dw));
+            rb[q] = ld_sel(anchor.base + koff, ulive && tap_ok(anchor.mask, t.dt, t.dh, t.dw));
         }
     };
     auto store_tiles = [&](int buf) {
-        if constexpr (MODE == MODE_WGRAD) {
+        if constexpr (PREC == 0) {
+            float* As = reinterpret_cast<float*>(smemA[buf]);
+            float* Bs = reinterpret_cast<float*>(smemB[buf]);
+            if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
-            for (int j = 0; j < A_PER; ++j) As[buf][a_k * LDA + a_m + 16 * j] = ra[j];
+                for (int j = 0; j < WA_PER; ++j) As[w_k * LDA + w_r + 16 * j] = ra[j];
 #pragma unroll
-            for (int j = 0; j < B_PER; ++j) Bs[buf][a_k * LDB + (tid >> 4) + 16 * j] = rb[j];
-        } else {
-            if constexpr (AVEC) {
-#pragma unroll
-                for (int j = 0; j < A_VPASS; ++j)
-                    if (v_m + 64 * j < BM) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) As[buf][(v_k + i) * LDA + v_m + 64 * j] = ra[4 * j + i];
-                    }
+                for (int j = 0; j < WB_PER; ++j) Bs[w_k * LDB + w_r + 16 * j] = rb[j];
             } else {
+                if constexpr (AVEC) {
 #pragma unroll
-                for (int j = 0; j < A_PER; ++j) As[buf][a_k * LDA + a_m + 16 * j] = ra[j];
+                    for (int j = 0; j < AV_PASS; ++j)
+                        if (v_m + AV_ROWS * j < BM) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) As[(v_k + i) * LDA + v_m + AV_ROWS * j] = ra[4 * j + i];
+                        }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < AS_PER; ++j) As[s_k * LDA + s_m + AS_ROWS * j] = ra[j];
+                }
+#pragma unroll
+                for (int j = 0; j < B_PER; ++j) Bs[(b_kq * B_PER + j) * LDB + b_n] = rb[j];
             }
+        } else {
+            unsigned short* As = reinterpret_cast<unsigned short*>(smemA[buf]);
+            unsigned short* Bs = reinterpret_cast<unsigned short*>(smemB[buf]);
+            if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
-            for (int j = 0; j < B_PER; ++j) Bs[buf][(b_k0 + B_ROWS * j) * LDB + b_n] = rb[j];
+                for (int q = 0; q < WA_PER * KSUB; ++q)
+                    As[(w_r + 16 * (q % WA_PER)) * KP + 16 * (q / WA_PER) + w_k] = (unsigned short)(pack_bf16x2(ra[q], 0.f) & 0xffffu);
+#pragma unroll
+                for (int q = 0; q < WB_PER * KSUB; ++q)
+                    Bs[(w_r + 16 * (q % WB_PER)) * KP + 16 * (q / WB_PER) + w_k] = (unsigned short)(pack_bf16x2(rb[q], 0.f) & 0xffffu);
+            } else {
+                if constexpr (AVEC) {
+#pragma unroll
+                    for (int j = 0; j < AV_PASS; ++j)
+                        if (v_m + AV_ROWS * j < BM) {
+                            uint2 pk;
+                            pk.x = pack_bf16x2(ra[4 * j], ra[4 * j + 1]);
+                            pk.y = pack_bf16x2(ra[4 * j + 2], ra[4 * j + 3]);
+                            *reinterpret_cast<uint2*>(As + (v_m + AV_ROWS * j) * KP + v_k) = pk;
+                        }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < AS_PER; ++j)
+                        As[(s_m + AS_ROWS * j) * KP + s_k] = (unsigned short)(pack_bf16x2(ra[j], 0.f) & 0xffffu);
+                }
+#pragma unroll
+                for (int h = 0; h < B_PER / 8; ++h) {
+                    uint4 pk;
+                    pk.x = pack_bf16x2(rb[8 * h], rb[8 * h + 1]);
+                    pk.y = pack_bf16x2(rb[8 * h + 2], rb[8 * h + 3]);
+                    pk.z = pack_bf16x2(rb[8 * h + 4], rb[8 * h + 5]);
+                    pk.w = pack_bf16x2(rb[8 * h + 6], rb[8 * h + 7]);
+                    *reinterpret_cast<uint4*>(Bs + b_n * KP + b_kq * B_PER + 8 * h) = pk;
+                }
+            }
         }
     };
 
@@ -287,38 +355,60 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     const bool dbg_load = !(a.flags & DBG_NOLOAD);
     prep(k_begin, nk > 0);
 #pragma unroll
-    for (int j = 0; j < A_LOADS; ++j) loadA(j, k_begin, nk > 0);
+    for (int q = 0; q < A_LOADS; ++q) loadA(q, k_begin, nk > 0);
 #pragma unroll
-    for (int j = 0; j < B_PER; ++j) loadB(j, k_begin, nk > 0);
+    for (int q = 0; q < B_LOADS; ++q) loadB(q, k_begin, nk > 0);
     store_tiles(0);
     __syncthreads();
     // Main loop, software-pipelined INSIDE the wave: the address math + global loads of tile it+1 are
-    // issued in NCH slices between the MFMA groups of tile it (an MFMA occupies the matrix pipe for 64
-    // cycles while the wave keeps issuing VALU/VMEM), the loaded registers are only touched by the LDS
-    // store after the last MFMA, and one barrier per K step flips the LDS buffers.
+    // issued in NCH slices between the MFMA groups of tile it, the loaded registers are only touched by
+    // the LDS store after the last MFMA, and one barrier per K step flips the LDS buffers.
+    constexpr int NCH = PREC ? 2 : 8;                       // MFMA groups per K step
+    constexpr int A_PER_CH = (A_LOADS + NCH - 1) / NCH, B_PER_CH = (B_LOADS + NCH - 1) / NCH;
     for (int it = 0; it < nk; ++it) {
         const int buf = it & 1;
         const bool has_next = (it + 1 < nk) && dbg_load;
         const int kn = k_begin + (it + 1) * BK;
-        const float* as = As[buf];
-        const float* bs = Bs[buf];
         prep(kn, has_next);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            if (c < A_LOADS) loadA(c, kn, has_next);
 #pragma unroll
-            for (int q = 0; q < B_PER_CH; ++q) loadB(c * B_PER_CH + q, kn, has_next);
-            float av[WM], bv[WN];
-            const int kr = 2 * c + (lane >> 5);
+            for (int q = 0; q < A_PER_CH; ++q)
+                if (c * A_PER_CH + q < A_LOADS) loadA(c * A_PER_CH + q, kn, has_next);
 #pragma unroll
-            for (int i = 0; i < WM; ++i) av[i] = as[kr * LDA + wm0 + i * 32 + (lane & 31)];
+            for (int q = 0; q < B_PER_CH; ++q)
+                if (c * B_PER_CH + q < B_LOADS) loadB(c * B_PER_CH + q, kn, has_next);
+            if constexpr (PREC == 0) {
+                const float* as = reinterpret_cast<const float*>(smemA[buf]);
+                const float* bs = reinterpret_cast<const float*>(smemB[buf]);
+                float av[WM], bv[WN];
+                const int kr = 2 * c + (lane >> 5);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bv[j] = bs[kr * LDB + wn0 + j * 32 + (lane & 31)];
+                for (int i = 0; i < WM; ++i) av[i] = as[kr * LDA + wm0 + i * 32 + (lane & 31)];
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int j = 0; j < WN; ++j) bv[j] = bs[kr * LDB + wn0 + j * 32 + (lane & 31)];
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            } else {
+                const unsigned short* as = reinterpret_cast<const unsigned short*>(smemA[buf]);
+                const unsigned short* bs = reinterpret_cast<const unsigned short*>(smemB[buf]);
+                bf16x8 av[WM], bv[WN];
+                const int ko = 16 * c + (lane >> 5) * 8;        // lanes 0-31: k 0..7, lanes 32-63: k 8..15 of the group
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+                    av[i] = *reinterpret_cast<const bf16x8*>(as + (wm0 + i * 32 + (lane & 31)) * KP + ko);
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    bv[j] = *reinterpret_cast<const bf16x8*>(bs + (wn0 + j * 32 + (lane & 31)) * KP + ko);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);      // keep the slices where they are
         }
         if (!(a.flags & DBG_NOSTORE)) store_tiles(buf ^ 1);   // harmless on the last step (buffer is never read)
@@ -447,7 +537,7 @@ int choose_bm(int M) {
 int choose_splits(int tiles, int K) {
     if (tiles >= 384) return 1;
     int want = (768 + tiles - 1) / tiles;
-    int maxs = K / (4 * BK);              // at least 4 K-steps per split
+    int maxs = K / (4 * 32);              // at least 4 (bf16) / 8 (fp32) K-steps per split
     if (maxs < 1) maxs = 1;
     int s = want < maxs ? want : maxs;
     static const int cap = getenv("OTAL_CONV_MAXSPLIT") ? atoi(getenv("OTAL_CONV_MAXSPLIT")) : 384;
@@ -470,14 +560,17 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
             if (splits < 2) splits = 1;
         }
     }
-    int kps = ((a.K + splits - 1) / splits + BK - 1) / BK * BK;
+    int kps = ((a.K + splits - 1) / splits + 31) / 32 * 32;      // multiple of both BK values
     splits = (a.K + kps - 1) / kps;
     a.splits = splits;
     a.k_per_split = kps;
     a.slab = splits > 1 ? (float*)ws : nullptr;
     const dim3 grid(tn, tm, splits);
-#define OTAL_LAUNCH(BM_, WM_, WN_, AV_) \
-    hipLaunchKernelGGL((conv_gemm_kernel<BM_, 128, WM_, WN_, MODE, AV_>), grid, dim3(NT), 0, st, a)
+#define OTAL_LAUNCH(BM_, WM_, WN_, AV_)                                                                       \
+    do {                                                                                                       \
+        if (a.prec) hipLaunchKernelGGL((conv_gemm_kernel<BM_, 128, WM_, WN_, MODE, AV_, 1>), grid, dim3(NT), 0, st, a); \
+        else hipLaunchKernelGGL((conv_gemm_kernel<BM_, 128, WM_, WN_, MODE, AV_, 0>), grid, dim3(NT), 0, st, a);        \
+    } while (0)
     const bool av = a.a_vec4 != 0;
     if constexpr (MODE == MODE_WGRAD) {
         if (BMsel == 128) OTAL_LAUNCH(128, 2, 2, false);
@@ -519,7 +612,7 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
 }
 
 extern "C" int otal_conv_fwd(const int* geom, const int64_t* strides, const float* x, const float* w,
-                             const float* scale, const float* shift, float* y, int relu,
+                             const float* scale, const float* shift, float* y, int relu, int precision,
                              void* ws, size_t ws_bytes, void* stream) {
     if (!geom || !strides || !x || !w || !y) return OTAL_E_NULL;
     ConvArgs a = {};
@@ -528,12 +621,13 @@ extern "C" int otal_conv_fwd(const int* geom, const int64_t* strides, const floa
     a.x = x; a.w = w; a.out = y; a.scale = scale; a.shift = shift;
     a.M = a.g.Cout; a.N = a.g.B * conv_out_positions(a.g); a.K = a.g.Cin * conv_kvol(a.g);
     a.flags = relu ? EPI_RELU : 0;
+    a.prec = precision ? 1 : 0;
     return launch_mode<MODE_FWD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int otal_conv_dgrad(const int* geom, const int64_t* strides, const float* dy, const float* wt_packed,
                                float* dx, int accumulate, const float* out_mask, const float* out_scale,
-                               void* ws, size_t ws_bytes, void* stream) {
+                               int precision, void* ws, size_t ws_bytes, void* stream) {
     if (!geom || !strides || !dy || !wt_packed || !dx) return OTAL_E_NULL;
     if ((out_mask == nullptr) != (out_scale == nullptr)) return OTAL_E_NULL;
     ConvArgs a = {};
@@ -544,11 +638,12 @@ extern "C" int otal_conv_dgrad(const int* geom, const int64_t* strides, const fl
     a.emask = out_mask; a.escale = out_scale;
     a.M = a.g.Cin; a.N = a.g.B * conv_in_positions(a.g); a.K = a.g.Cout * conv_kvol(a.g);
     a.flags = accumulate ? EPI_ACCUM : 0;
+    a.prec = precision ? 1 : 0;
     return launch_mode<MODE_DGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int otal_conv_wgrad(const int* geom, const int64_t* strides, const float* x, const float* dy,
-                               float* dw, int accumulate,
+                               float* dw, int accumulate, int precision,
                                void* ws, size_t ws_bytes, void* stream) {
     if (!geom || !strides || !x || !dy || !dw) return OTAL_E_NULL;
     ConvArgs a = {};
@@ -557,6 +652,7 @@ extern "C" int otal_conv_wgrad(const int* geom, const int64_t* strides, const fl
     a.x = x; a.dy = dy; a.out = dw;
     a.M = a.g.Cout; a.N = a.g.Cin * conv_kvol(a.g); a.K = a.g.B * conv_out_positions(a.g);
     a.flags = accumulate ? EPI_ACCUM : 0;
+    a.prec = precision ? 1 : 0;
     return launch_mode<MODE_WGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
 

@@ -245,3 +245,43 @@ def test_adam_flat_matches_torch():
     mo, vo = torch.zeros(n), torch.zeros(n)
     pp = p0.clone()
     O.adam_step(pp, g, mo, vo, 1, 1e-3, 1e-3)   # the oracle's own Adam agrees with torch for one step
+
+
+def _bf16_round(t):
+    return t.bfloat16().float()
+
+
+BF16_CASES = [((1, 3, 16, 24, 24), 64, (7, 7, 7), (2, 2, 2), False), ((1, 64, 6, 12, 12), 192, (3, 3, 3), (1, 1, 1), False),
+              ((2, 192, 4, 6, 6), 16, (1, 1, 1), (1, 1, 1), False), ((1, 96, 4, 6, 6), 208, (3, 3, 3), (1, 1, 1), False),
+              ((2, 832, 8, 6, 6), 512, (1, 6, 6), (1, 1, 1), True), ((2, 512, 64), 512, 3, 1, False),
+              ((2, 512, 32), 512, 3, 2, False), ((2, 512, 64), 15, 3, 1, False), ((1, 2048, 64), 512, 1, 1, False)]
+
+
+@pytest.mark.parametrize("case", BF16_CASES)
+def test_conv_bf16_operands_fp32_accumulate(case):
+    """precision=1: operands are rounded to bf16 (RNE) when staged, products are exact in fp32 and
+    accumulated in fp32 -- so the result must equal an fp32 convolution of the bf16-ROUNDED operands
+    up to summation order (1e-4 of scale; stated tolerance of the bf16 path)."""
+    from opental_amd.common import ops
+    shape, cout, k, s, sv = case
+    rs = np.random.RandomState(abs(hash(str(case))) % 10000)
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32))
+    kk = (k,) if isinstance(k, int) else k
+    w = torch.from_numpy((rs.randn(cout, shape[1], *kk) / np.sqrt(shape[1] * np.prod(kk))).astype(np.float32))
+    xq, wq = _bf16_round(x), _bf16_round(w)
+    xr, wr = xq.clone().requires_grad_(True), wq.clone().requires_grad_(True)
+    yr = ref_conv(xr, wr, None, k, s, sv)
+    dy = torch.from_numpy(rs.randn(*yr.shape).astype(np.float32))
+    dyq = _bf16_round(dy)
+    yr.backward(dyq)
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        y = ops.conv_forward(x.cuda(), w.cuda(), k, s, spatial_valid=sv)
+        dx = ops.conv_dgrad(dy.cuda(), w.cuda(), x.shape, k, s, spatial_valid=sv)
+        dw = ops.conv_wgrad(x.cuda(), dy.cuda(), w.shape, k, s, spatial_valid=sv)
+    finally:
+        ops.CONV_PRECISION = old
+    close(y, yr)
+    close(dx, xr.grad)
+    close(dw, wr.grad)

@@ -30,6 +30,7 @@ def main():
     names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(LAYERS)
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["fwd", "dgrad", "wgrad"]
+    ops.CONV_PRECISION = int(os.environ.get("OTAL_PREC", "0"))
     for name in names:
         shape, cout, k, s = LAYERS[name]
         x = torch.randn(*shape, device="cuda")
