@@ -41,6 +41,7 @@ struct ConvArgs {
     const float* scale;    // FWD epilogue: per-Cout scale (nullable -> 1)
     const float* shift;    // FWD epilogue: per-Cout shift / bias (nullable -> 0)
     float* slab;           // split-K workspace [splits][M][N] (nullable when splits == 1)
+    const int2* tab;       // FWD/DGRAD tap table: per k {element offset relative to the anchor, validity bit pattern}
     const float* emask;    // DGRAD epilogue (nullable): dx *= (emask[off] > 0) * escale[ci]  -- the ReLU/BN
     const float* escale;   //   backward of the layer that PRODUCED this conv's input, fused into the store
     int M, N, K;
@@ -223,7 +224,13 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int p = 0; p < KSUB; ++p) { wxp[p] = g_zero4; wdyp[p] = g_zero4; wt0[p] = wh0[p] = ww0[p] = 0; wtr[p] = 0u; }
 
+    int2 te[MODE == MODE_WGRAD ? 1 : B_PER];                // this K step's tap-table entries (scalar registers)
     auto prep = [&](int k0, bool live) {
+        if constexpr (MODE != MODE_WGRAD) {
+            const int2* tp = a.tab + (k0 + b_kq * B_PER);       // wave-uniform -> wide s_load; table is padded past K
+#pragma unroll
+            for (int q = 0; q < B_PER; ++q) te[q] = tp[q];
+        }
         if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
             for (int p = 0; p < KSUB; ++p) {
@@ -264,17 +271,13 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
                             ((unsigned)(ww0[p] + ((tp >> 16) & 255)) < (unsigned)g.Wi);
             rb[q] = ld_sel(wxp[p] + wcoff[j], ok);
         } else {
-            const int kk = k0 + b_kq * B_PER + q;                   // wave-uniform: tap math on the scalar unit
-            const bool ulive = live && kk < k_end;
-            const TapDec t = dec_tap_fd(fd, (uint32_t)kk);
-            int64_t koff;
-            if constexpr (MODE == MODE_FWD) {
-                koff = (int64_t)t.c * g.x_cs + (int64_t)t.dt * HWi + t.dh * g.Wi + t.dw;
-            } else {
-                koff = (int64_t)t.c * g.y_cs -
-                       (((int64_t)(t.dt >> (g.st - 1)) * g.Ho + (t.dh >> (g.sh - 1))) * g.Wo + (t.dw >> (g.sw - 1)));
-            }
-            rb[q] = ld_sel(anchor.base + koff, ulive && tap_ok(anchor.mask, t.dt, t.dh, t.dw));
+            // k is wave-uniform; its tap was decoded once per launch into the table: e.x = element offset
+            // relative to this thread's anchor, e.y = (1<<dt | 1<<(8+dh) | 1<<(16+dw)).  The tap is inside the
+            // tensor for this thread iff all three bits are set in the thread's validity mask.
+            const int kk = k0 + b_kq * B_PER + q;
+            const int2 e = te[q];
+            const bool ok = live && kk < k_end && (anchor.mask & (unsigned)e.y) == (unsigned)e.y;
+            rb[q] = ld_sel(anchor.base + e.x, ok);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -455,6 +458,27 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     }
 }
 
+// tap table: one entry per GEMM k of a FWD / DGRAD launch (plus padding entries that never match)
+template <int MODE>
+__global__ __launch_bounds__(256) void build_tap_table_kernel(int2* __restrict__ tab, ConvGeom g, int K, int Kpad) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= Kpad) return;
+    int2 e;
+    if (k >= K) { e.x = 0; e.y = -1; tab[k] = e; return; }
+    const TapDec t = dec_tap(g, k);
+    if (MODE == MODE_FWD) {
+        e.x = (int)((int64_t)t.c * g.x_cs + ((int64_t)t.dt * g.Hi + t.dh) * g.Wi + t.dw);
+    } else {
+        e.x = (int)((int64_t)t.c * g.y_cs -
+                    (((int64_t)(t.dt >> (g.st - 1)) * g.Ho + (t.dh >> (g.sh - 1))) * g.Wo + (t.dw >> (g.sw - 1))));
+    }
+    e.y = (1 << t.dt) | (1 << (8 + t.dh)) | (1 << (16 + t.dw));
+    tab[k] = e;
+}
+
+constexpr size_t TAB_PAD = 64;      // entries readable past K (a K step may run up to BK-1 rows over)
+static inline size_t tab_bytes(int K) { return (((size_t)K + TAB_PAD) * sizeof(int2) + 255) & ~(size_t)255; }
+
 // fixed-order reduction of the split-K slabs + the same epilogue
 template <int MODE>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
@@ -547,6 +571,17 @@ int choose_splits(int tiles, int K) {
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if (const char* d = getenv("OTAL_CONV_DEBUG")) a.flags |= (atoi(d) & (DBG_NOLOAD | DBG_NOSTORE | DBG_NOBARRIER));
+    if (MODE != MODE_WGRAD) {       // carve the tap table off the front of the workspace and build it
+        const size_t tb = tab_bytes(a.K);
+        if (!ws || ws_bytes < tb) return OTAL_E_UNSUPPORTED;
+        int2* tab = reinterpret_cast<int2*>(ws);
+        const int Kpad = a.K + (int)TAB_PAD;
+        hipLaunchKernelGGL((build_tap_table_kernel<MODE>), dim3((Kpad + 255) / 256), dim3(256), 0, st, tab, a.g, a.K, Kpad);
+        if (int e = otal_launch_status()) return e;
+        a.tab = tab;
+        ws = reinterpret_cast<char*>(ws) + tb;
+        ws_bytes -= tb;
+    }
     const int BMsel = choose_bm(a.M);
     const int BN = 128;
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + BN - 1) / BN;
@@ -608,7 +643,7 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
     const int BN = 128;
     const int tiles = (int)(((M + BMsel - 1) / BMsel) * ((N + BN - 1) / BN));
     const int s = choose_splits(tiles, (int)K);
-    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    return (mode == MODE_WGRAD ? 0 : tab_bytes((int)K)) + (s > 1 ? (size_t)s * M * N * sizeof(float) : 0);
 }
 
 extern "C" int otal_conv_fwd(const int* geom, const int64_t* strides, const float* x, const float* w,
