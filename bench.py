@@ -29,7 +29,8 @@ EDL = dict(evidence='exp', loss_type='log', iou_aware=True, with_focal=False, al
            ibm_start=10, momentum=0.99, num_bins=50)
 ACT = dict(margin=1.0, weight=0)
 W = dict(lw=1.0, cw=10.0, ctw=1.0, actw=1.0, ssl=0.001)   # experiments/opental/train_opental_final.sh
-PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
+PEAK_TFLOPS = {"f32": 157.3,     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
+               "bf16": 2500.0}   # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), not the 2:1-sparsity headline
 
 
 def synth_batch(batch, seed, device):
@@ -115,6 +116,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU (configs[2]: batch 8/GPU)")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
+                    help="arithmetic type of the convolution GEMMs (BASELINE.json configs[1]: bf16); f32 = parity path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -129,6 +132,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
+    from opental_amd.common import ops as _ops
+    _ops.CONV_PRECISION = 1 if args.dtype == "bf16" else 0
     trainer = build_trainer(device)
     clips, targets, scores = synth_batch(args.batch, 1000 + rank, device)
 
@@ -166,9 +171,10 @@ def main():
             e[0] += flops; e[1] += a.elapsed_time(b) * 1e-3; e[2] += 1
         tot_f = sum(e[0] for e in by.values()); tot_t = sum(e[1] for e in by.values()); tot_n = sum(e[2] for e in by.values())
         ach = tot_f / tot_t / 1e12
-        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad, f32 MFMA)",
-                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        peak = PEAK_TFLOPS[args.dtype]
+        roofline = {"bound": "mfma", "kernel": f"conv_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad, {args.dtype} MFMA operands, fp32 accumulate)",
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
                     "launches_per_step": tot_n // 2, "avg_launch_us": round(tot_t / tot_n * 1e6, 1),
                     "conv_time_ms_per_step": round(tot_t / 2 * 1e3, 2),
                     "by_mode_TFLOPs": {k: round(e[0] / e[1] / 1e12, 2) for k, e in by.items()}}
@@ -182,7 +188,7 @@ def main():
             "metric": "clips/sec training step, 256-frame THUMOS14 clips", "value": round(value, 3),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "OpenTAL THUMOS14 split_0 training step (configs/thumos14_opental_final.yaml, "
                                    "EDL+IBM loss, ssl branch off), 256x3x96x96 clips, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,

@@ -171,3 +171,38 @@ def test_ssl_triplet_branch(golden_dir):
         ref = float(O.triplet_cost(a, p, n, 1.0))
         got = float(forward_one_epoch(net, None, xh.cuda(), [t.cuda() for t in props], training=True, ssl=True))
     assert abs(got - ref) < 1e-4 * max(1.0, abs(ref))
+
+
+def test_bf16_compute_mode_stays_close_to_fp32(golden_dir):
+    """bf16-operand GEMMs (fp32 accumulate, fp32 tensors): the stated tolerance of the throughput
+    path.  Operand rounding is 2^-9 relative per element; through ~60 layers the outputs
+    stay within 3e-2 of the fp32 golden vectors (relative to each tensor's scale), the training cost
+    within 2 %, and every parameter gradient keeps a cosine > 0.98 with the fp32 gradient."""
+    from opental_amd.common import ops
+    from opental_amd.thumos14.train import forward_one_epoch, total_cost
+    fx = np.load(os.path.join(golden_dir, "thumos_b1.npz"))
+    net = build(fx)
+    x = torch.from_numpy(arch.make_clip(int(fx["clip_seed"]), 1)).cuda()
+    targets = [torch.from_numpy(fx["target_0"]).cuda()]
+    scores = torch.from_numpy(fx["scores"]).cuda()
+
+    def run(prec):
+        ops.CONV_PRECISION = prec
+        try:
+            net.zero_grad(set_to_none=True)
+            crit = _criterion("edl", 0)
+            out = net(x)
+            losses = forward_one_epoch(net, crit, x, targets, scores, training=True, ssl=False)
+            cost = total_cost(losses, W)
+            cost.backward()
+            return ({k: v.detach().clone() for k, v in out.items() if v is not None}, float(cost.detach()),
+                    {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+        finally:
+            ops.CONV_PRECISION = 0
+    o32, c32, g32 = run(0)
+    o16, c16, g16 = run(1)
+    for k in SMALL:
+        assert rel_err(o16[k].cpu().numpy(), fx["out_" + k]) < 3e-2, k
+    assert abs(c16 - c32) < 2e-2 * abs(c32)
+    worst = min(float(torch.nn.functional.cosine_similarity(g16[k].flatten(), g32[k].flatten(), dim=0)) for k in g32)
+    assert worst > 0.98, worst
