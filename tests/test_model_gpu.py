@@ -204,5 +204,9 @@ def test_bf16_compute_mode_stays_close_to_fp32(golden_dir):
     for k in SMALL:
         assert rel_err(o16[k].cpu().numpy(), fx["out_" + k]) < 3e-2, k
     assert abs(c16 - c32) < 2e-2 * abs(c32)
-    worst = min(float(torch.nn.functional.cosine_similarity(g16[k].flatten(), g32[k].flatten(), dim=0)) for k in g32)
-    assert worst > 0.98, worst
+    gmax = max(float(g.norm()) for g in g32.values())
+    cos = {k: float(torch.nn.functional.cosine_similarity(g16[k].flatten(), g32[k].flatten(), dim=0))
+           for k in g32 if float(g32[k].norm()) > 1e-7 * gmax}          # skip structurally zero gradients
+    assert len(cos) > 150
+    worst = min(cos, key=cos.get)
+    assert cos[worst] > 0.98, (worst, cos[worst])
