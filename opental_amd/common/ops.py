@@ -83,10 +83,30 @@ def _bs(t5):
     return bs, cs
 
 
+_GEOM_CACHE = {}
+
+
 def _geom_arrays(g, x5, y5):
     xb, xc = _bs(x5)
     yb, yc = _bs(y5)
-    return (ctypes.c_int * len(g))(*g), (ctypes.c_int64 * 4)(xb, xc, yb, yc)
+    key = (tuple(g), xb, xc, yb, yc)
+    hit = _GEOM_CACHE.get(key)
+    if hit is None:
+        hit = ((ctypes.c_int * len(g))(*g), (ctypes.c_int64 * 4)(xb, xc, yb, yc))
+        _GEOM_CACHE[key] = hit
+    return hit
+
+
+_MAKE_GEOM_CACHE = {}
+
+
+def _make_geom(B, Cin, Cout, in_thw, k, s, levels, spatial_valid):
+    key = (B, Cin, Cout, tuple(in_thw), k, s, levels if levels is None else tuple(levels), spatial_valid)
+    hit = _MAKE_GEOM_CACHE.get(key)
+    if hit is None:
+        hit = make_geom(B, Cin, Cout, in_thw, k, s, levels, spatial_valid)
+        _MAKE_GEOM_CACHE[key] = hit
+    return hit
 
 
 def _opt(t):
@@ -103,7 +123,7 @@ def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=F
     x5 = _as5(x)
     B, Cin, Ti, Hi, Wi = x5.shape
     Cout = w.shape[0]
-    g, outn = make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
+    g, outn = _make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
     if out is None:
         out = torch.empty((B, Cout) + outn, dtype=x.dtype, device=x.device)
         if x.dim() == 3:
@@ -142,7 +162,7 @@ def conv_dgrad(dy, w, x_shape, k, s, spatial_valid=False, levels=None, out=None,
     xs5 = tuple(x_shape) + (1, 1) if len(x_shape) == 3 else tuple(x_shape)
     B, Cin, Ti, Hi, Wi = xs5
     Cout = w.shape[0]
-    g, outn = make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
+    g, outn = _make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
     if out is None:
         if accumulate:
             raise RuntimeError("accumulate needs an existing buffer")
@@ -195,7 +215,7 @@ def conv_wgrad(x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None,
     x5, dy5 = _as5(x), _as5(dy)
     B, Cin, Ti, Hi, Wi = x5.shape
     Cout = w_shape[0]
-    g, outn = make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
+    g, outn = _make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
     if tuple(dy5.shape) != (B, Cout) + outn:
         raise RuntimeError(f"conv_wgrad: dy has shape {tuple(dy5.shape)}, expected {(B, Cout) + outn}")
     if out is None:
