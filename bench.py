@@ -55,7 +55,7 @@ def synth_batch(batch, seed, device):
     return clips, targets, torch.from_numpy(scores).to(device)
 
 
-def build_trainer(device, seed=2020):
+def build_trainer(device, seed=2020, force_collectives=False):
     from opental_amd.thumos14.BDNet import BDNet
     from opental_amd.thumos14.multisegment_loss import MultiSegmentLoss
     from opental_amd.thumos14.train import DetectorTrainer
@@ -65,7 +65,7 @@ def build_trainer(device, seed=2020):
     net = net.to(device).train()
     crit = MultiSegmentLoss(15, 0.5, 1.0, cls_loss_type='edl', edl_config=EDL, os_head=True, act_config=ACT).to(device)
     crit.cls_loss.epoch = 12            # past ibm_start: the IBM re-weighting runs inside the timed step
-    return DetectorTrainer(net, crit, W, lr=1e-5, weight_decay=1e-3)
+    return DetectorTrainer(net, crit, W, lr=1e-5, weight_decay=1e-3, force_collectives=force_collectives)
 
 
 def cpu_baseline(seconds_budget=20.0, threads=32):
@@ -129,16 +129,19 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    force_dist = bool(os.environ.get("OTAL_FORCE_DIST"))      # exercise the RCCL path on a single rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
     from opental_amd.common import ops as _ops
     _ops.CONV_PRECISION = 1 if args.dtype == "bf16" else 0
-    trainer = build_trainer(device)
+    trainer = build_trainer(device, force_collectives=force_dist)
     clips, targets, scores = synth_batch(args.batch, 1000 + rank, device)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -150,7 +153,7 @@ def main():
         trainer.step(clips, targets, scores)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -194,7 +197,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "grad_allreduce": "RCCL, flat-arena buckets overlapped with backward"},
             "roofline": roofline, "cpu_baseline": cpu}))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -108,7 +108,7 @@ class FlatArena:
 
 class DetectorTrainer:
     def __init__(self, net, criterion, loss_weights, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8,
-                 process_group=None, bucket_mb=48, distributed=None):
+                 process_group=None, bucket_mb=48, distributed=None, force_collectives=False):
         self.net, self.criterion, self.w = net, criterion, dict(loss_weights)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.distributed = dist.is_available() and dist.is_initialized() if distributed is None else distributed
@@ -117,7 +117,8 @@ class DetectorTrainer:
         self.arena = FlatArena(list(net.parameters()), bucket_mb << 20)
         self.step_count = 0
         self._pending, self._works = None, []
-        if self.distributed and self.world > 1:
+        self.collectives = self.distributed and (self.world > 1 or force_collectives)   # force: 1-rank RCCL smoke test
+        if self.collectives:
             for i, p in enumerate(self.arena.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(self.arena.bucket_of[i]))
 
@@ -132,7 +133,7 @@ class DetectorTrainer:
         return hook
 
     def _finish_allreduce(self):
-        if not (self.distributed and self.world > 1):
+        if not self.collectives:
             return
         # buckets whose parameters received no gradient this step still have to be reduced
         for b, left in enumerate(self._pending):
