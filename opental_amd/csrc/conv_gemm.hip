@@ -560,7 +560,7 @@ int choose_bm(int M) {
 // choose split-K so that the grid fills the chip (256 CUs) without shredding K
 int choose_splits(int tiles, int K) {
     if (tiles >= 384) return 1;
-    int want = (768 + tiles - 1) / tiles;
+    int want = (512 + tiles - 1) / tiles;      // two resident workgroups per CU are enough to hide the tails
     int maxs = K / (4 * 32);              // at least 4 (bf16) / 8 (fp32) K-steps per split
     if (maxs < 1) maxs = 1;
     int s = want < maxs ? want : maxs;

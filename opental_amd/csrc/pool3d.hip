@@ -95,20 +95,31 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restr
     const unsigned char* ab = arg + (int64_t)bc * Po;
     const int kt = S::kt(g), kh = S::kh(g), kw = S::kw(g);
     const int st = S::st(g), sh = S::sh(g), sw = S::sw(g);
-    // only the windows that actually cover (ti,hi,wi): to in [ceil((ti+pt-kt+1)/st), floor((ti+pt)/st)], etc.
-    // (4 candidates for the stride-2 pools instead of 9/27 divisibility tests)
+    // Branch-free gather over the taps: tap (dt,dh,dw) reaches output ((ti+pt-dt)/st, ...) when the division
+    // is exact and in range.  Both the winner byte and dy are loaded UNCONDITIONALLY from a clamped index
+    // and selected afterwards, so the loads of all taps are in flight together (a guarded load makes
+    // hipcc branch and wait per tap).  Fixed (dt,dh,dw) order -> deterministic sums.
     const int tn = ti + g.pt, hn = hi + g.ph, wn = wi + g.pw;
-    const int to_hi = min(tn / st, g.To - 1), ho_hi = min(hn / sh, g.Ho - 1), wo_hi = min(wn / sw, g.Wo - 1);
-    const int to_lo = max((tn - kt + st) / st, 0), ho_lo = max((hn - kh + sh) / sh, 0), wo_lo = max((wn - kw + sw) / sw, 0);
     float acc = 0.f;
-    for (int to = to_hi; to >= to_lo; --to) {            // descending output index == ascending tap (fixed order)
-        const int dt = tn - to * st;
-        for (int ho = ho_hi; ho >= ho_lo; --ho) {
-            const int dh = hn - ho * sh;
-            for (int wo = wo_hi; wo >= wo_lo; --wo) {
-                const int dw = wn - wo * sw;
-                const int o = (to * g.Ho + ho) * g.Wo + wo;
-                if (ab[o] == (dt * kh + dh) * kw + dw) acc += dyb[o];
+#pragma unroll
+    for (int dt = 0; dt < kt; ++dt) {
+        const int vt = tn - dt, to = vt / st;
+        const bool okt = vt >= 0 && vt - to * st == 0 && to < g.To;
+        const int toc = min(max(to, 0), g.To - 1);
+#pragma unroll
+        for (int dh = 0; dh < kh; ++dh) {
+            const int vh = hn - dh, ho = vh / sh;
+            const bool okh = okt && vh >= 0 && vh - ho * sh == 0 && ho < g.Ho;
+            const int hoc = min(max(ho, 0), g.Ho - 1);
+#pragma unroll
+            for (int dw = 0; dw < kw; ++dw) {
+                const int vw = wn - dw, wo = vw / sw;
+                const bool ok = okh && vw >= 0 && vw - wo * sw == 0 && wo < g.Wo;
+                const int woc = min(max(wo, 0), g.Wo - 1);
+                const int o = (toc * g.Ho + hoc) * g.Wo + woc;
+                const int a = ab[o];
+                const float d = dyb[o];
+                acc += (ok && a == (dt * kh + dh) * kw + dw) ? d : 0.f;
             }
         }
     }
