@@ -95,26 +95,30 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restr
     const unsigned char* ab = arg + (int64_t)bc * Po;
     const int kt = S::kt(g), kh = S::kh(g), kw = S::kw(g);
     const int st = S::st(g), sh = S::sh(g), sw = S::sw(g);
-    // Branch-free gather over the taps: tap (dt,dh,dw) reaches output ((ti+pt-dt)/st, ...) when the division
-    // is exact and in range.  Both the winner byte and dy are loaded UNCONDITIONALLY from a clamped index
-    // and selected afterwards, so the loads of all taps are in flight together (a guarded load makes
-    // hipcc branch and wait per tap).  Fixed (dt,dh,dw) order -> deterministic sums.
+    // Branch-free gather over the windows that can cover (ti,hi,wi): per axis at most ceil(k/s) outputs,
+    // o = (i+p)/s - c for c = 0..ceil(k/s)-1, reached through tap (i+p) - o*s when that tap is < k.
+    // The winner byte and dy are loaded UNCONDITIONALLY from a clamped index and selected afterwards, so
+    // all loads are in flight together (a guarded load makes hipcc branch and wait per tap).
+    // Descending output index == ascending tap: fixed order -> deterministic sums.
     const int tn = ti + g.pt, hn = hi + g.ph, wn = wi + g.pw;
+    constexpr int CT = KT ? (KT + ST - 1) / ST : 0, CH = KT ? (KH + SH - 1) / SH : 0, CW = KT ? (KW + SW - 1) / SW : 0;
+    const int ct = KT ? CT : (kt + st - 1) / st, ch = KT ? CH : (kh + sh - 1) / sh, cw = KT ? CW : (kw + sw - 1) / sw;
+    const int to0 = tn / st, ho0 = hn / sh, wo0 = wn / sw;
     float acc = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < kt; ++dt) {
-        const int vt = tn - dt, to = vt / st;
-        const bool okt = vt >= 0 && vt - to * st == 0 && to < g.To;
+    for (int a_ = 0; a_ < ct; ++a_) {
+        const int to = to0 - a_, dt = tn - to * st;
+        const bool okt = to >= 0 && to < g.To && dt < kt;
         const int toc = min(max(to, 0), g.To - 1);
 #pragma unroll
-        for (int dh = 0; dh < kh; ++dh) {
-            const int vh = hn - dh, ho = vh / sh;
-            const bool okh = okt && vh >= 0 && vh - ho * sh == 0 && ho < g.Ho;
+        for (int b_ = 0; b_ < ch; ++b_) {
+            const int ho = ho0 - b_, dh = hn - ho * sh;
+            const bool okh = okt && ho >= 0 && ho < g.Ho && dh < kh;
             const int hoc = min(max(ho, 0), g.Ho - 1);
 #pragma unroll
-            for (int dw = 0; dw < kw; ++dw) {
-                const int vw = wn - dw, wo = vw / sw;
-                const bool ok = okh && vw >= 0 && vw - wo * sw == 0 && wo < g.Wo;
+            for (int c_ = 0; c_ < cw; ++c_) {
+                const int wo = wo0 - c_, dw = wn - wo * sw;
+                const bool ok = okh && wo >= 0 && wo < g.Wo && dw < kw;
                 const int woc = min(max(wo, 0), g.Wo - 1);
                 const int o = (toc * g.Ho + hoc) * g.Wo + woc;
                 const int a = ab[o];
