@@ -152,12 +152,18 @@ class InceptionI3d(nn.Module):
         for u in units:
             if u.bn.training or (torch.is_grad_enabled() and u.bn.weight.requires_grad):
                 raise NotImplementedError("I3D BatchNorm must be frozen (freeze_bn + freeze_bn_affine, BDNet.py:39-49)")
-        folded = [u.folded_bn() for u in units]
-        offs = [0]
-        for sc, _ in folded:
-            offs.append(offs[-1] + sc.numel())
-        scale = torch.cat([sc for sc, _ in folded])
-        shift = torch.cat([sh for _, sh in folded])
+        # frozen BN folds to a constant per-channel (scale, shift): rebuild only when a BN tensor changed
+        # (load_state_dict / .to() bump the version counters or replace the storages)
+        key = tuple((u.bn.weight._version, u.bn.bias._version, u.bn.running_mean._version, u.bn.running_var._version,
+                     u.bn.weight.data_ptr(), u.bn.running_var.data_ptr()) for u in units)
+        if getattr(self, "_fold_key", None) != key:
+            folded = [u.folded_bn() for u in units]
+            offs = [0]
+            for sc, _ in folded:
+                offs.append(offs[-1] + sc.numel())
+            self._fold = (torch.cat([sc for sc, _ in folded]), torch.cat([sh for _, sh in folded]), offs)
+            self._fold_key = key
+        scale, shift, offs = self._fold
         outs = I3DFeaturesFunction.apply(x, plan, tuple(endpoints), scale, shift, offs,
                                          *[u.conv3d.weight for u in units])
         return dict(zip(endpoints, outs))
