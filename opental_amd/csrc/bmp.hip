@@ -8,8 +8,8 @@
 //   * the proposal windows of sample n are decoded (trunc + clamp) once per workgroup into LDS;
 //   * lanes run along k (proposals), so neighbouring lanes scan neighbouring LDS addresses and
 //     the output store is a coalesced row;
-//   * backward is a deterministic gather: each lane owns one input position i and adds the
-//     grad_out of every proposal whose arg-max is i, in ascending k.  No atomics.
+//   * backward is deterministic and atomic-free: arg-max per (row, proposal) in parallel, then one
+//     lane per row adds grad_out into an LDS grad_in tile in ascending k, then a coalesced write-out.
 //   * a level table lets ONE launch pool all pyramid levels (packed along T / N).
 // HBM-bound: bytes = 4*(C*T + C*N) + 16*N per sample forward (kernels/bmp).
 #include "common.h"
@@ -137,20 +137,24 @@ __global__ __launch_bounds__(256) void bmp_bwd_kernel(const T* __restrict__ gout
         }
     }
     __syncthreads();
-    {   // phase 2: gather, ascending k -> deterministic sums
+    // phase 2: scatter in LDS.  The input tile is no longer needed, its LDS space becomes the grad_in tile.
+    // One lane per row walks the proposals in ascending k and adds grad_out into grad_in[arg-max] -- a
+    // dependent chain per row (rows are independent), entirely in LDS, so every position receives its
+    // contributions in ascending k (deterministic) at O(N) per row instead of O(T*N).
+    for (int i = tid; i < ROWS * Tp; i += 256) rows[i] = 0.f;
+    __syncthreads();
+    if (tid < ROWS) {
+        float* gi = rows + tid * Tp;
+        const int* ar = arg + tid * Np;
+        const float* gr = g + tid * Np;
+        for (int k = 0; k < Nt; ++k) gi[ar[k]] += gr[k];
+    }
+    __syncthreads();
+    {
         const int tx = tid & ((1 << lxT) - 1), ty = tid >> lxT, nty = 256 >> lxT;
-        for (int r = ty; r < ROWS; r += nty) {
-            const int* ar = arg + r * Np;
-            const float* gr = g + r * Np;
-            for (int i = tx; i < Tt; i += (1 << lxT)) {
-                int kb, ke;
-                level_of_t(lt, i, kb, ke);
-                float acc = 0.f;
-                for (int k = kb; k < ke; ++k)
-                    if (ar[k] == i) acc += gr[k];
-                st_f32(gin, (size_t)(row0 + r) * Tt + i, acc);
-            }
-        }
+        for (int r = ty; r < ROWS; r += nty)
+            for (int i = tx; i < Tt; i += (1 << lxT))
+                st_f32(gin, (size_t)(row0 + r) * Tt + i, rows[r * Tp + i]);
     }
 }
 
