@@ -194,11 +194,16 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
         }
     }
     // A rows of this thread as 32-bit element offsets (-1 = out of range)
-    constexpr int A_ROWSN = MODE == MODE_WGRAD ? WA_PER : (AVEC ? AV_PASS : AS_PER);
+    // (WGRAD with AVEC: dy rows, 4 consecutive positions per float4 -- legal because P % 4 == 0 keeps a
+    //  group of 4 k inside one sample and 16-byte aligned)
+    constexpr int A_ROWSN = AVEC ? AV_PASS : (MODE == MODE_WGRAD ? WA_PER : AS_PER);
     int arow[A_ROWSN];
 #pragma unroll
     for (int j = 0; j < A_ROWSN; ++j) {
-        if constexpr (MODE == MODE_WGRAD) {
+        if constexpr (MODE == MODE_WGRAD && AVEC) {
+            const int m = m0 + v_m + AV_ROWS * j;
+            arow[j] = (v_m + AV_ROWS * j < BM && m < a.M) ? m * (int)g.y_cs : -1;
+        } else if constexpr (MODE == MODE_WGRAD) {
             const int m = m0 + w_r + 16 * j;
             arow[j] = m < a.M ? m * (int)g.y_cs : -1;
         } else if constexpr (AVEC) {
@@ -211,9 +216,9 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     }
 
     // ---- staging registers
-    constexpr int A_REGS = MODE == MODE_WGRAD ? WA_PER * KSUB : (AVEC ? 4 * AV_PASS : AS_PER);
+    constexpr int A_REGS = AVEC ? 4 * AV_PASS : (MODE == MODE_WGRAD ? WA_PER * KSUB : AS_PER);
     constexpr int B_REGS = MODE == MODE_WGRAD ? WB_PER * KSUB : B_PER;
-    constexpr int A_LOADS = MODE == MODE_WGRAD ? WA_PER * KSUB : (AVEC ? AV_PASS : AS_PER);
+    constexpr int A_LOADS = AVEC ? AV_PASS : (MODE == MODE_WGRAD ? WA_PER * KSUB : AS_PER);
     constexpr int B_LOADS = B_REGS;
     float ra[A_REGS], rb[B_REGS];
     // WGRAD per-(K step, sub-step) position state
@@ -225,7 +230,15 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     for (int p = 0; p < KSUB; ++p) { wxp[p] = g_zero4; wdyp[p] = g_zero4; wt0[p] = wh0[p] = ww0[p] = 0; wtr[p] = 0u; }
 
     int2 te[MODE == MODE_WGRAD ? 1 : B_PER];                // this K step's tap-table entries (scalar registers)
+    const float* wdy4 = g_zero4;                            // WGRAD+AVEC: dy + b*y_bs + p of this thread's 4 k
+    bool wok4 = false;
     auto prep = [&](int k0, bool live) {
+        if constexpr (MODE == MODE_WGRAD && AVEC) {
+            const int k = k0 + v_k;
+            wok4 = live && k < k_end;
+            const uint32_t kb = fd_div(fd.P, wok4 ? (uint32_t)k : 0u);          // sample index
+            wdy4 = a.dy + ((int64_t)kb * g.y_bs + (int64_t)((wok4 ? k : 0) - (int)(kb * fd.P.d)));
+        }
         if constexpr (MODE != MODE_WGRAD) {
             const int2* tp = a.tab + (k0 + b_kq * B_PER);       // wave-uniform -> wide s_load; table is padded past K
 #pragma unroll
@@ -250,7 +263,11 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
         }
     };
     auto loadA = [&](int q, int k0, bool live) {         // q-th A load of the K step
-        if constexpr (MODE == MODE_WGRAD) {
+        if constexpr (MODE == MODE_WGRAD && AVEC) {
+            const float* ap = (wok4 && arow[q] >= 0) ? wdy4 + arow[q] : g_zero4;
+            const float4 v = *reinterpret_cast<const float4*>(ap);
+            ra[4 * q] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
+        } else if constexpr (MODE == MODE_WGRAD) {
             const int p = q / WA_PER, j = q % WA_PER;
             ra[q] = ld_sel(wdyp[p] + arow[j], wtr[p] != 0u && arow[j] >= 0);
         } else if constexpr (AVEC) {
@@ -284,51 +301,57 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
         if constexpr (PREC == 0) {
             float* As = reinterpret_cast<float*>(smemA[buf]);
             float* Bs = reinterpret_cast<float*>(smemB[buf]);
-            if constexpr (MODE == MODE_WGRAD) {
+            // A
+            if constexpr (AVEC) {
+#pragma unroll
+                for (int j = 0; j < AV_PASS; ++j)
+                    if (v_m + AV_ROWS * j < BM) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) As[(v_k + i) * LDA + v_m + AV_ROWS * j] = ra[4 * j + i];
+                    }
+            } else if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
                 for (int j = 0; j < WA_PER; ++j) As[w_k * LDA + w_r + 16 * j] = ra[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < AS_PER; ++j) As[s_k * LDA + s_m + AS_ROWS * j] = ra[j];
+            }
+            // B
+            if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
                 for (int j = 0; j < WB_PER; ++j) Bs[w_k * LDB + w_r + 16 * j] = rb[j];
             } else {
-                if constexpr (AVEC) {
-#pragma unroll
-                    for (int j = 0; j < AV_PASS; ++j)
-                        if (v_m + AV_ROWS * j < BM) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) As[(v_k + i) * LDA + v_m + AV_ROWS * j] = ra[4 * j + i];
-                        }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < AS_PER; ++j) As[s_k * LDA + s_m + AS_ROWS * j] = ra[j];
-                }
 #pragma unroll
                 for (int j = 0; j < B_PER; ++j) Bs[(b_kq * B_PER + j) * LDB + b_n] = rb[j];
             }
         } else {
             unsigned short* As = reinterpret_cast<unsigned short*>(smemA[buf]);
             unsigned short* Bs = reinterpret_cast<unsigned short*>(smemB[buf]);
-            if constexpr (MODE == MODE_WGRAD) {
+            // A
+            if constexpr (AVEC) {
+#pragma unroll
+                for (int j = 0; j < AV_PASS; ++j)
+                    if (v_m + AV_ROWS * j < BM) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(ra[4 * j], ra[4 * j + 1]);
+                        pk.y = pack_bf16x2(ra[4 * j + 2], ra[4 * j + 3]);
+                        *reinterpret_cast<uint2*>(As + (v_m + AV_ROWS * j) * KP + v_k) = pk;
+                    }
+            } else if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
                 for (int q = 0; q < WA_PER * KSUB; ++q)
                     As[(w_r + 16 * (q % WA_PER)) * KP + 16 * (q / WA_PER) + w_k] = (unsigned short)(pack_bf16x2(ra[q], 0.f) & 0xffffu);
+            } else {
+#pragma unroll
+                for (int j = 0; j < AS_PER; ++j)
+                    As[(s_m + AS_ROWS * j) * KP + s_k] = (unsigned short)(pack_bf16x2(ra[j], 0.f) & 0xffffu);
+            }
+            // B
+            if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
                 for (int q = 0; q < WB_PER * KSUB; ++q)
                     Bs[(w_r + 16 * (q % WB_PER)) * KP + 16 * (q / WB_PER) + w_k] = (unsigned short)(pack_bf16x2(rb[q], 0.f) & 0xffffu);
             } else {
-                if constexpr (AVEC) {
-#pragma unroll
-                    for (int j = 0; j < AV_PASS; ++j)
-                        if (v_m + AV_ROWS * j < BM) {
-                            uint2 pk;
-                            pk.x = pack_bf16x2(ra[4 * j], ra[4 * j + 1]);
-                            pk.y = pack_bf16x2(ra[4 * j + 2], ra[4 * j + 3]);
-                            *reinterpret_cast<uint2*>(As + (v_m + AV_ROWS * j) * KP + v_k) = pk;
-                        }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < AS_PER; ++j)
-                        As[(s_m + AS_ROWS * j) * KP + s_k] = (unsigned short)(pack_bf16x2(ra[j], 0.f) & 0xffffu);
-                }
 #pragma unroll
                 for (int h = 0; h < B_PER / 8; ++h) {
                     uint4 pk;
@@ -586,7 +609,12 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int BN = 128;
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + BN - 1) / BN;
     a.fd = make_conv_fastdiv(a.g);
-    a.a_vec4 = (MODE != MODE_WGRAD) && (a.K % 4 == 0) && (((uintptr_t)a.w & 15) == 0) && BMsel >= 64;
+    if (MODE == MODE_WGRAD) {   // dy rows vectorise along positions when groups of 4 stay inside a sample and aligned
+        const int64_t P = conv_out_positions(a.g);
+        a.a_vec4 = (P % 4 == 0) && (a.g.y_bs % 4 == 0) && (a.g.y_cs % 4 == 0) && (((uintptr_t)a.dy & 15) == 0) && BMsel >= 64;
+    } else {
+        a.a_vec4 = (a.K % 4 == 0) && (((uintptr_t)a.w & 15) == 0) && BMsel >= 64;
+    }
     int splits = choose_splits(tm * tn, a.K);
     if (splits > 1) {
         const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
@@ -607,11 +635,7 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         else hipLaunchKernelGGL((conv_gemm_kernel<BM_, 128, WM_, WN_, MODE, AV_, 0>), grid, dim3(NT), 0, st, a);        \
     } while (0)
     const bool av = a.a_vec4 != 0;
-    if constexpr (MODE == MODE_WGRAD) {
-        if (BMsel == 128) OTAL_LAUNCH(128, 2, 2, false);
-        else if (BMsel == 96) OTAL_LAUNCH(96, 3, 1, false);
-        else if (BMsel == 64) OTAL_LAUNCH(64, 2, 1, false);
-        else OTAL_LAUNCH(32, 1, 1, false);
+    if (false) {
     } else {
         if (BMsel == 128) { if (av) OTAL_LAUNCH(128, 2, 2, true); else OTAL_LAUNCH(128, 2, 2, false); }
         else if (BMsel == 96) { if (av) OTAL_LAUNCH(96, 3, 1, true); else OTAL_LAUNCH(96, 3, 1, false); }

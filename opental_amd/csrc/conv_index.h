@@ -82,12 +82,13 @@ OTAL_HD TapDec dec_tap(const ConvGeom& g, int k) {     // k = ((c*kt + dt)*kh + 
     return d;
 }
 
-struct ConvFastDiv { FastDiv kw, kh, kt, Wo, Ho, To, Wi, Hi, Ti; };
+struct ConvFastDiv { FastDiv kw, kh, kt, Wo, Ho, To, Wi, Hi, Ti, P; };   // P = To*Ho*Wo
 inline ConvFastDiv make_conv_fastdiv(const ConvGeom& g) {
     ConvFastDiv f;
     f.kw = make_fastdiv(g.kw); f.kh = make_fastdiv(g.kh); f.kt = make_fastdiv(g.kt);
     f.Wo = make_fastdiv(g.Wo); f.Ho = make_fastdiv(g.Ho); f.To = make_fastdiv(g.To);
     f.Wi = make_fastdiv(g.Wi); f.Hi = make_fastdiv(g.Hi); f.Ti = make_fastdiv(g.Ti);
+    f.P = make_fastdiv((uint32_t)(g.To * g.Ho * g.Wo));
     return f;
 }
 OTAL_HD PosDec dec_pos_fd(uint32_t n, const FastDiv& T, const FastDiv& H, const FastDiv& W) {
