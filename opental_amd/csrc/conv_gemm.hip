@@ -41,6 +41,8 @@ struct ConvArgs {
     const float* scale;    // FWD epilogue: per-Cout scale (nullable -> 1)
     const float* shift;    // FWD epilogue: per-Cout shift / bias (nullable -> 0)
     float* slab;           // split-K workspace [splits][M][N] (nullable when splits == 1)
+    const float* zero;     // address of a 16-byte device zero word (kernel argument: taking the address of a
+                           // __device__ global inside the loop costs a GOT s_load + lgkmcnt(0) wait per element)
     const int2* tab;       // FWD/DGRAD tap table: per k {element offset relative to the anchor, validity bit pattern}
     const float* emask;    // DGRAD epilogue (nullable): dx *= (emask[off] > 0) * escale[ci]  -- the ReLU/BN
     const float* escale;   //   backward of the layer that PRODUCED this conv's input, fused into the store
@@ -114,8 +116,8 @@ __device__ __forceinline__ Anchor anchor_of_input(const ConvGeom& g, const float
 __device__ __forceinline__ bool tap_ok(unsigned mask, int dt, int dh, int dw) {
     return ((mask >> dt) & (mask >> (8 + dh)) & (mask >> (16 + dw)) & 1u) != 0;
 }
-__device__ __forceinline__ float ld_sel(const float* p, bool ok) {
-    const float* q = ok ? p : g_zero4;
+__device__ __forceinline__ float ld_sel(const float* p, bool ok, const float* zero) {
+    const float* q = ok ? p : zero;
     return *q;
 }
 
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
 
     const ConvGeom& g = a.g;
     const ConvFastDiv& fd = a.fd;
+    const float* const zp = a.zero;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     const int s_k = tid % BK, s_m = tid / BK;
     const int w_k = tid & 15, w_r = tid >> 4;
 
-    Anchor anchor = {g_zero4, 0u};           // FWD: this thread's output column; DGRAD: its input position
+    Anchor anchor = {zp, 0u};           // FWD: this thread's output column; DGRAD: its input position
     int wcoff[MODE == MODE_WGRAD ? WB_PER : 1];             // WGRAD: fixed (ci, tap) columns: element offset
     int wtap[MODE == MODE_WGRAD ? WB_PER : 1];              //        dt | dh << 8 | dw << 16, or -1
     if constexpr (MODE == MODE_FWD) {
@@ -227,15 +230,15 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     int wt0[KSUB], wh0[KSUB], ww0[KSUB];
     unsigned wtr[KSUB];
 #pragma unroll
-    for (int p = 0; p < KSUB; ++p) { wxp[p] = g_zero4; wdyp[p] = g_zero4; wt0[p] = wh0[p] = ww0[p] = 0; wtr[p] = 0u; }
+    for (int p = 0; p < KSUB; ++p) { wxp[p] = zp; wdyp[p] = zp; wt0[p] = wh0[p] = ww0[p] = 0; wtr[p] = 0u; }
 
     int2 te[MODE == MODE_WGRAD ? 1 : B_PER];                // this K step's tap-table entries (scalar registers)
-    const float* wdy4 = g_zero4;                            // WGRAD+AVEC: dy + b*y_bs + p of this thread's 4 k
+    const float* wdy4 = zp;                            // WGRAD+AVEC: dy + b*y_bs + p of this thread's 4 k
     bool wok4 = false;
     auto prep = [&](int k0, bool live) {
         if constexpr (MODE == MODE_WGRAD && AVEC) {
             const int k = k0 + v_k;
-            wok4 = live && k < k_end;
+            wok4 = live & (k < k_end);
             const uint32_t kb = fd_div(fd.P, wok4 ? (uint32_t)k : 0u);          // sample index
             wdy4 = a.dy + ((int64_t)kb * g.y_bs + (int64_t)((wok4 ? k : 0) - (int)(kb * fd.P.d)));
         }
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int p = 0; p < KSUB; ++p) {
                 const int k = k0 + 16 * p + w_k;
-                const bool kok = live && k < k_end;
+                const bool kok = live & (k < k_end);
                 const PosDec o = dec_pos_fd(kok ? k : 0, fd.To, fd.Ho, fd.Wo);
                 int lo, up;
                 level_bounds(g, o.t, g.Ti, lo, up);
@@ -264,19 +267,19 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     };
     auto loadA = [&](int q, int k0, bool live) {         // q-th A load of the K step
         if constexpr (MODE == MODE_WGRAD && AVEC) {
-            const float* ap = (wok4 && arow[q] >= 0) ? wdy4 + arow[q] : g_zero4;
+            const float* ap = (wok4 & (arow[q] >= 0)) ? wdy4 + arow[q] : zp;
             const float4 v = *reinterpret_cast<const float4*>(ap);
             ra[4 * q] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
         } else if constexpr (MODE == MODE_WGRAD) {
             const int p = q / WA_PER, j = q % WA_PER;
-            ra[q] = ld_sel(wdyp[p] + arow[j], wtr[p] != 0u && arow[j] >= 0);
+            ra[q] = ld_sel(wdyp[p] + arow[j], (wtr[p] != 0u) & (arow[j] >= 0), zp);
         } else if constexpr (AVEC) {
-            const bool ok = live && arow[q] >= 0 && k0 + v_k < k_end;
-            const float* ap = ok ? a.w + arow[q] + k0 : g_zero4;
+            const bool ok = (live & (arow[q] >= 0)) & (k0 + v_k < k_end);
+            const float* ap = ok ? a.w + arow[q] + k0 : zp;
             const float4 v = *reinterpret_cast<const float4*>(ap);
             ra[4 * q] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
         } else {
-            ra[q] = ld_sel(a.w + arow[q] + k0, live && arow[q] >= 0 && k0 + s_k < k_end);
+            ra[q] = ld_sel(a.w + arow[q] + k0, (live & (arow[q] >= 0)) & (k0 + s_k < k_end), zp);
         }
     };
     auto loadB = [&](int q, int k0, bool live) {         // q-th B load of the K step
@@ -286,15 +289,15 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
             const bool ok = (tp >= 0) & ((unsigned)(wt0[p] + (tp & 255)) < wtr[p]) &
                             ((unsigned)(wh0[p] + ((tp >> 8) & 255)) < (unsigned)g.Hi) &
                             ((unsigned)(ww0[p] + ((tp >> 16) & 255)) < (unsigned)g.Wi);
-            rb[q] = ld_sel(wxp[p] + wcoff[j], ok);
+            rb[q] = ld_sel(wxp[p] + wcoff[j], ok, zp);
         } else {
             // k is wave-uniform; its tap was decoded once per launch into the table: e.x = element offset
             // relative to this thread's anchor, e.y = (1<<dt | 1<<(8+dh) | 1<<(16+dw)).  The tap is inside the
             // tensor for this thread iff all three bits are set in the thread's validity mask.
             const int kk = k0 + b_kq * B_PER + q;
             const int2 e = te[q];
-            const bool ok = live && kk < k_end && (anchor.mask & (unsigned)e.y) == (unsigned)e.y;
-            rb[q] = ld_sel(anchor.base + e.x, ok);
+            const bool ok = (live & (kk < k_end)) & ((anchor.mask & (unsigned)e.y) == (unsigned)e.y);
+            rb[q] = ld_sel(anchor.base + e.x, ok, zp);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -591,8 +594,19 @@ int choose_splits(int tiles, int K) {
     return s < 1 ? 1 : (s > cap ? cap : s);
 }
 
+static const float* zero_word_address() {
+    static const float* z = nullptr;         // address of a module global: constant for the process lifetime
+    if (!z) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero4)) == hipSuccess) z = static_cast<const float*>(p);
+    }
+    return z;
+}
+
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    a.zero = zero_word_address();
+    if (!a.zero) return OTAL_E_UNSUPPORTED;
     if (const char* d = getenv("OTAL_CONV_DEBUG")) a.flags |= (atoi(d) & (DBG_NOLOAD | DBG_NOSTORE | DBG_NOBARRIER));
     if (MODE != MODE_WGRAD) {       // carve the tap table off the front of the workspace and build it
         const size_t tb = tab_bytes(a.K);
