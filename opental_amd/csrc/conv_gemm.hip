@@ -51,6 +51,12 @@ struct ConvArgs {
     int flags;
     int a_vec4;            // A rows are 16-byte aligned and K % 4 == 0 -> float4 weight loads
     int prec;              // 0: fp32 MFMA (exact), 1: bf16 MFMA operands, fp32 accumulate
+    // chunked bf16 path (conv_gemm_bf16c_kernel): K re-ordered k = ((c/8) * kvol + tap) * 8 + c%8, padded to Kp
+    const int2* ctab;      // per 8-k chunk {byte offset (tap + first channel) relative to the anchor, validity bits}
+    const unsigned short* wp;   // A operand packed by the prologue: bf16 [Mpad][Kp], zero padded
+    unsigned src_bytes;    // extent of the gathered tensor (buffer descriptor num_records; also the OOB offset)
+    unsigned wp_bytes;
+    int Kp;
 };
 
 // ---- operand element fetch -------------------------------------------------------------------
@@ -122,12 +128,63 @@ __device__ __forceinline__ float ld_sel(const float* p, bool ok, const float* ze
 }
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {     // v_cvt_pk_bf16_f32: RNE, lo in bits 0..15
+    const hw_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, hw_bf16x2));
+}
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {     // round to nearest even, lo in bits 0..15
     unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
     a += 0x7fffu + ((a >> 16) & 1u);
     b += 0x7fffu + ((b >> 16) & 1u);
     return (a >> 16) | (b & 0xffff0000u);
+}
+
+// ---- epilogue.  C/D map of the 32x32 MFMAs: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int MODE, int WM, int WN>
+__device__ __forceinline__ void store_acc(const ConvArgs& a, const f32x16 (&acc)[WM][WN], int m0, int n0, int wm0, int wn0,
+                                          int lane, int split) {
+    const ConvGeom& g = a.g;
+    const ConvFastDiv& fd = a.fd;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + wn0 + j * 32 + (lane & 31);
+        if (n >= a.N) continue;
+        int64_t nbase = 0;
+        if (a.splits == 1) {
+            if constexpr (MODE == MODE_FWD) nbase = conv_out_offset(g, dec_pos_fd(n, fd.To, fd.Ho, fd.Wo), 0);
+            else if constexpr (MODE == MODE_DGRAD) nbase = conv_in_offset(g, dec_pos_fd(n, fd.Ti, fd.Hi, fd.Wi), 0);
+            else nbase = n;
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= a.M) continue;
+                float v = acc[i][j][r];
+                if (a.splits > 1) {
+                    a.slab[((int64_t)split * a.M + m) * a.N + n] = v;
+                    continue;
+                }
+                int64_t off;
+                if constexpr (MODE == MODE_FWD) {
+                    if (a.scale) v *= a.scale[m];
+                    if (a.shift) v += a.shift[m];
+                    if (a.flags & EPI_RELU) v = fmaxf(v, 0.f);
+                    off = nbase + (int64_t)m * g.y_cs;
+                } else if constexpr (MODE == MODE_DGRAD) {
+                    off = nbase + (int64_t)m * g.x_cs;
+                    if (a.emask) v = a.emask[off] > 0.f ? v * a.escale[m] : 0.f;
+                } else {
+                    off = (int64_t)m * a.N + nbase;
+                }
+                if (a.flags & EPI_ACCUM) v += a.out[off];
+                a.out[off] = v;
+            }
+    }
 }
 
 // PREC 0: fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32; BK = 16, LDS tiles k-major [k][m]).
@@ -444,43 +501,198 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
         if (!(a.flags & DBG_NOBARRIER)) __syncthreads();
     }
 
-    // ---- epilogue.  C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    store_acc<MODE, WM, WN>(a, acc, m0, n0, wm0, wn0, lane, split);
+}
+
+// =================================================================================================
+// Chunked bf16 kernel (FWD / DGRAD, channel count % 8 == 0): the vector ALU, not the matrix core, bounded
+// the generic kernel above (rocprofv3: ~40 VALU + 21 SALU instructions per MFMA, profiles/r01_pmc_sq_*):
+// per gathered element it paid a validity test, a pointer select, 64-bit address math and a software
+// bf16 rounding.  Here
+//   * K is re-ordered in chunks of 8 channels x one tap, k = ((c/8) * kvol + tap) * 8 + c%8 (padded to a multiple
+//     of 32), so the 8 consecutive k a thread fetches share one tap: ONE validity test + ONE offset select per 8
+//     loads; the 27 taps of a channel block are adjacent in K, so neighbouring taps re-hit the same lines in L1;
+//   * loads are buffer_load_dword with the per-thread byte offset in a VGPR and the channel stride i*cs in an
+//     SGPR; an invalid tap selects an offset == num_records and the hardware bounds check returns 0.0;
+//   * the weights are packed ONCE per launch by the prologue kernel into bf16 [Mpad][Kp] (zero padded: no row /
+//     tail predicates, 8-byte loads, no conversion in the loop);
+//   * activations are rounded with v_cvt_pk_bf16_f32 (RNE) while they are staged into LDS.
+// Result: ~5 VALU per MFMA.  MFMA loop, LDS layout (80-byte pitch) and epilogue are those of the generic kernel.
+template <int BM, int WM, int WN, int MODE>
+__global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
+    constexpr int BN = 128, BK = 32, KP = 40;
+    constexpr int A_PIECES = BM / 32;                       // 8-byte weight pieces per thread per K step
+    __shared__ __attribute__((aligned(16))) unsigned short smA[2][BM * KP];
+    __shared__ __attribute__((aligned(16))) unsigned short smB[2][BN * KP];
+
+    const ConvGeom& g = a.g;
+    const ConvFastDiv& fd = a.fd;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int split = blockIdx.z;
+    const int k_begin = split * a.k_per_split;
+    const int k_end = min(a.Kp, k_begin + a.k_per_split);
+    const int nk = (k_end - k_begin) / BK;                  // Kp and k_per_split are multiples of 32
+
+    const float* src = MODE == MODE_FWD ? a.x : a.dy;
+    const int cs_bytes = (int)((MODE == MODE_FWD ? g.x_cs : g.y_cs) * 4);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)a.src_bytes, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, (int)a.wp_bytes, 0x00020000);
+
+    // gather anchor of this thread's column: byte offset of its window origin + per-axis validity mask
+    const int b_n = tid & (BN - 1);
+    const int b_kq = __builtin_amdgcn_readfirstlane(tid >> 7);       // which 16-k half of the K step
+    unsigned voff0, vmask;
+    {
+        const int n = n0 + b_n;
+        Anchor an;
+        if constexpr (MODE == MODE_FWD) an = anchor_of_output(g, src, dec_pos_fd(n < a.N ? n : 0, fd.To, fd.Ho, fd.Wo), n < a.N);
+        else an = anchor_of_input(g, src, dec_pos_fd(n < a.N ? n : 0, fd.Ti, fd.Hi, fd.Wi), n < a.N);
+        voff0 = (unsigned)((an.base - src) * 4);            // may be "negative": the sum with a valid tap offset is not
+        vmask = an.mask;
+    }
+    // weight pieces: piece p = tid + 256 j -> row p >> 3, 4 bf16 at k = (p & 7) * 4
+    unsigned voffA[A_PIECES];
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = n0 + wn0 + j * 32 + (lane & 31);
-        if (n >= a.N) continue;
-        int64_t nbase = 0;
-        if (a.splits == 1) {
-            if constexpr (MODE == MODE_FWD) nbase = conv_out_offset(g, dec_pos_fd(n, fd.To, fd.Ho, fd.Wo), 0);
-            else if constexpr (MODE == MODE_DGRAD) nbase = conv_in_offset(g, dec_pos_fd(n, fd.Ti, fd.Hi, fd.Wi), 0);
-            else nbase = n;
+    for (int j = 0; j < A_PIECES; ++j) {
+        const int p = tid + NT * j;
+        voffA[j] = (unsigned)(((m0 + (p >> 3)) * a.Kp + (p & 7) * 4) * 2);
+    }
+
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 ra[A_PIECES];
+    float rb[16];
+    auto loadA = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < A_PIECES; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b64(rw, voffA[j], k0 * 2, 0);
+    };
+    // chunk-table entries of the NEXT K step, fetched one step ahead as single 64-bit scalar loads
+    const unsigned long long* ctab64 = reinterpret_cast<const unsigned long long*>(a.ctab) + b_kq * 2;
+    unsigned long long ce[2], ce_next[2];
+    auto loadT = [&](int k0) {
+        ce_next[0] = ctab64[(k0 >> 3)];
+        ce_next[1] = ctab64[(k0 >> 3) + 1];
+    };
+    auto loadB = [&](int h) {                              // h-th 8-k chunk of this thread's 16
+        const unsigned ex = (unsigned)ce[h], ey = (unsigned)(ce[h] >> 32);
+        const unsigned sel = (vmask & ey) == ey ? 0xffffffffu : 0u;
+        const unsigned vo = ((voff0 + ex) & sel) | (a.src_bytes & ~sel);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            rb[8 * h + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * cs_bytes, 0));
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned short* As = smA[buf];
+        unsigned short* Bs = smB[buf];
+#pragma unroll
+        for (int j = 0; j < A_PIECES; ++j) {
+            const int p = tid + NT * j;
+            *reinterpret_cast<u32x2*>(As + (p >> 3) * KP + (p & 7) * 4) = ra[j];
         }
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+        for (int h = 0; h < 2; ++h) {
+            uint4 pk;
+            pk.x = cvt_pk_bf16(rb[8 * h], rb[8 * h + 1]);
+            pk.y = cvt_pk_bf16(rb[8 * h + 2], rb[8 * h + 3]);
+            pk.z = cvt_pk_bf16(rb[8 * h + 4], rb[8 * h + 5]);
+            pk.w = cvt_pk_bf16(rb[8 * h + 6], rb[8 * h + 7]);
+            *reinterpret_cast<uint4*>(Bs + b_n * KP + b_kq * 16 + 8 * h) = pk;
+        }
+    };
+
+    constexpr int WAVES_N = BN / (32 * WN);
+    const int wm0 = (wave / WAVES_N) * (32 * WM);
+    const int wn0 = (wave % WAVES_N) * (32 * WN);
+    f32x16 acc[WM][WN];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= a.M) continue;
-                float v = acc[i][j][r];
-                if (a.splits > 1) {
-                    a.slab[((int64_t)split * a.M + m) * a.N + n] = v;
-                    continue;
-                }
-                int64_t off;
-                if constexpr (MODE == MODE_FWD) {
-                    if (a.scale) v *= a.scale[m];
-                    if (a.shift) v += a.shift[m];
-                    if (a.flags & EPI_RELU) v = fmaxf(v, 0.f);
-                    off = nbase + (int64_t)m * g.y_cs;
-                } else if constexpr (MODE == MODE_DGRAD) {
-                    off = nbase + (int64_t)m * g.x_cs;
-                    if (a.emask) v = a.emask[off] > 0.f ? v * a.escale[m] : 0.f;
-                } else {
-                    off = (int64_t)m * a.N + nbase;
-                }
-                if (a.flags & EPI_ACCUM) v += a.out[off];
-                a.out[off] = v;
-            }
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    loadT(k_begin);
+    ce[0] = ce_next[0]; ce[1] = ce_next[1];
+    loadT(k_begin + BK);
+    if (nk > 0) {
+        loadA(k_begin);
+        loadB(0);
+        loadB(1);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const int buf = it & 1;
+        ce[0] = ce_next[0]; ce[1] = ce_next[1];             // entries of step it+1 (loaded during step it-1)
+        loadT(k_begin + (it + 2) * BK);
+        // the table and the packed weights are padded by a full K step, so the prefetch past the last step of a
+        // launch is harmless (it reads real or padding entries and its LDS buffer is never consumed)
+        const int kn = k_begin + (it + 1) * BK;
+        const unsigned short* as = smA[buf];
+        const unsigned short* bs = smB[buf];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c == 0) { loadA(kn); loadB(0); } else loadB(1);
+            bf16x8 av[WM], bv[WN];
+            const int ko = 16 * c + (lane >> 5) * 8;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                av[i] = *reinterpret_cast<const bf16x8*>(as + (wm0 + i * 32 + (lane & 31)) * KP + ko);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                bv[j] = *reinterpret_cast<const bf16x8*>(bs + (wn0 + j * 32 + (lane & 31)) * KP + ko);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    store_acc<MODE, WM, WN>(a, acc, m0, n0, wm0, wn0, lane, split);
+}
+
+// prologue of the chunked path: chunk table + bf16 weight pack in one launch.
+//   wsrc: FWD W (M=Cout, C=Cin, kvol);  DGRAD packed W^T (M=Cin, C=Cout, kvol)  -> wp[m][tap * C + c]
+template <int MODE>
+__global__ __launch_bounds__(256) void prep_chunks_kernel(int2* __restrict__ ctab, unsigned* __restrict__ wp,
+                                                          const float* __restrict__ wsrc, ConvGeom g, int M, int Mpad,
+                                                          int C, int kvol, int K, int Kp, int nchunk) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid < nchunk) {
+        const int k0 = (int)gid * 8;
+        int2 e;
+        e.x = 0; e.y = -1;
+        if (k0 < K) {
+            const int j = k0 >> 3, cb = j / kvol, tap = j - cb * kvol, c0 = cb * 8;      // k = ((c/8) * kvol + tap) * 8 + c % 8
+            const int khw = g.kh * g.kw;
+            const int dt = tap / khw, r = tap - dt * khw, dh = r / g.kw, dw = r - dh * g.kw;
+            int64_t off;
+            if (MODE == MODE_FWD) off = (int64_t)c0 * g.x_cs + ((int64_t)dt * g.Hi + dh) * g.Wi + dw;
+            else off = (int64_t)c0 * g.y_cs -
+                       (((int64_t)(dt >> (g.st - 1)) * g.Ho + (dh >> (g.sh - 1))) * g.Wo + (dw >> (g.sw - 1)));
+            e.x = (int)(unsigned)(off * 4);
+            e.y = (1 << dt) | (1 << (8 + dh)) | (1 << (16 + dw));
+        }
+        ctab[gid] = e;
+    }
+    const int half = Kp / 2;
+    const int64_t pairs = (int64_t)Mpad * half;
+    for (int64_t p = gid; p < pairs; p += (int64_t)gridDim.x * 256) {
+        const int m = (int)(p / half), k = (int)(p - (int64_t)m * half) * 2;
+        float v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kk = k + i;
+            const int j = kk >> 3, cb = j / kvol, tap = j - cb * kvol, c = cb * 8 + (kk & 7);
+            v[i] = (m < M && kk < K) ? wsrc[((int64_t)m * C + c) * kvol + tap] : 0.f;
+        }
+        wp[p] = cvt_pk_bf16(v[0], v[1]);
     }
 }
 
@@ -603,8 +815,89 @@ static const float* zero_word_address() {
     return z;
 }
 
+// ---- chunked bf16 path: eligibility, workspace layout [chunk table][packed bf16 weights][split-K slabs]
+constexpr int CHUNK_PAD = 16;       // table entries readable past Kp/8 (two K steps of prefetch)
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+static inline int chunk_kp(int K) { return (K + 31) / 32 * 32; }
+static inline size_t chunk_tab_bytes(int K) { return align256(((size_t)chunk_kp(K) / 8 + CHUNK_PAD) * sizeof(int2)); }
+static inline size_t chunk_wp_bytes(int M, int BM, int K) {      // + one K step so the prefetch past Kp stays inside
+    return align256(((size_t)((M + BM - 1) / BM * BM) * chunk_kp(K) + 64) * sizeof(unsigned short));
+}
+// extent in bytes of the tensor the gather reads (channel-sliced views: strides come from the caller)
+static inline int64_t gather_extent_bytes(const ConvGeom& g, int mode) {
+    if (mode == MODE_FWD) return 4 * ((int64_t)(g.B - 1) * g.x_bs + (int64_t)(g.Cin - 1) * g.x_cs + conv_in_positions(g));
+    return 4 * ((int64_t)(g.B - 1) * g.y_bs + (int64_t)(g.Cout - 1) * g.y_cs + conv_out_positions(g));
+}
+static inline bool chunk_eligible(const ConvGeom& g, int mode, int prec) {
+    if (!prec || mode == MODE_WGRAD) return false;
+    if (getenv("OTAL_CONV_NOCHUNK")) return false;
+    const int C = mode == MODE_FWD ? g.Cin : g.Cout;
+    if (C % 8) return false;
+    const int64_t ext = gather_extent_bytes(g, mode);
+    return ext > 0 && ext < (int64_t)0xfffffff0u;       // 32-bit buffer offsets
+}
+
+template <int MODE>
+int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int C = MODE == MODE_FWD ? a.g.Cin : a.g.Cout;
+    const int kvol = conv_kvol(a.g);
+    const int BMsel = choose_bm(a.M);
+    const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + 127) / 128;
+    const int Mpad = tm * BMsel;
+    a.Kp = chunk_kp(a.K);
+    const size_t tb = chunk_tab_bytes(a.K), wb = chunk_wp_bytes(a.M, BMsel, a.K);
+    if (!ws || ws_bytes < tb + wb) return OTAL_E_UNSUPPORTED;
+    int2* ctab = reinterpret_cast<int2*>(ws);
+    unsigned short* wp = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ws) + tb);
+    const int nchunk = a.Kp / 8 + CHUNK_PAD;
+    {
+        const int64_t pairs = (int64_t)Mpad * (a.Kp / 2);
+        int64_t blocks = (pairs + 255) / 256;
+        if (blocks < (nchunk + 255) / 256) blocks = (nchunk + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL((prep_chunks_kernel<MODE>), dim3((unsigned)blocks), dim3(256), 0, st, ctab,
+                           reinterpret_cast<unsigned*>(wp), a.w, a.g, a.M, Mpad, C, kvol, a.K, a.Kp, nchunk);
+        if (int e = otal_launch_status()) return e;
+    }
+    a.ctab = ctab; a.wp = wp;
+    a.src_bytes = (unsigned)gather_extent_bytes(a.g, MODE);
+    a.wp_bytes = (unsigned)wb;
+    ws = reinterpret_cast<char*>(ws) + tb + wb;
+    ws_bytes -= tb + wb;
+    a.fd = make_conv_fastdiv(a.g);
+    int splits = choose_splits(tm * tn, a.Kp);
+    if (splits > 1) {
+        const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
+        if (ws_bytes < need) {
+            splits = (int)(ws_bytes / ((size_t)a.M * a.N * sizeof(float)));
+            if (splits < 2) splits = 1;
+        }
+    }
+    const int kps = ((a.Kp + splits - 1) / splits + 31) / 32 * 32;
+    splits = (a.Kp + kps - 1) / kps;
+    a.splits = splits;
+    a.k_per_split = kps;
+    a.slab = splits > 1 ? (float*)ws : nullptr;
+    const dim3 grid(tn, tm, splits);
+    if (BMsel == 128) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<128, 2, 2, MODE>), grid, dim3(NT), 0, st, a);
+    else if (BMsel == 96) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<96, 3, 1, MODE>), grid, dim3(NT), 0, st, a);
+    else if (BMsel == 64) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<64, 2, 1, MODE>), grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((conv_gemm_bf16c_kernel<32, 1, 1, MODE>), grid, dim3(NT), 0, st, a);
+    if (int e = otal_launch_status()) return e;
+    if (splits > 1) {
+        const int64_t total = (int64_t)a.M * a.N;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL((splitk_reduce_kernel<MODE>), dim3(blocks), dim3(256), 0, st, a);
+        return otal_launch_status();
+    }
+    return 0;
+}
+
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    if constexpr (MODE != MODE_WGRAD) {
+        if (chunk_eligible(a.g, MODE, a.prec)) return launch_chunked<MODE>(a, ws, ws_bytes, st);
+    }
     a.zero = zero_word_address();
     if (!a.zero) return OTAL_E_UNSUPPORTED;
     if (const char* d = getenv("OTAL_CONV_DEBUG")) a.flags |= (atoi(d) & (DBG_NOLOAD | DBG_NOSTORE | DBG_NOBARRIER));
@@ -681,7 +974,13 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
     const int BN = 128;
     const int tiles = (int)(((M + BMsel - 1) / BMsel) * ((N + BN - 1) / BN));
     const int s = choose_splits(tiles, (int)K);
-    return (mode == MODE_WGRAD ? 0 : tab_bytes((int)K)) + (s > 1 ? (size_t)s * M * N * sizeof(float) : 0);
+    // precision is not an argument here: size for whichever path needs more (generic tap table vs chunk table + packed weights)
+    size_t front = mode == MODE_WGRAD ? 0 : tab_bytes((int)K);
+    if (mode != MODE_WGRAD) {
+        const size_t cf = chunk_tab_bytes((int)K) + chunk_wp_bytes((int)M, BMsel, (int)K);
+        if (cf > front) front = cf;
+    }
+    return front + (s > 1 ? (size_t)(s + 1) * M * N * sizeof(float) : 0);
 }
 
 extern "C" int otal_conv_fwd(const int* geom, const int64_t* strides, const float* x, const float* w,
