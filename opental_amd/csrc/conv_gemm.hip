@@ -128,6 +128,8 @@ __device__ __forceinline__ float ld_sel(const float* p, bool ok, const float* ze
 }
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+struct Words4 { unsigned a, b, c, d; };
+struct Words2 { unsigned a, b; };
 typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {     // v_cvt_pk_bf16_f32: RNE, lo in bits 0..15
@@ -518,12 +520,24 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
 //     tail predicates, 8-byte loads, no conversion in the loop);
 //   * activations are rounded with v_cvt_pk_bf16_f32 (RNE) while they are staged into LDS.
 // Result: ~5 VALU per MFMA.  MFMA loop, LDS layout (80-byte pitch) and epilogue are those of the generic kernel.
-template <int BM, int WM, int WN, int MODE>
+// CW = consecutive positions one thread fetches per load (the texture addresser is the next bound after the VALU:
+// a wave64 buffer_load_dword costs ~14 CU cycles whatever it returns, a dwordx4 ~23 -- tools/ubench/bufcheck.hip):
+//   CW 1: thread = 1 position x 16 k (two chunks), 16 dword loads          -- any geometry
+//   CW 4: thread = 4 positions x 4 k of the wave's chunk, 4 dwordx4 loads  -- stride 1, Wo == Wi, W % 4 == 0, kw in {1,3}
+//   CW 2: thread = 2 positions x 8 k of the wave's chunk, 8 dwordx2 loads  -- same with W % 2 == 0
+// With CW > 1 the w-axis validity is not a per-thread bit any more: the vector is contiguous in w, a tap shifted by
+// -1 / +1 invalidates only its FIRST / LAST element and only for the thread whose vector touches the row start / end,
+// so two conditional zeroings per vector replace the per-element test.  LDS rows are permuted
+// (row(n) = (n % CW) * PB + n / CW) so that both the staged writes and the ds_read_b128 operand reads stay
+// conflict free (PB = 36 / 72, searched with the bank model of MI355X_MICROARCH.md).
+template <int BM, int WM, int WN, int MODE, int CW>
 __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
     constexpr int BN = 128, BK = 32, KP = 40;
-    constexpr int A_PIECES = BM / 32;                       // 8-byte weight pieces per thread per K step
+    constexpr int PB = CW == 4 ? 36 : (CW == 2 ? 72 : 0);   // LDS row-block pitch of the position permutation
+    constexpr int B_ROWS = CW == 1 ? BN : (CW - 1) * PB + BN / CW;
+    constexpr int A_PIECES = (BM * 4 + NT - 1) / NT;        // 16-byte weight pieces per thread per K step
     __shared__ __attribute__((aligned(16))) unsigned short smA[2][BM * KP];
-    __shared__ __attribute__((aligned(16))) unsigned short smB[2][BN * KP];
+    __shared__ __attribute__((aligned(16))) unsigned short smB[2][B_ROWS * KP];
 
     const ConvGeom& g = a.g;
     const ConvFastDiv& fd = a.fd;
@@ -542,70 +556,158 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)a.src_bytes, 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, (int)a.wp_bytes, 0x00020000);
 
-    // gather anchor of this thread's column: byte offset of its window origin + per-axis validity mask
-    const int b_n = tid & (BN - 1);
-    const int b_kq = __builtin_amdgcn_readfirstlane(tid >> 7);       // which 16-k half of the K step
-    unsigned voff0, vmask;
+    // ---- thread -> B tile map
+    //  CW 1: column b_n = tid & 127, chunks (tid >> 7) * 2 + {0, 1} of the K step
+    //  CW 4: columns 4q..4q+3 (q = tid & 31), chunk = wave, k = (lane >> 5) * 4 + i inside it
+    //  CW 2: columns 2q, 2q+1 (q = lane),     chunk = wave, k = i
+    const int b_q = CW == 1 ? (tid & 127) : (CW == 4 ? (tid & 31) : lane);
+    const int b_kq = __builtin_amdgcn_readfirstlane(tid >> 7);
+    unsigned voff0, vmask, keepL_thr = 0u, keepR_thr = 0u;      // keep*_thr: all-ones when this thread's vector touches the row start / end
     {
-        const int n = n0 + b_n;
+        const int n = n0 + CW * b_q;
         Anchor an;
-        if constexpr (MODE == MODE_FWD) an = anchor_of_output(g, src, dec_pos_fd(n < a.N ? n : 0, fd.To, fd.Ho, fd.Wo), n < a.N);
-        else an = anchor_of_input(g, src, dec_pos_fd(n < a.N ? n : 0, fd.Ti, fd.Hi, fd.Wi), n < a.N);
+        PosDec pd;
+        if constexpr (MODE == MODE_FWD) {
+            pd = dec_pos_fd(n < a.N ? n : 0, fd.To, fd.Ho, fd.Wo);
+            an = anchor_of_output(g, src, pd, n < a.N);
+        } else {
+            pd = dec_pos_fd(n < a.N ? n : 0, fd.Ti, fd.Hi, fd.Wi);
+            an = anchor_of_input(g, src, pd, n < a.N);
+        }
         voff0 = (unsigned)((an.base - src) * 4);            // may be "negative": the sum with a valid tap offset is not
         vmask = an.mask;
+        if constexpr (CW > 1) {
+            voff0 += (unsigned)((CW == 4 ? (lane >> 5) * 4 : 0) * cs_bytes);
+            keepL_thr = pd.w == 0 ? 0xffffffffu : 0u;
+            keepR_thr = pd.w + CW == g.Wi ? 0xffffffffu : 0u;
+        }
     }
-    // weight pieces: piece p = tid + 256 j -> row p >> 3, 4 bf16 at k = (p & 7) * 4
+    // weight pieces: piece p = tid + 256 j -> row p >> 2, 8 bf16 at k = (p & 3) * 8
     unsigned voffA[A_PIECES];
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) {
         const int p = tid + NT * j;
-        voffA[j] = (unsigned)(((m0 + (p >> 3)) * a.Kp + (p & 7) * 4) * 2);
+        voffA[j] = (unsigned)(((m0 + (p >> 2)) * a.Kp + (p & 3) * 8) * 2);
     }
 
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 ra[A_PIECES];
-    float rb[16];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[A_PIECES];
+    float rb[16];                                           // CW 1: [chunk h][k i]; CW 4: [k i][pos j]; CW 2: [k i][pos j]
     auto loadA = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < A_PIECES; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b64(rw, voffA[j], k0 * 2, 0);
+        for (int j = 0; j < A_PIECES; ++j)
+            if ((BM * 4) % NT == 0 || tid + NT * j < BM * 4)
+                ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, voffA[j], k0 * 2, 0);
     };
-    // chunk-table entries of the NEXT K step, fetched one step ahead as single 64-bit scalar loads
-    const unsigned long long* ctab64 = reinterpret_cast<const unsigned long long*>(a.ctab) + b_kq * 2;
-    unsigned long long ce[2], ce_next[2];
+    // chunk-table entries of the NEXT K step, fetched one step ahead as 64-bit scalar loads
+    constexpr int NE = CW == 1 ? 2 : 1;
+    const unsigned long long* ctab64 = reinterpret_cast<const unsigned long long*>(a.ctab) + (CW == 1 ? b_kq * 2 : wave);
+    unsigned long long ce[NE], ce_next[NE];
     auto loadT = [&](int k0) {
-        ce_next[0] = ctab64[(k0 >> 3)];
-        ce_next[1] = ctab64[(k0 >> 3) + 1];
-    };
-    auto loadB = [&](int h) {                              // h-th 8-k chunk of this thread's 16
-        const unsigned ex = (unsigned)ce[h], ey = (unsigned)(ce[h] >> 32);
-        const unsigned sel = (vmask & ey) == ey ? 0xffffffffu : 0u;
-        const unsigned vo = ((voff0 + ex) & sel) | (a.src_bytes & ~sel);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            rb[8 * h + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * cs_bytes, 0));
+        for (int h = 0; h < NE; ++h) ce_next[h] = ctab64[(k0 >> 3) + h];
     };
+    auto loadB = [&](int h) {
+        if constexpr (CW == 1) {                           // h-th 8-k chunk of this thread's 16
+            const unsigned ex = (unsigned)ce[h], ey = (unsigned)(ce[h] >> 32);
+            const unsigned sel = (vmask & ey) == ey ? 0xffffffffu : 0u;
+            const unsigned vo = ((voff0 + ex) & sel) | (a.src_bytes & ~sel);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                rb[8 * h + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * cs_bytes, 0));
+        } else {
+            const unsigned ex = (unsigned)ce[0], ey = (unsigned)(ce[0] >> 32);
+            const unsigned eth = ey & 0x8000ffffu;                 // t / h bits (+ the never-valid bit of padding entries)
+            const unsigned dwb = (ey >> 16) & 0xffu;               // 1 << dw
+            // w shift of this tap relative to the centre: FWD dw - pw, DGRAD pw - dw
+            const bool below = (dwb & ((1u << g.pw) - 1u)) != 0u, above = (dwb >> (g.pw + 1)) != 0u;
+            const unsigned sneg = (MODE == MODE_FWD ? below : above) ? 0xffffffffu : 0u;
+            const unsigned spos = (MODE == MODE_FWD ? above : below) ? 0xffffffffu : 0u;
+            const unsigned keepL = ~(keepL_thr & sneg), keepR = ~(keepR_thr & spos);
+            const unsigned sel = (vmask & eth) == eth ? 0xffffffffu : 0u;
+            const unsigned vo = ((voff0 + ex) & sel) | (a.src_bytes & ~sel);
+            constexpr int NL = 16 / CW;                            // loads per thread per K step
+            if (h == 0) {
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    // (the loaded vector is bit-cast to a plain struct: hipcc 7.2 miscompiles `v[i] & mask` on the
+                    //  builtin's vector result -- elements 1 and 2 come back as element 0)
+                    if constexpr (CW == 4) {
+                        const Words4 v = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, i * cs_bytes, 0));
+                        rb[4 * i] = __builtin_bit_cast(float, v.a & keepL);
+                        rb[4 * i + 1] = __builtin_bit_cast(float, v.b);
+                        rb[4 * i + 2] = __builtin_bit_cast(float, v.c);
+                        rb[4 * i + 3] = __builtin_bit_cast(float, v.d & keepR);
+                    } else {
+                        const Words2 v = __builtin_bit_cast(Words2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, i * cs_bytes, 0));
+                        rb[2 * i] = __builtin_bit_cast(float, v.a & keepL);
+                        rb[2 * i + 1] = __builtin_bit_cast(float, v.b & keepR);
+                    }
+                }
+                // a vector whose first element lies 4 bytes in front of the tensor (very first row, tap shifted by -1)
+                // is rejected as a whole by the bounds check: re-fetch its other elements one by one.  The branch is
+                // wave-uniform (ballot) and taken by one wave of the grid; lanes select their own result.
+                const bool neg = vo >= 0xfffffff0u;
+                if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
+#pragma unroll
+                    for (int i = 0; i < NL; ++i)
+#pragma unroll
+                        for (int j = 1; j < CW; ++j) {
+                            unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? vo + 4u * j : a.src_bytes, i * cs_bytes, 0);
+                            if (j == CW - 1) v &= keepR;
+                            rb[CW * i + j] = neg ? __builtin_bit_cast(float, v) : rb[CW * i + j];
+                        }
+                }
+            }
+        }
+    };
+    auto prow = [&](int n) { return CW == 1 ? n : (n % CW) * PB + n / CW; };     // LDS row of tile column n
     auto store_tiles = [&](int buf) {
         unsigned short* As = smA[buf];
         unsigned short* Bs = smB[buf];
 #pragma unroll
         for (int j = 0; j < A_PIECES; ++j) {
             const int p = tid + NT * j;
-            *reinterpret_cast<u32x2*>(As + (p >> 3) * KP + (p & 7) * 4) = ra[j];
+            if ((BM * 4) % NT == 0 || p < BM * 4) *reinterpret_cast<u32x4*>(As + (p >> 2) * KP + (p & 3) * 8) = ra[j];
         }
+        if constexpr (CW == 1) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            uint4 pk;
-            pk.x = cvt_pk_bf16(rb[8 * h], rb[8 * h + 1]);
-            pk.y = cvt_pk_bf16(rb[8 * h + 2], rb[8 * h + 3]);
-            pk.z = cvt_pk_bf16(rb[8 * h + 4], rb[8 * h + 5]);
-            pk.w = cvt_pk_bf16(rb[8 * h + 6], rb[8 * h + 7]);
-            *reinterpret_cast<uint4*>(Bs + b_n * KP + b_kq * 16 + 8 * h) = pk;
+            for (int h = 0; h < 2; ++h) {
+                uint4 pk;
+                pk.x = cvt_pk_bf16(rb[8 * h], rb[8 * h + 1]);
+                pk.y = cvt_pk_bf16(rb[8 * h + 2], rb[8 * h + 3]);
+                pk.z = cvt_pk_bf16(rb[8 * h + 4], rb[8 * h + 5]);
+                pk.w = cvt_pk_bf16(rb[8 * h + 6], rb[8 * h + 7]);
+                *reinterpret_cast<uint4*>(Bs + b_q * KP + b_kq * 16 + 8 * h) = pk;
+            }
+        } else if constexpr (CW == 4) {                    // rb[k i][pos j]: per position 4 bf16 (k = ksub .. ksub+3)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x2 pk;
+                pk[0] = cvt_pk_bf16(rb[j], rb[4 + j]);
+                pk[1] = cvt_pk_bf16(rb[8 + j], rb[12 + j]);
+                *reinterpret_cast<u32x2*>(Bs + (j * PB + b_q) * KP + wave * 8 + (lane >> 5) * 4) = pk;
+            }
+        } else {                                           // rb[k i][pos j]: per position 8 bf16
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 pk;
+                pk.x = cvt_pk_bf16(rb[j], rb[2 + j]);
+                pk.y = cvt_pk_bf16(rb[4 + j], rb[6 + j]);
+                pk.z = cvt_pk_bf16(rb[8 + j], rb[10 + j]);
+                pk.w = cvt_pk_bf16(rb[12 + j], rb[14 + j]);
+                *reinterpret_cast<uint4*>(Bs + (j * PB + b_q) * KP + wave * 8) = pk;
+            }
         }
     };
 
     constexpr int WAVES_N = BN / (32 * WN);
     const int wm0 = (wave / WAVES_N) * (32 * WM);
     const int wn0 = (wave % WAVES_N) * (32 * WN);
+    int brow[WN];                                           // LDS element offset of this lane's B rows
+#pragma unroll
+    for (int j = 0; j < WN; ++j) brow[j] = prow(wn0 + j * 32 + (lane & 31)) * KP + (lane >> 5) * 8;
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -615,7 +717,8 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     loadT(k_begin);
-    ce[0] = ce_next[0]; ce[1] = ce_next[1];
+#pragma unroll
+    for (int h = 0; h < NE; ++h) ce[h] = ce_next[h];
     loadT(k_begin + BK);
     if (nk > 0) {
         loadA(k_begin);
@@ -626,24 +729,24 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
     __syncthreads();
     for (int it = 0; it < nk; ++it) {
         const int buf = it & 1;
-        ce[0] = ce_next[0]; ce[1] = ce_next[1];             // entries of step it+1 (loaded during step it-1)
-        loadT(k_begin + (it + 2) * BK);
-        // the table and the packed weights are padded by a full K step, so the prefetch past the last step of a
+        // the table and the packed weights are padded by two K steps, so the prefetch past the last step of a
         // launch is harmless (it reads real or padding entries and its LDS buffer is never consumed)
         const int kn = k_begin + (it + 1) * BK;
+#pragma unroll
+        for (int h = 0; h < NE; ++h) ce[h] = ce_next[h];   // entries of step it+1 (loaded during step it-1)
+        loadT(k_begin + (it + 2) * BK);
         const unsigned short* as = smA[buf];
         const unsigned short* bs = smB[buf];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (c == 0) { loadA(kn); loadB(0); } else loadB(1);
             bf16x8 av[WM], bv[WN];
-            const int ko = 16 * c + (lane >> 5) * 8;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                av[i] = *reinterpret_cast<const bf16x8*>(as + (wm0 + i * 32 + (lane & 31)) * KP + ko);
+                av[i] = *reinterpret_cast<const bf16x8*>(as + (wm0 + i * 32 + (lane & 31)) * KP + 16 * c + (lane >> 5) * 8);
 #pragma unroll
             for (int j = 0; j < WN; ++j)
-                bv[j] = *reinterpret_cast<const bf16x8*>(bs + (wn0 + j * 32 + (lane & 31)) * KP + ko);
+                bv[j] = *reinterpret_cast<const bf16x8*>(bs + brow[j] + 16 * c);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -837,6 +940,16 @@ static inline bool chunk_eligible(const ConvGeom& g, int mode, int prec) {
     return ext > 0 && ext < (int64_t)0xfffffff0u;       // 32-bit buffer offsets
 }
 
+// positions one thread may fetch with a single vector load (see conv_gemm_bf16c_kernel)
+static inline int chunk_vector_width(const ConvGeom& g) {
+    if (const char* e = getenv("OTAL_CONV_CW")) { if (atoi(e) == 1) return 1; }
+    if (g.st != 1 || g.sh != 1 || g.sw != 1 || g.nlev > 1) return 1;
+    if (g.Wo != g.Wi || (g.kw != 1 && g.kw != 3) || g.pw != (g.kw - 1) / 2) return 1;
+    if (g.Wi % 4 == 0) return 4;
+    if (g.Wi % 2 == 0) return 2;
+    return 1;
+}
+
 template <int MODE>
 int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int C = MODE == MODE_FWD ? a.g.Cin : a.g.Cout;
@@ -879,10 +992,18 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     a.k_per_split = kps;
     a.slab = splits > 1 ? (float*)ws : nullptr;
     const dim3 grid(tn, tm, splits);
-    if (BMsel == 128) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<128, 2, 2, MODE>), grid, dim3(NT), 0, st, a);
-    else if (BMsel == 96) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<96, 3, 1, MODE>), grid, dim3(NT), 0, st, a);
-    else if (BMsel == 64) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<64, 2, 1, MODE>), grid, dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((conv_gemm_bf16c_kernel<32, 1, 1, MODE>), grid, dim3(NT), 0, st, a);
+    const int cw = chunk_vector_width(a.g);
+#define OTAL_LAUNCH_C(BM_, WM_, WN_)                                                                                   \
+    do {                                                                                                               \
+        if (cw == 4) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<BM_, WM_, WN_, MODE, 4>), grid, dim3(NT), 0, st, a);   \
+        else if (cw == 2) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<BM_, WM_, WN_, MODE, 2>), grid, dim3(NT), 0, st, a); \
+        else hipLaunchKernelGGL((conv_gemm_bf16c_kernel<BM_, WM_, WN_, MODE, 1>), grid, dim3(NT), 0, st, a);           \
+    } while (0)
+    if (BMsel == 128) OTAL_LAUNCH_C(128, 2, 2);
+    else if (BMsel == 96) OTAL_LAUNCH_C(96, 3, 1);
+    else if (BMsel == 64) OTAL_LAUNCH_C(64, 2, 1);
+    else OTAL_LAUNCH_C(32, 1, 1);
+#undef OTAL_LAUNCH_C
     if (int e = otal_launch_status()) return e;
     if (splits > 1) {
         const int64_t total = (int64_t)a.M * a.N;

@@ -254,7 +254,10 @@ def _bf16_round(t):
 BF16_CASES = [((1, 3, 16, 24, 24), 64, (7, 7, 7), (2, 2, 2), False), ((1, 64, 6, 12, 12), 192, (3, 3, 3), (1, 1, 1), False),
               ((2, 192, 4, 6, 6), 16, (1, 1, 1), (1, 1, 1), False), ((1, 96, 4, 6, 6), 208, (3, 3, 3), (1, 1, 1), False),
               ((2, 832, 8, 6, 6), 512, (1, 6, 6), (1, 1, 1), True), ((2, 512, 64), 512, 3, 1, False),
-              ((2, 512, 32), 512, 3, 2, False), ((2, 512, 64), 15, 3, 1, False), ((1, 2048, 64), 512, 1, 1, False)]
+              ((2, 512, 32), 512, 3, 2, False), ((2, 512, 64), 15, 3, 1, False), ((1, 2048, 64), 512, 1, 1, False),
+              # vector-gather paths: 4 positions per load (W % 4 == 0) and 2 (W % 2 == 0), batch > 1, 1x1x1 and 3x1x1 taps
+              ((2, 16, 3, 24, 24), 40, (3, 3, 3), (1, 1, 1), False), ((2, 24, 5, 6, 6), 64, (3, 3, 3), (1, 1, 1), False),
+              ((2, 64, 4, 12, 12), 96, (1, 1, 1), (1, 1, 1), False), ((1, 32, 6, 8, 8), 48, (3, 1, 1), (1, 1, 1), False)]
 
 
 @pytest.mark.parametrize("case", BF16_CASES)
