@@ -57,6 +57,10 @@ struct ConvArgs {
     unsigned src_bytes;    // extent of the gathered tensor (buffer descriptor num_records; also the OOB offset)
     unsigned wp_bytes;
     int Kp;
+    // vector WGRAD path (conv_wgrad_bf16v_kernel)
+    const int2* ptab;      // per CW-position group {byte offset of its window origin in x, t/h validity bits | row-edge flags}
+    unsigned dy_bytes;     // extent of dy (buffer descriptor of the A operand)
+    int P;                 // positions per sample (To*Ho*Wo), a multiple of 32 on this path
 };
 
 // ---- operand element fetch -------------------------------------------------------------------
@@ -760,6 +764,222 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
     store_acc<MODE, WM, WN>(a, acc, m0, n0, wm0, wn0, lane, split);
 }
 
+// =================================================================================================
+// Vector WGRAD (bf16 operands, stride-1 SAME convolutions with kw in {1,3}, W even, To*Ho*Wo % 32 == 0):
+//   dW[co][(ci,tap)] = sum over positions  dy[co][pos] * x[ci][pos + tap - pad]
+// Both MFMA operands want 8 CONSECUTIVE POSITIONS per lane, and positions are contiguous in memory for a fixed
+// channel, so each thread owns ONE column (ci, tap) of the tile for the whole launch and walks along the positions
+// with wide loads: per K step (32 positions) 16 positions = 2 operand vectors, fetched as CW-position groups
+// (CW = 8 / 4 / 2 by the divisibility of W; a group never leaves its row).  Validity is decided per GROUP:
+//   t / h : one test of the group's bit mask (from the per-launch position table, wave-uniform -> scalar loads)
+//           against the thread's constant tap bits; an invalid group selects the out-of-range offset (reads 0.0)
+//   w     : a tap shifted by -1 / +1 invalidates only the FIRST / LAST element of a group that touches the row
+//           start / end: two conditional zeroings.
+// The generic kernel spent ~65 VALU instructions per MFMA on per-element decode + predicates and stored bf16
+// values to LDS one by one; here it is ~7 per MFMA, all LDS stores are 8 / 16 bytes wide, and every global load
+// moves 16 bytes per lane (the texture addresser is the limiter: tools/ubench/bufcheck.hip).
+// dy rows are fetched as 16-byte pieces (4 positions) with a scalar sample/position offset.
+template <int BM, int WM, int WN, int CW>
+__global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) {
+    constexpr int BN = 128, BK = 32, KP = 40;
+    constexpr int A_PIECES = BM / 32;                       // 16-byte dy pieces (4 positions) per thread per K step
+    constexpr int NG = 16 / CW;                             // position groups per thread per K step
+    __shared__ __attribute__((aligned(16))) unsigned short smA[2][BM * KP];
+    __shared__ __attribute__((aligned(16))) unsigned short smB[2][BN * KP];
+
+    const ConvGeom& g = a.g;
+    const ConvFastDiv& fd = a.fd;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int split = blockIdx.z;
+    const int k_begin = split * a.k_per_split;
+    const int k_end = min(a.K, k_begin + a.k_per_split);
+    const int nk = (k_end - k_begin) / BK;                  // K and k_per_split are multiples of 32
+
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.src_bytes, 0x00020000);
+    const auto rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
+
+    // ---- this thread's B column: n = (ci, dt, dh, dw); columns past N are clamped (their results are never stored)
+    const int b_n = tid & (BN - 1);
+    const int b_kq = __builtin_amdgcn_readfirstlane(tid >> 7);       // which 16-position half of the K step
+    unsigned coloff, tbits, thrL, thrR;
+    {
+        const int n = min(n0 + b_n, a.N - 1);
+        const TapDec t = dec_tap_fd(fd, (uint32_t)n);
+        coloff = (unsigned)(((int64_t)t.c * g.x_cs + ((int64_t)t.dt * g.Hi + t.dh) * g.Wi + t.dw) * 4);
+        tbits = (1u << t.dt) | (1u << (8 + t.dh));
+        thrL = t.dw < g.pw ? 0xffffffffu : 0u;              // this tap reads one element to the left / right of the centre
+        thrR = t.dw > g.pw ? 0xffffffffu : 0u;
+    }
+    // ---- dy pieces: piece p = tid + 256 j -> row p >> 3, positions (p & 7) * 4 .. + 3 of the K step
+    unsigned voffA[A_PIECES];
+#pragma unroll
+    for (int j = 0; j < A_PIECES; ++j) {
+        const int p = tid + NT * j;
+        const int m = min(m0 + (p >> 3), a.M - 1);
+        voffA[j] = (unsigned)(((int64_t)m * g.y_cs + (p & 7) * 4) * 4);
+    }
+
+    Words4 ra[A_PIECES];
+    float rb[16];
+    // position -> (sample, position in sample): a K step never leaves its sample (P % 32 == 0)
+    auto dy_soff = [&](int k0) {
+        const int kc = min(k0, a.K - BK);                   // the prefetch past the end re-reads the last step
+        const uint32_t b = fd_div(fd.P, (uint32_t)kc);
+        return (int)(((int64_t)b * g.y_bs + (kc - (int)(b * fd.P.d))) * 4);
+    };
+    auto loadA = [&](int k0) {
+        const int so = dy_soff(k0);
+#pragma unroll
+        for (int j = 0; j < A_PIECES; ++j)
+            ra[j] = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rdy, voffA[j], so, 0));
+    };
+    // position-table entries of the NEXT K step (64-bit scalar loads, one step ahead)
+    const unsigned long long* ptab64 = reinterpret_cast<const unsigned long long*>(a.ptab) + b_kq * NG;
+    unsigned long long pe[NG], pe_next[NG];
+    auto loadT = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < NG; ++q) pe_next[q] = ptab64[k0 / CW + q];
+    };
+    auto loadB = [&](int q) {                              // q-th position group of this thread's 16 positions
+        const unsigned ex = (unsigned)pe[q], ey = (unsigned)(pe[q] >> 32);
+        const unsigned sel = (ey & tbits) == tbits ? 0xffffffffu : 0u;
+        const unsigned vo = ((ex + coloff) & sel) | (a.src_bytes & ~sel);
+        const unsigned eL = (ey & 0x10000u) ? 0xffffffffu : 0u, eR = (ey & 0x20000u) ? 0xffffffffu : 0u;
+        const unsigned keepL = ~(thrL & eL), keepR = ~(thrR & eR);
+        float* r = rb + CW * q;
+        if constexpr (CW == 8) {
+            const Words4 v0 = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0));
+            const Words4 v1 = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 16, 0));
+            r[0] = __builtin_bit_cast(float, v0.a & keepL); r[1] = __builtin_bit_cast(float, v0.b);
+            r[2] = __builtin_bit_cast(float, v0.c);         r[3] = __builtin_bit_cast(float, v0.d);
+            r[4] = __builtin_bit_cast(float, v1.a);         r[5] = __builtin_bit_cast(float, v1.b);
+            r[6] = __builtin_bit_cast(float, v1.c);         r[7] = __builtin_bit_cast(float, v1.d & keepR);
+        } else if constexpr (CW == 4) {
+            const Words4 v0 = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0));
+            r[0] = __builtin_bit_cast(float, v0.a & keepL); r[1] = __builtin_bit_cast(float, v0.b);
+            r[2] = __builtin_bit_cast(float, v0.c);         r[3] = __builtin_bit_cast(float, v0.d & keepR);
+        } else {
+            const Words2 v0 = __builtin_bit_cast(Words2, __builtin_amdgcn_raw_buffer_load_b64(rx, vo, 0, 0));
+            r[0] = __builtin_bit_cast(float, v0.a & keepL); r[1] = __builtin_bit_cast(float, v0.b & keepR);
+        }
+        // a group that starts 4 bytes in front of the tensor (channel 0, first row, tap shifted by -1) is rejected as a
+        // whole by the bounds check: re-fetch its other elements one by one (wave-uniform branch, a few waves per launch)
+        const bool neg = vo >= 0xfffffff0u;
+        if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
+#pragma unroll
+            for (int j = 1; j < CW; ++j) {                 // (the check does not wrap: voffset 0xfffffffc + 16 is out of range too)
+                unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rx, neg ? vo + 4u * j : a.src_bytes, 0, 0);
+                if (j == CW - 1) v &= keepR;
+                r[j] = neg ? __builtin_bit_cast(float, v) : r[j];
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned short* As = smA[buf];
+        unsigned short* Bs = smB[buf];
+#pragma unroll
+        for (int j = 0; j < A_PIECES; ++j) {
+            const int p = tid + NT * j;
+            Words2 pk;
+            pk.a = cvt_pk_bf16(__builtin_bit_cast(float, ra[j].a), __builtin_bit_cast(float, ra[j].b));
+            pk.b = cvt_pk_bf16(__builtin_bit_cast(float, ra[j].c), __builtin_bit_cast(float, ra[j].d));
+            *reinterpret_cast<Words2*>(As + (p >> 3) * KP + (p & 7) * 4) = pk;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 pk;
+            pk.x = cvt_pk_bf16(rb[8 * h], rb[8 * h + 1]);
+            pk.y = cvt_pk_bf16(rb[8 * h + 2], rb[8 * h + 3]);
+            pk.z = cvt_pk_bf16(rb[8 * h + 4], rb[8 * h + 5]);
+            pk.w = cvt_pk_bf16(rb[8 * h + 6], rb[8 * h + 7]);
+            *reinterpret_cast<uint4*>(Bs + b_n * KP + b_kq * 16 + 8 * h) = pk;
+        }
+    };
+
+    constexpr int WAVES_N = BN / (32 * WN);
+    const int wm0 = (wave / WAVES_N) * (32 * WM);
+    const int wn0 = (wave % WAVES_N) * (32 * WN);
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    loadT(k_begin);
+#pragma unroll
+    for (int q = 0; q < NG; ++q) pe[q] = pe_next[q];
+    loadT(k_begin + BK);
+    if (nk > 0) {
+        loadA(k_begin);
+#pragma unroll
+        for (int q = 0; q < NG; ++q) loadB(q);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const int buf = it & 1;
+        const int kn = k_begin + (it + 1) * BK;
+#pragma unroll
+        for (int q = 0; q < NG; ++q) pe[q] = pe_next[q];   // entries of step it+1 (loaded during step it-1; table is padded)
+        loadT(k_begin + (it + 2) * BK);
+        const unsigned short* as = smA[buf];
+        const unsigned short* bs = smB[buf];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c == 0) loadA(kn);
+#pragma unroll
+            for (int q = 0; q < NG / 2 + (NG == 1); ++q)
+                if (c * (NG / 2) + q < NG && (NG > 1 || c == 0)) loadB(c * (NG / 2) + q);
+            bf16x8 av[WM], bv[WN];
+            const int ko = 16 * c + (lane >> 5) * 8;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                av[i] = *reinterpret_cast<const bf16x8*>(as + (wm0 + i * 32 + (lane & 31)) * KP + ko);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                bv[j] = *reinterpret_cast<const bf16x8*>(bs + (wn0 + j * 32 + (lane & 31)) * KP + ko);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    store_acc<MODE_WGRAD, WM, WN>(a, acc, m0, n0, wm0, wn0, lane, split);
+}
+
+// position table of the vector WGRAD: one entry per group of CW consecutive output positions
+__global__ __launch_bounds__(256) void build_pos_table_kernel(int2* __restrict__ tab, ConvGeom g, ConvFastDiv fd, int CW,
+                                                              int ngroups, int npad) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npad) return;
+    int2 e;
+    e.x = 0; e.y = 0;                                        // padding: no tap bit set -> never valid
+    if (i < ngroups) {
+        const PosDec o = dec_pos_fd((uint32_t)i * CW, fd.To, fd.Ho, fd.Wo);
+        const int t0 = o.t - g.pt, h0 = o.h - g.ph, w0 = o.w - g.pw;
+        unsigned m = 0;
+        for (int d = 0; d < 8; ++d) {
+            m |= (unsigned)(d < g.kt && t0 + d >= 0 && t0 + d < g.Ti) << d;
+            m |= (unsigned)(d < g.kh && h0 + d >= 0 && h0 + d < g.Hi) << (8 + d);
+        }
+        if (o.w == 0) m |= 0x10000u;
+        if (o.w + CW == g.Wo) m |= 0x20000u;
+        e.x = (int)(unsigned)(((int64_t)o.b * g.x_bs + ((int64_t)t0 * g.Hi + h0) * g.Wi + w0) * 4);
+        e.y = (int)m;
+    }
+    tab[i] = e;
+}
+
 // prologue of the chunked path: chunk table + bf16 weight pack in one launch.
 //   wsrc: FWD W (M=Cout, C=Cin, kvol);  DGRAD packed W^T (M=Cin, C=Cout, kvol)  -> wp[m][tap * C + c]
 template <int MODE>
@@ -1014,8 +1234,82 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     return 0;
 }
 
+// ---- vector WGRAD: eligibility, workspace layout [position table][split-K slabs]
+constexpr int PTAB_PAD = 64;        // entries readable past the last group (two K steps of prefetch at CW = 2 -> 32)
+static inline int wgrad_vector_width(const ConvGeom& g, int prec) {
+    if (!prec || getenv("OTAL_CONV_NOVEC_WGRAD")) return 0;
+    if (g.st != 1 || g.sh != 1 || g.sw != 1 || g.nlev > 1) return 0;
+    if (g.To != g.Ti || g.Ho != g.Hi || g.Wo != g.Wi) return 0;
+    if ((g.kw != 1 && g.kw != 3) || g.pw != (g.kw - 1) / 2) return 0;
+    if (conv_out_positions(g) % 32) return 0;
+    const int64_t ex = 4 * ((int64_t)(g.B - 1) * g.x_bs + (int64_t)(g.Cin - 1) * g.x_cs + conv_in_positions(g));
+    const int64_t ey = 4 * ((int64_t)(g.B - 1) * g.y_bs + (int64_t)(g.Cout - 1) * g.y_cs + conv_out_positions(g));
+    if (ex <= 0 || ey <= 0 || ex >= (int64_t)0xfffffff0u || ey >= (int64_t)0xfffffff0u) return 0;
+    if (g.Wi % 8 == 0) return 8;
+    if (g.Wi % 4 == 0) return 4;
+    if (g.Wi % 2 == 0) return 2;
+    return 0;
+}
+static inline size_t ptab_bytes(const ConvGeom& g, int cw) {
+    return align256(((size_t)g.B * conv_out_positions(g) / cw + PTAB_PAD) * sizeof(int2));
+}
+
+int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int BMsel = choose_bm(a.M);
+    const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + 127) / 128;
+    const size_t tb = ptab_bytes(a.g, cw);
+    if (!ws || ws_bytes < tb) return OTAL_E_UNSUPPORTED;
+    a.fd = make_conv_fastdiv(a.g);
+    a.P = conv_out_positions(a.g);
+    a.src_bytes = (unsigned)gather_extent_bytes(a.g, MODE_FWD);
+    a.dy_bytes = (unsigned)gather_extent_bytes(a.g, MODE_DGRAD);
+    int2* ptab = reinterpret_cast<int2*>(ws);
+    const int ngroups = a.K / cw, npad = ngroups + PTAB_PAD;
+    hipLaunchKernelGGL(build_pos_table_kernel, dim3((npad + 255) / 256), dim3(256), 0, st, ptab, a.g, a.fd, cw, ngroups, npad);
+    if (int e = otal_launch_status()) return e;
+    a.ptab = ptab;
+    ws = reinterpret_cast<char*>(ws) + tb;
+    ws_bytes -= tb;
+    int splits = choose_splits(tm * tn, a.K);
+    if (splits > 1) {
+        const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
+        if (ws_bytes < need) {
+            splits = (int)(ws_bytes / ((size_t)a.M * a.N * sizeof(float)));
+            if (splits < 2) splits = 1;
+        }
+    }
+    const int kps = ((a.K + splits - 1) / splits + 31) / 32 * 32;
+    splits = (a.K + kps - 1) / kps;
+    a.splits = splits;
+    a.k_per_split = kps;
+    a.slab = splits > 1 ? (float*)ws : nullptr;
+    const dim3 grid(tn, tm, splits);
+#define OTAL_LAUNCH_W(BM_, WM_, WN_)                                                                                   \
+    do {                                                                                                               \
+        if (cw == 8) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<BM_, WM_, WN_, 8>), grid, dim3(NT), 0, st, a);        \
+        else if (cw == 4) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<BM_, WM_, WN_, 4>), grid, dim3(NT), 0, st, a);   \
+        else hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<BM_, WM_, WN_, 2>), grid, dim3(NT), 0, st, a);                \
+    } while (0)
+    if (BMsel == 128) OTAL_LAUNCH_W(128, 2, 2);
+    else if (BMsel == 96) OTAL_LAUNCH_W(96, 3, 1);
+    else if (BMsel == 64) OTAL_LAUNCH_W(64, 2, 1);
+    else OTAL_LAUNCH_W(32, 1, 1);
+#undef OTAL_LAUNCH_W
+    if (int e = otal_launch_status()) return e;
+    if (splits > 1) {
+        const int64_t total = (int64_t)a.M * a.N;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL((splitk_reduce_kernel<MODE_WGRAD>), dim3(blocks), dim3(256), 0, st, a);
+        return otal_launch_status();
+    }
+    return 0;
+}
+
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    if constexpr (MODE == MODE_WGRAD) {
+        if (const int cw = wgrad_vector_width(a.g, a.prec)) return launch_wgrad_vector(a, cw, ws, ws_bytes, st);
+    }
     if constexpr (MODE != MODE_WGRAD) {
         if (chunk_eligible(a.g, MODE, a.prec)) return launch_chunked<MODE>(a, ws, ws_bytes, st);
     }
@@ -1096,7 +1390,7 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
     const int tiles = (int)(((M + BMsel - 1) / BMsel) * ((N + BN - 1) / BN));
     const int s = choose_splits(tiles, (int)K);
     // precision is not an argument here: size for whichever path needs more (generic tap table vs chunk table + packed weights)
-    size_t front = mode == MODE_WGRAD ? 0 : tab_bytes((int)K);
+    size_t front = mode == MODE_WGRAD ? ptab_bytes(g, 2) : tab_bytes((int)K);
     if (mode != MODE_WGRAD) {
         const size_t cf = chunk_tab_bytes((int)K) + chunk_wp_bytes((int)M, BMsel, (int)K);
         if (cf > front) front = cf;
