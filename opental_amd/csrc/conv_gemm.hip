@@ -134,6 +134,13 @@ __device__ __forceinline__ float ld_sel(const float* p, bool ok, const float* ze
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 struct Words4 { unsigned a, b, c, d; };
 struct Words2 { unsigned a, b; };
+// a + b with 32-bit wrap-around, hidden from the compiler: hipcc folds `voffset + constant` into the buffer
+// instruction's immediate offset, and the hardware adds that immediate WITHOUT wrapping (0xfffffffc + 4 is out of range)
+__device__ __forceinline__ unsigned wrap_add(unsigned a, unsigned b) {
+    unsigned r = a + b;
+    asm volatile("" : "+v"(r));
+    return r;
+}
 typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {     // v_cvt_pk_bf16_f32: RNE, lo in bits 0..15
@@ -534,8 +541,13 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
 // so two conditional zeroings per vector replace the per-element test.  LDS rows are permuted
 // (row(n) = (n % CW) * PB + n / CW) so that both the staged writes and the ds_read_b128 operand reads stay
 // conflict free (PB = 36 / 72, searched with the bank model of MI355X_MICROARCH.md).
-template <int BM, int WM, int WN, int MODE, int CW>
+//   KWV (with CW 1, forward only): for layers whose channel count is not a multiple of 8 (Conv3d_1a: Cin = 3) a chunk
+//   is the kw-run of ONE (ci, dt, dh) row padded to 8 taps, k = ((ci*kt + dt)*kh + dh)*8 + dw.  The 8 taps are
+//   contiguous in memory whatever the stride: two dwordx4 per chunk; t / h validity per chunk as before, w validity
+//   is a per-THREAD constant (the anchor's w bits) applied as 8 masks.
+template <int BM, int WM, int WN, int MODE, int CW, bool KWV = false>
 __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
+    static_assert(!KWV || (CW == 1 && MODE == MODE_FWD), "kw-vector mode");
     constexpr int BN = 128, BK = 32, KP = 40;
     constexpr int PB = CW == 4 ? 36 : (CW == 2 ? 72 : 0);   // LDS row-block pitch of the position permutation
     constexpr int B_ROWS = CW == 1 ? BN : (CW - 1) * PB + BN / CW;
@@ -586,6 +598,11 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
             keepR_thr = pd.w + CW == g.Wi ? 0xffffffffu : 0u;
         }
     }
+    unsigned keepw[KWV ? 8 : 1];                            // KWV: all-ones where tap dw of this thread's window is inside the row
+    if constexpr (KWV) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) keepw[j] = (vmask >> (16 + j)) & 1u ? 0xffffffffu : 0u;
+    }
     // weight pieces: piece p = tid + 256 j -> row p >> 2, 8 bf16 at k = (p & 3) * 8
     unsigned voffA[A_PIECES];
 #pragma unroll
@@ -613,7 +630,27 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
         for (int h = 0; h < NE; ++h) ce_next[h] = ctab64[(k0 >> 3) + h];
     };
     auto loadB = [&](int h) {
-        if constexpr (CW == 1) {                           // h-th 8-k chunk of this thread's 16
+        if constexpr (KWV) {                               // h-th chunk = 8 consecutive w taps of one (ci, dt, dh) row
+            const unsigned ex = (unsigned)ce[h], ey = (unsigned)(ce[h] >> 32);
+            const unsigned sel = (vmask & ey) == ey ? 0xffffffffu : 0u;
+            const unsigned vo = ((voff0 + ex) & sel) | (a.src_bytes & ~sel);
+            const Words4 v0 = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+            const Words4 v1 = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16u, 0, 0));
+            float* r = rb + 8 * h;
+            r[0] = __builtin_bit_cast(float, v0.a & keepw[0]); r[1] = __builtin_bit_cast(float, v0.b & keepw[1]);
+            r[2] = __builtin_bit_cast(float, v0.c & keepw[2]); r[3] = __builtin_bit_cast(float, v0.d & keepw[3]);
+            r[4] = __builtin_bit_cast(float, v1.a & keepw[4]); r[5] = __builtin_bit_cast(float, v1.b & keepw[5]);
+            r[6] = __builtin_bit_cast(float, v1.c & keepw[6]); r[7] = __builtin_bit_cast(float, v1.d & keepw[7]);
+            // first load starting in front of the tensor (first row, left padding): rejected as a whole -> refetch
+            const bool neg = vo >= 0xfffffff0u;
+            if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
+#pragma unroll
+                for (int j = 1; j < 8; ++j) {              // (the second vector's immediate offset does not wrap either)
+                    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? wrap_add(vo, 4u * j) : a.src_bytes, 0, 0);
+                    r[j] = neg ? __builtin_bit_cast(float, v & keepw[j]) : r[j];
+                }
+            }
+        } else if constexpr (CW == 1) {                    // h-th 8-k chunk of this thread's 16
             const unsigned ex = (unsigned)ce[h], ey = (unsigned)(ce[h] >> 32);
             const unsigned sel = (vmask & ey) == ey ? 0xffffffffu : 0u;
             const unsigned vo = ((voff0 + ex) & sel) | (a.src_bytes & ~sel);
@@ -658,7 +695,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
                     for (int i = 0; i < NL; ++i)
 #pragma unroll
                         for (int j = 1; j < CW; ++j) {
-                            unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? vo + 4u * j : a.src_bytes, i * cs_bytes, 0);
+                            unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? wrap_add(vo, 4u * j) : a.src_bytes, i * cs_bytes, 0);
                             if (j == CW - 1) v &= keepR;
                             rb[CW * i + j] = neg ? __builtin_bit_cast(float, v) : rb[CW * i + j];
                         }
@@ -872,7 +909,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
         if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
 #pragma unroll
             for (int j = 1; j < CW; ++j) {                 // (the check does not wrap: voffset 0xfffffffc + 16 is out of range too)
-                unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rx, neg ? vo + 4u * j : a.src_bytes, 0, 0);
+                unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rx, neg ? wrap_add(vo, 4u * j) : a.src_bytes, 0, 0);
                 if (j == CW - 1) v &= keepR;
                 r[j] = neg ? __builtin_bit_cast(float, v) : r[j];
             }
@@ -985,8 +1022,34 @@ __global__ __launch_bounds__(256) void build_pos_table_kernel(int2* __restrict__
 template <int MODE>
 __global__ __launch_bounds__(256) void prep_chunks_kernel(int2* __restrict__ ctab, unsigned* __restrict__ wp,
                                                           const float* __restrict__ wsrc, ConvGeom g, int M, int Mpad,
-                                                          int C, int kvol, int K, int Kp, int nchunk) {
+                                                          int C, int kvol, int K, int Kp, int nchunk, int kwv) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (kwv) {      // forward only: chunk j = (ci, dt, dh) row, k = j * 8 + dw (dw >= kw: zero weight)
+        if (gid < nchunk) {
+            const int j = (int)gid;
+            int2 e;
+            e.x = 0; e.y = -1;
+            if (j * 8 < K) {
+                const int ci = j / (g.kt * g.kh), r = j - ci * (g.kt * g.kh), dt = r / g.kh, dh = r - dt * g.kh;
+                e.x = (int)(unsigned)(((int64_t)ci * g.x_cs + ((int64_t)dt * g.Hi + dh) * g.Wi) * 4);
+                e.y = (1 << dt) | (1 << (8 + dh));
+            }
+            ctab[gid] = e;
+        }
+        const int half = Kp / 2;
+        const int64_t pairs = (int64_t)Mpad * half;
+        for (int64_t p = gid; p < pairs; p += (int64_t)gridDim.x * 256) {
+            const int m = (int)(p / half), k = (int)(p - (int64_t)m * half) * 2;
+            float v[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kk = k + i, j = kk >> 3, dw = kk & 7;
+                v[i] = (m < M && kk < K && dw < g.kw) ? wsrc[((int64_t)m * C * g.kt * g.kh + j) * g.kw + dw] : 0.f;
+            }
+            wp[p] = cvt_pk_bf16(v[0], v[1]);
+        }
+        return;
+    }
     if (gid < nchunk) {
         const int k0 = (int)gid * 8;
         int2 e;
@@ -1155,7 +1218,7 @@ static inline bool chunk_eligible(const ConvGeom& g, int mode, int prec) {
     if (!prec || mode == MODE_WGRAD) return false;
     if (getenv("OTAL_CONV_NOCHUNK")) return false;
     const int C = mode == MODE_FWD ? g.Cin : g.Cout;
-    if (C % 8) return false;
+    if (C % 8 && !(mode == MODE_FWD && g.kw >= 3 && !getenv("OTAL_CONV_NOKWV"))) return false;    // forward has the kw-vector mode
     const int64_t ext = gather_extent_bytes(g, mode);
     return ext > 0 && ext < (int64_t)0xfffffff0u;       // 32-bit buffer offsets
 }
@@ -1174,6 +1237,8 @@ template <int MODE>
 int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int C = MODE == MODE_FWD ? a.g.Cin : a.g.Cout;
     const int kvol = conv_kvol(a.g);
+    const bool kwv = MODE == MODE_FWD && (C % 8) != 0;
+    if (kwv) a.K = a.g.Cin * a.g.kt * a.g.kh * 8;          // kw padded to 8 taps per (ci, dt, dh) row
     const int BMsel = choose_bm(a.M);
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + 127) / 128;
     const int Mpad = tm * BMsel;
@@ -1189,7 +1254,7 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         if (blocks < (nchunk + 255) / 256) blocks = (nchunk + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL((prep_chunks_kernel<MODE>), dim3((unsigned)blocks), dim3(256), 0, st, ctab,
-                           reinterpret_cast<unsigned*>(wp), a.w, a.g, a.M, Mpad, C, kvol, a.K, a.Kp, nchunk);
+                           reinterpret_cast<unsigned*>(wp), a.w, a.g, a.M, Mpad, C, kvol, a.K, a.Kp, nchunk, kwv ? 1 : 0);
         if (int e = otal_launch_status()) return e;
     }
     a.ctab = ctab; a.wp = wp;
@@ -1219,7 +1284,16 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         else if (cw == 2) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<BM_, WM_, WN_, MODE, 2>), grid, dim3(NT), 0, st, a); \
         else hipLaunchKernelGGL((conv_gemm_bf16c_kernel<BM_, WM_, WN_, MODE, 1>), grid, dim3(NT), 0, st, a);           \
     } while (0)
-    if (BMsel == 128) OTAL_LAUNCH_C(128, 2, 2);
+    if constexpr (MODE == MODE_FWD) {
+        if (kwv) {
+            if (BMsel == 128) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<128, 2, 2, MODE_FWD, 1, true>), grid, dim3(NT), 0, st, a);
+            else if (BMsel == 96) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<96, 3, 1, MODE_FWD, 1, true>), grid, dim3(NT), 0, st, a);
+            else if (BMsel == 64) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<64, 2, 1, MODE_FWD, 1, true>), grid, dim3(NT), 0, st, a);
+            else hipLaunchKernelGGL((conv_gemm_bf16c_kernel<32, 1, 1, MODE_FWD, 1, true>), grid, dim3(NT), 0, st, a);
+        }
+    }
+    if (kwv) {
+    } else if (BMsel == 128) OTAL_LAUNCH_C(128, 2, 2);
     else if (BMsel == 96) OTAL_LAUNCH_C(96, 3, 1);
     else if (BMsel == 64) OTAL_LAUNCH_C(64, 2, 1);
     else OTAL_LAUNCH_C(32, 1, 1);
@@ -1392,7 +1466,8 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
     // precision is not an argument here: size for whichever path needs more (generic tap table vs chunk table + packed weights)
     size_t front = mode == MODE_WGRAD ? ptab_bytes(g, 2) : tab_bytes((int)K);
     if (mode != MODE_WGRAD) {
-        const size_t cf = chunk_tab_bytes((int)K) + chunk_wp_bytes((int)M, BMsel, (int)K);
+        const int Kc = mode == MODE_FWD && g.Cin * g.kt * g.kh * 8 > K ? g.Cin * g.kt * g.kh * 8 : (int)K;   // kw-vector mode pads kw to 8
+        const size_t cf = chunk_tab_bytes(Kc) + chunk_wp_bytes((int)M, BMsel, Kc);
         if (cf > front) front = cf;
     }
     return front + (s > 1 ? (size_t)(s + 1) * M * N * sizeof(float) : 0);

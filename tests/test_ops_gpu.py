@@ -288,3 +288,34 @@ def test_conv_bf16_operands_fp32_accumulate(case):
     close(y, yr)
     close(dx, xr.grad)
     close(dw, wr.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout,k,s", [((1, 8, 2, 8, 8), 16, (3, 3, 3), (1, 1, 1)), ((1, 8, 2, 4, 4), 16, (3, 3, 3), (1, 1, 1)),
+                                            ((1, 8, 2, 6, 6), 16, (3, 3, 3), (1, 1, 1)), ((1, 3, 4, 16, 16), 8, (7, 7, 7), (2, 2, 2))])
+def test_conv_bf16_vector_starting_before_tensor(shape, cout, k, s):
+    """Vector gathers whose first element lies in FRONT of the tensor (channel 0, first row, tap shifted left) are
+    rejected as a whole by the buffer bounds check; the kernels re-fetch the remaining elements.  Large values in
+    the first row make a dropped element flagrant (fwd, dgrad through the same gather on dy, wgrad)."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32))
+    x[0, 0, 0, 0, :] = 64.0
+    w = _bf16_round(torch.from_numpy((rs.randn(cout, shape[1], *k) * 0.25).astype(np.float32)))
+    xq = _bf16_round(x)
+    xr, wr = xq.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = ref_conv(xr, wr, None, k, s, False)
+    dy = _bf16_round(torch.from_numpy(rs.randn(*yr.shape).astype(np.float32)))
+    dy[0, 0, 0, 0, :] = 64.0
+    yr.backward(dy)
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        y = ops.conv_forward(xq.cuda(), w.cuda(), k, s)
+        dx = ops.conv_dgrad(dy.cuda(), w.cuda(), x.shape, k, s)
+        dw = ops.conv_wgrad(xq.cuda(), dy.cuda(), w.shape, k, s)
+    finally:
+        ops.CONV_PRECISION = old
+    close(y, yr)
+    close(dx, xr.grad)
+    close(dw, wr.grad)
