@@ -27,7 +27,7 @@ namespace {
 
 constexpr int NT = 256, BK_MIN = 16;
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
-enum { EPI_RELU = 1, EPI_ACCUM = 2, DBG_NOLOAD = 4, DBG_NOSTORE = 8, DBG_NOBARRIER = 16 };   // DBG_*: ablation only (OTAL_CONV_DEBUG)
+enum { EPI_RELU = 1, EPI_ACCUM = 2, DBG_NOLOAD = 4, DBG_NOSTORE = 8, DBG_NOBARRIER = 16, EPI_NPAD8 = 32 };   // DBG_*: ablation only (OTAL_CONV_DEBUG)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -191,6 +191,9 @@ __device__ __forceinline__ void store_acc(const ConvArgs& a, const f32x16 (&acc)
                 } else if constexpr (MODE == MODE_DGRAD) {
                     off = nbase + (int64_t)m * g.x_cs;
                     if (a.emask) v = a.emask[off] > 0.f ? v * a.escale[m] : 0.f;
+                } else if (a.flags & EPI_NPAD8) {          // columns are (row, dw padded to 8): drop the padding, compact to kw
+                    if ((n & 7) >= g.kw) continue;
+                    off = (int64_t)m * ((a.N >> 3) * g.kw) + (n >> 3) * g.kw + (n & 7);
                 } else {
                     off = (int64_t)m * a.N + nbase;
                 }
@@ -816,11 +819,16 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
 // values to LDS one by one; here it is ~7 per MFMA, all LDS stores are 8 / 16 bytes wide, and every global load
 // moves 16 bytes per lane (the texture addresser is the limiter: tools/ubench/bufcheck.hip).
 // dy rows are fetched as 16-byte pieces (4 positions) with a scalar sample/position offset.
-template <int BM, int WM, int WN, int CW>
+// S2 (w stride 2, kw <= 7 -- Conv3d_1a): 8 output positions read the 16-float window x[2*wo0 - pw + dw + 2j], so a
+// thread owns the column PAIR (dw = 2i, 2i+1) of one (ci, dt, dh) row: the window's even elements are the operand
+// vector of column 2i, the odd ones of column 2i+1 (columns are padded to 8 per row; EPI_NPAD8 drops the padding).
+// Thread = (pair = tid & 63, position group = wave): 4 dwordx4 per K step, validity of the window's ends by compare.
+template <int BM, int WM, int WN, int CW, bool S2 = false>
 __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) {
+    static_assert(!S2 || CW == 8, "pair mode works on groups of 8 output positions");
     constexpr int BN = 128, BK = 32, KP = 40;
     constexpr int A_PIECES = BM / 32;                       // 16-byte dy pieces (4 positions) per thread per K step
-    constexpr int NG = 16 / CW;                             // position groups per thread per K step
+    constexpr int NG = S2 ? 1 : 16 / CW;                    // position groups per thread per K step
     __shared__ __attribute__((aligned(16))) unsigned short smA[2][BM * KP];
     __shared__ __attribute__((aligned(16))) unsigned short smB[2][BN * KP];
 
@@ -840,10 +848,21 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
     const auto rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
 
     // ---- this thread's B column: n = (ci, dt, dh, dw); columns past N are clamped (their results are never stored)
-    const int b_n = tid & (BN - 1);
-    const int b_kq = __builtin_amdgcn_readfirstlane(tid >> 7);       // which 16-position half of the K step
-    unsigned coloff, tbits, thrL, thrR;
-    {
+    const int b_n = S2 ? 2 * (tid & 63) : (tid & (BN - 1));          // S2: first column of this thread's pair
+    const int b_kq = __builtin_amdgcn_readfirstlane(S2 ? (tid >> 6) : (tid >> 7));   // position group(s) of the K step
+    unsigned coloff, tbits, thrL = 0u, thrR = 0u;
+    int dw0 = 0;                                            // S2: dw of the even column
+    if constexpr (S2) {
+        const int n = min(n0 + b_n, a.N - 2);
+        const int row = n >> 3;                             // (ci*kt + dt)*kh + dh
+        const uint32_t q1 = fd_div(fd.kh, (uint32_t)row);
+        const int dh = row - (int)(q1 * fd.kh.d);
+        const uint32_t ci = fd_div(fd.kt, q1);
+        const int dt = (int)(q1 - ci * fd.kt.d);
+        dw0 = n & 6;
+        coloff = (unsigned)(((int64_t)ci * g.x_cs + ((int64_t)dt * g.Hi + dh) * g.Wi + dw0) * 4);
+        tbits = (1u << dt) | (1u << (8 + dh));
+    } else {
         const int n = min(n0 + b_n, a.N - 1);
         const TapDec t = dec_tap_fd(fd, (uint32_t)n);
         coloff = (unsigned)(((int64_t)t.c * g.x_cs + ((int64_t)t.dt * g.Hi + t.dh) * g.Wi + t.dw) * 4);
@@ -877,6 +896,38 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
     // position-table entries of the NEXT K step (64-bit scalar loads, one step ahead)
     const unsigned long long* ptab64 = reinterpret_cast<const unsigned long long*>(a.ptab) + b_kq * NG;
     unsigned long long pe[NG], pe_next[NG];
+    auto loadB_s2 = [&]() {                                 // 16-float window of this thread's column pair
+        const unsigned ex = (unsigned)pe[0], ey = (unsigned)(pe[0] >> 32);
+        const unsigned sel = (ey & tbits) == tbits ? 0xffffffffu : 0u;
+        const unsigned vo = ((ex + coloff) & sel) | (a.src_bytes & ~sel);
+        const int first = (int)((ey >> 16) & 0xffu) - 16 + dw0;          // x index (w) of window element 0
+        const int lo = -first, hi = g.Wi - first;                         // element e is inside the row iff lo <= e < hi
+        Words4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 16 * q, 0));
+        unsigned e[16] = {v[0].a, v[0].b, v[0].c, v[0].d, v[1].a, v[1].b, v[1].c, v[1].d,
+                          v[2].a, v[2].b, v[2].c, v[2].d, v[3].a, v[3].b, v[3].c, v[3].d};
+        const bool neg = vo >= 0xffffffc0u;                 // window starting in front of the tensor: refetch element-wise
+        if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
+#pragma unroll
+            for (int j = 1; j < 16; ++j) {
+                const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rx, neg ? wrap_add(vo, 4u * j) : a.src_bytes, 0, 0);
+                e[j] = neg ? w : e[j];
+            }
+        }
+        // only the first / last four elements can fall outside the row (pw <= 3, checked on the host)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e[j] = j >= lo ? e[j] : 0u;
+            e[12 + j] = 12 + j < hi ? e[12 + j] : 0u;
+        }
+        // even elements -> rb[0..7] (column dw0), odd -> rb[8..15] (column dw0 + 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            rb[j] = __builtin_bit_cast(float, e[2 * j]);
+            rb[8 + j] = __builtin_bit_cast(float, e[2 * j + 1]);
+        }
+    };
     auto loadT = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < NG; ++q) pe_next[q] = ptab64[k0 / CW + q];
@@ -933,7 +984,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
             pk.y = cvt_pk_bf16(rb[8 * h + 2], rb[8 * h + 3]);
             pk.z = cvt_pk_bf16(rb[8 * h + 4], rb[8 * h + 5]);
             pk.w = cvt_pk_bf16(rb[8 * h + 6], rb[8 * h + 7]);
-            *reinterpret_cast<uint4*>(Bs + b_n * KP + b_kq * 16 + 8 * h) = pk;
+            if constexpr (S2) *reinterpret_cast<uint4*>(Bs + (b_n + h) * KP + b_kq * 8) = pk;     // rows = the two columns
+            else *reinterpret_cast<uint4*>(Bs + b_n * KP + b_kq * 16 + 8 * h) = pk;
         }
     };
 
@@ -954,8 +1006,11 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
     loadT(k_begin + BK);
     if (nk > 0) {
         loadA(k_begin);
+        if constexpr (S2) loadB_s2();
+        else {
 #pragma unroll
-        for (int q = 0; q < NG; ++q) loadB(q);
+            for (int q = 0; q < NG; ++q) loadB(q);
+        }
         store_tiles(0);
     }
     __syncthreads();
@@ -970,9 +1025,12 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (c == 0) loadA(kn);
+            if constexpr (S2) {
+                if (c == 0) loadB_s2();
+            } else {
 #pragma unroll
-            for (int q = 0; q < NG / 2 + (NG == 1); ++q)
-                if (c * (NG / 2) + q < NG && (NG > 1 || c == 0)) loadB(c * (NG / 2) + q);
+                for (int q = 0; q < NG / 2; ++q) loadB(c * (NG / 2) + q);
+            }
             bf16x8 av[WM], bv[WN];
             const int ko = 16 * c + (lane >> 5) * 8;
 #pragma unroll
@@ -1003,14 +1061,18 @@ __global__ __launch_bounds__(256) void build_pos_table_kernel(int2* __restrict__
     e.x = 0; e.y = 0;                                        // padding: no tap bit set -> never valid
     if (i < ngroups) {
         const PosDec o = dec_pos_fd((uint32_t)i * CW, fd.To, fd.Ho, fd.Wo);
-        const int t0 = o.t - g.pt, h0 = o.h - g.ph, w0 = o.w - g.pw;
+        const int t0 = o.t * g.st - g.pt, h0 = o.h * g.sh - g.ph, w0 = o.w * g.sw - g.pw;
         unsigned m = 0;
         for (int d = 0; d < 8; ++d) {
             m |= (unsigned)(d < g.kt && t0 + d >= 0 && t0 + d < g.Ti) << d;
             m |= (unsigned)(d < g.kh && h0 + d >= 0 && h0 + d < g.Hi) << (8 + d);
         }
-        if (o.w == 0) m |= 0x10000u;
-        if (o.w + CW == g.Wo) m |= 0x20000u;
+        if (g.sw == 2) {
+            m |= ((unsigned)(w0 + 16) & 0xffu) << 16;       // pair mode: x index of the window origin (+16)
+        } else {
+            if (o.w == 0) m |= 0x10000u;
+            if (o.w + CW == g.Wo) m |= 0x20000u;
+        }
         e.x = (int)(unsigned)(((int64_t)o.b * g.x_bs + ((int64_t)t0 * g.Hi + h0) * g.Wi + w0) * 4);
         e.y = (int)m;
     }
@@ -1121,6 +1183,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
         } else if (MODE == MODE_DGRAD) {
             off = conv_in_offset(g, dec_pos_fd(n, a.fd.Ti, a.fd.Hi, a.fd.Wi), m);
             if (a.emask) v = a.emask[off] > 0.f ? v * a.escale[m] : 0.f;
+        } else if (a.flags & EPI_NPAD8) {
+            if ((n & 7) >= g.kw) continue;
+            off = (int64_t)m * ((a.N >> 3) * g.kw) + (n >> 3) * g.kw + (n & 7);
         } else {
             off = idx;
         }
@@ -1310,6 +1375,15 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 
 // ---- vector WGRAD: eligibility, workspace layout [position table][split-K slabs]
 constexpr int PTAB_PAD = 64;        // entries readable past the last group (two K steps of prefetch at CW = 2 -> 32)
+// stride-2 pair mode of the vector WGRAD (Conv3d_1a): window ends must stay within 4 elements of the row
+static inline bool wgrad_pair_mode(const ConvGeom& g, int prec) {
+    if (!prec || getenv("OTAL_CONV_NOVEC_WGRAD") || g.nlev > 1) return false;
+    if (g.sw != 2 || g.st > 2 || g.sh > 2 || g.kw > 7 || g.pw > 3 || g.Wo % 8 || conv_out_positions(g) % 32) return false;
+    if (g.Wi - (2 * (g.Wo - 8) - g.pw + 6) < 12) return false;      // last window: elements 0..11 inside the row
+    const int64_t ex = 4 * ((int64_t)(g.B - 1) * g.x_bs + (int64_t)(g.Cin - 1) * g.x_cs + conv_in_positions(g));
+    const int64_t ey = 4 * ((int64_t)(g.B - 1) * g.y_bs + (int64_t)(g.Cout - 1) * g.y_cs + conv_out_positions(g));
+    return ex > 0 && ey > 0 && ex < (int64_t)0xffffff00u && ey < (int64_t)0xfffffff0u;
+}
 static inline int wgrad_vector_width(const ConvGeom& g, int prec) {
     if (!prec || getenv("OTAL_CONV_NOVEC_WGRAD")) return 0;
     if (g.st != 1 || g.sh != 1 || g.sw != 1 || g.nlev > 1) return 0;
@@ -1329,6 +1403,11 @@ static inline size_t ptab_bytes(const ConvGeom& g, int cw) {
 }
 
 int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStream_t st) {
+    const bool pair = a.g.sw == 2;
+    if (pair) {                                             // columns padded to 8 per (ci, dt, dh) row
+        a.N = a.g.Cin * a.g.kt * a.g.kh * 8;
+        a.flags |= EPI_NPAD8;
+    }
     const int BMsel = choose_bm(a.M);
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + 127) / 128;
     const size_t tb = ptab_bytes(a.g, cw);
@@ -1364,7 +1443,12 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
         else if (cw == 4) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<BM_, WM_, WN_, 4>), grid, dim3(NT), 0, st, a);   \
         else hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<BM_, WM_, WN_, 2>), grid, dim3(NT), 0, st, a);                \
     } while (0)
-    if (BMsel == 128) OTAL_LAUNCH_W(128, 2, 2);
+    if (pair) {
+        if (BMsel == 128) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<128, 2, 2, 8, true>), grid, dim3(NT), 0, st, a);
+        else if (BMsel == 96) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<96, 3, 1, 8, true>), grid, dim3(NT), 0, st, a);
+        else if (BMsel == 64) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<64, 2, 1, 8, true>), grid, dim3(NT), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<32, 1, 1, 8, true>), grid, dim3(NT), 0, st, a);
+    } else if (BMsel == 128) OTAL_LAUNCH_W(128, 2, 2);
     else if (BMsel == 96) OTAL_LAUNCH_W(96, 3, 1);
     else if (BMsel == 64) OTAL_LAUNCH_W(64, 2, 1);
     else OTAL_LAUNCH_W(32, 1, 1);
@@ -1382,6 +1466,7 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if constexpr (MODE == MODE_WGRAD) {
+        if (wgrad_pair_mode(a.g, a.prec)) return launch_wgrad_vector(a, 8, ws, ws_bytes, st);
         if (const int cw = wgrad_vector_width(a.g, a.prec)) return launch_wgrad_vector(a, cw, ws, ws_bytes, st);
     }
     if constexpr (MODE != MODE_WGRAD) {
@@ -1458,7 +1543,10 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
     int64_t M, N, K;
     if (mode == MODE_FWD) { M = g.Cout; N = (int64_t)g.B * conv_out_positions(g); K = (int64_t)g.Cin * kvol; }
     else if (mode == MODE_DGRAD) { M = g.Cin; N = (int64_t)g.B * conv_in_positions(g); K = (int64_t)g.Cout * kvol; }
-    else { M = g.Cout; N = (int64_t)g.Cin * kvol; K = (int64_t)g.B * conv_out_positions(g); }
+    else {
+        M = g.Cout; N = (int64_t)g.Cin * kvol; K = (int64_t)g.B * conv_out_positions(g);
+        if (g.sw == 2 && g.kw <= 7) N = (int64_t)g.Cin * g.kt * g.kh * 8;      // pair mode pads each kw row to 8 columns
+    }
     const int BMsel = choose_bm((int)M);
     const int BN = 128;
     const int tiles = (int)(((M + BMsel - 1) / BMsel) * ((N + BN - 1) / BN));

@@ -292,7 +292,8 @@ def test_conv_bf16_operands_fp32_accumulate(case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,cout,k,s", [((1, 8, 2, 8, 8), 16, (3, 3, 3), (1, 1, 1)), ((1, 8, 2, 4, 4), 16, (3, 3, 3), (1, 1, 1)),
-                                            ((1, 8, 2, 6, 6), 16, (3, 3, 3), (1, 1, 1)), ((1, 3, 4, 16, 16), 8, (7, 7, 7), (2, 2, 2))])
+                                            ((1, 8, 2, 6, 6), 16, (3, 3, 3), (1, 1, 1)), ((1, 3, 4, 16, 16), 8, (7, 7, 7), (2, 2, 2)),
+                                            ((2, 3, 8, 32, 32), 64, (7, 7, 7), (2, 2, 2))])
 def test_conv_bf16_vector_starting_before_tensor(shape, cout, k, s):
     """Vector gathers whose first element lies in FRONT of the tensor (channel 0, first row, tap shifted left) are
     rejected as a whole by the buffer bounds check; the kernels re-fetch the remaining elements.  Large values in
