@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 4
+#define OTAL_ABI_VERSION 5
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -94,7 +94,9 @@ int otal_bmp_bwd_levels(const void* grad_out, const void* in, const float* seg, 
  * mode   : 0 forward, 1 data gradient, 2 weight gradient.
  * precision: 0 = fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32, the parity path);
  *            1 = operands rounded to bf16 when staged into LDS, v_mfma_f32_32x32x16_bf16, fp32
- *                accumulation and fp32 tensors in HBM (the throughput path). */
+ *                accumulation and fp32 tensors in HBM (the throughput path).
+ *            bit 1 (value 2), otal_conv_dgrad only: `wt_packed` points at the FORWARD-layout weight
+ *                (Cout, Cin, kvol); the launch re-orders it itself (no otal_conv_pack_wt call needed). */
 size_t otal_conv_workspace_bytes(const int* geom, int mode);
 
 /* y = act(scale[co] * conv(x, w) + shift[co]); scale/shift nullable (frozen BN folded, or bias). */

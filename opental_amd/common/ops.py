@@ -171,8 +171,10 @@ def conv_dgrad(dy, w, x_shape, k, s, spatial_valid=False, levels=None, out=None,
     _check(x5, "dx"); _check(dy5, "dy")
     if tuple(dy5.shape) != (B, Cout) + outn:
         raise RuntimeError(f"conv_dgrad: dy has shape {tuple(dy5.shape)}, expected {(B, Cout) + outn}")
-    if wt is None:
-        wt = pack_wt(w)
+    prec = int(CONV_PRECISION)
+    if wt is None:          # hand the forward-layout weight over; the launch re-orders it in its own prologue
+        wt = w if w.is_contiguous() else w.contiguous()
+        prec |= 2
     ga, sa = _geom_arrays(g, x5, dy5)
     ws = workspace(dy.device)
     ev = _prof_begin()
@@ -181,7 +183,7 @@ def conv_dgrad(dy, w, x_shape, k, s, spatial_valid=False, levels=None, out=None,
         if tuple(m5.shape) != tuple(x5.shape) or tuple(_bs(m5)) != tuple(_bs(x5)):
             raise RuntimeError("out_mask must share dx's shape and layout")
     L.check(L.lib().otal_conv_dgrad(ga, sa, L.ptr(dy5), L.ptr(wt), L.ptr(x5),
-                                    int(accumulate), _opt(out_mask), _opt(out_scale), int(CONV_PRECISION),
+                                    int(accumulate), _opt(out_mask), _opt(out_scale), prec,
                                     L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
             "otal_conv_dgrad")
     _prof_end(ev, "dgrad", g)

@@ -61,6 +61,7 @@ struct ConvArgs {
     const int2* ptab;      // per CW-position group {byte offset of its window origin in x, t/h validity bits | row-edge flags}
     unsigned dy_bytes;     // extent of dy (buffer descriptor of the A operand)
     int P;                 // positions per sample (To*Ho*Wo), a multiple of 32 on this path
+    int w_natural;         // DGRAD: `w` is the forward-layout weight (Cout, Cin, kvol), not the packed transpose
 };
 
 // ---- operand element fetch -------------------------------------------------------------------
@@ -1084,7 +1085,7 @@ __global__ __launch_bounds__(256) void build_pos_table_kernel(int2* __restrict__
 template <int MODE>
 __global__ __launch_bounds__(256) void prep_chunks_kernel(int2* __restrict__ ctab, unsigned* __restrict__ wp,
                                                           const float* __restrict__ wsrc, ConvGeom g, int M, int Mpad,
-                                                          int C, int kvol, int K, int Kp, int nchunk, int kwv) {
+                                                          int C, int kvol, int K, int Kp, int nchunk, int kwv, int natural) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (kwv) {      // forward only: chunk j = (ci, dt, dh) row, k = j * 8 + dw (dw >= kw: zero weight)
         if (gid < nchunk) {
@@ -1138,7 +1139,9 @@ __global__ __launch_bounds__(256) void prep_chunks_kernel(int2* __restrict__ cta
         for (int i = 0; i < 2; ++i) {
             const int kk = k + i;
             const int j = kk >> 3, cb = j / kvol, tap = j - cb * kvol, c = cb * 8 + (kk & 7);
-            v[i] = (m < M && kk < K) ? wsrc[((int64_t)m * C + c) * kvol + tap] : 0.f;
+            // source layout: [m][c][tap] (forward W, or the packed W^T of DGRAD) / natural W seen from DGRAD: [c][m][tap]
+            const int64_t si = natural ? ((int64_t)c * M + m) : ((int64_t)m * C + c);
+            v[i] = (m < M && kk < K) ? wsrc[si * kvol + tap] : 0.f;
         }
         wp[p] = cvt_pk_bf16(v[0], v[1]);
     }
@@ -1247,13 +1250,18 @@ int choose_bm(int M) {
 }
 
 // choose split-K so that the grid fills the chip (256 CUs) without shredding K
-int choose_splits(int tiles, int K) {
-    if (tiles >= 384) return 1;
-    int want = (512 + tiles - 1) / tiles;      // two resident workgroups per CU are enough to hide the tails
-    int maxs = K / (4 * 32);              // at least 4 (bf16) / 8 (fp32) K-steps per split
+int choose_splits(int tiles, int K, int prec = 1) {
+    static const int target = getenv("OTAL_CONV_SPLIT_BLOCKS") ? atoi(getenv("OTAL_CONV_SPLIT_BLOCKS")) : 512;
+    // bf16: >= 8 K steps of 32 per split (fewer, larger slabs: measured +4 % step throughput over 4);
+    // fp32 parity path: 128 k per split as in the version the gradient-parity fixtures were validated with
+    static const int minsteps_env = getenv("OTAL_CONV_SPLIT_MINSTEPS") ? atoi(getenv("OTAL_CONV_SPLIT_MINSTEPS")) : 0;
+    const int minsteps = minsteps_env ? minsteps_env : (prec ? 8 : 4);
+    static const int cap = getenv("OTAL_CONV_MAXSPLIT") ? atoi(getenv("OTAL_CONV_MAXSPLIT")) : 384;
+    if (tiles >= target * 3 / 4) return 1;
+    int want = (target + tiles - 1) / tiles;   // two resident workgroups per CU are enough to hide the tails
+    int maxs = K / (minsteps * 32);            // at least `minsteps` (bf16) / 2x (fp32) K-steps per split
     if (maxs < 1) maxs = 1;
     int s = want < maxs ? want : maxs;
-    static const int cap = getenv("OTAL_CONV_MAXSPLIT") ? atoi(getenv("OTAL_CONV_MAXSPLIT")) : 384;
     return s < 1 ? 1 : (s > cap ? cap : s);
 }
 
@@ -1319,7 +1327,7 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         if (blocks < (nchunk + 255) / 256) blocks = (nchunk + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL((prep_chunks_kernel<MODE>), dim3((unsigned)blocks), dim3(256), 0, st, ctab,
-                           reinterpret_cast<unsigned*>(wp), a.w, a.g, a.M, Mpad, C, kvol, a.K, a.Kp, nchunk, kwv ? 1 : 0);
+                           reinterpret_cast<unsigned*>(wp), a.w, a.g, a.M, Mpad, C, kvol, a.K, a.Kp, nchunk, kwv ? 1 : 0, a.w_natural);
         if (int e = otal_launch_status()) return e;
     }
     a.ctab = ctab; a.wp = wp;
@@ -1472,6 +1480,21 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if constexpr (MODE != MODE_WGRAD) {
         if (chunk_eligible(a.g, MODE, a.prec)) return launch_chunked<MODE>(a, ws, ws_bytes, st);
     }
+    if constexpr (MODE == MODE_DGRAD) {
+        if (a.w_natural) {          // the generic kernel wants W^T packed (Cin, Cout, kvol): build it at the front of the workspace
+            const int kvol = conv_kvol(a.g);
+            const size_t wb = align256((size_t)a.g.Cin * a.g.Cout * kvol * sizeof(float));
+            if (!ws || ws_bytes < wb) return OTAL_E_UNSUPPORTED;
+            const int64_t total = (int64_t)a.g.Cout * a.g.Cin * kvol;
+            const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+            hipLaunchKernelGGL(pack_wt_kernel, dim3(blocks), dim3(256), 0, st, a.w, reinterpret_cast<float*>(ws), a.g.Cout, a.g.Cin, kvol);
+            if (int e = otal_launch_status()) return e;
+            a.w = reinterpret_cast<const float*>(ws);
+            a.w_natural = 0;
+            ws = reinterpret_cast<char*>(ws) + wb;
+            ws_bytes -= wb;
+        }
+    }
     a.zero = zero_word_address();
     if (!a.zero) return OTAL_E_UNSUPPORTED;
     if (const char* d = getenv("OTAL_CONV_DEBUG")) a.flags |= (atoi(d) & (DBG_NOLOAD | DBG_NOSTORE | DBG_NOBARRIER));
@@ -1496,7 +1519,7 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     } else {
         a.a_vec4 = (a.K % 4 == 0) && (((uintptr_t)a.w & 15) == 0) && BMsel >= 64;
     }
-    int splits = choose_splits(tm * tn, a.K);
+    int splits = choose_splits(tm * tn, a.K, a.prec);
     if (splits > 1) {
         const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
         if (!ws || ws_bytes < need) {       // shrink to what the workspace allows
@@ -1550,7 +1573,7 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
     const int BMsel = choose_bm((int)M);
     const int BN = 128;
     const int tiles = (int)(((M + BMsel - 1) / BMsel) * ((N + BN - 1) / BN));
-    const int s = choose_splits(tiles, (int)K);
+    const int s = choose_splits(tiles, (int)K, 0);      // the fp32 rule splits finer: size for it
     // precision is not an argument here: size for whichever path needs more (generic tap table vs chunk table + packed weights)
     size_t front = mode == MODE_WGRAD ? ptab_bytes(g, 2) : tab_bytes((int)K);
     if (mode != MODE_WGRAD) {
@@ -1558,6 +1581,7 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
         const size_t cf = chunk_tab_bytes(Kc) + chunk_wp_bytes((int)M, BMsel, Kc);
         if (cf > front) front = cf;
     }
+    if (mode == MODE_DGRAD) front += align256((size_t)g.Cin * g.Cout * kvol * sizeof(float));    // natural-layout weights on the generic path
     return front + (s > 1 ? (size_t)(s + 1) * M * N * sizeof(float) : 0);
 }
 
@@ -1571,7 +1595,7 @@ extern "C" int otal_conv_fwd(const int* geom, const int64_t* strides, const floa
     a.x = x; a.w = w; a.out = y; a.scale = scale; a.shift = shift;
     a.M = a.g.Cout; a.N = a.g.B * conv_out_positions(a.g); a.K = a.g.Cin * conv_kvol(a.g);
     a.flags = relu ? EPI_RELU : 0;
-    a.prec = precision ? 1 : 0;
+    a.prec = (precision & 1) ? 1 : 0;
     return launch_mode<MODE_FWD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -1588,7 +1612,8 @@ extern "C" int otal_conv_dgrad(const int* geom, const int64_t* strides, const fl
     a.emask = out_mask; a.escale = out_scale;
     a.M = a.g.Cin; a.N = a.g.B * conv_in_positions(a.g); a.K = a.g.Cout * conv_kvol(a.g);
     a.flags = accumulate ? EPI_ACCUM : 0;
-    a.prec = precision ? 1 : 0;
+    a.prec = (precision & 1) ? 1 : 0;
+    a.w_natural = (precision & 2) ? 1 : 0;
     return launch_mode<MODE_DGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -1602,7 +1627,7 @@ extern "C" int otal_conv_wgrad(const int* geom, const int64_t* strides, const fl
     a.x = x; a.dy = dy; a.out = dw;
     a.M = a.g.Cout; a.N = a.g.Cin * conv_kvol(a.g); a.K = a.g.B * conv_out_positions(a.g);
     a.flags = accumulate ? EPI_ACCUM : 0;
-    a.prec = precision ? 1 : 0;
+    a.prec = (precision & 1) ? 1 : 0;
     return launch_mode<MODE_WGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
 
