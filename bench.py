@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU (configs[2]: batch 8/GPU)")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
                     help="arithmetic type of the convolution GEMMs (BASELINE.json configs[1]: bf16); f32 = parity path")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the training step from one captured HIP graph (auto: fall back to eager launches if capture fails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -145,6 +147,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graphed = False
+    if args.graph != "off":
+        try:
+            trainer.capture_step(clips, targets, scores)
+            graphed = True
+        except Exception as e:                      # noqa: BLE001 -- any capture failure means eager launches
+            if args.graph == "on":
+                raise
+            trainer._graph = None
+            torch.cuda.synchronize()
+            if rank == 0:
+                print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {str(e)[:200]}); eager launches", file=sys.stderr)
     for _ in range(args.warmup):
         trainer.step(clips, targets, scores)
     barrier()
@@ -163,11 +177,13 @@ def main():
     roofline = None
     if rank == 0 and not args.no_roofline:
         from opental_amd.common import ops
+        saved_graph, trainer._graph = trainer._graph, None      # per-launch HIP events need eager launches
         ops.CONV_PROFILE = []
         for _ in range(2):
             trainer.step(clips, targets, scores)
         torch.cuda.synchronize()
         prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+        trainer._graph = saved_graph
         by = {}
         for mode, flops, a, b in prof:
             e = by.setdefault(mode, [0.0, 0.0, 0])
@@ -195,7 +211,8 @@ def main():
             "config": {"workload": "OpenTAL THUMOS14 split_0 training step (configs/thumos14_opental_final.yaml, "
                                    "EDL+IBM loss, ssl branch off), 256x3x96x96 clips, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "grad_allreduce": "RCCL, flat-arena buckets overlapped with backward"},
+                       "parallelism": f"dp{world}", "grad_allreduce": "RCCL, flat-arena buckets overlapped with backward",
+                       "launch": "one captured HIP graph per step" if graphed else "eager launches"},
             "roofline": roofline, "cpu_baseline": cpu}))
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -178,6 +178,13 @@ int otal_softnms_classes(const float* seg, const float* score, const float* unct
 int otal_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* The same update with the two bias corrections {1 - beta1^t, sqrt(1 - beta2^t)} read from DEVICE memory
+ * (written by the host before the launch): no launch argument changes between steps, so a training step can be
+ * captured once in a HIP graph and replayed.  Replaces the same reference lines as otal_adam_flat. */
+int otal_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, const float* bias_corr, float grad_scale,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

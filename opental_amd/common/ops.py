@@ -330,3 +330,20 @@ def adam_flat(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_dec
                                    ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2),
                                    ctypes.c_float(eps), ctypes.c_float(weight_decay), int(step),
                                    ctypes.c_float(grad_scale), L.stream()), "otal_adam_flat")
+
+
+def adam_bias_corrections(step, beta1=0.9, beta2=0.999):
+    """{1 - beta1^t, sqrt(1 - beta2^t)} in double, rounded once -- the values otal_adam_flat derives on the host."""
+    import math
+    import numpy as np
+    b1, b2 = float(np.float32(beta1)), float(np.float32(beta2))      # the C entry point receives the betas as floats
+    return [float(np.float32(1.0 - math.pow(b1, step))), float(np.float32(math.sqrt(1.0 - math.pow(b2, step))))]
+
+
+def adam_flat_dev(p, g, m, v, bias_corr, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    """adam_flat with the bias corrections in a 2-float device tensor (graph-replayable launch)."""
+    L.require_device(p, g, m, v, bias_corr)
+    L.check(L.lib().otal_adam_flat_dev(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), ctypes.c_int64(p.numel()),
+                                       ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2),
+                                       ctypes.c_float(eps), ctypes.c_float(weight_decay), L.ptr(bias_corr),
+                                       ctypes.c_float(grad_scale), L.stream()), "otal_adam_flat_dev")

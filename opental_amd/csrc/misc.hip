@@ -62,6 +62,26 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
     }
 }
 
+// same update with the bias corrections read from device memory: the launch arguments do not change from step
+// to step, so the whole training step can be replayed from a captured HIP graph
+__global__ __launch_bounds__(256) void adam_flat_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                            float lr, float b1, float b2, float eps, float wd,
+                                                            const float* __restrict__ bias_corr, float grad_scale) {
+    const float bc1 = bias_corr[0], bc2_sqrt = bias_corr[1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gi = g[i] * grad_scale;
+        const float pi = p[i];
+        gi = gi + wd * pi;
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
 }  // namespace
 
 extern "C" int otal_proposal_windows(const float* loc, float* seg, float* frame_seg, int B, int nlev,
@@ -89,5 +109,17 @@ extern "C" int otal_adam_flat(float* p, const float* g, float* m, float* v, int6
     const int blocks = (int)(blocks64 < 4096 ? blocks64 : 4096);
     hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
                        beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    return otal_launch_status();
+}
+
+extern "C" int otal_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, const float* bias_corr,
+                                  float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || !bias_corr) return OTAL_E_NULL;
+    if (n <= 0) return OTAL_E_SHAPE;
+    const int64_t blocks64 = (n + 255) / 256;
+    const int blocks = (int)(blocks64 < 4096 ? blocks64 : 4096);
+    hipLaunchKernelGGL(adam_flat_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                       beta2, eps, weight_decay, bias_corr, grad_scale);
     return otal_launch_status();
 }

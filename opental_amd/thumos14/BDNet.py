@@ -167,6 +167,14 @@ class CoarsePyramid(nn.Module):
             t = t // 2
         self.levels = tuple(int(v) for v in np.concatenate([[0], np.cumsum(self.level_lengths)]))
 
+    def _priors_on(self, device):
+        """The concatenated prior centres on `device`, uploaded once (a host->device copy cannot be captured in a graph)."""
+        cached = getattr(self, '_priors_dev', None)
+        if cached is None or cached.device != device:
+            cached = torch.cat(self.priors, 0).to(device)
+            self._priors_dev = cached
+        return cached
+
     # ------------------------------------------------------------------ pieces
     def _deconv(self, x):
         for i in (0, 3, 6):
@@ -223,7 +231,7 @@ class CoarsePyramid(nn.Module):
         prop_conf = tr(self.prop_conf_head(self._drop(conf_prop_feat)))
         prop_act = tr(self.prop_actionness_head(conf_prop_feat)) if self.os_head else None
         center = tr(self.center_head(loc_prop_feat, lev))
-        priors = torch.cat(self.priors, 0).to(loc.device)
+        priors = self._priors_on(loc.device)
         outs = (loc, conf, prop_loc, prop_conf, center, priors, start, end,
                 start_loc_prop, end_loc_prop, start_conf_prop, end_conf_prop, act, prop_act)
         ctr_feat = prop_ctr_feat = None

@@ -117,6 +117,8 @@ class DetectorTrainer:
         self.arena = FlatArena(list(net.parameters()), bucket_mb << 20)
         self.step_count = 0
         self._pending, self._works = None, []
+        self._graph = None          # (CUDAGraph, static inputs, static outputs) once capture_step() succeeded
+        self._bias_corr = None      # 2-float device tensor: Adam bias corrections of the step being run
         self.collectives = self.distributed and (self.world > 1 or force_collectives)   # force: 1-rank RCCL smoke test
         if self.collectives:
             for i, p in enumerate(self.arena.params):
@@ -159,6 +161,8 @@ class DetectorTrainer:
         return cost, losses
 
     def step(self, clips, targets, scores, ssl_clips=None, ssl_targets=None):
+        if self._graph is not None and ssl_clips is None:
+            return self._replay(clips, targets, scores)
         self.arena.grad.zero_()
         self._pending = list(self.arena.bucket_size)
         cost, losses = self.compute_cost(clips, targets, scores, ssl_clips, ssl_targets)
@@ -172,6 +176,70 @@ class DetectorTrainer:
         """Adam (L2 weight decay in the gradient, train.py:321-323) on the flat arena: one launch."""
         ops.adam_flat(self.arena.flat, self.arena.grad, self.arena.m, self.arena.v, self.step_count, self.lr,
                       self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
+
+    # ---- the same step as ONE HIP graph: ~1500 launches per step are replayed without host involvement
+    def _graph_body(self, clips, targets, scores):
+        self.arena.grad.zero_()
+        self._pending = list(self.arena.bucket_size)
+        cost, losses = self.compute_cost(clips, targets, scores)
+        cost.backward()
+        self._finish_allreduce()
+        ops.adam_flat_dev(self.arena.flat, self.arena.grad, self.arena.m, self.arena.v, self._bias_corr, self.lr,
+                          self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
+        return cost.detach(), losses
+
+    def capture_step(self, clips, targets, scores, warmup=2):
+        """Capture forward + losses + backward (+ gradient all-reduce) + Adam for inputs of these shapes.
+
+        The captured launches bake in every host-side scalar of the step; the only one that changes per step --
+        Adam's bias correction -- lives in device memory and is refreshed before each replay.  Quantities that
+        change per EPOCH (the evidential loss's annealing coefficient) need a re-capture at the epoch boundary.
+        `warmup` eager steps run first on a side stream (they are real optimisation steps)."""
+        dev = clips.device
+        self._graph = None
+        self._bias_corr = torch.zeros(2, dtype=torch.float32, device=dev)
+        clone = lambda t: None if t is None else ([u.clone() for u in t] if isinstance(t, (list, tuple)) else t.clone())
+        static = tuple(clone(t) for t in (clips, targets, scores))
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._set_bias(self.step_count + 1)
+                self._graph_body(*static)
+                self.step_count += 1
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        self._set_bias(self.step_count + 1)
+        with torch.cuda.graph(graph):
+            out = self._graph_body(*static)
+        self.step_count += 0        # capture does not execute
+        self._graph = (graph, static, out)
+        return self
+
+    def _set_bias(self, step):
+        bc = ops.adam_bias_corrections(step, self.betas[0], self.betas[1])
+        self._bias_corr.copy_(torch.tensor(bc, dtype=torch.float32), non_blocking=False)
+
+    def _replay(self, clips, targets, scores):
+        graph, static, out = self._graph
+        pairs = []
+        for dst, src in zip(static, (clips, targets, scores)):
+            if isinstance(dst, list):
+                if len(dst) != len(src):
+                    raise RuntimeError("captured step replayed with a different batch; call capture_step again")
+                pairs += list(zip(dst, src))
+            elif dst is not None:
+                pairs.append((dst, src))
+        for dst, src in pairs:
+            if dst.data_ptr() != src.data_ptr():
+                if dst.shape != src.shape:      # ragged targets: the per-sample row counts are baked into the capture
+                    raise RuntimeError("captured step replayed with different input shapes; call capture_step again")
+                dst.copy_(src, non_blocking=True)
+        self.step_count += 1
+        self._set_bias(self.step_count)
+        graph.replay()
+        return out
 
     def grad_norm(self):
         """get_grad_norm (train.py:133-140), as a device tensor."""
