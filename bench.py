@@ -191,7 +191,9 @@ def main():
         tot_f = sum(e[0] for e in by.values()); tot_t = sum(e[1] for e in by.values()); tot_n = sum(e[2] for e in by.values())
         ach = tot_f / tot_t / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        roofline = {"bound": "mfma", "kernel": f"conv_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad, {args.dtype} MFMA operands, fp32 accumulate)",
+        roofline = {"bound": "mfma", "kernel": ("conv_gemm_bf16c_kernel (fwd/dgrad) + conv_wgrad_bf16v_kernel (wgrad) + conv_gemm_kernel (irregular geometries)"
+                               if args.dtype == "bf16" else "conv_gemm_kernel") +
+                              f": implicit-GEMM convolution, {args.dtype} MFMA operands, fp32 accumulate; per-op time incl. prologue and split-K reduce",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None,
                     "launches_per_step": tot_n // 2, "avg_launch_us": round(tot_t / tot_n * 1e6, 1),
