@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 5
+#define OTAL_ABI_VERSION 6
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -184,6 +184,24 @@ int otal_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, floa
 int otal_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                        float beta2, float eps, float weight_decay, const float* bias_corr, float grad_scale,
                        void* stream);
+
+/* MultiSegmentLoss + EvidenceLoss ('log', exp evidence, IBM re-weighting, IoU calibration) + ActionnessLoss (PU BCE,
+ * rank weight 0) of the OpenTAL final recipe, forward AND backward in one single-workgroup launch.
+ * Replaces AFSD/thumos14/multisegment_loss.py:92-259, cls_loss.py:120-129,:132-168,:212-278,:288-339 and their autograd
+ * graph.  All tensors fp32 contiguous: loc/prop_loc (B,K,2), conf/prop_conf (B,K,C), center/act/prop_act (B,K),
+ * priors (K), gt (B,G,3) = padded [start,end,label] with gvalid (B,G) bytes; weight_accum (num_bins) is the IBM EMA
+ * state, updated in place (conf first, then prop_conf, as the reference does).
+ * losses: 7 floats {loc, conf, prop_loc, prop_conf (+IoU calibration), center, act, prop_act}, normalised as the
+ * reference's forward.  grads (otal_detection_loss_grad_floats): d loss_i / d input of the term that owns it, in the
+ * order dloc[loc term], dloc[center term], dprop_loc[prop_loc term], dprop_loc[center term] (each (B,K,2)),
+ * dconf, dprop_conf ((B,K,C)), dcenter, dact, dprop_act ((B,K)).  scratch: otal_detection_loss_scratch_floats. */
+size_t otal_detection_loss_scratch_floats(int B, int K);
+size_t otal_detection_loss_grad_floats(int B, int K, int C);
+int otal_detection_loss(const float* loc, const float* conf, const float* prop_loc, const float* prop_conf,
+                        const float* center, const float* act, const float* prop_act, const float* priors,
+                        const float* gt, const unsigned char* gvalid, float* weight_accum, int B, int K, int C, int G,
+                        float clip_length, float overlap_thresh, int ibm_active, int num_bins, float momentum,
+                        int iou_aware, float* losses, float* grads, float* scratch, void* stream);
 
 #ifdef __cplusplus
 }

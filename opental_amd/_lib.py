@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libopental_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 F32, BF16 = 0, 1
 
 _lib = None

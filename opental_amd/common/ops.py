@@ -347,3 +347,51 @@ def adam_flat_dev(p, g, m, v, bias_corr, lr, beta1=0.9, beta2=0.999, eps=1e-8, w
                                        ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2),
                                        ctypes.c_float(eps), ctypes.c_float(weight_decay), L.ptr(bias_corr),
                                        ctypes.c_float(grad_scale), L.stream()), "otal_adam_flat_dev")
+
+
+# ----------------------------------------------------------------------------- fused detection loss
+class DetectionLossFunction(torch.autograd.Function):
+    """The seven loss terms of MultiSegmentLoss (EDL recipe) from ONE launch that also produces every gradient
+    (csrc/loss.hip); backward only scales the stored gradients by the incoming scalars."""
+
+    @staticmethod
+    def forward(ctx, loc, conf, prop_loc, prop_conf, center, act, prop_act, priors, gt, gvalid, weight_accum,
+                clip_length, overlap, ibm_active, num_bins, momentum, iou_aware):
+        B, K, C = conf.shape
+        G = gt.shape[1]
+        tens = [t.contiguous().float() for t in (loc, conf, prop_loc, prop_conf, center, act, prop_act, priors, gt)]
+        L.require_device(*tens)
+        gv = gvalid.contiguous().to(torch.uint8)
+        lib = L.lib()
+        lib.otal_detection_loss_grad_floats.restype = ctypes.c_size_t
+        lib.otal_detection_loss_scratch_floats.restype = ctypes.c_size_t
+        ng = lib.otal_detection_loss_grad_floats(B, K, C)
+        ns = lib.otal_detection_loss_scratch_floats(B, K)
+        losses = torch.empty(7, dtype=torch.float32, device=loc.device)
+        grads = torch.empty(ng, dtype=torch.float32, device=loc.device)
+        scratch = torch.empty(ns, dtype=torch.float32, device=loc.device)
+        L.check(lib.otal_detection_loss(*[L.ptr(t) for t in tens], L.ptr(gv), L.ptr(weight_accum), B, K, C, G,
+                                        ctypes.c_float(clip_length), ctypes.c_float(overlap), int(ibm_active),
+                                        int(num_bins), ctypes.c_float(momentum), int(iou_aware), L.ptr(losses),
+                                        L.ptr(grads), L.ptr(scratch), L.stream()), "otal_detection_loss")
+        ctx.save_for_backward(grads)
+        ctx.dims = (B, K, C)
+        return tuple(losses[i] for i in range(7))
+
+    @staticmethod
+    def backward(ctx, g_l, g_c, g_pl, g_pc, g_ct, g_a, g_pa):
+        (grads,) = ctx.saved_tensors
+        B, K, C = ctx.dims
+        A = B * K
+        o = 0
+        def take(n, shape):
+            nonlocal o
+            v = grads[o:o + n].view(shape)
+            o += n
+            return v
+        dloc_l, dloc_ct = take(2 * A, (B, K, 2)), take(2 * A, (B, K, 2))
+        dpl_pl, dpl_ct = take(2 * A, (B, K, 2)), take(2 * A, (B, K, 2))
+        dconf, dpconf = take(A * C, (B, K, C)), take(A * C, (B, K, C))
+        dcen, dact, dpact = take(A, (B, K)), take(A, (B, K)), take(A, (B, K))
+        return (dloc_l * g_l + dloc_ct * g_ct, dconf * g_c, dpl_pl * g_pl + dpl_ct * g_ct, dpconf * g_pc,
+                dcen * g_ct, dact * g_a, dpact * g_pa) + (None,) * 10

@@ -1,0 +1,358 @@
+// opental_amd/csrc/loss.hip -- MultiSegmentLoss + EvidenceLoss + ActionnessLoss of the OpenTAL final recipe,
+// forward AND backward, as ONE single-workgroup launch.
+//
+// Replaces (reference AFSD/thumos14): multisegment_loss.py:92-259 (anchor<->GT matching, GIoU / L1 / quality-BCE
+// terms, normalisers), cls_loss.py:132-168,212-278 (EvidenceLoss 'log' with exp evidence and the influence-balanced
+// 50-bin EMA re-weighting), cls_loss.py:120-129 (IoU calibration), cls_loss.py:288-339 (positive-unlabelled
+// actionness BCE) and the autograd graph behind them -- ~400 ATen launches and ~60 host syncs per step in the
+// reference, ~400 tiny launches in this package's own torch formulation.
+//
+// The problem is tiny (B*126 anchors, <= a few thousand) and full of global dependencies (positive counts
+// normalise every term, the IBM histogram must be complete before any weight is read, the PU loss ranks all
+// negatives), so it runs in ONE workgroup of 1024 threads: phases separated by __syncthreads(), per-anchor
+// intermediates in a global scratch area, reductions in a fixed order (deterministic, unlike index_add_).
+// Latency-bound by construction (SURVEY 8d puts the losses under "launch latency"); the win is 400 launches -> 1.
+//
+// Supported configuration = the final recipe: evidence 'exp', loss_type 'log', os_head, size_average False,
+// actionness rank-term weight 0.  Everything else stays on the torch formulation (thumos14/multisegment_loss.py).
+#include "common.h"
+
+namespace {
+
+constexpr int LT = 1024;            // threads of the single workgroup
+constexpr int MAX_BINS = 64;
+constexpr float F_EPS = 1.1920928955078125e-07f;     // torch.finfo(float32).eps
+
+struct LossArgs {
+    const float *loc, *conf, *prop_loc, *prop_conf, *center, *act, *prop_act, *priors, *gt;
+    const unsigned char* gvalid;
+    float* weight_accum;            // in/out, num_bins
+    float* losses;                  // 7: l, c, prop_l, prop_c, ct, act, prop_act
+    // gradients: dloc_l(A,2) dloc_ct(A,2) dprop_loc_pl(A,2) dprop_loc_ct(A,2) dconf(A,C) dprop_conf(A,C) dcenter(A) dact(A) dprop_act(A)
+    float* grads;
+    float* scratch;                 // per-anchor intermediates, SCR floats per anchor
+    int B, K, C, G;
+    float clip, overlap;
+    int ibm_active, num_bins, iou_aware;
+    float momentum;
+};
+constexpr int SCR = 12;             // loc_t0, loc_t1, conf_t, prop_conf_t, iou, prop_loc_t0, prop_loc_t1, ghat, slot, binpos, per, used
+
+// ---- deterministic block reductions ---------------------------------------------------------------
+__device__ float block_sum(float v, float* red) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    red[t] = v;
+    __syncthreads();
+    for (int s = LT / 2; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// torch.minimum / maximum backward: a tie sends half of the gradient to each side
+__device__ __forceinline__ float dmin_da(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
+__device__ __forceinline__ float dmax_da(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
+
+struct TIoU { float iou, inter, uni, d0, d1; };   // d*: d iou / d pred_*
+__device__ TIoU tiou_grad(float p0, float p1, float t0, float t1) {
+    TIoU r;
+    r.inter = fminf(p0, t0) + fminf(p1, t1);
+    r.uni = (t0 + t1) + (p0 + p1) - r.inter;
+    const float uc = fmaxf(r.uni, F_EPS);
+    r.iou = r.inter / uc;
+    const float di0 = dmin_da(p0, t0), di1 = dmin_da(p1, t1);
+    const float du0 = 1.f - di0, du1 = 1.f - di1;
+    const float live = r.uni >= F_EPS ? 1.f : 0.f;       // clamp(min=eps) backward
+    r.d0 = di0 / uc - r.inter * du0 * live / (uc * uc);
+    r.d1 = di1 / uc - r.inter * du1 * live / (uc * uc);
+    return r;
+}
+
+// EvidenceLoss statistics of one anchor row (cls_loss.py:132-160): per = log S - log alpha_y, IBM slot
+struct Edl { float per, S, ay, ghat; int slot, binpos; };
+__device__ Edl edl_row(const float* z, int C, int y, int num_bins) {
+    Edl e;
+    float S = 0.f, l1 = 0.f, ay = 1.f;
+    for (int k = 0; k < C; ++k) {
+        const float a = expf(fminf(fmaxf(z[k], -10.f), 10.f)) + 1.f;
+        S += a;
+        l1 += fabsf(z[k]);
+        if (k == y) ay = a;
+    }
+    e.S = S; e.ay = ay;
+    e.per = logf(S) - logf(ay);
+    const float u = (float)C / S;
+    const float gnorm = fabsf(1.f / ay - u);
+    e.ghat = gnorm * l1;
+    const long bins = (long)ceilf(gnorm * (float)num_bins);
+    e.binpos = bins > 0 ? 1 : 0;
+    long sl = (bins - 1) % num_bins;
+    if (sl < 0) sl += num_bins;                           // python-style remainder: bin 0 reads slot -1
+    e.slot = (int)sl;
+    return e;
+}
+
+__global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
+    __shared__ float red[LT];
+    __shared__ float wacc[MAX_BINS];
+    __shared__ int icnt[4];
+    const int t = threadIdx.x;
+    const int A = a.B * a.K, C = a.C;
+    float* g_loc_l = a.grads;
+    float* g_loc_ct = g_loc_l + 2 * A;
+    float* g_pl_pl = g_loc_ct + 2 * A;
+    float* g_pl_ct = g_pl_pl + 2 * A;
+    float* g_conf = g_pl_ct + 2 * A;
+    float* g_pconf = g_conf + (size_t)A * C;
+    float* g_center = g_pconf + (size_t)A * C;
+    float* g_act = g_center + A;
+    float* g_pact = g_act + A;
+
+    if (t < 4) icnt[t] = 0;
+    if (t < a.num_bins) wacc[t] = a.weight_accum[t];
+    __syncthreads();
+
+    // ---- phase 1: matching (multisegment_loss.py:120-153), no gradient
+    int npos = 0, nppos = 0;
+    for (int i = t; i < A; i += LT) {
+        const int b = i / a.K, k = i - b * a.K;
+        const float c = a.priors[k];
+        const float big = a.clip * 2.f;
+        float best_area = 0.f;
+        int best = 0;
+        for (int g = 0; g < a.G; ++g) {
+            const float left = (c - a.gt[(b * a.G + g) * 3]) * a.clip, right = (a.gt[(b * a.G + g) * 3 + 1] - c) * a.clip;
+            float area = left + right;
+            if (left < 0.f || right < 0.f || !a.gvalid[b * a.G + g]) area = big;
+            if (g == 0 || area < best_area) { best_area = area; best = g; }     // first minimum, like torch.min
+        }
+        const float g0 = a.gt[(b * a.G + best) * 3], g1 = a.gt[(b * a.G + best) * 3 + 1], lab = a.gt[(b * a.G + best) * 3 + 2];
+        const float lt0 = (c - g0) * a.clip, lt1 = (g1 - c) * a.clip;
+        const int conf_t = best_area >= big ? 0 : (int)lab;
+        const float p0 = a.loc[2 * i], p1 = a.loc[2 * i + 1];
+        const TIoU q = tiou_grad(p0, p1, lt0, lt1);
+        const int pconf_t = q.iou < a.overlap ? 0 : conf_t;
+        const float w = p0 + p1;
+        float* s = a.scratch + (size_t)i * SCR;
+        s[0] = lt0; s[1] = lt1; s[2] = (float)conf_t; s[3] = (float)pconf_t; s[4] = q.iou;
+        s[5] = (lt0 - p0) / (0.5f * w); s[6] = (lt1 - p1) / (0.5f * w);
+        npos += conf_t > 0; nppos += pconf_t > 0;
+    }
+    atomicAdd(&icnt[0], npos);
+    atomicAdd(&icnt[1], nppos);
+    __syncthreads();
+    const float Nf = (float)max(icnt[0], 1), PNf = (float)max(icnt[1], 1);
+
+    // ---- phases 2-4 (conf) and 5-7 (prop_conf): EvidenceLoss with IBM re-weighting (cls_loss.py:132-168)
+    float loss_cls[2];
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* logits = pass == 0 ? a.conf : a.prop_conf;
+        float* gout = pass == 0 ? g_conf : g_pconf;
+        const float norm = pass == 0 ? Nf : PNf;
+        for (int i = t; i < A; i += LT) {
+            float* s = a.scratch + (size_t)i * SCR;
+            const int tgt = (int)s[2 + pass];
+            const int y = max(tgt - 1, 0);
+            const Edl e = edl_row(logits + (size_t)i * C, C, y, a.num_bins);
+            s[7] = e.ghat; s[8] = (float)e.slot; s[9] = (float)e.binpos; s[10] = e.per;
+        }
+        __syncthreads();
+        if (a.ibm_active) {     // the 50-bin EMA: one thread per bin walks the anchors in index order (deterministic)
+            if (t < a.num_bins) {
+                float tot = 0.f, cnt = 0.f;
+                for (int i = 0; i < A; ++i) {
+                    const float* s = a.scratch + (size_t)i * SCR;
+                    if (s[2 + pass] > 0.f && (int)s[8] == t && s[9] > 0.f) { tot += s[7]; cnt += 1.f; }
+                }
+                if (cnt > 0.f) wacc[t] = a.momentum * wacc[t] + (1.f - a.momentum) * tot / fmaxf(cnt, 1.f);
+            }
+            __syncthreads();
+        }
+        float part = 0.f;
+        for (int i = t; i < A; i += LT) {
+            const float* s = a.scratch + (size_t)i * SCR;
+            const int tgt = (int)s[2 + pass];
+            const float* z = logits + (size_t)i * C;
+            float* gz = gout + (size_t)i * C;
+            if (tgt > 0) {
+                const float wgt = a.ibm_active ? wacc[(int)s[8]] : 1.f;
+                part += wgt * s[10];
+                const int y = tgt - 1;
+                float S = 0.f, ay = 1.f;
+                for (int k = 0; k < C; ++k) {
+                    const float al = expf(fminf(fmaxf(z[k], -10.f), 10.f)) + 1.f;
+                    S += al;
+                    if (k == y) ay = al;
+                }
+                for (int k = 0; k < C; ++k) {
+                    const float zk = z[k];
+                    const float da = (zk >= -10.f && zk <= 10.f) ? expf(zk) : 0.f;      // clamp backward is inclusive
+                    gz[k] = wgt * (1.f / S - (k == y ? 1.f / ay : 0.f)) * da / norm;
+                }
+            } else {
+                for (int k = 0; k < C; ++k) gz[k] = 0.f;
+            }
+        }
+        loss_cls[pass] = block_sum(part, red) / norm;
+    }
+    if (t < a.num_bins) a.weight_accum[t] = wacc[t];
+
+    // ---- IoU calibration on prop_conf (cls_loss.py:120-129; pairing quirk of multisegment_loss.py:234-236)
+    if (a.iou_aware) {
+        float part = 0.f;
+        for (int j = t; j < A; j += LT) {
+            const int kk = j / a.B, bb = j - kk * a.B;                 // iou_pred.transpose(0,1).reshape(-1)[j]
+            float iou = a.scratch[(size_t)(bb * a.K + kk) * SCR + 4];
+            if (iou < 0.f) iou = 1e-3f;
+            const float* z = a.prop_conf + (size_t)j * C;
+            float S = 0.f;
+            for (int k = 0; k < C; ++k) S += expf(fminf(fmaxf(z[k], -10.f), 10.f)) + 1.f;
+            const float u = (float)C / S;
+            part += -iou * logf(1.f - u) - (1.f - iou) * logf(u);
+            const float dreg_du = iou / (1.f - u) - (1.f - iou) / u;
+            float* gz = g_pconf + (size_t)j * C;
+            for (int k = 0; k < C; ++k) {
+                const float zk = z[k];
+                const float da = (zk >= -10.f && zk <= 10.f) ? expf(zk) : 0.f;
+                gz[k] += dreg_du * (-(float)C / (S * S)) * da / (float)A;
+            }
+        }
+        loss_cls[1] += block_sum(part, red) / (float)A;
+    }
+
+    // ---- localisation (GIoU over positives), refined L1, quality BCE with the non-detached tIoU target
+    float pl = 0.f, ppl = 0.f, pct = 0.f;
+    for (int i = t; i < A; i += LT) {
+        const float* s = a.scratch + (size_t)i * SCR;
+        const bool pos = s[2] > 0.f, ppos = s[3] > 0.f;
+        const float p0 = a.loc[2 * i], p1 = a.loc[2 * i + 1], t0 = s[0], t1 = s[1];
+        float dl0 = 0.f, dl1 = 0.f, dct_l0 = 0.f, dct_l1 = 0.f, dct_p0 = 0.f, dct_p1 = 0.f, dcen = 0.f;
+        if (pos) {
+            const TIoU q = tiou_grad(p0, p1, t0, t1);
+            const float hull = fmaxf(p0, t0) + fmaxf(p1, t1);
+            const float hc = fmaxf(hull, F_EPS), hlive = hull >= F_EPS ? 1.f : 0.f;
+            pl += 1.f - (q.iou - (hull - q.uni) / hc);
+            const float dh0 = dmax_da(p0, t0), dh1 = dmax_da(p1, t1);
+            const float du0 = 1.f - dmin_da(p0, t0), du1 = 1.f - dmin_da(p1, t1);
+            dl0 = (-q.d0 + ((dh0 - du0) * hc - (hull - q.uni) * dh0 * hlive) / (hc * hc)) / Nf;
+            dl1 = (-q.d1 + ((dh1 - du1) * hc - (hull - q.uni) * dh1 * hlive) / (hc * hc)) / Nf;
+            // quality head: cur = 0.5 * w * prop_loc + loc
+            const float w = p0 + p1, r0 = a.prop_loc[2 * i], r1 = a.prop_loc[2 * i + 1];
+            const float c0 = 0.5f * w * r0 + p0, c1 = 0.5f * w * r1 + p1;
+            const TIoU qq = tiou_grad(c0, c1, t0, t1);
+            const float qv = fmaxf(qq.iou, 0.f), qlive = qq.iou >= 0.f ? 1.f : 0.f;
+            const float x = a.center[i];
+            const float ex = expf(-fabsf(x));
+            pct += fmaxf(x, 0.f) - x * qv + log1pf(ex);
+            const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+            dcen = ((x >= 0.f ? 1.f : 0.f) - qv - sg * ex / (1.f + ex)) / Nf;
+            const float gq0 = -x * qlive * qq.d0 / Nf, gq1 = -x * qlive * qq.d1 / Nf;   // d loss / d cur
+            dct_p0 = gq0 * 0.5f * w; dct_p1 = gq1 * 0.5f * w;
+            const float common = 0.5f * (gq0 * r0 + gq1 * r1);
+            dct_l0 = common + gq0; dct_l1 = common + gq1;
+        }
+        float dpp0 = 0.f, dpp1 = 0.f;
+        if (ppos) {
+            const float e0 = a.prop_loc[2 * i] - s[5], e1 = a.prop_loc[2 * i + 1] - s[6];
+            ppl += fabsf(e0) + fabsf(e1);
+            dpp0 = (e0 > 0.f ? 1.f : (e0 < 0.f ? -1.f : 0.f)) / PNf;
+            dpp1 = (e1 > 0.f ? 1.f : (e1 < 0.f ? -1.f : 0.f)) / PNf;
+        }
+        g_loc_l[2 * i] = dl0; g_loc_l[2 * i + 1] = dl1;
+        g_loc_ct[2 * i] = dct_l0; g_loc_ct[2 * i + 1] = dct_l1;
+        g_pl_pl[2 * i] = dpp0; g_pl_pl[2 * i + 1] = dpp1;
+        g_pl_ct[2 * i] = dct_p0; g_pl_ct[2 * i + 1] = dct_p1;
+        g_center[i] = dcen;
+    }
+    const float loss_l = block_sum(pl, red) / Nf;
+    const float loss_pl = block_sum(ppl, red) / PNf;
+    const float loss_ct = block_sum(pct, red) / Nf;
+
+    // ---- positive-unlabelled actionness BCE (cls_loss.py:288-339), rank term off (weight 0 in the final recipe)
+    float loss_a[2];
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* pred = pass == 0 ? a.act : a.prop_act;
+        float* gout = pass == 0 ? g_act : g_pact;
+        const int np = icnt[pass], nn = A - np;
+        const int top_m = min(np, nn) - 1;
+        int used_cnt = 0;
+        for (int i = t; i < A; i += LT) {
+            float* s = a.scratch + (size_t)i * SCR;
+            const bool pos = s[2 + pass] > 0.f;
+            bool used = pos;
+            if (!pos) {
+                if (top_m > 0) {        // rank among the negatives, ascending score, ties by index
+                    const float x = pred[i];
+                    int rank = 0;
+                    for (int j = 0; j < A; ++j) {
+                        if (a.scratch[(size_t)j * SCR + 2 + pass] > 0.f) continue;
+                        const float y = pred[j];
+                        rank += (y < x) || (y == x && j < i);
+                    }
+                    used = rank < top_m;
+                } else {
+                    used = true;
+                }
+            }
+            s[11] = used ? 1.f : 0.f;
+            used_cnt += used;
+        }
+        __syncthreads();
+        if (t == 0) icnt[2 + pass] = 0;
+        __syncthreads();
+        atomicAdd(&icnt[2 + pass], used_cnt);
+        __syncthreads();
+        const float cntf = (float)icnt[2 + pass];
+        float part = 0.f;
+        for (int i = t; i < A; i += LT) {
+            const float* s = a.scratch + (size_t)i * SCR;
+            const float x = pred[i], y = s[2 + pass] > 0.f ? 1.f : 0.f;
+            float gx = 0.f;
+            if (s[11] > 0.f) {
+                part += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+                gx = (1.f / (1.f + expf(-x)) - y) / cntf;
+            }
+            gout[i] = gx;
+        }
+        loss_a[pass] = block_sum(part, red) / cntf;
+        __syncthreads();
+    }
+
+    if (t == 0) {
+        a.losses[0] = loss_l; a.losses[1] = loss_cls[0]; a.losses[2] = loss_pl; a.losses[3] = loss_cls[1];
+        a.losses[4] = loss_ct; a.losses[5] = loss_a[0]; a.losses[6] = loss_a[1];
+    }
+}
+
+}  // namespace
+
+extern "C" size_t otal_detection_loss_scratch_floats(int B, int K) { return (size_t)B * K * SCR; }
+
+extern "C" size_t otal_detection_loss_grad_floats(int B, int K, int C) {
+    const size_t A = (size_t)B * K;
+    return 4 * 2 * A + 2 * A * C + 3 * A;
+}
+
+extern "C" int otal_detection_loss(const float* loc, const float* conf, const float* prop_loc, const float* prop_conf,
+                                   const float* center, const float* act, const float* prop_act, const float* priors,
+                                   const float* gt, const unsigned char* gvalid, float* weight_accum, int B, int K,
+                                   int C, int G, float clip_length, float overlap_thresh, int ibm_active, int num_bins,
+                                   float momentum, int iou_aware, float* losses, float* grads, float* scratch,
+                                   void* stream) {
+    if (!loc || !conf || !prop_loc || !prop_conf || !center || !act || !prop_act || !priors || !gt || !gvalid ||
+        !weight_accum || !losses || !grads || !scratch) return OTAL_E_NULL;
+    if (B <= 0 || K <= 0 || C <= 0 || G <= 0) return OTAL_E_SHAPE;
+    if (num_bins <= 0 || num_bins > MAX_BINS) return OTAL_E_UNSUPPORTED;
+    LossArgs a;
+    a.loc = loc; a.conf = conf; a.prop_loc = prop_loc; a.prop_conf = prop_conf; a.center = center; a.act = act;
+    a.prop_act = prop_act; a.priors = priors; a.gt = gt; a.gvalid = gvalid; a.weight_accum = weight_accum;
+    a.losses = losses; a.grads = grads; a.scratch = scratch;
+    a.B = B; a.K = K; a.C = C; a.G = G; a.clip = clip_length; a.overlap = overlap_thresh;
+    a.ibm_active = ibm_active; a.num_bins = num_bins; a.iou_aware = iou_aware; a.momentum = momentum;
+    hipLaunchKernelGGL(detection_loss_kernel, dim3(1), dim3(LT), 0, (hipStream_t)stream, a);
+    return otal_launch_status();
+}

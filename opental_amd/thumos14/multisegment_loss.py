@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from .cls_loss import ActionnessLoss, EvidenceLoss, FocalLoss_Ori
 
 _EPS = torch.finfo(torch.float32).eps
+FUSED = True      # single-launch HIP loss for the final recipe (set False to force the torch formulation)
 
 
 def _tiou(pred, target):
@@ -104,6 +105,13 @@ class MultiSegmentLoss(nn.Module):
         prop_loc_t = (loc_t - loc) / (0.5 * w)
         return loc_t, conf_t, prop_loc_t, prop_conf_t, iou
 
+    def _fused_ok(self, loc):
+        """The single-launch HIP loss (csrc/loss.hip) covers the final recipe; other settings use the torch formulation."""
+        cl = self.cls_loss
+        return (FUSED and loc.is_cuda and loc.dtype == torch.float32 and self.cls_loss_type == 'edl' and self.os_head
+                and not self.size_average and cl.loss_type == 'log' and cl.evidence == 'exp' and cl.num_bins <= 64
+                and self.act_loss.weight == 0 and not self.act_loss.size_average and not cl.size_average)
+
     def forward(self, output_dict, targets, pre_locs=None):
         loc, conf = output_dict['loc'], output_dict['conf']
         prop_loc, prop_conf = output_dict['prop_loc'], output_dict['prop_conf']
@@ -111,6 +119,14 @@ class MultiSegmentLoss(nn.Module):
         act, prop_act = output_dict['act'], output_dict['prop_act']
         B, K = loc.shape[0], priors.shape[0]
         C = self.num_classes
+        if self._fused_ok(loc):
+            from ..common.ops import DetectionLossFunction
+            gt, valid = pad_targets(targets, loc.device) if isinstance(targets, (list, tuple)) else targets
+            cl = self.cls_loss
+            return DetectionLossFunction.apply(
+                loc, conf, prop_loc, prop_conf, center.reshape(B, K), act.reshape(B, K), prop_act.reshape(B, K),
+                priors[:, 0], gt, valid, cl.weight_accum, float(self.clip_length), float(self.overlap_thresh),
+                bool(cl.with_ibm and cl.epoch >= cl.ibm_start), cl.num_bins, float(cl.momentum), bool(self.iou_aware))
         loc_t, conf_t, prop_loc_t, prop_conf_t, iou_pred = self.match(loc.detach(), priors, targets)
         pos, prop_pos = conf_t > 0, prop_conf_t > 0
         zero = loc.new_zeros(())

@@ -1,0 +1,59 @@
+"""GPU: the single-launch HIP detection loss (csrc/loss.hip) against this package's torch
+formulation of the same reference code (which is pinned to the reference through tests/golden): the seven loss
+values, every gradient and the IBM EMA state, for batches with and without positives, before and after ibm_start."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EDL = dict(evidence='exp', loss_type='log', iou_aware=True, with_focal=False, alpha=0.25, gamma=2, with_ibm=True,
+           ibm_start=10, momentum=0.99, num_bins=50)
+ACT = dict(margin=1.0, weight=0)
+
+
+def _inputs(B, seed, n_gt, dev):
+    rs = np.random.RandomState(seed)
+    K, C = 126, 15
+    t = lambda *s, scale=1.0: torch.tensor((rs.randn(*s) * scale).astype(np.float32), device=dev, requires_grad=True)
+    priors = torch.cat([torch.tensor([[(c + 0.5) / n] for c in range(n)]) for n in (64, 32, 16, 8, 4, 2)]).to(dev)
+    loc = torch.tensor(np.exp(rs.randn(B, K, 2) * 0.5 + 2.0).astype(np.float32), device=dev, requires_grad=True)
+    out = dict(loc=loc, conf=t(B, K, C, scale=2.0), prop_loc=t(B, K, 2, scale=0.3), prop_conf=t(B, K, C, scale=2.0),
+               center=t(B, K, 1), priors=priors, act=t(B, K, 1), prop_act=t(B, K, 1))
+    targets = []
+    for _ in range(B):
+        rows = []
+        for _ in range(n_gt):
+            ln = rs.uniform(0.05, 0.5); st = rs.uniform(0, 1 - ln)
+            rows.append([st, st + ln, float(rs.randint(1, 16))])
+        targets.append(torch.tensor(rows, dtype=torch.float32, device=dev).reshape(-1, 3))
+    return out, targets
+
+
+@pytest.mark.parametrize("B,n_gt,epoch", [(1, 2, 0), (2, 3, 12), (8, 2, 12), (3, 1, 12)])
+def test_fused_loss_matches_torch_formulation(B, n_gt, epoch):
+    from opental_amd.thumos14 import multisegment_loss as M
+    dev = torch.device("cuda", 0)
+    res = []
+    for fused in (False, True):
+        M.FUSED = fused
+        try:
+            crit = M.MultiSegmentLoss(15, 0.5, 1.0, cls_loss_type='edl', edl_config=EDL, os_head=True, act_config=ACT).to(dev)
+            crit.cls_loss.epoch = epoch
+            crit.cls_loss.weight_accum.copy_(torch.linspace(0.5, 1.5, 50))
+            out, targets = _inputs(B, 7 + B, n_gt, dev)
+            losses = crit(out, targets)
+            assert ('DetectionLossFunction' in type(losses[0].grad_fn).__name__) == fused, type(losses[0].grad_fn).__name__
+            w = [1.0, 10.0, 1.0, 10.0, 1.0, 1.0, 1.0]
+            sum(l * wi for l, wi in zip(losses, w)).backward()
+            grads = {k: v.grad.clone() for k, v in out.items() if v.requires_grad}
+            res.append(([float(l) for l in losses], grads, crit.cls_loss.weight_accum.clone()))
+        finally:
+            M.FUSED = True
+    (l0, g0, w0), (l1, g1, w1) = res
+    assert np.allclose(l0, l1, rtol=2e-5, atol=1e-6), (l0, l1)
+    assert torch.allclose(w0, w1, rtol=1e-5, atol=1e-7)
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * max(scale, 1e-6), (k, scale)
+        assert scale > 0
