@@ -21,6 +21,8 @@ namespace {
 
 constexpr int LT = 1024;            // threads of the single workgroup
 constexpr int MAX_BINS = 64;
+constexpr int MAX_A = 2048;         // anchors (B * K) the single-workgroup kernel accepts (LDS-resident scan / sort arrays)
+constexpr int HSEG = LT / MAX_BINS; // histogram: anchors are cut in HSEG segments, thread = (segment, bin)
 constexpr float F_EPS = 1.1920928955078125e-07f;     // torch.finfo(float32).eps
 
 struct LossArgs {
@@ -100,6 +102,12 @@ __global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
     __shared__ float red[LT];
     __shared__ float wacc[MAX_BINS];
     __shared__ int icnt[4];
+    // per-anchor arrays every thread scans (rank counting, histogram): LDS-resident, A <= MAX_A
+    __shared__ float s_val[MAX_A];              // ghat (EDL passes) / actionness score (PU passes)
+    __shared__ unsigned char s_slot[MAX_A];     // IBM slot
+    __shared__ unsigned char s_flag[MAX_A];     // bit0: row counts for the histogram / is a negative
+    __shared__ float h_tot[HSEG][MAX_BINS], h_cnt[HSEG][MAX_BINS];
+    __shared__ unsigned long long skey[MAX_A];  // PU loss: (order-preserving score bits << 32 | anchor index), sorted ascending
     const int t = threadIdx.x;
     const int A = a.B * a.K, C = a.C;
     float* g_loc_l = a.grads;
@@ -159,16 +167,25 @@ __global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
             const int y = max(tgt - 1, 0);
             const Edl e = edl_row(logits + (size_t)i * C, C, y, a.num_bins);
             s[7] = e.ghat; s[8] = (float)e.slot; s[9] = (float)e.binpos; s[10] = e.per;
+            s_val[i] = e.ghat; s_slot[i] = (unsigned char)e.slot; s_flag[i] = (tgt > 0 && e.binpos) ? 1 : 0;
         }
         __syncthreads();
-        if (a.ibm_active) {     // the 50-bin EMA: one thread per bin walks the anchors in index order (deterministic)
+        if (a.ibm_active) {     // the 50-bin EMA, deterministic: thread = (segment of anchors, bin) sums its segment in
+                                // index order, then one thread per bin adds the HSEG partials in segment order
+            const int bin = t % MAX_BINS, seg = t / MAX_BINS;
+            const int per_seg = (A + HSEG - 1) / HSEG;
+            float tot = 0.f, cnt = 0.f;
+            if (bin < a.num_bins) {
+                const int hi = min(A, (seg + 1) * per_seg);
+                for (int i = seg * per_seg; i < hi; ++i)
+                    if (s_flag[i] && s_slot[i] == bin) { tot += s_val[i]; cnt += 1.f; }
+            }
+            h_tot[seg][bin] = tot; h_cnt[seg][bin] = cnt;
+            __syncthreads();
             if (t < a.num_bins) {
-                float tot = 0.f, cnt = 0.f;
-                for (int i = 0; i < A; ++i) {
-                    const float* s = a.scratch + (size_t)i * SCR;
-                    if (s[2 + pass] > 0.f && (int)s[8] == t && s[9] > 0.f) { tot += s[7]; cnt += 1.f; }
-                }
-                if (cnt > 0.f) wacc[t] = a.momentum * wacc[t] + (1.f - a.momentum) * tot / fmaxf(cnt, 1.f);
+                float tt = 0.f, cc = 0.f;
+                for (int sg = 0; sg < HSEG; ++sg) { tt += h_tot[sg][t]; cc += h_cnt[sg][t]; }
+                if (cc > 0.f) wacc[t] = a.momentum * wacc[t] + (1.f - a.momentum) * tt / fmaxf(cc, 1.f);
             }
             __syncthreads();
         }
@@ -279,25 +296,45 @@ __global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
         float* gout = pass == 0 ? g_act : g_pact;
         const int np = icnt[pass], nn = A - np;
         const int top_m = min(np, nn) - 1;
+        // rank of every negative among the negatives (ascending score, ties by index) = its position after an exact
+        // bitonic sort of 64-bit keys in LDS; positives and padding carry the largest key and sort behind them
         int used_cnt = 0;
+        int n2 = 1;
+        while (n2 < A) n2 <<= 1;
+        __syncthreads();
+        for (int i = t; i < n2; i += LT) {
+            unsigned hi = 0xffffffffu;
+            if (i < A && !(a.scratch[(size_t)i * SCR + 2 + pass] > 0.f)) {
+                const unsigned u = __float_as_uint(pred[i]);
+                hi = u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+                if (hi == 0xffffffffu) hi = 0xfffffffeu;             // keep the sentinel unique to non-negatives
+            }
+            skey[i] = ((unsigned long long)hi << 32) | (unsigned)i;
+            if (i < A) s_flag[i] = (hi == 0xffffffffu) ? 1 : (top_m > 0 ? 0 : 1);      // used: positives; negatives decided below
+        }
+        __syncthreads();
+        if (top_m > 0) {
+            for (int k = 2; k <= n2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = t; i < n2; i += LT) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const unsigned long long x = skey[i], y = skey[ixj];
+                            const bool up = (i & k) == 0;
+                            if ((x > y) == up) { skey[i] = y; skey[ixj] = x; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int p_ = t; p_ < min(top_m, A); p_ += LT) {
+                const unsigned long long kv = skey[p_];
+                if ((unsigned)(kv >> 32) != 0xffffffffu) s_flag[(unsigned)kv] = 1;
+            }
+            __syncthreads();
+        }
         for (int i = t; i < A; i += LT) {
             float* s = a.scratch + (size_t)i * SCR;
-            const bool pos = s[2 + pass] > 0.f;
-            bool used = pos;
-            if (!pos) {
-                if (top_m > 0) {        // rank among the negatives, ascending score, ties by index
-                    const float x = pred[i];
-                    int rank = 0;
-                    for (int j = 0; j < A; ++j) {
-                        if (a.scratch[(size_t)j * SCR + 2 + pass] > 0.f) continue;
-                        const float y = pred[j];
-                        rank += (y < x) || (y == x && j < i);
-                    }
-                    used = rank < top_m;
-                } else {
-                    used = true;
-                }
-            }
+            const bool used = s_flag[i] != 0;
             s[11] = used ? 1.f : 0.f;
             used_cnt += used;
         }
@@ -346,7 +383,7 @@ extern "C" int otal_detection_loss(const float* loc, const float* conf, const fl
     if (!loc || !conf || !prop_loc || !prop_conf || !center || !act || !prop_act || !priors || !gt || !gvalid ||
         !weight_accum || !losses || !grads || !scratch) return OTAL_E_NULL;
     if (B <= 0 || K <= 0 || C <= 0 || G <= 0) return OTAL_E_SHAPE;
-    if (num_bins <= 0 || num_bins > MAX_BINS) return OTAL_E_UNSUPPORTED;
+    if (num_bins <= 0 || num_bins > MAX_BINS || (long)B * K > MAX_A) return OTAL_E_UNSUPPORTED;
     LossArgs a;
     a.loc = loc; a.conf = conf; a.prop_loc = prop_loc; a.prop_conf = prop_conf; a.center = center; a.act = act;
     a.prop_act = prop_act; a.priors = priors; a.gt = gt; a.gvalid = gvalid; a.weight_accum = weight_accum;

@@ -108,7 +108,8 @@ class MultiSegmentLoss(nn.Module):
     def _fused_ok(self, loc):
         """The single-launch HIP loss (csrc/loss.hip) covers the final recipe; other settings use the torch formulation."""
         cl = self.cls_loss
-        return (FUSED and loc.is_cuda and loc.dtype == torch.float32 and self.cls_loss_type == 'edl' and self.os_head
+        return (FUSED and loc.is_cuda and loc.dtype == torch.float32 and loc.shape[0] * loc.shape[1] <= 2048
+                and self.cls_loss_type == 'edl' and self.os_head
                 and not self.size_average and cl.loss_type == 'log' and cl.evidence == 'exp' and cl.num_bins <= 64
                 and self.act_loss.weight == 0 and not self.act_loss.size_average and not cl.size_average)
 
