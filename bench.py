@@ -148,7 +148,9 @@ def main():
         torch.cuda.synchronize()
 
     graphed = False
-    if args.graph != "off":
+    # auto: capture only on a single rank -- multi-rank capture of the RCCL hooks could not be exercised on the 1-GPU
+    # development boxes (the single-rank forced-collective capture works); N > 1 runs use the eager path unless --graph on
+    if args.graph == "on" or (args.graph == "auto" and world == 1):
         try:
             trainer.capture_step(clips, targets, scores)
             graphed = True

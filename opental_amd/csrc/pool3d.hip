@@ -280,6 +280,97 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_lds_kernel(const float* __r
     }
 }
 
+// ---- 3x3x3 / stride 1 / pad 1 on P x P planes (the nine Inception branch pools: P = 12, 6, 3): plane size as a
+// template constant, so every tap offset is an LDS immediate and the index decode is shifts/multiplies.  The generic
+// LDS kernels spent most of their time on per-tap address arithmetic (VALU-bound: 140 us for a 151 MB tensor).
+template <int P>
+__global__ __launch_bounds__(256) void maxpool333_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             unsigned char* __restrict__ arg, PoolGeom g, int TT) {
+    extern __shared__ float sm[];
+    constexpr int Q = P + 2, PL = Q * Q, PP = P * P;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    const int to0 = blockIdx.x * TT;
+    const int tt = min(TT, g.To - to0);
+    const int TL = tt + 2;
+    const float* xb = x + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs;
+    for (int i = threadIdx.x; i < TL * PL; i += 256) {
+        const int tl = i / PL, r = i - tl * PL, hl = r / Q, wl = r - hl * Q;
+        const int ti = to0 - 1 + tl, hi = hl - 1, wi = wl - 1;
+        const bool in = (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)P && (unsigned)wi < (unsigned)P;
+        const float v = xb[in ? (ti * P + hi) * P + wi : 0];
+        sm[i] = in ? v : 0.f;
+    }
+    __syncthreads();
+    const int Pn = g.To * PP;
+    for (int i = threadIdx.x; i < tt * PP; i += 256) {
+        const int tq = i / PP, r = i - tq * PP, ho = r / P, wo = r - ho * P;
+        const float* base = sm + (tq * Q + ho) * Q + wo;
+        float best = 0.f;
+        int win = 0;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) {
+                    const float v = base[(dt * Q + dh) * Q + dw];
+                    if ((dt | dh | dw) == 0 || v > best || v != v) { best = v; win = (dt * 3 + dh) * 3 + dw; }
+                }
+        const int wdt = win / 9, wr = win - wdt * 9, wdh = wr / 3, wdw = wr - wdh * 3;
+        const int ti = to0 + tq - 1 + wdt, hi = ho - 1 + wdh, wi = wo - 1 + wdw;
+        const bool in = (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)P && (unsigned)wi < (unsigned)P;
+        const int p = to0 * PP + i;
+        y[(int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p] = best;
+        arg[(int64_t)bc * Pn + p] = (unsigned char)(in ? win : 255);
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void maxpool333_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                             float* __restrict__ dx, PoolGeom g, int accumulate,
+                                                             const float* __restrict__ emask, const float* __restrict__ escale,
+                                                             int TI) {
+    extern __shared__ float2 sm2[];             // {dy, winner tap as int bits}; halo: {0, 255}
+    constexpr int Q = P + 2, PL = Q * Q, PP = P * P;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    const int ti0 = blockIdx.x * TI;
+    const int tin = min(TI, g.Ti - ti0);
+    const int TLo = tin + 2;                    // output planes ti0-1 .. ti0+tin
+    const float* dyb = dy + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs;
+    const unsigned char* ab = arg + (int64_t)bc * g.To * PP;
+    for (int i = threadIdx.x; i < TLo * PL; i += 256) {
+        const int tl = i / PL, r = i - tl * PL, hl = r / Q, wl = r - hl * Q;
+        const int to = ti0 - 1 + tl, ho = hl - 1, wo = wl - 1;
+        const bool in = (unsigned)to < (unsigned)g.To && (unsigned)ho < (unsigned)P && (unsigned)wo < (unsigned)P;
+        const int o = in ? (to * P + ho) * P + wo : 0;
+        const float d = dyb[o];
+        const int a = ab[o];
+        sm2[i] = make_float2(in ? d : 0.f, __int_as_float(in ? a : 255));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < tin * PP; i += 256) {
+        const int tq = i / PP, r = i - tq * PP, hi = r / P, wi = r - hi * P;
+        // input (ti,hi,wi) is tap (dt,dh,dw) of output (ti+1-dt, hi+1-dh, wi+1-dw); LDS index of output o is o+1 per axis
+        const float2* base = sm2 + ((tq + 2) * Q + (hi + 2)) * Q + (wi + 2);
+        float acc = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) {
+                    const float2 e = base[-((dt * Q + dh) * Q + dw)];
+                    acc += __float_as_int(e.y) == (dt * 3 + dh) * 3 + dw ? e.x : 0.f;     // ascending tap order: deterministic
+                }
+        const int p = ti0 * PP + i;
+        const int64_t off = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + p;
+        if (emask) acc = emask[off] > 0.f ? acc * escale[c] : 0.f;
+        dx[off] = accumulate ? dx[off] + acc : acc;
+    }
+}
+
 int fill(PoolGeom& g, const int* d, const int64_t* s) {
     // d: B,C, Ti,Hi,Wi, To,Ho,Wo, kt,kh,kw, st,sh,sw, pt,ph,pw
     g.B = d[0]; g.C = d[1]; g.Ti = d[2]; g.Hi = d[3]; g.Wi = d[4]; g.To = d[5]; g.Ho = d[6]; g.Wo = d[7];
@@ -302,6 +393,12 @@ int fill(PoolGeom& g, const int* d, const int64_t* s) {
 }
 
 constexpr size_t POOL_LDS_BUDGET = 48 * 1024;
+// the Inception branch pools: 3x3x3, stride 1, pad 1, square planes of side 12 / 6 / 3 with T unchanged
+static inline bool is_333_s1(const PoolGeom& g) {
+    return g.kt == 3 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 1 && g.ph == 1 && g.pw == 1 &&
+           g.Hi == g.Wi && (g.Hi == 12 || g.Hi == 6 || g.Hi == 3) && g.To == g.Ti && g.Ho == g.Hi && g.Wo == g.Wi &&
+           (int64_t)g.Ti * g.Hi * g.Wi < (1LL << 30);
+}
 // output planes per block (forward): ~4096 outputs, staged input planes within the LDS budget; 0 = does not fit
 int fwd_planes(const PoolGeom& g, size_t& lds) {
     int tt = 4096 / (g.Ho * g.Wo);
@@ -345,6 +442,17 @@ extern "C" int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
+    if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
+        int tt = 4096 / (g.Hi * g.Wi);
+        tt = tt < 1 ? 1 : (tt > g.To ? g.To : tt);
+        while (tt > 1 && (size_t)(tt + 2) * (g.Hi + 2) * (g.Wi + 2) * sizeof(float) > POOL_LDS_BUDGET) --tt;
+        const size_t l3 = (size_t)(tt + 2) * (g.Hi + 2) * (g.Wi + 2) * sizeof(float);
+        const dim3 grid((g.To + tt - 1) / tt, g.B * g.C);
+        if (g.Hi == 12) hipLaunchKernelGGL(maxpool333_fwd_kernel<12>, grid, dim3(256), l3, st_, x, y, argtap, g, tt);
+        else if (g.Hi == 6) hipLaunchKernelGGL(maxpool333_fwd_kernel<6>, grid, dim3(256), l3, st_, x, y, argtap, g, tt);
+        else hipLaunchKernelGGL(maxpool333_fwd_kernel<3>, grid, dim3(256), l3, st_, x, y, argtap, g, tt);
+        return otal_launch_status();
+    }
     size_t lds = 0;
     // staging pays when the taps overlap (stride 1: every input is read kvol times); the strided pools read each input
     // ~2 times and were measured faster with direct loads (r01: 230 vs 514 us for the 1x3x3 / (1,2,2) pool)
@@ -368,6 +476,17 @@ extern "C" int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
+    if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
+        int ti = 4096 / (g.Hi * g.Wi);
+        ti = ti < 1 ? 1 : (ti > g.Ti ? g.Ti : ti);
+        while (ti > 1 && (size_t)(ti + 2) * (g.Hi + 2) * (g.Wi + 2) * sizeof(float2) > POOL_LDS_BUDGET) --ti;
+        const size_t l3 = (size_t)(ti + 2) * (g.Hi + 2) * (g.Wi + 2) * sizeof(float2);
+        const dim3 grid((g.Ti + ti - 1) / ti, g.B * g.C);
+        if (g.Hi == 12) hipLaunchKernelGGL(maxpool333_bwd_kernel<12>, grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, ti);
+        else if (g.Hi == 6) hipLaunchKernelGGL(maxpool333_bwd_kernel<6>, grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, ti);
+        else hipLaunchKernelGGL(maxpool333_bwd_kernel<3>, grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, ti);
+        return otal_launch_status();
+    }
     size_t lds = 0;
     int tlo_max = 0;
     const int ti = getenv("OTAL_POOL_NOLDS") ? 0 : bwd_planes(g, tlo_max, lds);
