@@ -204,6 +204,25 @@ __device__ __forceinline__ void store_acc(const ConvArgs& a, const f32x16 (&acc)
     }
 }
 
+// XCD-aware tile order.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  Give every
+// XCD a CONTIGUOUS range of logical tiles instead, ordered so that the tiles which read the same gathered data are
+// neighbours: FWD / DGRAD -- the M tiles of one position tile, then the next position tile (shared halo rows);
+// WGRAD -- all (N, M) tiles of one split (they read the same positions of x and dy), then the next split.
+// A bijection for any grid; placement is an optimisation only (the id -> XCD map is not architecturally guaranteed).
+struct TileId { int x, y, z; };
+__device__ __forceinline__ TileId xcd_tile(bool y_fastest) {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int total = gx * gy * gz;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int xcd = lin & 7, idx = lin >> 3;
+    const int full = total >> 3, rem = total & 7;
+    int l = xcd * full + min(xcd, rem) + idx;
+    TileId t;
+    if (y_fastest) { t.y = l % gy; l /= gy; t.x = l % gx; t.z = l / gx; }
+    else { t.x = l % gx; l /= gx; t.y = l % gy; t.z = l / gy; }
+    return t;
+}
+
 // PREC 0: fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32; BK = 16, LDS tiles k-major [k][m]).
 // PREC 1: operands rounded to bf16 while they are staged into LDS, v_mfma_f32_32x32x16_bf16 with fp32
 //         accumulation (16x the matrix rate; BK = 32, LDS tiles k-contiguous [m][k] with an 80-byte row
@@ -225,9 +244,10 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    const int split = blockIdx.z;
+    const TileId tile = xcd_tile(MODE != MODE_WGRAD);
+    const int m0 = tile.y * BM;
+    const int n0 = tile.x * BN;
+    const int split = tile.z;
     const int k_begin = split * a.k_per_split;
     const int k_end = min(a.K, k_begin + a.k_per_split);
     const int HWi = g.Hi * g.Wi;
@@ -564,9 +584,10 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    const int split = blockIdx.z;
+    const TileId tile = xcd_tile(true);
+    const int m0 = tile.y * BM;
+    const int n0 = tile.x * BN;
+    const int split = tile.z;
     const int k_begin = split * a.k_per_split;
     const int k_end = min(a.Kp, k_begin + a.k_per_split);
     const int nk = (k_end - k_begin) / BK;                  // Kp and k_per_split are multiples of 32
@@ -838,9 +859,10 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    const int split = blockIdx.z;
+    const TileId tile = xcd_tile(false);
+    const int m0 = tile.y * BM;
+    const int n0 = tile.x * BN;
+    const int split = tile.z;
     const int k_begin = split * a.k_per_split;
     const int k_end = min(a.K, k_begin + a.k_per_split);
     const int nk = (k_end - k_begin) / BK;                  // K and k_per_split are multiples of 32
