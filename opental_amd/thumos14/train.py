@@ -80,13 +80,14 @@ class FlatArena:
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.offsets = []
+        self.offsets, self.grad_views = [], []
         off = 0
         for p in self.params:
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view(p.shape)
-            p.grad = self.grad[off:off + k].view(p.shape)
+            self.grad_views.append(self.grad[off:off + k].view(p.shape))
+            p.grad = self.grad_views[-1]
             self.offsets.append(off)
             off += k
         self.numel = n
@@ -102,8 +103,10 @@ class FlatArena:
                 self.buckets.append((lo, hi))
                 lo, cur = hi, 0
         self.bucket_size = [0] * len(self.buckets)
-        for b in self.bucket_of:
+        self.bucket_members = [[] for _ in self.buckets]
+        for i, b in enumerate(self.bucket_of):
             self.bucket_size[b] += 1
+            self.bucket_members[b].append(i)
 
 
 class DetectorTrainer:
@@ -120,29 +123,62 @@ class DetectorTrainer:
         self._graph = None          # (CUDAGraph, static inputs, static outputs) once capture_step() succeeded
         self._bias_corr = None      # 2-float device tensor: Adam bias corrections of the step being run
         self.collectives = self.distributed and (self.world > 1 or force_collectives)   # force: 1-rank RCCL smoke test
-        if self.collectives:
-            for i, p in enumerate(self.arena.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(self.arena.bucket_of[i]))
+        self._flushed = None
+        for i, p in enumerate(self.arena.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(self.arena.bucket_of[i]))
 
-    # ---- gradient all-reduce, overlapped with backward
+    # ---- gradients -> flat arena (+ all-reduce), bucket by bucket, overlapped with backward
+    # Parameters enter backward with .grad = None, so autograd ADOPTS each incoming gradient tensor instead of
+    # launching `arena_view += grad` per parameter (~190 tiny kernels per step + a 179 MB zero fill); when the last
+    # gradient of a bucket has arrived, one multi-tensor copy moves the bucket into the arena and, in data-parallel
+    # runs, its all-reduce starts.
     def _make_hook(self, b):
         def hook(_param):
+            if self._pending is None:
+                return
             self._pending[b] -= 1
             if self._pending[b] == 0:
-                lo, hi = self.arena.buckets[b]
-                self._works.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                                   async_op=True))
+                self._flush_bucket(b)
         return hook
+
+    def _flush_bucket(self, b):
+        if self._flushed[b]:
+            return
+        self._flushed[b] = True
+        a = self.arena
+        dst, src = [], []
+        for i in a.bucket_members[b]:
+            g = a.params[i].grad
+            if g is None:
+                a.grad_views[i].zero_()                 # parameter unused this step
+            elif g.data_ptr() != a.grad_views[i].data_ptr():
+                dst.append(a.grad_views[i]); src.append(g)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if self.collectives:
+            lo, hi = a.buckets[b]
+            self._works.append(dist.all_reduce(a.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def begin_backward(self):
+        """Call before cost.backward(): gradients start undefined, buckets open."""
+        for p in self.arena.params:
+            p.grad = None
+        self._pending = list(self.arena.bucket_size)
+        self._flushed = [False] * len(self.arena.buckets)
+
+    def end_backward(self):
+        """Call after cost.backward(): flush the buckets that did not complete (unused parameters), wait for the
+        all-reduces, and leave every .grad aliasing its arena slice."""
+        for b in range(len(self.arena.buckets)):
+            self._flush_bucket(b)
+        self._pending = None
+        for p, v in zip(self.arena.params, self.arena.grad_views):
+            p.grad = v
+        self._finish_allreduce()
 
     def _finish_allreduce(self):
         if not self.collectives:
             return
-        # buckets whose parameters received no gradient this step still have to be reduced
-        for b, left in enumerate(self._pending):
-            if left > 0:
-                lo, hi = self.arena.buckets[b]
-                self._works.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                                   async_op=True))
         for w in self._works:
             w.wait()
         self._works = []
@@ -163,11 +199,10 @@ class DetectorTrainer:
     def step(self, clips, targets, scores, ssl_clips=None, ssl_targets=None):
         if self._graph is not None and ssl_clips is None:
             return self._replay(clips, targets, scores)
-        self.arena.grad.zero_()
-        self._pending = list(self.arena.bucket_size)
         cost, losses = self.compute_cost(clips, targets, scores, ssl_clips, ssl_targets)
+        self.begin_backward()
         cost.backward()
-        self._finish_allreduce()
+        self.end_backward()
         self.step_count += 1
         self.optimizer_update()
         return cost.detach(), losses
@@ -179,11 +214,10 @@ class DetectorTrainer:
 
     # ---- the same step as ONE HIP graph: ~1500 launches per step are replayed without host involvement
     def _graph_body(self, clips, targets, scores):
-        self.arena.grad.zero_()
-        self._pending = list(self.arena.bucket_size)
         cost, losses = self.compute_cost(clips, targets, scores)
+        self.begin_backward()
         cost.backward()
-        self._finish_allreduce()
+        self.end_backward()
         ops.adam_flat_dev(self.arena.flat, self.arena.grad, self.arena.m, self.arena.v, self._bias_corr, self.lr,
                           self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
         return cost.detach(), losses
@@ -211,7 +245,8 @@ class DetectorTrainer:
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         self._set_bias(self.step_count + 1)
-        with torch.cuda.graph(graph):
+        # thread_local: RCCL's watchdog thread polls events concurrently; only this thread's calls must be capture-safe
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out = self._graph_body(*static)
         self.step_count += 0        # capture does not execute
         self._graph = (graph, static, out)

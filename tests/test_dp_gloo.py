@@ -92,10 +92,10 @@ def test_two_ranks_match_single_process_on_the_global_batch():
     class Both(type(tr)):
         pass
     for step in range(3):
-        tr.arena.grad.zero_()
-        tr._pending = list(tr.arena.bucket_size)
         cost = sum(((net(xs[r, step]) - ys[r, step]) ** 2).mean() for r in range(world)) / world
+        tr.begin_backward()
         cost.backward()
+        tr.end_backward()
         tr.step_count += 1
         tr.optimizer_update()
     assert torch.allclose(tr.arena.flat, res[0][1], rtol=1e-5, atol=1e-6)
