@@ -62,6 +62,8 @@ struct ConvArgs {
     unsigned dy_bytes;     // extent of dy (buffer descriptor of the A operand)
     int P;                 // positions per sample (To*Ho*Wo), a multiple of 32 on this path
     int w_natural;         // DGRAD: `w` is the forward-layout weight (Cout, Cin, kvol), not the packed transpose
+    // batched epilogue (store_acc): byte extents of the output (and of the split-K slabs) when they fit 32-bit offsets, else 0
+    unsigned out_bytes, slab_bytes;
 };
 
 // ---- operand element fetch -------------------------------------------------------------------
@@ -157,9 +159,19 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {     // rou
 }
 
 // ---- epilogue.  C/D map of the 32x32 MFMAs: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// Epilogue.  The first version walked the tile element by element -- load mask, wait, load scale, wait, load old value,
+// wait, store, with a branch per element -- so every output cost three serialised memory latencies: the 1x1 layers (one
+// K step per block) ran at 1.6 TB/s and even Conv3d_2c spent >10 % of its time here.  Now:
+//   * per-ROW values (folded BN scale / shift, the producer's BN scale for the fused ReLU/BN backward) are staged ONCE
+//     per workgroup in LDS (the A tile's buffer is free after the main loop);
+//   * uniform options (mask, accumulate, ReLU, split-K) are hoisted out of the element loops;
+//   * the 16 mask / accumulate loads of a 32x32 MFMA tile are issued back to back, then the 16 stores;
+//   * rows >= M / columns >= N select an out-of-range buffer offset (loads return 0, stores are dropped): no branches.
+// `rows` = LDS scratch of at least 2*BM floats.  Needs the output (and slabs) to fit 32-bit byte offsets; otherwise the
+// element-wise fallback below runs.
 template <int MODE, int WM, int WN>
-__device__ __forceinline__ void store_acc(const ConvArgs& a, const f32x16 (&acc)[WM][WN], int m0, int n0, int wm0, int wn0,
-                                          int lane, int split) {
+__device__ __forceinline__ void store_acc_slow(const ConvArgs& a, const f32x16 (&acc)[WM][WN], int m0, int n0, int wm0, int wn0,
+                                               int lane, int split) {
     const ConvGeom& g = a.g;
     const ConvFastDiv& fd = a.fd;
 #pragma unroll
@@ -201,6 +213,106 @@ __device__ __forceinline__ void store_acc(const ConvArgs& a, const f32x16 (&acc)
                 if (a.flags & EPI_ACCUM) v += a.out[off];
                 a.out[off] = v;
             }
+    }
+}
+
+template <int MODE, int WM, int WN, int BM>
+__device__ __forceinline__ void store_acc(const ConvArgs& a, const f32x16 (&acc)[WM][WN], int m0, int n0, int wm0, int wn0,
+                                          int lane, int split, float* rows) {
+    const bool slabs = a.splits > 1;
+    if ((slabs ? a.slab_bytes : a.out_bytes) == 0u) {
+        store_acc_slow<MODE, WM, WN>(a, acc, m0, n0, wm0, wn0, lane, split);
+        return;
+    }
+    const ConvGeom& g = a.g;
+    const ConvFastDiv& fd = a.fd;
+    constexpr unsigned OOB = 0xffffffffu;
+    if (slabs) {            // raw partial sums: slab[split][m][n]
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.slab, 0, (int)a.slab_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + wn0 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const unsigned vo = (n < a.N && m < a.M) ? (unsigned)((((unsigned)split * a.M + m) * (unsigned)a.N + n) * 4u) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rs, vo, 0, 0);
+                }
+        }
+        return;
+    }
+    // ---- per-row values -> LDS
+    __syncthreads();        // every wave is done reading the operand tiles
+    for (int r = threadIdx.x; r < BM; r += NT) {
+        const int m = m0 + r;
+        float s0 = 1.f, s1 = 0.f;
+        if (m < a.M) {
+            if constexpr (MODE == MODE_FWD) { if (a.scale) s0 = a.scale[m]; if (a.shift) s1 = a.shift[m]; }
+            else if constexpr (MODE == MODE_DGRAD) { if (a.escale) s0 = a.escale[m]; }
+        }
+        rows[2 * r] = s0; rows[2 * r + 1] = s1;
+    }
+    __syncthreads();
+    const auto ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const auto rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.emask ? a.emask : a.out), 0, (int)a.out_bytes, 0x00020000);
+    const bool relu = (a.flags & EPI_RELU) != 0, accum = (a.flags & EPI_ACCUM) != 0, masked = MODE == MODE_DGRAD && a.emask != nullptr;
+    const unsigned row_stride = MODE == MODE_FWD ? (unsigned)g.y_cs : (MODE == MODE_DGRAD ? (unsigned)g.x_cs : 0u);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + wn0 + j * 32 + (lane & 31);
+        const bool okn = n < a.N;
+        unsigned nbase = 0;
+        if constexpr (MODE == MODE_FWD) nbase = (unsigned)conv_out_offset(g, dec_pos_fd(okn ? n : 0, fd.To, fd.Ho, fd.Wo), 0);
+        else if constexpr (MODE == MODE_DGRAD) nbase = (unsigned)conv_in_offset(g, dec_pos_fd(okn ? n : 0, fd.Ti, fd.Hi, fd.Wi), 0);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            unsigned vo[16];
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + lr;
+                bool ok = okn && m < a.M;
+                unsigned off;
+                if constexpr (MODE == MODE_WGRAD) {
+                    if (a.flags & EPI_NPAD8) {     // columns are (row, dw padded to 8): drop the padding, compact to kw
+                        ok = ok && (n & 7) < g.kw;
+                        off = (unsigned)m * (unsigned)((a.N >> 3) * g.kw) + (unsigned)((n >> 3) * g.kw + (n & 7));
+                    } else {
+                        off = (unsigned)m * (unsigned)a.N + (unsigned)n;
+                    }
+                } else {
+                    off = nbase + (unsigned)m * row_stride;
+                }
+                vo[r] = ok ? off * 4u : OOB;
+                float x = acc[i][j][r];
+                if constexpr (MODE == MODE_FWD) {
+                    x = x * rows[2 * lr] + rows[2 * lr + 1];
+                    if (relu) x = fmaxf(x, 0.f);
+                } else if constexpr (MODE == MODE_DGRAD) {
+                    x *= rows[2 * lr];              // escale (1 when there is no mask)
+                }
+                v[r] = x;
+            }
+            if (masked) {
+                float mk[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mk[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, vo[r], 0, 0));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
+            }
+            if (accum) {
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, vo[r], 0, 0));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += old[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, vo[r], 0, 0);
+        }
     }
 }
 
@@ -538,7 +650,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
         if (!(a.flags & DBG_NOBARRIER)) __syncthreads();
     }
 
-    store_acc<MODE, WM, WN>(a, acc, m0, n0, wm0, wn0, lane, split);
+    store_acc<MODE, WM, WN, BM>(a, acc, m0, n0, wm0, wn0, lane, split, reinterpret_cast<float*>(smemA[0]));
 }
 
 // =================================================================================================
@@ -823,7 +935,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
         store_tiles(buf ^ 1);
         __syncthreads();
     }
-    store_acc<MODE, WM, WN>(a, acc, m0, n0, wm0, wn0, lane, split);
+    store_acc<MODE, WM, WN, BM>(a, acc, m0, n0, wm0, wn0, lane, split, reinterpret_cast<float*>(smA[0]));
 }
 
 // =================================================================================================
@@ -1072,7 +1184,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
         store_tiles(buf ^ 1);
         __syncthreads();
     }
-    store_acc<MODE_WGRAD, WM, WN>(a, acc, m0, n0, wm0, wn0, lane, split);
+    store_acc<MODE_WGRAD, WM, WN, BM>(a, acc, m0, n0, wm0, wn0, lane, split, reinterpret_cast<float*>(smA[0]));
 }
 
 // position table of the vector WGRAD: one entry per group of CW consecutive output positions
@@ -1296,6 +1408,19 @@ static const float* zero_word_address() {
     return z;
 }
 
+// byte extents for the batched epilogue (0 = does not fit 32-bit offsets -> element-wise fallback)
+template <int MODE>
+static void set_epilogue_extents(ConvArgs& a) {
+    const ConvGeom& g = a.g;
+    int64_t out;
+    if (MODE == MODE_FWD) out = 4 * ((int64_t)(g.B - 1) * g.y_bs + (int64_t)(g.Cout - 1) * g.y_cs + conv_out_positions(g));
+    else if (MODE == MODE_DGRAD) out = 4 * ((int64_t)(g.B - 1) * g.x_bs + (int64_t)(g.Cin - 1) * g.x_cs + conv_in_positions(g));
+    else out = 4 * (int64_t)g.Cout * g.Cin * conv_kvol(g);
+    a.out_bytes = (out > 0 && out < (int64_t)0xfffffff0u && !getenv("OTAL_CONV_SLOW_EPILOGUE")) ? (unsigned)out : 0u;
+    const int64_t slab = 4 * (int64_t)a.splits * a.M * a.N;
+    a.slab_bytes = (a.splits > 1 && slab < (int64_t)0xfffffff0u && !getenv("OTAL_CONV_SLOW_EPILOGUE")) ? (unsigned)slab : 0u;
+}
+
 // ---- chunked bf16 path: eligibility, workspace layout [chunk table][packed bf16 weights][split-K slabs]
 constexpr int CHUNK_PAD = 16;       // table entries readable past Kp/8 (two K steps of prefetch)
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1371,6 +1496,7 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     a.splits = splits;
     a.k_per_split = kps;
     a.slab = splits > 1 ? (float*)ws : nullptr;
+    set_epilogue_extents<MODE>(a);
     const dim3 grid(tn, tm, splits);
     const int cw = chunk_vector_width(a.g);
 #define OTAL_LAUNCH_C(BM_, WM_, WN_)                                                                                   \
@@ -1466,6 +1592,7 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
     a.splits = splits;
     a.k_per_split = kps;
     a.slab = splits > 1 ? (float*)ws : nullptr;
+    set_epilogue_extents<MODE_WGRAD>(a);
     const dim3 grid(tn, tm, splits);
 #define OTAL_LAUNCH_W(BM_, WM_, WN_)                                                                                   \
     do {                                                                                                               \
@@ -1554,6 +1681,7 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     a.splits = splits;
     a.k_per_split = kps;
     a.slab = splits > 1 ? (float*)ws : nullptr;
+    set_epilogue_extents<MODE>(a);
     const dim3 grid(tn, tm, splits);
 #define OTAL_LAUNCH(BM_, WM_, WN_, AV_)                                                                       \
     do {                                                                                                       \
