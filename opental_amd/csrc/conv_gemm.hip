@@ -1302,33 +1302,67 @@ __global__ __launch_bounds__(256) void build_tap_table_kernel(int2* __restrict__
 constexpr size_t TAB_PAD = 64;      // entries readable past K (a K step may run up to BK-1 rows over)
 static inline size_t tab_bytes(int K) { return (((size_t)K + TAB_PAD) * sizeof(int2) + 255) & ~(size_t)255; }
 
-// fixed-order reduction of the split-K slabs + the same epilogue
-template <int MODE>
+// fixed-order reduction of the split-K slabs + the same epilogue.  V consecutive elements per thread (float4 when the
+// slab size allows); the loads of 8 splits are issued together and THEN added in split order -- the sum order (and so the
+// result) is the one of a plain loop, without its one-load-in-flight dependency chain.
+template <int MODE, int V>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
     const ConvGeom& g = a.g;
     const int64_t total = (int64_t)a.M * a.N;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int m = (int)(idx / a.N), n = (int)(idx - (int64_t)m * a.N);
-        float v = 0.f;
-        for (int s = 0; s < a.splits; ++s) v += a.slab[(int64_t)s * total + idx];
-        int64_t off;
-        if (MODE == MODE_FWD) {
-            if (a.scale) v *= a.scale[m];
-            if (a.shift) v += a.shift[m];
-            if (a.flags & EPI_RELU) v = fmaxf(v, 0.f);
-            off = conv_out_offset(g, dec_pos_fd(n, a.fd.To, a.fd.Ho, a.fd.Wo), m);
-        } else if (MODE == MODE_DGRAD) {
-            off = conv_in_offset(g, dec_pos_fd(n, a.fd.Ti, a.fd.Hi, a.fd.Wi), m);
-            if (a.emask) v = a.emask[off] > 0.f ? v * a.escale[m] : 0.f;
-        } else if (a.flags & EPI_NPAD8) {
-            if ((n & 7) >= g.kw) continue;
-            off = (int64_t)m * ((a.N >> 3) * g.kw) + (n >> 3) * g.kw + (n & 7);
-        } else {
-            off = idx;
+    struct alignas(4 * V) vec_t { float f[V]; };
+    for (int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V; base < total; base += (int64_t)gridDim.x * 256 * V) {
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int s0 = 0; s0 < a.splits; s0 += 8) {
+            vec_t tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int sidx = min(s0 + u, a.splits - 1);          // clamped: the surplus loads are not added
+                tmp[u] = *reinterpret_cast<const vec_t*>(a.slab + (int64_t)sidx * total + base);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < a.splits) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] += tmp[u].f[e];
+                }
         }
-        if (a.flags & EPI_ACCUM) v += a.out[off];
-        a.out[off] = v;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int64_t idx = base + e;
+            const int m = (int)(idx / a.N), n = (int)(idx - (int64_t)m * a.N);
+            float v = acc[e];
+            int64_t off;
+            if (MODE == MODE_FWD) {
+                if (a.scale) v *= a.scale[m];
+                if (a.shift) v += a.shift[m];
+                if (a.flags & EPI_RELU) v = fmaxf(v, 0.f);
+                off = conv_out_offset(g, dec_pos_fd(n, a.fd.To, a.fd.Ho, a.fd.Wo), m);
+            } else if (MODE == MODE_DGRAD) {
+                off = conv_in_offset(g, dec_pos_fd(n, a.fd.Ti, a.fd.Hi, a.fd.Wi), m);
+                if (a.emask) v = a.emask[off] > 0.f ? v * a.escale[m] : 0.f;
+            } else if (a.flags & EPI_NPAD8) {
+                if ((n & 7) >= g.kw) continue;
+                off = (int64_t)m * ((a.N >> 3) * g.kw) + (n >> 3) * g.kw + (n & 7);
+            } else {
+                off = idx;
+            }
+            if (a.flags & EPI_ACCUM) v += a.out[off];
+            a.out[off] = v;
+        }
     }
+}
+
+template <int MODE>
+static int launch_splitk_reduce(const ConvArgs& a, hipStream_t st) {
+    const int64_t total = (int64_t)a.M * a.N;
+    const bool v4 = (total % 4 == 0) && (((uintptr_t)a.slab & 15) == 0);
+    const int64_t work = v4 ? total / 4 : total;
+    const int blocks = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    if (v4) hipLaunchKernelGGL((splitk_reduce_kernel<MODE, 4>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((splitk_reduce_kernel<MODE, 1>), dim3(blocks), dim3(256), 0, st, a);
+    return otal_launch_status();
 }
 
 // W (Cout, Cin, kvol) -> W^T packed (Cin, Cout, kvol): the A operand of DGRAD
@@ -1521,10 +1555,7 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 #undef OTAL_LAUNCH_C
     if (int e = otal_launch_status()) return e;
     if (splits > 1) {
-        const int64_t total = (int64_t)a.M * a.N;
-        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL((splitk_reduce_kernel<MODE>), dim3(blocks), dim3(256), 0, st, a);
-        return otal_launch_status();
+        return launch_splitk_reduce<MODE>(a, st);
     }
     return 0;
 }
@@ -1612,10 +1643,7 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
 #undef OTAL_LAUNCH_W
     if (int e = otal_launch_status()) return e;
     if (splits > 1) {
-        const int64_t total = (int64_t)a.M * a.N;
-        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL((splitk_reduce_kernel<MODE_WGRAD>), dim3(blocks), dim3(256), 0, st, a);
-        return otal_launch_status();
+        return launch_splitk_reduce<MODE_WGRAD>(a, st);
     }
     return 0;
 }
@@ -1699,10 +1727,7 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 #undef OTAL_LAUNCH
     if (int e = otal_launch_status()) return e;
     if (splits > 1) {
-        const int64_t total = (int64_t)a.M * a.N;
-        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL((splitk_reduce_kernel<MODE>), dim3(blocks), dim3(256), 0, st, a);
-        return otal_launch_status();
+        return launch_splitk_reduce<MODE>(a, st);
     }
     return 0;
 }
