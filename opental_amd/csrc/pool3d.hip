@@ -340,34 +340,69 @@ __global__ __launch_bounds__(256) void maxpool333_bwd_kernel(const float* __rest
     const int TLo = tin + 2;                    // output planes ti0-1 .. ti0+tin
     const float* dyb = dy + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs;
     const unsigned char* ab = arg + (int64_t)bc * g.To * PP;
-    for (int i = threadIdx.x; i < TLo * PL; i += 256) {
-        const int tl = i / PL, r = i - tl * PL, hl = r / Q, wl = r - hl * Q;
-        const int to = ti0 - 1 + tl, ho = hl - 1, wo = wl - 1;
-        const bool in = (unsigned)to < (unsigned)g.To && (unsigned)ho < (unsigned)P && (unsigned)wo < (unsigned)P;
-        const int o = in ? (to * P + ho) * P + wo : 0;
-        const float d = dyb[o];
-        const int a = ab[o];
-        sm2[i] = make_float2(in ? d : 0.f, __int_as_float(in ? a : 255));
+#ifndef OTAL_POOL_U
+#define OTAL_POOL_U 8       // measured on MI355X (tools/micro_pool.py): 8 staged loads in flight, output loop unbatched
+#endif
+#ifndef OTAL_POOL_UO
+#define OTAL_POOL_UO 1
+#endif
+    constexpr int U = OTAL_POOL_U;              // staging loads in flight per thread
+    for (int i0 = threadIdx.x; i0 < TLo * PL; i0 += 256 * U) {
+        float d[U];
+        int a[U];
+        bool in[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 256 * u;
+            const int tl = i / PL, r = i - tl * PL, hl = r / Q, wl = r - hl * Q;
+            const int to = ti0 - 1 + tl, ho = hl - 1, wo = wl - 1;
+            in[u] = i < TLo * PL && (unsigned)to < (unsigned)g.To && (unsigned)ho < (unsigned)P && (unsigned)wo < (unsigned)P;
+            const int o = in[u] ? (to * P + ho) * P + wo : 0;
+            d[u] = dyb[o];
+            a[u] = ab[o];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + 256 * u < TLo * PL) sm2[i0 + 256 * u] = make_float2(in[u] ? d[u] : 0.f, __int_as_float(in[u] ? a[u] : 255));
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < tin * PP; i += 256) {
-        const int tq = i / PP, r = i - tq * PP, hi = r / P, wi = r - hi * P;
-        // input (ti,hi,wi) is tap (dt,dh,dw) of output (ti+1-dt, hi+1-dh, wi+1-dw); LDS index of output o is o+1 per axis
-        const float2* base = sm2 + ((tq + 2) * Q + (hi + 2)) * Q + (wi + 2);
-        float acc = 0.f;
+    constexpr int UO = OTAL_POOL_UO;
+    const float esc = emask ? escale[c] : 1.f;
+    for (int i0 = threadIdx.x; i0 < tin * PP; i0 += 256 * UO) {
+        float acc[UO], mk[UO], old[UO];
+        int64_t off[UO];
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt)
+        for (int u = 0; u < UO; ++u) {
+            const int i = min(i0 + 256 * u, tin * PP - 1);
+            off[u] = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ti0 * PP + i;
+            mk[u] = emask ? emask[off[u]] : 1.f;
+            old[u] = accumulate ? dx[off[u]] : 0.f;
+        }
 #pragma unroll
-            for (int dh = 0; dh < 3; ++dh)
+        for (int u = 0; u < UO; ++u) {
+            const int i = min(i0 + 256 * u, tin * PP - 1);
+            const int tq = i / PP, r = i - tq * PP, hi = r / P, wi = r - hi * P;
+            // input (ti,hi,wi) is tap (dt,dh,dw) of output (ti+1-dt, hi+1-dh, wi+1-dw); LDS index of output o is o+1 per axis
+            const float2* base = sm2 + ((tq + 2) * Q + (hi + 2)) * Q + (wi + 2);
+            float s_ = 0.f;
 #pragma unroll
-                for (int dw = 0; dw < 3; ++dw) {
-                    const float2 e = base[-((dt * Q + dh) * Q + dw)];
-                    acc += __float_as_int(e.y) == (dt * 3 + dh) * 3 + dw ? e.x : 0.f;     // ascending tap order: deterministic
-                }
-        const int p = ti0 * PP + i;
-        const int64_t off = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + p;
-        if (emask) acc = emask[off] > 0.f ? acc * escale[c] : 0.f;
-        dx[off] = accumulate ? dx[off] + acc : acc;
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const float2 e = base[-((dt * Q + dh) * Q + dw)];
+                        s_ += __float_as_int(e.y) == (dt * 3 + dh) * 3 + dw ? e.x : 0.f;     // ascending tap order: deterministic
+                    }
+            acc[u] = s_;
+        }
+#pragma unroll
+        for (int u = 0; u < UO; ++u) {
+            if (i0 + 256 * u >= tin * PP) continue;
+            float v = acc[u];
+            if (emask) v = mk[u] > 0.f ? v * esc : 0.f;         // ReLU/BN backward of the pooled layer
+            dx[off[u]] = old[u] + v;
+        }
     }
 }
 
