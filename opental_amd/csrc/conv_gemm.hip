@@ -766,6 +766,10 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
 #pragma unroll
         for (int h = 0; h < NE; ++h) ce_next[h] = ctab64[(k0 >> 3) + h];
     };
+    // loadB only ISSUES the loads.  Everything that touches the loaded values -- the row-edge masks and the rare
+    // "vector starts in front of the tensor" re-fetch -- runs in fixB() at LDS-store time, behind the MFMAs: applied
+    // right after the loads it made hipcc wait for the gather (s_waitcnt vmcnt) BEFORE the matrix work of the step.
+    // The table entries ce[] of the tile being stored are still resident then, so offsets / masks are recomputed.
     auto loadB = [&](int h) {
         if constexpr (KWV) {                               // h-th chunk = 8 consecutive w taps of one (ci, dt, dh) row
             const unsigned ex = (unsigned)ce[h], ey = (unsigned)(ce[h] >> 32);
@@ -774,19 +778,10 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
             const Words4 v0 = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
             const Words4 v1 = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16u, 0, 0));
             float* r = rb + 8 * h;
-            r[0] = __builtin_bit_cast(float, v0.a & keepw[0]); r[1] = __builtin_bit_cast(float, v0.b & keepw[1]);
-            r[2] = __builtin_bit_cast(float, v0.c & keepw[2]); r[3] = __builtin_bit_cast(float, v0.d & keepw[3]);
-            r[4] = __builtin_bit_cast(float, v1.a & keepw[4]); r[5] = __builtin_bit_cast(float, v1.b & keepw[5]);
-            r[6] = __builtin_bit_cast(float, v1.c & keepw[6]); r[7] = __builtin_bit_cast(float, v1.d & keepw[7]);
-            // first load starting in front of the tensor (first row, left padding): rejected as a whole -> refetch
-            const bool neg = vo >= 0xfffffff0u;
-            if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
-#pragma unroll
-                for (int j = 1; j < 8; ++j) {              // (the second vector's immediate offset does not wrap either)
-                    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? wrap_add(vo, 4u * j) : a.src_bytes, 0, 0);
-                    r[j] = neg ? __builtin_bit_cast(float, v & keepw[j]) : r[j];
-                }
-            }
+            r[0] = __builtin_bit_cast(float, v0.a); r[1] = __builtin_bit_cast(float, v0.b);
+            r[2] = __builtin_bit_cast(float, v0.c); r[3] = __builtin_bit_cast(float, v0.d);
+            r[4] = __builtin_bit_cast(float, v1.a); r[5] = __builtin_bit_cast(float, v1.b);
+            r[6] = __builtin_bit_cast(float, v1.c); r[7] = __builtin_bit_cast(float, v1.d);
         } else if constexpr (CW == 1) {                    // h-th 8-k chunk of this thread's 16
             const unsigned ex = (unsigned)ce[h], ey = (unsigned)(ce[h] >> 32);
             const unsigned sel = (vmask & ey) == ey ? 0xffffffffu : 0u;
@@ -794,9 +789,50 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 rb[8 * h + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * cs_bytes, 0));
-        } else {
+        } else if (h == 0) {
             const unsigned ex = (unsigned)ce[0], ey = (unsigned)(ce[0] >> 32);
             const unsigned eth = ey & 0x8000ffffu;                 // t / h bits (+ the never-valid bit of padding entries)
+            const unsigned sel = (vmask & eth) == eth ? 0xffffffffu : 0u;
+            const unsigned vo = ((voff0 + ex) & sel) | (a.src_bytes & ~sel);
+            constexpr int NL = 16 / CW;                            // loads per thread per K step
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                // (the loaded vector is bit-cast to a plain struct: hipcc 7.2 miscompiles element access combined with
+                //  bit operations on the builtin's vector result -- elements 1 and 2 come back as element 0)
+                if constexpr (CW == 4) {
+                    const Words4 v = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, i * cs_bytes, 0));
+                    rb[4 * i] = __builtin_bit_cast(float, v.a); rb[4 * i + 1] = __builtin_bit_cast(float, v.b);
+                    rb[4 * i + 2] = __builtin_bit_cast(float, v.c); rb[4 * i + 3] = __builtin_bit_cast(float, v.d);
+                } else {
+                    const Words2 v = __builtin_bit_cast(Words2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, i * cs_bytes, 0));
+                    rb[2 * i] = __builtin_bit_cast(float, v.a); rb[2 * i + 1] = __builtin_bit_cast(float, v.b);
+                }
+            }
+        }
+    };
+    auto fixB = [&]() {
+        if constexpr (KWV) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned ex = (unsigned)ce[h], ey = (unsigned)(ce[h] >> 32);
+                const unsigned sel = (vmask & ey) == ey ? 0xffffffffu : 0u;
+                const unsigned vo = ((voff0 + ex) & sel) | (a.src_bytes & ~sel);
+                float* r = rb + 8 * h;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = __builtin_bit_cast(float, __float_as_uint(r[j]) & keepw[j]);
+                // first load starting in front of the tensor (first row, left padding): rejected as a whole -> refetch
+                const bool neg = vo >= 0xfffffff0u;
+                if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
+#pragma unroll
+                    for (int j = 1; j < 8; ++j) {          // (the second vector's immediate offset does not wrap either)
+                        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? wrap_add(vo, 4u * j) : a.src_bytes, 0, 0);
+                        r[j] = neg ? __builtin_bit_cast(float, v & keepw[j]) : r[j];
+                    }
+                }
+            }
+        } else if constexpr (CW > 1) {
+            const unsigned ex = (unsigned)ce[0], ey = (unsigned)(ce[0] >> 32);
+            const unsigned eth = ey & 0x8000ffffu;
             const unsigned dwb = (ey >> 16) & 0xffu;               // 1 << dw
             // w shift of this tap relative to the centre: FWD dw - pw, DGRAD pw - dw
             const bool below = (dwb & ((1u << g.pw) - 1u)) != 0u, above = (dwb >> (g.pw + 1)) != 0u;
@@ -805,43 +841,31 @@ __global__ __launch_bounds__(NT) void conv_gemm_bf16c_kernel(const ConvArgs a) {
             const unsigned keepL = ~(keepL_thr & sneg), keepR = ~(keepR_thr & spos);
             const unsigned sel = (vmask & eth) == eth ? 0xffffffffu : 0u;
             const unsigned vo = ((voff0 + ex) & sel) | (a.src_bytes & ~sel);
-            constexpr int NL = 16 / CW;                            // loads per thread per K step
-            if (h == 0) {
+            constexpr int NL = 16 / CW;
 #pragma unroll
-                for (int i = 0; i < NL; ++i) {
-                    // (the loaded vector is bit-cast to a plain struct: hipcc 7.2 miscompiles `v[i] & mask` on the
-                    //  builtin's vector result -- elements 1 and 2 come back as element 0)
-                    if constexpr (CW == 4) {
-                        const Words4 v = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, i * cs_bytes, 0));
-                        rb[4 * i] = __builtin_bit_cast(float, v.a & keepL);
-                        rb[4 * i + 1] = __builtin_bit_cast(float, v.b);
-                        rb[4 * i + 2] = __builtin_bit_cast(float, v.c);
-                        rb[4 * i + 3] = __builtin_bit_cast(float, v.d & keepR);
-                    } else {
-                        const Words2 v = __builtin_bit_cast(Words2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, i * cs_bytes, 0));
-                        rb[2 * i] = __builtin_bit_cast(float, v.a & keepL);
-                        rb[2 * i + 1] = __builtin_bit_cast(float, v.b & keepR);
+            for (int i = 0; i < NL; ++i) {
+                rb[CW * i] = __builtin_bit_cast(float, __float_as_uint(rb[CW * i]) & keepL);
+                rb[CW * i + CW - 1] = __builtin_bit_cast(float, __float_as_uint(rb[CW * i + CW - 1]) & keepR);
+            }
+            // a vector whose first element lies 4 bytes in front of the tensor (very first row, tap shifted by -1)
+            // is rejected as a whole by the bounds check: re-fetch its other elements one by one.  The branch is
+            // wave-uniform (ballot) and taken by one wave of the grid; lanes select their own result.
+            const bool neg = vo >= 0xfffffff0u;
+            if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
+#pragma unroll
+                for (int i = 0; i < NL; ++i)
+#pragma unroll
+                    for (int j = 1; j < CW; ++j) {
+                        unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? wrap_add(vo, 4u * j) : a.src_bytes, i * cs_bytes, 0);
+                        if (j == CW - 1) v &= keepR;
+                        rb[CW * i + j] = neg ? __builtin_bit_cast(float, v) : rb[CW * i + j];
                     }
-                }
-                // a vector whose first element lies 4 bytes in front of the tensor (very first row, tap shifted by -1)
-                // is rejected as a whole by the bounds check: re-fetch its other elements one by one.  The branch is
-                // wave-uniform (ballot) and taken by one wave of the grid; lanes select their own result.
-                const bool neg = vo >= 0xfffffff0u;
-                if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
-#pragma unroll
-                    for (int i = 0; i < NL; ++i)
-#pragma unroll
-                        for (int j = 1; j < CW; ++j) {
-                            unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? wrap_add(vo, 4u * j) : a.src_bytes, i * cs_bytes, 0);
-                            if (j == CW - 1) v &= keepR;
-                            rb[CW * i + j] = neg ? __builtin_bit_cast(float, v) : rb[CW * i + j];
-                        }
-                }
             }
         }
     };
     auto prow = [&](int n) { return CW == 1 ? n : (n % CW) * PB + n / CW; };     // LDS row of tile column n
     auto store_tiles = [&](int buf) {
+        fixB();
         unsigned short* As = smA[buf];
         unsigned short* Bs = smB[buf];
 #pragma unroll
@@ -1031,77 +1055,92 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
     // position-table entries of the NEXT K step (64-bit scalar loads, one step ahead)
     const unsigned long long* ptab64 = reinterpret_cast<const unsigned long long*>(a.ptab) + b_kq * NG;
     unsigned long long pe[NG], pe_next[NG];
-    auto loadB_s2 = [&]() {                                 // 16-float window of this thread's column pair
+    // The loaders only ISSUE loads; masks, the rare re-fetch and (S2) the even/odd split are applied by fixB() at
+    // LDS-store time, behind the MFMAs -- done right after the loads they made the wave wait for its gather first.
+    auto loadB_s2 = [&]() {                                 // 16-float window of this thread's column pair -> rb[0..15] in window order
+        const unsigned ex = (unsigned)pe[0], ey = (unsigned)(pe[0] >> 32);
+        const unsigned sel = (ey & tbits) == tbits ? 0xffffffffu : 0u;
+        const unsigned vo = ((ex + coloff) & sel) | (a.src_bytes & ~sel);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const Words4 v = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 16 * q, 0));
+            rb[4 * q] = __builtin_bit_cast(float, v.a); rb[4 * q + 1] = __builtin_bit_cast(float, v.b);
+            rb[4 * q + 2] = __builtin_bit_cast(float, v.c); rb[4 * q + 3] = __builtin_bit_cast(float, v.d);
+        }
+    };
+    auto fixB_s2 = [&]() {
         const unsigned ex = (unsigned)pe[0], ey = (unsigned)(pe[0] >> 32);
         const unsigned sel = (ey & tbits) == tbits ? 0xffffffffu : 0u;
         const unsigned vo = ((ex + coloff) & sel) | (a.src_bytes & ~sel);
         const int first = (int)((ey >> 16) & 0xffu) - 16 + dw0;          // x index (w) of window element 0
         const int lo = -first, hi = g.Wi - first;                         // element e is inside the row iff lo <= e < hi
-        Words4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 16 * q, 0));
-        unsigned e[16] = {v[0].a, v[0].b, v[0].c, v[0].d, v[1].a, v[1].b, v[1].c, v[1].d,
-                          v[2].a, v[2].b, v[2].c, v[2].d, v[3].a, v[3].b, v[3].c, v[3].d};
         const bool neg = vo >= 0xffffffc0u;                 // window starting in front of the tensor: refetch element-wise
         if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
 #pragma unroll
             for (int j = 1; j < 16; ++j) {
                 const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rx, neg ? wrap_add(vo, 4u * j) : a.src_bytes, 0, 0);
-                e[j] = neg ? w : e[j];
+                rb[j] = neg ? __builtin_bit_cast(float, w) : rb[j];
             }
         }
         // only the first / last four elements can fall outside the row (pw <= 3, checked on the host)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            e[j] = j >= lo ? e[j] : 0u;
-            e[12 + j] = 12 + j < hi ? e[12 + j] : 0u;
-        }
-        // even elements -> rb[0..7] (column dw0), odd -> rb[8..15] (column dw0 + 1)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            rb[j] = __builtin_bit_cast(float, e[2 * j]);
-            rb[8 + j] = __builtin_bit_cast(float, e[2 * j + 1]);
+            rb[j] = j >= lo ? rb[j] : 0.f;
+            rb[12 + j] = 12 + j < hi ? rb[12 + j] : 0.f;
         }
     };
     auto loadT = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < NG; ++q) pe_next[q] = ptab64[k0 / CW + q];
     };
-    auto loadB = [&](int q) {                              // q-th position group of this thread's 16 positions
+    auto loadB = [&](int q) {                              // q-th position group of this thread's 16 positions (issue only)
         const unsigned ex = (unsigned)pe[q], ey = (unsigned)(pe[q] >> 32);
         const unsigned sel = (ey & tbits) == tbits ? 0xffffffffu : 0u;
         const unsigned vo = ((ex + coloff) & sel) | (a.src_bytes & ~sel);
-        const unsigned eL = (ey & 0x10000u) ? 0xffffffffu : 0u, eR = (ey & 0x20000u) ? 0xffffffffu : 0u;
-        const unsigned keepL = ~(thrL & eL), keepR = ~(thrR & eR);
         float* r = rb + CW * q;
         if constexpr (CW == 8) {
             const Words4 v0 = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0));
             const Words4 v1 = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 16, 0));
-            r[0] = __builtin_bit_cast(float, v0.a & keepL); r[1] = __builtin_bit_cast(float, v0.b);
-            r[2] = __builtin_bit_cast(float, v0.c);         r[3] = __builtin_bit_cast(float, v0.d);
-            r[4] = __builtin_bit_cast(float, v1.a);         r[5] = __builtin_bit_cast(float, v1.b);
-            r[6] = __builtin_bit_cast(float, v1.c);         r[7] = __builtin_bit_cast(float, v1.d & keepR);
+            r[0] = __builtin_bit_cast(float, v0.a); r[1] = __builtin_bit_cast(float, v0.b);
+            r[2] = __builtin_bit_cast(float, v0.c); r[3] = __builtin_bit_cast(float, v0.d);
+            r[4] = __builtin_bit_cast(float, v1.a); r[5] = __builtin_bit_cast(float, v1.b);
+            r[6] = __builtin_bit_cast(float, v1.c); r[7] = __builtin_bit_cast(float, v1.d);
         } else if constexpr (CW == 4) {
             const Words4 v0 = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0));
-            r[0] = __builtin_bit_cast(float, v0.a & keepL); r[1] = __builtin_bit_cast(float, v0.b);
-            r[2] = __builtin_bit_cast(float, v0.c);         r[3] = __builtin_bit_cast(float, v0.d & keepR);
+            r[0] = __builtin_bit_cast(float, v0.a); r[1] = __builtin_bit_cast(float, v0.b);
+            r[2] = __builtin_bit_cast(float, v0.c); r[3] = __builtin_bit_cast(float, v0.d);
         } else {
             const Words2 v0 = __builtin_bit_cast(Words2, __builtin_amdgcn_raw_buffer_load_b64(rx, vo, 0, 0));
-            r[0] = __builtin_bit_cast(float, v0.a & keepL); r[1] = __builtin_bit_cast(float, v0.b & keepR);
+            r[0] = __builtin_bit_cast(float, v0.a); r[1] = __builtin_bit_cast(float, v0.b);
         }
-        // a group that starts 4 bytes in front of the tensor (channel 0, first row, tap shifted by -1) is rejected as a
-        // whole by the bounds check: re-fetch its other elements one by one (wave-uniform branch, a few waves per launch)
-        const bool neg = vo >= 0xfffffff0u;
-        if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
+    };
+    auto fixB = [&]() {
+        if constexpr (S2) { fixB_s2(); return; }
 #pragma unroll
-            for (int j = 1; j < CW; ++j) {                 // (the check does not wrap: voffset 0xfffffffc + 16 is out of range too)
-                unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rx, neg ? wrap_add(vo, 4u * j) : a.src_bytes, 0, 0);
-                if (j == CW - 1) v &= keepR;
-                r[j] = neg ? __builtin_bit_cast(float, v) : r[j];
+        for (int q = 0; q < NG; ++q) {
+            const unsigned ex = (unsigned)pe[q], ey = (unsigned)(pe[q] >> 32);
+            const unsigned sel = (ey & tbits) == tbits ? 0xffffffffu : 0u;
+            const unsigned vo = ((ex + coloff) & sel) | (a.src_bytes & ~sel);
+            const unsigned eL = (ey & 0x10000u) ? 0xffffffffu : 0u, eR = (ey & 0x20000u) ? 0xffffffffu : 0u;
+            const unsigned keepL = ~(thrL & eL), keepR = ~(thrR & eR);
+            float* r = rb + CW * q;
+            r[0] = __builtin_bit_cast(float, __float_as_uint(r[0]) & keepL);
+            r[CW - 1] = __builtin_bit_cast(float, __float_as_uint(r[CW - 1]) & keepR);
+            // a group that starts 4 bytes in front of the tensor (channel 0, first row, tap shifted by -1) is rejected as a
+            // whole by the bounds check: re-fetch its other elements one by one (wave-uniform branch, a few waves per launch)
+            const bool neg = vo >= 0xfffffff0u;
+            if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
+#pragma unroll
+                for (int j = 1; j < CW; ++j) {             // (the check does not wrap: voffset 0xfffffffc + 16 is out of range too)
+                    unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rx, neg ? wrap_add(vo, 4u * j) : a.src_bytes, 0, 0);
+                    if (j == CW - 1) v &= keepR;
+                    r[j] = neg ? __builtin_bit_cast(float, v) : r[j];
+                }
             }
         }
     };
     auto store_tiles = [&](int buf) {
+        fixB();
         unsigned short* As = smA[buf];
         unsigned short* Bs = smB[buf];
 #pragma unroll
@@ -1115,12 +1154,19 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             uint4 pk;
-            pk.x = cvt_pk_bf16(rb[8 * h], rb[8 * h + 1]);
-            pk.y = cvt_pk_bf16(rb[8 * h + 2], rb[8 * h + 3]);
-            pk.z = cvt_pk_bf16(rb[8 * h + 4], rb[8 * h + 5]);
-            pk.w = cvt_pk_bf16(rb[8 * h + 6], rb[8 * h + 7]);
-            if constexpr (S2) *reinterpret_cast<uint4*>(Bs + (b_n + h) * KP + b_kq * 8) = pk;     // rows = the two columns
-            else *reinterpret_cast<uint4*>(Bs + b_n * KP + b_kq * 16 + 8 * h) = pk;
+            if constexpr (S2) {     // window order in rb: even elements are column dw0's vector, odd ones column dw0+1's
+                pk.x = cvt_pk_bf16(rb[h], rb[2 + h]);
+                pk.y = cvt_pk_bf16(rb[4 + h], rb[6 + h]);
+                pk.z = cvt_pk_bf16(rb[8 + h], rb[10 + h]);
+                pk.w = cvt_pk_bf16(rb[12 + h], rb[14 + h]);
+                *reinterpret_cast<uint4*>(Bs + (b_n + h) * KP + b_kq * 8) = pk;     // rows = the two columns
+            } else {
+                pk.x = cvt_pk_bf16(rb[8 * h], rb[8 * h + 1]);
+                pk.y = cvt_pk_bf16(rb[8 * h + 2], rb[8 * h + 3]);
+                pk.z = cvt_pk_bf16(rb[8 * h + 4], rb[8 * h + 5]);
+                pk.w = cvt_pk_bf16(rb[8 * h + 6], rb[8 * h + 7]);
+                *reinterpret_cast<uint4*>(Bs + b_n * KP + b_kq * 16 + 8 * h) = pk;
+            }
         }
     };
 
