@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 6
+#define OTAL_ABI_VERSION 7
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -202,6 +202,14 @@ int otal_detection_loss(const float* loc, const float* conf, const float* prop_l
                         const float* gt, const unsigned char* gvalid, float* weight_accum, int B, int K, int C, int G,
                         float clip_length, float overlap_thresh, int ibm_active, int num_bins, float momentum,
                         int iou_aware, float* losses, float* grads, float* scratch, void* stream);
+
+/* Clip preparation on the device: uint8 frames (T',Hs,Ws,3) -> normalised fp32 batch (B,3,T,Ho,Wo).
+ * Replaces AFSD/common/thumos_dataset.py:136-137,:246-262 and videotransforms.py:44-124 (temporal zero padding,
+ * random / centre crop, horizontal flip, float(), (x/255)*2-1, THWC -> CTHW).  params: device array of B records
+ * {int64 frame0 (element offset of the clip's first frame in `frames`), int32 valid_t, crop_i, crop_j, flip}
+ * = 24 bytes each (8-byte aligned); the random decisions are taken on the host exactly as the reference takes them. */
+int otal_prepare_clips(const unsigned char* frames, const void* params, float* out, int B, int T, int Hs, int Ws,
+                       int Ho, int Wo, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,62 @@
+// opental_amd/csrc/input.hip -- clip preparation on the device.
+//
+// Replaces the host-side tail of THUMOS_Dataset.__getitem__ (AFSD/common/thumos_dataset.py:246-262) and the transforms
+// it calls (AFSD/common/videotransforms.py:44-124): temporal slice + zero padding to clip_length, random / centre crop,
+// horizontal flip, uint8 -> float, (x / 255) * 2 - 1, and the (T,H,W,3) -> (3,T,H,W) transpose of load_video_data
+// (thumos_dataset.py:136-137).  The reference does all of it in numpy per sample and ships a 28 MB fp32 clip to the
+// GPU; here the uint8 frames (4x smaller) are uploaded and one launch writes the normalised batch.  The random crop
+// offsets and flip decisions stay on the host (same `random` calls, see common/input_pipeline.py) and arrive as
+// parameters, so results are reproducible against the reference bit for bit.
+// HBM-bound: 3 bytes read + 12 bytes written per pixel.
+#include "common.h"
+
+namespace {
+
+struct ClipParams {      // one per clip, device array
+    long long frame0;    // element offset of this clip's first frame in the uint8 frame buffer
+    int valid_t;         // frames available (the rest of the clip is zero BEFORE normalisation, i.e. -1.0 after it)
+    int crop_i, crop_j;  // top-left corner of the crop in the source frame
+    int flip;            // 1: mirror along W after cropping
+};
+
+__global__ __launch_bounds__(256) void prepare_clips_kernel(const unsigned char* __restrict__ frames,
+                                                            const ClipParams* __restrict__ params, float* __restrict__ out,
+                                                            int T, int Hs, int Ws, int Ho, int Wo) {
+    const int b = blockIdx.y;
+    const ClipParams p = params[b];
+    const int plane = Ho * Wo;
+    const long long vol = (long long)T * plane;
+    float* ob = out + (long long)b * 3 * vol;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < vol; idx += (long long)gridDim.x * 256) {
+        const int t = (int)(idx / plane);
+        const int r = (int)(idx - (long long)t * plane);
+        const int y = r / Wo, x = r - y * Wo;
+        float v0, v1, v2;
+        if (t < p.valid_t) {
+            const int xs = p.crop_j + (p.flip ? Wo - 1 - x : x);
+            const unsigned char* px = frames + p.frame0 + (((long long)t * Hs + (p.crop_i + y)) * Ws + xs) * 3;
+            v0 = ((float)px[0] / 255.0f) * 2.0f - 1.0f;     // same operation order as the reference (no fma: -ffp-contract=off)
+            v1 = ((float)px[1] / 255.0f) * 2.0f - 1.0f;
+            v2 = ((float)px[2] / 255.0f) * 2.0f - 1.0f;
+        } else {
+            v0 = v1 = v2 = (0.0f / 255.0f) * 2.0f - 1.0f;
+        }
+        ob[idx] = v0;
+        ob[vol + idx] = v1;
+        ob[2 * vol + idx] = v2;
+    }
+}
+
+}  // namespace
+
+extern "C" int otal_prepare_clips(const unsigned char* frames, const void* params, float* out, int B, int T, int Hs,
+                                  int Ws, int Ho, int Wo, void* stream) {
+    if (!frames || !params || !out) return OTAL_E_NULL;
+    if (B <= 0 || T <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0 || Ho > Hs || Wo > Ws) return OTAL_E_SHAPE;
+    if (B > 65535) return OTAL_E_UNSUPPORTED;
+    const long long vol = (long long)T * Ho * Wo;
+    const int bx = (int)((vol + 255) / 256 < 4096 ? (vol + 255) / 256 : 4096);
+    hipLaunchKernelGGL(prepare_clips_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, frames,
+                       static_cast<const ClipParams*>(params), out, T, Hs, Ws, Ho, Wo);
+    return otal_launch_status();
+}
