@@ -276,6 +276,99 @@ class DetectorTrainer:
         graph.replay()
         return out
 
+    # ---- checkpoints in the reference's file formats (train.py:106-131), SURVEY 8f rank 2
+    def optimizer_state_dict(self):
+        """The Adam state as `torch.optim.Adam(net.parameters(), ...).state_dict()` would hold it (the reference's
+        optimizer, train.py:321-323): per-parameter `step` / `exp_avg` / `exp_avg_sq`, indices in net.parameters() order
+        (frozen parameters are listed in the group but carry no state)."""
+        allp = list(self.net.parameters())
+        index = {id(p): i for i, p in enumerate(allp)}
+        state = {}
+        if self.step_count > 0:
+            for p, off in zip(self.arena.params, self.arena.offsets):
+                k = p.numel()
+                state[index[id(p)]] = {'step': torch.tensor(float(self.step_count)),
+                                       'exp_avg': self.arena.m[off:off + k].view(p.shape).clone(),
+                                       'exp_avg_sq': self.arena.v[off:off + k].view(p.shape).clone()}
+        group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.wd, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'params': list(range(len(allp)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        allp = list(self.net.parameters())
+        where = {id(p): (off, p) for p, off in zip(self.arena.params, self.arena.offsets)}
+        steps = set()
+        self.arena.m.zero_(); self.arena.v.zero_()
+        for i, st in sd['state'].items():
+            hit = where.get(id(allp[int(i)]))
+            if hit is None:
+                continue
+            off, p = hit
+            k = p.numel()
+            self.arena.m[off:off + k].copy_(st['exp_avg'].reshape(-1))
+            self.arena.v[off:off + k].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise RuntimeError("per-parameter step counts differ; the flat Adam keeps one")
+        self.step_count = steps.pop() if steps else 0
+        g = sd['param_groups'][0]
+        self.lr, self.betas, self.eps, self.wd = g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']
+        self._graph = None
+
+    def save_model(self, epoch, checkpoint_path, train_state_path):
+        """`save_model` of the reference (train.py:106-118): weights as checkpoint-{epoch}.ckpt (the same 446 keys),
+        optimizer + RNG states as checkpoint_{epoch}.ckpt, plus the '-latest' links.  Extra key 'weight_accum': the IBM
+        EMA state, which the reference forgets to checkpoint (it is a registered buffer here, so it is in the weights
+        file as well when present)."""
+        import os, random
+        import numpy as np
+        os.makedirs(checkpoint_path, exist_ok=True); os.makedirs(train_state_path, exist_ok=True)
+        model_file = os.path.join(checkpoint_path, 'checkpoint-{}.ckpt'.format(epoch))
+        torch.save({k: v.detach().clone() for k, v in self.net.state_dict().items()}, model_file)   # views of the arena: clone
+        states = [random.getstate(), np.random.get_state(), torch.get_rng_state()]
+        if torch.cuda.is_available():
+            states.append(torch.cuda.get_rng_state())
+        state_file = os.path.join(train_state_path, 'checkpoint_{}.ckpt'.format(epoch))
+        extra = {}
+        wa = getattr(getattr(self.criterion, 'cls_loss', None), 'weight_accum', None)
+        if wa is not None:
+            extra['weight_accum'] = wa.detach().clone()
+        torch.save(dict({'optimizer': self.optimizer_state_dict(), 'state': states}, **extra), state_file)
+        for src, dst in ((model_file, os.path.join(checkpoint_path, 'checkpoint-latest.ckpt')),
+                         (state_file, os.path.join(train_state_path, 'checkpoint_latest.ckpt'))):
+            if os.path.lexists(dst):
+                os.remove(dst)
+            os.symlink(os.path.abspath(src), dst)
+        return model_file, state_file
+
+    def resume_training(self, resume, checkpoint_path, train_state_path, restore_rng=True):
+        """`resume_training` of the reference (train.py:121-131); accepts the reference's own files."""
+        import os, random
+        import numpy as np
+        start_epoch = 1
+        if resume > 0:
+            start_epoch += resume
+            sd = torch.load(os.path.join(checkpoint_path, 'checkpoint-{}.ckpt'.format(resume)), map_location='cpu')
+            own = self.net.state_dict()
+            missing = [k for k in own if k not in sd]
+            if missing:
+                raise RuntimeError(f"checkpoint lacks {len(missing)} keys, e.g. {missing[:3]}")
+            with torch.no_grad():
+                for k, v in own.items():
+                    v.copy_(sd[k])                      # in place: parameters stay views of the flat arena
+            st = torch.load(os.path.join(train_state_path, 'checkpoint_{}.ckpt'.format(resume)), map_location='cpu',
+                            weights_only=False)
+            self.load_optimizer_state_dict(st['optimizer'])
+            if 'weight_accum' in st and hasattr(getattr(self.criterion, 'cls_loss', None), 'weight_accum'):
+                self.criterion.cls_loss.weight_accum.copy_(st['weight_accum'])
+            if restore_rng:
+                states = st['state']
+                random.setstate(states[0]); np.random.set_state(states[1]); torch.set_rng_state(states[2])
+                if torch.cuda.is_available() and len(states) > 3:
+                    torch.cuda.set_rng_state(states[3])
+        return start_epoch
+
     def grad_norm(self):
         """get_grad_norm (train.py:133-140), as a device tensor."""
         return self.arena.grad.norm(2)

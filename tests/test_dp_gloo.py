@@ -111,3 +111,34 @@ def test_arena_views_alias_parameters():
     covered = sorted(a.buckets)
     assert covered[0][0] == 0 and covered[-1][1] == a.numel
     assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+
+
+def test_checkpoint_round_trip_and_reference_optimizer_format(tmp_path):
+    """save_model / resume_training (reference train.py:106-131): a resumed trainer continues
+    bit-identically, and the optimizer file loads into the reference's optimizer, torch.optim.Adam(net.parameters())."""
+    tr, net = _make_trainer(False)
+    g = torch.Generator().manual_seed(5)
+    xs, ys = torch.randn(6, 5, 8, generator=g), torch.randn(6, 5, 1, generator=g)
+    for s in range(3):
+        tr.step(xs[s], ys[s], None)
+    ck, st = str(tmp_path / "ckpt"), str(tmp_path / "state")
+    mf, sf = tr.save_model(3, ck, st)
+    sd = torch.load(mf)
+    assert list(sd.keys()) == list(net.state_dict().keys())
+    assert all(v.untyped_storage().nbytes() == v.numel() * 4 for v in sd.values())     # clones, not arena views
+    for s in range(3, 6):
+        tr.step(xs[s], ys[s], None)
+    tr2, net2 = _make_trainer(False)
+    assert tr2.resume_training(3, ck, st) == 4 and tr2.step_count == 3
+    for s in range(3, 6):
+        tr2.step(xs[s], ys[s], None)
+    assert torch.equal(tr.arena.flat, tr2.arena.flat) and torch.equal(tr.arena.m, tr2.arena.m)
+    # the reference's optimizer accepts the file and holds the same moments
+    ref_net = Toy()
+    opt = torch.optim.Adam(ref_net.parameters(), lr=1e-2, weight_decay=1e-3)
+    opt.load_state_dict(torch.load(sf, weights_only=False)['optimizer'])
+    tr3, net3 = _make_trainer(False)
+    tr3.resume_training(3, ck, st)
+    for i, p in enumerate(net3.parameters()):
+        off = tr3.arena.offsets[[id(q) for q in tr3.arena.params].index(id(p))]
+        assert torch.equal(opt.state[list(ref_net.parameters())[i]]['exp_avg'].reshape(-1), tr3.arena.m[off:off + p.numel()])
