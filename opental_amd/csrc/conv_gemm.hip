@@ -1451,7 +1451,9 @@ int fill_geom(ConvGeom& g, const int* d) {
 }
 
 // tile height: least padded M, with a small penalty for the lower arithmetic intensity of short tiles
-int choose_bm(int M) {
+int choose_bm(int M, int tall = 0) {
+    static const int tall_env = getenv("OTAL_CONV_TALL") ? atoi(getenv("OTAL_CONV_TALL")) : 1;    // bit0: fwd/dgrad (on: 2c fwd +16 %), bit1: wgrad (off: -9 %)
+    if ((tall & tall_env) && M % 192 == 0) return 192;     // one 192-row tile re-fetches the gathered operand half as often
     const int cand[4] = {128, 96, 64, 32};
     const double pen[4] = {1.00, 1.03, 1.10, 1.30};
     int best = 128;
@@ -1539,7 +1541,7 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int kvol = conv_kvol(a.g);
     const bool kwv = MODE == MODE_FWD && (C % 8) != 0;
     if (kwv) a.K = a.g.Cin * a.g.kt * a.g.kh * 8;          // kw padded to 8 taps per (ci, dt, dh) row
-    const int BMsel = choose_bm(a.M);
+    const int BMsel = choose_bm(a.M, kwv ? 0 : 1);
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + 127) / 128;
     const int Mpad = tm * BMsel;
     a.Kp = chunk_kp(a.K);
@@ -1594,7 +1596,8 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         }
     }
     if (kwv) {
-    } else if (BMsel == 128) OTAL_LAUNCH_C(128, 2, 2);
+    } else if (BMsel == 192) OTAL_LAUNCH_C(192, 6, 1);
+    else if (BMsel == 128) OTAL_LAUNCH_C(128, 2, 2);
     else if (BMsel == 96) OTAL_LAUNCH_C(96, 3, 1);
     else if (BMsel == 64) OTAL_LAUNCH_C(64, 2, 1);
     else OTAL_LAUNCH_C(32, 1, 1);
@@ -1641,7 +1644,7 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
         a.N = a.g.Cin * a.g.kt * a.g.kh * 8;
         a.flags |= EPI_NPAD8;
     }
-    const int BMsel = choose_bm(a.M);
+    const int BMsel = choose_bm(a.M, pair ? 0 : 2);
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + 127) / 128;
     const size_t tb = ptab_bytes(a.g, cw);
     if (!ws || ws_bytes < tb) return OTAL_E_UNSUPPORTED;
@@ -1682,7 +1685,8 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
         else if (BMsel == 96) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<96, 3, 1, 8, true>), grid, dim3(NT), 0, st, a);
         else if (BMsel == 64) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<64, 2, 1, 8, true>), grid, dim3(NT), 0, st, a);
         else hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<32, 1, 1, 8, true>), grid, dim3(NT), 0, st, a);
-    } else if (BMsel == 128) OTAL_LAUNCH_W(128, 2, 2);
+    } else if (BMsel == 192) OTAL_LAUNCH_W(192, 6, 1);
+    else if (BMsel == 128) OTAL_LAUNCH_W(128, 2, 2);
     else if (BMsel == 96) OTAL_LAUNCH_W(96, 3, 1);
     else if (BMsel == 64) OTAL_LAUNCH_W(64, 2, 1);
     else OTAL_LAUNCH_W(32, 1, 1);
@@ -1799,7 +1803,8 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
     size_t front = mode == MODE_WGRAD ? ptab_bytes(g, 2) : tab_bytes((int)K);
     if (mode != MODE_WGRAD) {
         const int Kc = mode == MODE_FWD && g.Cin * g.kt * g.kh * 8 > K ? g.Cin * g.kt * g.kh * 8 : (int)K;   // kw-vector mode pads kw to 8
-        const size_t cf = chunk_tab_bytes(Kc) + chunk_wp_bytes((int)M, BMsel, Kc);
+        size_t cf = chunk_tab_bytes(Kc) + chunk_wp_bytes((int)M, BMsel, Kc);
+        if (M % 192 == 0) { const size_t ct = chunk_tab_bytes(Kc) + chunk_wp_bytes((int)M, 192, Kc); if (ct > cf) cf = ct; }
         if (cf > front) front = cf;
     }
     if (mode == MODE_DGRAD) front += align256((size_t)g.Cin * g.Cout * kvol * sizeof(float));    // natural-layout weights on the generic path
