@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 7
+#define OTAL_ABI_VERSION 8
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -102,7 +102,7 @@ size_t otal_conv_workspace_bytes(const int* geom, int mode);
 /* y = act(scale[co] * conv(x, w) + shift[co]); scale/shift nullable (frozen BN folded, or bias). */
 int otal_conv_fwd(const int* geom, const int64_t* strides, const float* x, const float* w,
                   const float* scale, const float* shift, float* y, int relu, int precision,
-                  void* ws, size_t ws_bytes, void* stream);
+                  const void* prologue, void* ws, size_t ws_bytes, void* stream);
 
 /* dx (+)= m * conv_transpose(dy, w); when out_mask/out_scale are given,
  * m = (out_mask[dx offset] > 0) * out_scale[ci]: the ReLU + frozen-BN backward of the layer that
@@ -110,11 +110,29 @@ int otal_conv_fwd(const int* geom, const int64_t* strides, const float* x, const
  * is already the gradient w.r.t. its convolution output.  wt_packed = otal_conv_pack_wt(w). */
 int otal_conv_dgrad(const int* geom, const int64_t* strides, const float* dy, const float* wt_packed,
                     float* dx, int accumulate, const float* out_mask, const float* out_scale,
-                    int precision, void* ws, size_t ws_bytes, void* stream);
+                    int precision, const void* prologue, void* ws, size_t ws_bytes, void* stream);
 
 /* dw (+)= sum_{b,pos} dy[b,co,pos] * x[b,ci,pos*s + tap - pad] */
 int otal_conv_wgrad(const int* geom, const int64_t* strides, const float* x, const float* dy,
-                    float* dw, int accumulate, int precision, void* ws, size_t ws_bytes, void* stream);
+                    float* dw, int accumulate, int precision, const void* prologue, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* Persistent prologues.  A bf16 launch first builds its tables and (fwd / dgrad) re-packs the weights to bf16; by default
+ * that happens inside every launch, in the workspace.  A caller that runs the same layers repeatedly (a training loop) can
+ * own one region per (layer, mode) instead and pass it as `prologue` (NULL = build in the workspace):
+ *   otal_conv_prologue_bytes : region size, 0 when this launch has no reusable prologue (generic kernel)
+ *   otal_conv_prologue       : fill the region now; for fwd / dgrad also emit the descriptor (host memory,
+ *                              otal_conv_prologue_desc_bytes) and return the workgroups it needs; wgrad regions hold a
+ *                              geometry-only table and never need refreshing
+ *   otal_conv_prologue_batch : after the weights changed, refresh n fwd / dgrad regions in ONE launch from the
+ *                              descriptors copied to DEVICE memory; device_starts[n+1] = prefix sums of the workgroup
+ *                              counts otal_conv_prologue returned, total_blocks = their sum
+ * The regions must be refreshed before the first launch that follows a weight update. */
+size_t otal_conv_prologue_bytes(const int* geom, const int64_t* strides, int mode, int precision);
+size_t otal_conv_prologue_desc_bytes(void);
+int otal_conv_prologue(const int* geom, const int64_t* strides, int mode, const float* w, int precision, void* region,
+                       size_t region_bytes, void* host_desc, void* stream);
+int otal_conv_prologue_batch(int n, const void* device_descs, const int* device_starts, int total_blocks, void* stream);
 
 /* (Cout,Cin,kvol) -> (Cin,Cout,kvol): the A operand of the data-gradient GEMM. */
 int otal_conv_pack_wt(const float* w, float* wt, int Cout, int Cin, int kvol, void* stream);

@@ -117,6 +117,98 @@ def _k3(k):
     return (k, 1, 1) if isinstance(k, int) else tuple(k)
 
 
+
+# ----------------------------------------------------------------------------- persistent conv prologues
+class PrologueCache:
+    """Per-(layer, mode) regions holding what a bf16 conv launch otherwise rebuilds every time in its workspace: the
+    gather tables and, for fwd / dgrad, the weights re-packed to bf16 (see include/opental_hip.h, "Persistent
+    prologues").  Protocol (DetectorTrainer.step): `activate()` at the START of a step refreshes every known fwd / dgrad
+    region from the current weights in ONE launch, then every conv of the step that finds its region skips its own
+    prologue; a launch seen for the first time builds its region on the spot (and is part of the batch from then on).
+    Regions are only used between activate() and deactivate(), i.e. while the weights cannot change under them."""
+
+    def __init__(self, persistent_range=None):
+        # [lo, hi) device address range of the weights that outlive a step (the trainer's flat parameter arena).  Only
+        # weights inside it are cached: the batch descriptors keep raw pointers, and a temporary (e.g. the transposed
+        # weight of the collapsed projection) would be freed under them.
+        self.persistent_range = persistent_range
+        self.entries = {}            # key -> region tensor | None (no reusable prologue)
+        self.descs = []              # host descriptors (bytes) of the fwd / dgrad regions
+        self.blocks = []             # workgroups each of them needs
+        self.dev_starts = None
+        self.dev_descs = None
+        self.dirty = False
+
+    def region(self, mode, ga, sa, key, w, prec):
+        if key in self.entries:
+            return self.entries[key]
+        lib = L.lib()
+        lib.otal_conv_prologue_bytes.restype = ctypes.c_size_t
+        lib.otal_conv_prologue_desc_bytes.restype = ctypes.c_size_t
+        nbytes = lib.otal_conv_prologue_bytes(ga, sa, mode, prec)
+        if nbytes == 0:
+            self.entries[key] = None
+            return None
+        dev = w.device if w is not None else torch.device("cuda", torch.cuda.current_device())
+        reg = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        desc = ctypes.create_string_buffer(lib.otal_conv_prologue_desc_bytes())
+        rc = lib.otal_conv_prologue(ga, sa, mode, L.ptr(w) if w is not None else None, prec, L.ptr(reg),
+                                    ctypes.c_size_t(nbytes), desc, L.stream())
+        if rc < 0:
+            raise RuntimeError(f"otal_conv_prologue failed: {rc}")
+        if rc > 0:                   # fwd / dgrad: needs refreshing whenever the weights change
+            self.descs.append(desc.raw)
+            self.blocks.append(int(rc))
+            self.dirty = True
+        self.entries[key] = reg
+        return reg
+
+    def refresh(self):
+        """Re-pack every registered fwd / dgrad region from the current weights: one launch."""
+        if not self.descs:
+            return
+        if self.dirty:
+            host = torch.frombuffer(bytearray(b"".join(self.descs)), dtype=torch.uint8)
+            dev = next(iter(v for v in self.entries.values() if v is not None)).device
+            self.dev_descs = host.to(dev)
+            starts = [0]
+            for nb in self.blocks:
+                starts.append(starts[-1] + nb)
+            self.dev_starts = torch.tensor(starts, dtype=torch.int32).to(dev)
+            self.total_blocks = starts[-1]
+            self.dirty = False
+        L.check(L.lib().otal_conv_prologue_batch(len(self.descs), L.ptr(self.dev_descs), L.ptr(self.dev_starts),
+                                                 int(self.total_blocks), L.stream()), "otal_conv_prologue_batch")
+
+
+PROLOGUES = None        # the active PrologueCache, or None (every launch builds its own prologue)
+
+
+def activate_prologues(cache):
+    global PROLOGUES
+    PROLOGUES = cache
+    if cache is not None:
+        cache.refresh()
+
+
+def deactivate_prologues():
+    global PROLOGUES
+    PROLOGUES = None
+
+
+def _prologue(mode, ga, sa, g, x5, y5, w, prec):
+    c = PROLOGUES
+    if c is None or not (prec & 1):
+        return None
+    if mode != 2:
+        r = c.persistent_range
+        if r is None or not (r[0] <= w.data_ptr() < r[1]):
+            return None
+    key = (mode, w.data_ptr() if (w is not None and mode != 2) else 0, tuple(g), _bs(x5), _bs(y5), prec)
+    reg = c.region(mode, ga, sa, key, w, prec)
+    return None if reg is None else L.ptr(reg)
+
+
 def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=False, levels=None, out=None):
     """y = act(scale * conv_SAME(x, w) + shift).  x (B,Cin,T[,H,W]); w (Cout,Cin,*k)."""
     k, s = _k3(k), _k3(s)
@@ -137,8 +229,9 @@ def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=F
     ga, sa = _geom_arrays(g, x5, y5)
     ws = workspace(x.device)
     ev = _prof_begin()
+    pre = _prologue(0, ga, sa, g, x5, y5, w, int(CONV_PRECISION))
     L.check(L.lib().otal_conv_fwd(ga, sa, L.ptr(x5), L.ptr(w), _opt(scale), _opt(shift), L.ptr(y5), int(relu),
-                                  int(CONV_PRECISION), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()), "otal_conv_fwd")
+                                  int(CONV_PRECISION), pre, L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()), "otal_conv_fwd")
     _prof_end(ev, "fwd", g)
     return out
 
@@ -182,8 +275,9 @@ def conv_dgrad(dy, w, x_shape, k, s, spatial_valid=False, levels=None, out=None,
         m5 = _as5(out_mask)
         if tuple(m5.shape) != tuple(x5.shape) or tuple(_bs(m5)) != tuple(_bs(x5)):
             raise RuntimeError("out_mask must share dx's shape and layout")
+    pre = _prologue(1, ga, sa, g, x5, dy5, wt, prec) if (prec & 2) else None     # regions are keyed on the live weight tensor
     L.check(L.lib().otal_conv_dgrad(ga, sa, L.ptr(dy5), L.ptr(wt), L.ptr(x5),
-                                    int(accumulate), _opt(out_mask), _opt(out_scale), prec,
+                                    int(accumulate), _opt(out_mask), _opt(out_scale), prec, pre,
                                     L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
             "otal_conv_dgrad")
     _prof_end(ev, "dgrad", g)
@@ -230,8 +324,9 @@ def conv_wgrad(x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None,
     ga, sa = _geom_arrays(g, x5, dy5)
     ws = workspace(x.device)
     ev = _prof_begin()
+    pre = _prologue(2, ga, sa, g, x5, dy5, x, int(CONV_PRECISION))
     L.check(L.lib().otal_conv_wgrad(ga, sa, L.ptr(x5), L.ptr(dy5), L.ptr(out),
-                                    int(accumulate), int(CONV_PRECISION), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
+                                    int(accumulate), int(CONV_PRECISION), pre, L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
             "otal_conv_wgrad")
     _prof_end(ev, "wgrad", g)
     return out

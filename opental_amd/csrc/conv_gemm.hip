@@ -22,6 +22,7 @@
 #include "common.h"
 #include "conv_index.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -64,6 +65,7 @@ struct ConvArgs {
     int w_natural;         // DGRAD: `w` is the forward-layout weight (Cout, Cin, kvol), not the packed transpose
     // batched epilogue (store_acc): byte extents of the output (and of the split-K slabs) when they fit 32-bit offsets, else 0
     unsigned out_bytes, slab_bytes;
+    const void* pre;       // persistent prologue region filled earlier (otal_conv_prologue[_batch]); null: build it in the workspace
 };
 
 // ---- operand element fetch -------------------------------------------------------------------
@@ -1262,11 +1264,24 @@ __global__ __launch_bounds__(256) void build_pos_table_kernel(int2* __restrict__
 
 // prologue of the chunked path: chunk table + bf16 weight pack in one launch.
 //   wsrc: FWD W (M=Cout, C=Cin, kvol);  DGRAD packed W^T (M=Cin, C=Cout, kvol)  -> wp[m][tap * C + c]
+// One prologue = one PrepDesc; the batch kernel (blockIdx.y = layer) refreshes the persistent regions of every known
+// layer in ONE launch at the start of a training step (otal_conv_prologue_batch).
+struct PrepDesc {
+    int2* ctab;
+    unsigned* wp;
+    const float* wsrc;
+    ConvGeom g;
+    int M, Mpad, C, kvol, K, Kp, nchunk, kwv, natural, mode;
+};
+
 template <int MODE>
-__global__ __launch_bounds__(256) void prep_chunks_kernel(int2* __restrict__ ctab, unsigned* __restrict__ wp,
-                                                          const float* __restrict__ wsrc, ConvGeom g, int M, int Mpad,
-                                                          int C, int kvol, int K, int Kp, int nchunk, int kwv, int natural) {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void prep_chunks_body(const PrepDesc& d, unsigned bid, unsigned nblk) {
+    int2* __restrict__ ctab = d.ctab;
+    unsigned* __restrict__ wp = d.wp;
+    const float* __restrict__ wsrc = d.wsrc;
+    const ConvGeom& g = d.g;
+    const int M = d.M, Mpad = d.Mpad, C = d.C, kvol = d.kvol, K = d.K, Kp = d.Kp, nchunk = d.nchunk, kwv = d.kwv, natural = d.natural;
+    const int64_t gid = (int64_t)bid * 256 + threadIdx.x;
     if (kwv) {      // forward only: chunk j = (ci, dt, dh) row, k = j * 8 + dw (dw >= kw: zero weight)
         if (gid < nchunk) {
             const int j = (int)gid;
@@ -1281,7 +1296,7 @@ __global__ __launch_bounds__(256) void prep_chunks_kernel(int2* __restrict__ cta
         }
         const int half = Kp / 2;
         const int64_t pairs = (int64_t)Mpad * half;
-        for (int64_t p = gid; p < pairs; p += (int64_t)gridDim.x * 256) {
+        for (int64_t p = gid; p < pairs; p += (int64_t)nblk * 256) {
             const int m = (int)(p / half), k = (int)(p - (int64_t)m * half) * 2;
             float v[2];
 #pragma unroll
@@ -1312,7 +1327,7 @@ __global__ __launch_bounds__(256) void prep_chunks_kernel(int2* __restrict__ cta
     }
     const int half = Kp / 2;
     const int64_t pairs = (int64_t)Mpad * half;
-    for (int64_t p = gid; p < pairs; p += (int64_t)gridDim.x * 256) {
+    for (int64_t p = gid; p < pairs; p += (int64_t)nblk * 256) {
         const int m = (int)(p / half), k = (int)(p - (int64_t)m * half) * 2;
         float v[2];
 #pragma unroll
@@ -1325,6 +1340,23 @@ __global__ __launch_bounds__(256) void prep_chunks_kernel(int2* __restrict__ cta
         }
         wp[p] = cvt_pk_bf16(v[0], v[1]);
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void prep_chunks_kernel(const PrepDesc d) { prep_chunks_body<MODE>(d, blockIdx.x, gridDim.x); }
+
+// 1-D grid; starts[l] .. starts[l+1] are the workgroups of layer l (each layer gets exactly what its own launch would use)
+__global__ __launch_bounds__(256) void prep_chunks_batch_kernel(const PrepDesc* __restrict__ descs, const int* __restrict__ starts, int n) {
+    const int b = blockIdx.x;
+    int lo = 0, hi = n;                     // largest l with starts[l] <= b
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (starts[mid] <= b) lo = mid; else hi = mid;
+    }
+    const PrepDesc& d = descs[lo];
+    const unsigned bid = (unsigned)(b - starts[lo]), nblk = (unsigned)(starts[lo + 1] - starts[lo]);
+    if (d.mode == MODE_FWD) prep_chunks_body<MODE_FWD>(d, bid, nblk);
+    else prep_chunks_body<MODE_DGRAD>(d, bid, nblk);
 }
 
 // tap table: one entry per GEMM k of a FWD / DGRAD launch (plus padding entries that never match)
@@ -1535,6 +1567,27 @@ static inline int chunk_vector_width(const ConvGeom& g) {
     return 1;
 }
 
+// descriptor of a chunk-path prologue (a.K must already be the path's K: kw-vector mode pads it)
+template <int MODE>
+static void fill_prep_desc(PrepDesc& d, const ConvArgs& a, int2* ctab, unsigned short* wp) {
+    const int C = MODE == MODE_FWD ? a.g.Cin : a.g.Cout;
+    const bool kwv = MODE == MODE_FWD && (C % 8) != 0;
+    const int BMsel = choose_bm(a.M, kwv ? 0 : 1);
+    d.ctab = ctab; d.wp = reinterpret_cast<unsigned*>(wp); d.wsrc = a.w; d.g = a.g;
+    d.M = a.M; d.Mpad = (a.M + BMsel - 1) / BMsel * BMsel; d.C = C; d.kvol = conv_kvol(a.g);
+    d.K = a.K; d.Kp = chunk_kp(a.K); d.nchunk = d.Kp / 8 + CHUNK_PAD; d.kwv = kwv ? 1 : 0; d.natural = a.w_natural; d.mode = MODE;
+}
+static inline unsigned prep_blocks(const PrepDesc& d) {
+    const int64_t pairs = (int64_t)d.Mpad * (d.Kp / 2);
+    int64_t blocks = (pairs + 255) / 256;
+    if (blocks < (d.nchunk + 255) / 256) blocks = (d.nchunk + 255) / 256;
+    return (unsigned)(blocks > 2048 ? 2048 : blocks);
+}
+static void launch_prep(const PrepDesc& d, hipStream_t st) {
+    if (d.mode == MODE_FWD) hipLaunchKernelGGL((prep_chunks_kernel<MODE_FWD>), dim3(prep_blocks(d)), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((prep_chunks_kernel<MODE_DGRAD>), dim3(prep_blocks(d)), dim3(256), 0, st, d);
+}
+
 template <int MODE>
 int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int C = MODE == MODE_FWD ? a.g.Cin : a.g.Cout;
@@ -1546,24 +1599,25 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int Mpad = tm * BMsel;
     a.Kp = chunk_kp(a.K);
     const size_t tb = chunk_tab_bytes(a.K), wb = chunk_wp_bytes(a.M, BMsel, a.K);
-    if (!ws || ws_bytes < tb + wb) return OTAL_E_UNSUPPORTED;
-    int2* ctab = reinterpret_cast<int2*>(ws);
-    unsigned short* wp = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ws) + tb);
-    const int nchunk = a.Kp / 8 + CHUNK_PAD;
-    {
-        const int64_t pairs = (int64_t)Mpad * (a.Kp / 2);
-        int64_t blocks = (pairs + 255) / 256;
-        if (blocks < (nchunk + 255) / 256) blocks = (nchunk + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL((prep_chunks_kernel<MODE>), dim3((unsigned)blocks), dim3(256), 0, st, ctab,
-                           reinterpret_cast<unsigned*>(wp), a.w, a.g, a.M, Mpad, C, kvol, a.K, a.Kp, nchunk, kwv ? 1 : 0, a.w_natural);
+    int2* ctab;
+    unsigned short* wp;
+    if (a.pre) {            // tables + packed weights were prepared into a caller-owned region
+        ctab = reinterpret_cast<int2*>(const_cast<void*>(a.pre));
+        wp = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(const_cast<void*>(a.pre)) + tb);
+    } else {
+        if (!ws || ws_bytes < tb + wb) return OTAL_E_UNSUPPORTED;
+        ctab = reinterpret_cast<int2*>(ws);
+        wp = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ws) + tb);
+        PrepDesc d;
+        fill_prep_desc<MODE>(d, a, ctab, wp);
+        launch_prep(d, st);
         if (int e = otal_launch_status()) return e;
+        ws = reinterpret_cast<char*>(ws) + tb + wb;
+        ws_bytes -= tb + wb;
     }
     a.ctab = ctab; a.wp = wp;
     a.src_bytes = (unsigned)gather_extent_bytes(a.g, MODE);
     a.wp_bytes = (unsigned)wb;
-    ws = reinterpret_cast<char*>(ws) + tb + wb;
-    ws_bytes -= tb + wb;
     a.fd = make_conv_fastdiv(a.g);
     int splits = choose_splits(tm * tn, a.Kp);
     if (splits > 1) {
@@ -1647,18 +1701,23 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
     const int BMsel = choose_bm(a.M, pair ? 0 : 2);
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + 127) / 128;
     const size_t tb = ptab_bytes(a.g, cw);
-    if (!ws || ws_bytes < tb) return OTAL_E_UNSUPPORTED;
     a.fd = make_conv_fastdiv(a.g);
     a.P = conv_out_positions(a.g);
     a.src_bytes = (unsigned)gather_extent_bytes(a.g, MODE_FWD);
     a.dy_bytes = (unsigned)gather_extent_bytes(a.g, MODE_DGRAD);
-    int2* ptab = reinterpret_cast<int2*>(ws);
-    const int ngroups = a.K / cw, npad = ngroups + PTAB_PAD;
-    hipLaunchKernelGGL(build_pos_table_kernel, dim3((npad + 255) / 256), dim3(256), 0, st, ptab, a.g, a.fd, cw, ngroups, npad);
-    if (int e = otal_launch_status()) return e;
+    int2* ptab;
+    if (a.pre) {
+        ptab = reinterpret_cast<int2*>(const_cast<void*>(a.pre));      // geometry-only table, built once by the caller
+    } else {
+        if (!ws || ws_bytes < tb) return OTAL_E_UNSUPPORTED;
+        ptab = reinterpret_cast<int2*>(ws);
+        const int ngroups = a.K / cw, npad = ngroups + PTAB_PAD;
+        hipLaunchKernelGGL(build_pos_table_kernel, dim3((npad + 255) / 256), dim3(256), 0, st, ptab, a.g, a.fd, cw, ngroups, npad);
+        if (int e = otal_launch_status()) return e;
+        ws = reinterpret_cast<char*>(ws) + tb;
+        ws_bytes -= tb;
+    }
     a.ptab = ptab;
-    ws = reinterpret_cast<char*>(ws) + tb;
-    ws_bytes -= tb;
     int splits = choose_splits(tm * tn, a.K);
     if (splits > 1) {
         const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
@@ -1813,7 +1872,7 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
 
 extern "C" int otal_conv_fwd(const int* geom, const int64_t* strides, const float* x, const float* w,
                              const float* scale, const float* shift, float* y, int relu, int precision,
-                             void* ws, size_t ws_bytes, void* stream) {
+                             const void* prologue, void* ws, size_t ws_bytes, void* stream) {
     if (!geom || !strides || !x || !w || !y) return OTAL_E_NULL;
     ConvArgs a = {};
     if (int e = fill_geom(a.g, geom)) return e;
@@ -1822,12 +1881,13 @@ extern "C" int otal_conv_fwd(const int* geom, const int64_t* strides, const floa
     a.M = a.g.Cout; a.N = a.g.B * conv_out_positions(a.g); a.K = a.g.Cin * conv_kvol(a.g);
     a.flags = relu ? EPI_RELU : 0;
     a.prec = (precision & 1) ? 1 : 0;
+    a.pre = prologue;
     return launch_mode<MODE_FWD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int otal_conv_dgrad(const int* geom, const int64_t* strides, const float* dy, const float* wt_packed,
                                float* dx, int accumulate, const float* out_mask, const float* out_scale,
-                               int precision, void* ws, size_t ws_bytes, void* stream) {
+                               int precision, const void* prologue, void* ws, size_t ws_bytes, void* stream) {
     if (!geom || !strides || !dy || !wt_packed || !dx) return OTAL_E_NULL;
     if ((out_mask == nullptr) != (out_scale == nullptr)) return OTAL_E_NULL;
     ConvArgs a = {};
@@ -1840,12 +1900,13 @@ extern "C" int otal_conv_dgrad(const int* geom, const int64_t* strides, const fl
     a.flags = accumulate ? EPI_ACCUM : 0;
     a.prec = (precision & 1) ? 1 : 0;
     a.w_natural = (precision & 2) ? 1 : 0;
+    a.pre = prologue;
     return launch_mode<MODE_DGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int otal_conv_wgrad(const int* geom, const int64_t* strides, const float* x, const float* dy,
                                float* dw, int accumulate, int precision,
-                               void* ws, size_t ws_bytes, void* stream) {
+                               const void* prologue, void* ws, size_t ws_bytes, void* stream) {
     if (!geom || !strides || !x || !dy || !dw) return OTAL_E_NULL;
     ConvArgs a = {};
     if (int e = fill_geom(a.g, geom)) return e;
@@ -1854,6 +1915,7 @@ extern "C" int otal_conv_wgrad(const int* geom, const int64_t* strides, const fl
     a.M = a.g.Cout; a.N = a.g.Cin * conv_kvol(a.g); a.K = a.g.B * conv_out_positions(a.g);
     a.flags = accumulate ? EPI_ACCUM : 0;
     a.prec = (precision & 1) ? 1 : 0;
+    a.pre = prologue;
     return launch_mode<MODE_WGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -1863,5 +1925,86 @@ extern "C" int otal_conv_pack_wt(const float* w, float* wt, int Cout, int Cin, i
     const int64_t total = (int64_t)Cout * Cin * kvol;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(pack_wt_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, Cout, Cin, kvol);
+    return otal_launch_status();
+}
+
+// ---- persistent prologues (tables + packed bf16 weights in a caller-owned region) ------------------------------------
+namespace {
+// which prologue a launch with this geometry would run: 0 none (generic kernel), 1 chunk path (fwd / dgrad), 2 position table
+int prologue_kind(const ConvGeom& g, int mode, int precision) {
+    const int prec = precision & 1;
+    if (mode == MODE_WGRAD) {
+        if (wgrad_pair_mode(g, prec)) return 2;
+        return wgrad_vector_width(g, prec) ? 2 : 0;
+    }
+    return chunk_eligible(g, mode, prec) ? 1 : 0;
+}
+int fill_args_for_prologue(ConvArgs& a, const int* geom, const int64_t* strides, int mode, const float* w, int precision) {
+    if (int e = fill_geom(a.g, geom)) return e;
+    a.g.x_bs = strides[0]; a.g.x_cs = strides[1]; a.g.y_bs = strides[2]; a.g.y_cs = strides[3];
+    a.w = w;
+    a.prec = precision & 1;
+    a.w_natural = (mode == MODE_DGRAD && (precision & 2)) ? 1 : 0;
+    const int kvol = conv_kvol(a.g);
+    if (mode == MODE_FWD) { a.M = a.g.Cout; a.K = a.g.Cin * kvol; if (a.g.Cin % 8) a.K = a.g.Cin * a.g.kt * a.g.kh * 8; }
+    else if (mode == MODE_DGRAD) { a.M = a.g.Cin; a.K = a.g.Cout * kvol; }
+    else { a.M = a.g.Cout; a.K = a.g.B * conv_out_positions(a.g); }
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t otal_conv_prologue_bytes(const int* geom, const int64_t* strides, int mode, int precision) {
+    ConvArgs a = {};
+    if (!geom || !strides || fill_args_for_prologue(a, geom, strides, mode, nullptr, precision)) return 0;
+    const int kind = prologue_kind(a.g, mode, precision);
+    if (kind == 1) {
+        const bool kwv = mode == MODE_FWD && (a.g.Cin % 8) != 0;
+        return chunk_tab_bytes(a.K) + chunk_wp_bytes(a.M, choose_bm(a.M, kwv ? 0 : 1), a.K);
+    }
+    if (kind == 2) return ptab_bytes(a.g, a.g.sw == 2 ? 8 : wgrad_vector_width(a.g, a.prec));
+    return 0;
+}
+
+extern "C" size_t otal_conv_prologue_desc_bytes(void) { return sizeof(PrepDesc); }
+
+// Fills `region` now (one launch).  For fwd / dgrad also writes the descriptor otal_conv_prologue_batch consumes into
+// host_desc (nullable) and returns the number of workgroups that descriptor needs (> 0); wgrad returns 0; errors < 0.
+extern "C" int otal_conv_prologue(const int* geom, const int64_t* strides, int mode, const float* w, int precision,
+                                  void* region, size_t region_bytes, void* host_desc, void* stream) {
+    if (!geom || !strides || !region) return OTAL_E_NULL;
+    ConvArgs a = {};
+    if (int e = fill_args_for_prologue(a, geom, strides, mode, w, precision)) return e;
+    const int kind = prologue_kind(a.g, mode, precision);
+    if (kind == 0 || region_bytes < otal_conv_prologue_bytes(geom, strides, mode, precision)) return OTAL_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 2) {
+        const int cw = a.g.sw == 2 ? 8 : wgrad_vector_width(a.g, a.prec);
+        a.fd = make_conv_fastdiv(a.g);
+        const int ngroups = a.K / cw, npad = ngroups + PTAB_PAD;
+        hipLaunchKernelGGL(build_pos_table_kernel, dim3((npad + 255) / 256), dim3(256), 0, st, reinterpret_cast<int2*>(region),
+                           a.g, a.fd, cw, ngroups, npad);
+        if (int e = otal_launch_status()) return e > 0 ? -100 - e : e;
+        return 0;
+    }
+    if (!w) return OTAL_E_NULL;
+    PrepDesc d;
+    int2* ctab = reinterpret_cast<int2*>(region);
+    unsigned short* wp = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(region) + chunk_tab_bytes(a.K));
+    if (mode == MODE_FWD) fill_prep_desc<MODE_FWD>(d, a, ctab, wp); else fill_prep_desc<MODE_DGRAD>(d, a, ctab, wp);
+    launch_prep(d, st);
+    if (int e = otal_launch_status()) return e > 0 ? -100 - e : e;
+    if (host_desc) memcpy(host_desc, &d, sizeof(d));
+    return (int)prep_blocks(d);
+}
+
+// Re-runs n fwd / dgrad prologues (descriptors in DEVICE memory, as written by otal_conv_prologue) in ONE launch;
+// device_starts[n+1] = prefix sums of the workgroup counts otal_conv_prologue returned, total_blocks = device_starts[n].
+extern "C" int otal_conv_prologue_batch(int n, const void* device_descs, const int* device_starts, int total_blocks,
+                                        void* stream) {
+    if (n <= 0) return 0;
+    if (!device_descs || !device_starts) return OTAL_E_NULL;
+    if (total_blocks <= 0) return OTAL_E_SHAPE;
+    hipLaunchKernelGGL(prep_chunks_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const PrepDesc*>(device_descs), device_starts, n);
     return otal_launch_status();
 }

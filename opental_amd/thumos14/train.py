@@ -120,6 +120,8 @@ class DetectorTrainer:
         self.arena = FlatArena(list(net.parameters()), bucket_mb << 20)
         self.step_count = 0
         self._pending, self._works = None, []
+        lo = self.arena.flat.data_ptr()
+        self._prologues = ops.PrologueCache((lo, lo + 4 * self.arena.numel))   # per-layer tables + bf16 weights, refreshed once per step
         self._graph = None          # (CUDAGraph, static inputs, static outputs) once capture_step() succeeded
         self._bias_corr = None      # 2-float device tensor: Adam bias corrections of the step being run
         self.collectives = self.distributed and (self.world > 1 or force_collectives)   # force: 1-rank RCCL smoke test
@@ -199,10 +201,14 @@ class DetectorTrainer:
     def step(self, clips, targets, scores, ssl_clips=None, ssl_targets=None):
         if self._graph is not None and ssl_clips is None:
             return self._replay(clips, targets, scores)
-        cost, losses = self.compute_cost(clips, targets, scores, ssl_clips, ssl_targets)
-        self.begin_backward()
-        cost.backward()
-        self.end_backward()
+        ops.activate_prologues(self._prologues)        # ONE launch re-packs the weights of every known conv layer
+        try:
+            cost, losses = self.compute_cost(clips, targets, scores, ssl_clips, ssl_targets)
+            self.begin_backward()
+            cost.backward()
+            self.end_backward()
+        finally:
+            ops.deactivate_prologues()
         self.step_count += 1
         self.optimizer_update()
         return cost.detach(), losses
@@ -214,10 +220,14 @@ class DetectorTrainer:
 
     # ---- the same step as ONE HIP graph: ~1500 launches per step are replayed without host involvement
     def _graph_body(self, clips, targets, scores):
-        cost, losses = self.compute_cost(clips, targets, scores)
-        self.begin_backward()
-        cost.backward()
-        self.end_backward()
+        ops.activate_prologues(self._prologues)
+        try:
+            cost, losses = self.compute_cost(clips, targets, scores)
+            self.begin_backward()
+            cost.backward()
+            self.end_backward()
+        finally:
+            ops.deactivate_prologues()
         ops.adam_flat_dev(self.arena.flat, self.arena.grad, self.arena.m, self.arena.v, self._bias_corr, self.lr,
                           self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
         return cost.detach(), losses
@@ -242,6 +252,8 @@ class DetectorTrainer:
                 self._graph_body(*static)
                 self.step_count += 1
         torch.cuda.current_stream(dev).wait_stream(side)
+        ops.activate_prologues(self._prologues)     # upload the descriptors of regions created by the last warm-up step
+        ops.deactivate_prologues()                  # (a host->device copy cannot be captured)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         self._set_bias(self.step_count + 1)
