@@ -478,7 +478,8 @@ extern "C" int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
     if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
-        int tt = 4096 / (g.Hi * g.Wi);
+        static const int tile_elems = getenv("OTAL_POOL_TILE") ? atoi(getenv("OTAL_POOL_TILE")) : 4096;
+        int tt = tile_elems / (g.Hi * g.Wi);
         tt = tt < 1 ? 1 : (tt > g.To ? g.To : tt);
         while (tt > 1 && (size_t)(tt + 2) * (g.Hi + 2) * (g.Wi + 2) * sizeof(float) > POOL_LDS_BUDGET) --tt;
         const size_t l3 = (size_t)(tt + 2) * (g.Hi + 2) * (g.Wi + 2) * sizeof(float);
@@ -512,7 +513,10 @@ extern "C" int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
     if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
-        int ti = 4096 / (g.Hi * g.Wi);
+        // smaller t-tiles than the forward: ~16 KB of LDS per workgroup keeps 8 of them resident per CU, so one
+        // workgroup's staging overlaps the others' gather (measured: 1152 elements 245 us, 4096 elements 310 us on 3c)
+        static const int tile_elems = getenv("OTAL_POOL_TILE") ? atoi(getenv("OTAL_POOL_TILE")) : 1152;
+        int ti = tile_elems / (g.Hi * g.Wi);
         ti = ti < 1 ? 1 : (ti > g.Ti ? g.Ti : ti);
         while (ti > 1 && (size_t)(ti + 2) * (g.Hi + 2) * (g.Wi + 2) * sizeof(float2) > POOL_LDS_BUDGET) --ti;
         const size_t l3 = (size_t)(ti + 2) * (g.Hi + 2) * (g.Wi + 2) * sizeof(float2);
