@@ -262,3 +262,36 @@ def test_graph_replayed_step_matches_eager_steps():
         assert max(abs(x - y) for x, y in zip(ca, cg)) <= 10.0 * cs + 1e-6 * abs(ca[0]), (ca, cb, cg)
     finally:
         ops.CONV_PRECISION = old
+
+
+@pytest.mark.gpu
+def test_persistent_prologues_do_not_change_the_trajectory():
+    """ops.PrologueCache (tables + bf16-packed weights refreshed once per step, include/opental_hip.h "Persistent
+    prologues") against launches that build their prologue themselves: same parameters after three steps, bit for bit,
+    and the cache really is in use (regions registered, none for weights outside the arena)."""
+    import bench
+    from opental_amd.common import ops
+    dev = torch.device("cuda", 0)
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        clips, targets, scores = bench.synth_batch(1, 78, dev)
+
+        def run(cached):
+            tr = bench.build_trainer(dev, seed=12)
+            tr.lr = 1e-4
+            if not cached:
+                tr._prologues = None            # activate_prologues(None): every launch packs for itself
+            for _ in range(3):
+                tr.step(clips, targets, scores)
+            torch.cuda.synchronize()
+            return tr
+
+        a, b = run(False), run(True)
+        assert torch.equal(a.arena.flat, b.arena.flat)
+        regs = [v for v in b._prologues.entries.values() if v is not None]
+        assert len(regs) > 100 and len(b._prologues.descs) > 80
+        lo, hi = b._prologues.persistent_range
+        assert hi - lo == 4 * b.arena.numel
+    finally:
+        ops.CONV_PRECISION = old
