@@ -1535,6 +1535,201 @@ static void set_epilogue_extents(ConvArgs& a) {
     a.slab_bytes = (a.splits > 1 && slab < (int64_t)0xfffffff0u && !getenv("OTAL_CONV_SLOW_EPILOGUE")) ? (unsigned)slab : 0u;
 }
 
+// =================================================================================================
+// Direct 3x3x3 convolution (bf16 operands; stride 1, SAME, P % 128 == 0, channel count % 16 == 0, W <= 24).
+// The gather kernels above re-fetch every input element 27 times through L1 and are bound by the texture addresser /
+// L2->L1 rate.  Here a K step is (temporal tap dt, 16 input channels): the workgroup stages ONCE the span of input
+// positions [n0 - W - 1, n0 + 127 + W + 1] of plane offset dt (128 + 2W + 2 positions x 16 channels, bf16, 48-byte
+// position pitch) and the 144-wide slice of the packed weights, and feeds all 9 in-plane taps from LDS: the tap only
+// shifts the lane's LDS address by a uniform amount, out-of-range taps are replaced by zero operands with the lane's
+// validity bits.  Per K step and wave: 27 MFMAs (BM = 96) against ~10 sixteen-byte loads per thread -- the matrix core,
+// not the load path, is the long pole.  DGRAD is the same kernel on dy with the taps flipped in the weight pack.
+struct DirectArgs {
+    ConvArgs c;                 // geometry, tensors, epilogue options (M, N, out, scale, ... as for the other kernels)
+    const unsigned short* wp;   // packed weights [Mpad][C/16][3 dt][9 taps][16] bf16
+    int C, Ktot;                // source channels, C * 27
+    unsigned wp_bytes;
+};
+
+template <int BM, int MODE>
+__global__ __launch_bounds__(NT) void conv3_direct_kernel(const DirectArgs d) {
+    constexpr int WM = BM / 32, PX = 48, PA = 304, SPAN_MAX = 180;
+    constexpr int A_PIECES = (BM * 18 + NT - 1) / NT;       // 16-byte weight pieces per thread per K step
+    constexpr int X_ITEMS = (SPAN_MAX / 4 + 1) * 8;         // (quad of positions, channel pair) items per K step, upper bound
+    constexpr int X_ITERS = (X_ITEMS + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) unsigned char smA[2][BM * PA];
+    __shared__ __attribute__((aligned(16))) unsigned char smX[2][SPAN_MAX * PX];
+    const ConvArgs& a = d.c;
+    const ConvGeom& g = a.g;
+    const ConvFastDiv& fd = a.fd;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const TileId tile = xcd_tile(true);
+    const int m0 = tile.y * BM, n0 = tile.x * 128;
+    const int W = g.Wi, HW = g.Hi * g.Wi;
+    const int span = 128 + 2 * W + 2, nq = (span + 3) >> 2;
+    const float* src = MODE == MODE_FWD ? a.x : a.dy;
+    const int64_t sbs = MODE == MODE_FWD ? g.x_bs : g.y_bs, scs = MODE == MODE_FWD ? g.x_cs : g.y_cs;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)a.src_bytes, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(d.wp), 0, (int)d.wp_bytes, 0x00020000);
+    // the tile lies inside one sample (P % 128 == 0): sample b, first position p0
+    const uint32_t bsm = fd_div(fd.P, (uint32_t)n0);
+    const int p0 = n0 - (int)(bsm * fd.P.d);
+    const unsigned tile_off = (unsigned)(((int64_t)bsm * sbs + p0 - (W + 1)) * 4);      // byte offset of span element 0 at dt = 1, channel 0
+
+    // this lane's output position: validity of the 3 + 3 + 3 taps (FWD form; DGRAD uses flipped taps in the pack)
+    const int nl = n0 + wave * 32 + (lane & 31);
+    unsigned tmask, hwmask = 0;
+    {
+        const PosDec o = dec_pos_fd(nl < a.N ? nl : 0, fd.To, fd.Ho, fd.Wo);
+        const bool live = nl < a.N;
+        tmask = 0;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) tmask |= (unsigned)(live && (unsigned)(o.t + dt - 1) < (unsigned)g.Ti) << dt;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw)
+                hwmask |= (unsigned)((unsigned)(o.h + dh - 1) < (unsigned)g.Hi && (unsigned)(o.w + dw - 1) < (unsigned)g.Wi) << (dh * 3 + dw);
+    }
+    // ---- per-thread load items
+    unsigned xvo[X_ITERS];          // byte offset of (quad, channel pair) relative to (dt = 1, chunk 0), or 0xffffffff if unused
+    int xlds[X_ITERS];
+#pragma unroll
+    for (int i = 0; i < X_ITERS; ++i) {
+        const int item = tid + NT * i;
+        const int q = item % nq, cp = item / nq;
+        const bool used = cp < 8;
+        xvo[i] = used ? tile_off + (unsigned)((2 * cp * scs + 4 * q) * 4) : 0xffffffffu;
+        xlds[i] = (4 * q) * PX + cp * 4;
+    }
+    unsigned avo[A_PIECES];
+#pragma unroll
+    for (int j = 0; j < A_PIECES; ++j) {
+        const int p = tid + NT * j;
+        avo[j] = (unsigned)(((m0 + p / 18) * d.Ktot * 2) + (p % 18) * 16);
+    }
+    unsigned rx[X_ITERS][2][4];
+    Words4 ra[A_PIECES];
+    const int nsteps = (d.C >> 4) * 3;
+    auto load_x = [&](int s) {
+        const int cb = s / 3, dt = s - cb * 3;
+        const unsigned so = (unsigned)(((int64_t)cb * 16 * scs + (int64_t)(dt - 1) * HW) * 4);
+#pragma unroll
+        for (int i = 0; i < X_ITERS; ++i) {
+            const unsigned vo = xvo[i] == 0xffffffffu ? a.src_bytes : xvo[i] + so;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const Words4 v = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, h ? (int)(scs * 4) : 0, 0));
+                rx[i][h][0] = v.a; rx[i][h][1] = v.b; rx[i][h][2] = v.c; rx[i][h][3] = v.d;
+            }
+        }
+    };
+    auto load_a = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < A_PIECES; ++j)
+            if ((BM * 18) % NT == 0 || tid + NT * j < BM * 18)
+                ra[j] = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rw, avo[j], s * 288, 0));
+    };
+    auto store = [&](int buf, int s) {
+        const int cb = s / 3, dt = s - cb * 3;
+        const unsigned so = (unsigned)(((int64_t)cb * 16 * scs + (int64_t)(dt - 1) * HW) * 4);
+#pragma unroll
+        for (int i = 0; i < X_ITERS; ++i) {
+            if (xvo[i] == 0xffffffffu) continue;
+            // a quad that starts in front of the tensor is rejected as a whole: re-fetch its in-range elements (rare lanes)
+            const unsigned vo = xvo[i] + so;
+            const bool neg = vo >= 0xfffffff0u;
+            if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int e = 1; e < 4; ++e) {
+                        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? wrap_add(vo, 4u * e) : a.src_bytes,
+                                                                                 h ? (int)(scs * 4) : 0, 0);
+                        rx[i][h][e] = neg ? v : rx[i][h][e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                *reinterpret_cast<unsigned*>(smX[buf] + xlds[i] + e * PX) =
+                    cvt_pk_bf16(__uint_as_float(rx[i][0][e]), __uint_as_float(rx[i][1][e]));
+        }
+#pragma unroll
+        for (int j = 0; j < A_PIECES; ++j) {
+            const int p = tid + NT * j;
+            if ((BM * 18) % NT == 0 || p < BM * 18) *reinterpret_cast<Words4*>(smA[buf] + (p / 18) * PA + (p % 18) * 16) = ra[j];
+        }
+    };
+
+    f32x16 acc[WM][1];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    load_x(0);
+    load_a(0);
+    store(0, 0);
+    __syncthreads();
+    const int xrow = (wave * 32 + (lane & 31) + W + 1) * PX + (lane >> 5) * 16;     // this lane's own position in the span
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        const int dt = s % 3;
+        const bool tok = (tmask >> dt) & 1u;
+        const int sn = s + 1 < nsteps ? s + 1 : s;          // the prefetch past the end re-reads the last step
+#pragma unroll
+        for (int g9 = 0; g9 < 9; ++g9) {
+            if (g9 == 0) load_x(sn);
+            if (g9 == 1) load_a(sn);
+            const int dh = g9 / 3, dw = g9 - dh * 3;
+            bf16x8 av[WM], bv;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                av[i] = *reinterpret_cast<const bf16x8*>(smA[buf] + (i * 32 + (lane & 31)) * PA + g9 * 32 + (lane >> 5) * 16);
+            bv = *reinterpret_cast<const bf16x8*>(smX[buf] + xrow + ((dh - 1) * W + (dw - 1)) * PX);
+            const bool ok = tok && ((hwmask >> g9) & 1u);
+            const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            bv = ok ? bv : zero;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv, acc[i][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        store(buf ^ 1, sn);
+        __syncthreads();
+    }
+    store_acc<MODE, WM, 1, BM>(a, acc, m0, n0, 0, wave * 32, lane, 0, reinterpret_cast<float*>(smA[0]));
+}
+
+// weights -> [Mpad][cb][dt][dh*3+dw][16] bf16.  FWD: A[m][..] = w[m][cb*16+c][dt][dh][dw];
+// DGRAD (natural layout W (Cout, Cin, 27)): A[m = ci][..] = w[co = cb*16+c][ci][2-dt][2-dh][2-dw]
+template <int MODE>
+__global__ __launch_bounds__(256) void pack_direct_kernel(unsigned* __restrict__ wp, const float* __restrict__ w, int M, int Mpad,
+                                                          int C, int natural) {
+    const int Ktot = C * 27;
+    const int64_t pairs = (int64_t)Mpad * Ktot / 2;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (int64_t)gridDim.x * 256) {
+        const int m = (int)(p / (Ktot / 2)), k = (int)(p - (int64_t)m * (Ktot / 2)) * 2;
+        float v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kk = k + i;
+            const int c16 = kk & 15, g9 = (kk >> 4) % 9, sdt = (kk >> 4) / 9, dt = sdt % 3, cb = sdt / 3;
+            const int c = cb * 16 + c16;
+            float x = 0.f;
+            if (m < M) {
+                if (MODE == MODE_FWD) x = w[((int64_t)m * C + c) * 27 + dt * 9 + g9];
+                else if (natural) x = w[((int64_t)c * M + m) * 27 + (2 - dt) * 9 + (8 - g9)];
+                else x = w[((int64_t)m * C + c) * 27 + (2 - dt) * 9 + (8 - g9)];      // packed W^T (Cin, Cout, 27)
+            }
+            v[i] = x;
+        }
+        wp[p] = cvt_pk_bf16(v[0], v[1]);
+    }
+}
+
 // ---- chunked bf16 path: eligibility, workspace layout [chunk table][packed bf16 weights][split-K slabs]
 constexpr int CHUNK_PAD = 16;       // table entries readable past Kp/8 (two K steps of prefetch)
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1757,6 +1952,60 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
     return 0;
 }
 
+// ---- direct 3x3x3 path: eligibility and launch
+static inline int direct_bm(int M) {
+    if (M % 96 == 0) return 96;
+    if (M % 64 == 0) return 64;
+    const int pad64 = (M + 63) / 64 * 64;
+    return (pad64 - M) * 5 <= M ? 64 : 0;          // accept <= 20 % padded rows
+}
+static inline bool direct_eligible(const ConvGeom& g, int mode, int prec, int M) {
+    static const bool off = getenv("OTAL_CONV_NODIRECT") != nullptr;
+    if (off || !prec || mode == MODE_WGRAD || g.nlev > 1) return false;
+    if (g.kt != 3 || g.kh != 3 || g.kw != 3 || g.st != 1 || g.sh != 1 || g.sw != 1 || g.pt != 1 || g.ph != 1 || g.pw != 1) return false;
+    if (g.To != g.Ti || g.Ho != g.Hi || g.Wo != g.Wi || g.Wi > 24) return false;
+    const int P = conv_out_positions(g);
+    const int C = mode == MODE_FWD ? g.Cin : g.Cout;
+    if (P % 128 || C % 16 || !direct_bm(M)) return false;
+    const int BM = direct_bm(M);
+    static const int min_tiles = getenv("OTAL_CONV_DIRECT_MINTILES") ? atoi(getenv("OTAL_CONV_DIRECT_MINTILES")) : 256;
+    if ((int64_t)((M + BM - 1) / BM) * ((int64_t)g.B * P / 128) < min_tiles) return false;  // no split-K on this path
+    const int64_t ext = gather_extent_bytes(g, mode);
+    return ext > 0 && ext < (1LL << 31);
+}
+static inline size_t direct_wp_bytes(int M, int C) {
+    const int BM = direct_bm(M);
+    return align256((size_t)((M + BM - 1) / BM * BM) * C * 27 * 2 + 1024);
+}
+
+template <int MODE>
+int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int C = MODE == MODE_FWD ? a.g.Cin : a.g.Cout;
+    const int BM = direct_bm(a.M);
+    const int tm = (a.M + BM - 1) / BM, Mpad = tm * BM;
+    const size_t wb = direct_wp_bytes(a.M, C);
+    if (!ws || ws_bytes < wb) return OTAL_E_UNSUPPORTED;
+    {
+        const int64_t pairs = (int64_t)Mpad * C * 27 / 2;
+        const int blocks = (int)((pairs + 255) / 256 < 2048 ? (pairs + 255) / 256 : 2048);
+        hipLaunchKernelGGL((pack_direct_kernel<MODE>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<unsigned*>(ws), a.w,
+                           a.M, Mpad, C, a.w_natural);
+        if (int e = otal_launch_status()) return e;
+    }
+    DirectArgs d;
+    a.fd = make_conv_fastdiv(a.g);
+    a.src_bytes = (unsigned)gather_extent_bytes(a.g, MODE);
+    a.splits = 1; a.k_per_split = 0; a.slab = nullptr;
+    set_epilogue_extents<MODE>(a);
+    d.c = a;
+    d.wp = reinterpret_cast<const unsigned short*>(ws);
+    d.C = C; d.Ktot = C * 27; d.wp_bytes = (unsigned)wb;
+    const dim3 grid(a.N / 128, tm, 1);
+    if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE>), grid, dim3(NT), 0, st, d);
+    else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE>), grid, dim3(NT), 0, st, d);
+    return otal_launch_status();
+}
+
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if constexpr (MODE == MODE_WGRAD) {
@@ -1764,6 +2013,7 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         if (const int cw = wgrad_vector_width(a.g, a.prec)) return launch_wgrad_vector(a, cw, ws, ws_bytes, st);
     }
     if constexpr (MODE != MODE_WGRAD) {
+        if (direct_eligible(a.g, MODE, a.prec, a.M)) return launch_direct<MODE>(a, ws, ws_bytes, st);
         if (chunk_eligible(a.g, MODE, a.prec)) return launch_chunked<MODE>(a, ws, ws_bytes, st);
     }
     if constexpr (MODE == MODE_DGRAD) {
@@ -1864,6 +2114,7 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
         const int Kc = mode == MODE_FWD && g.Cin * g.kt * g.kh * 8 > K ? g.Cin * g.kt * g.kh * 8 : (int)K;   // kw-vector mode pads kw to 8
         size_t cf = chunk_tab_bytes(Kc) + chunk_wp_bytes((int)M, BMsel, Kc);
         if (M % 192 == 0) { const size_t ct = chunk_tab_bytes(Kc) + chunk_wp_bytes((int)M, 192, Kc); if (ct > cf) cf = ct; }
+        if (direct_eligible(g, mode, 1, (int)M)) { const size_t dd = direct_wp_bytes((int)M, mode == MODE_FWD ? g.Cin : g.Cout); if (dd > cf) cf = dd; }
         if (cf > front) front = cf;
     }
     if (mode == MODE_DGRAD) front += align256((size_t)g.Cin * g.Cout * kvol * sizeof(float));    // natural-layout weights on the generic path
@@ -1937,6 +2188,8 @@ int prologue_kind(const ConvGeom& g, int mode, int precision) {
         if (wgrad_pair_mode(g, prec)) return 2;
         return wgrad_vector_width(g, prec) ? 2 : 0;
     }
+    const int M = mode == MODE_FWD ? g.Cout : g.Cin;
+    if (direct_eligible(g, mode, prec, M)) return 0;     // the direct path packs per launch (for now)
     return chunk_eligible(g, mode, prec) ? 1 : 0;
 }
 int fill_args_for_prologue(ConvArgs& a, const int* geom, const int64_t* strides, int mode, const float* w, int precision) {

@@ -16,3 +16,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+# let small test shapes reach the direct 3x3x3 kernel (the product default keeps it for grids that fill the chip)
+import os as _os
+_os.environ.setdefault("OTAL_CONV_DIRECT_MINTILES", "1")
