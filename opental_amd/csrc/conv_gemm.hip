@@ -1598,8 +1598,8 @@ __global__ __launch_bounds__(NT) void conv3_direct_kernel(const DirectArgs d) {
 #pragma unroll
     for (int i = 0; i < X_ITERS; ++i) {
         const int item = tid + NT * i;
-        const int q = item % nq, cp = item / nq;
-        const bool used = cp < 8;
+        const int cp = item & 7, q = item >> 3;            // channel pair fastest: consecutive lanes write consecutive LDS dwords
+        const bool used = q < nq;
         xvo[i] = used ? tile_off + (unsigned)((2 * cp * scs + 4 * q) * 4) : 0xffffffffu;
         xlds[i] = (4 * q) * PX + cp * 4;
     }
