@@ -247,7 +247,7 @@ __device__ __forceinline__ void store_acc(const ConvArgs& a, const f32x16 (&acc)
     }
     // ---- per-row values -> LDS
     __syncthreads();        // every wave is done reading the operand tiles
-    for (int r = threadIdx.x; r < BM; r += NT) {
+    for (int r = threadIdx.x; r < BM; r += (int)blockDim.x) {
         const int m = m0 + r;
         float s0 = 1.f, s1 = 0.f;
         if (m < a.M) {
@@ -1551,12 +1551,13 @@ struct DirectArgs {
     unsigned wp_bytes;
 };
 
-template <int BM, int MODE>
-__global__ __launch_bounds__(NT) void conv3_direct_kernel(const DirectArgs d) {
-    constexpr int WM = BM / 32, PX = 48, PA = 304, SPAN_MAX = 180;
-    constexpr int A_PIECES = (BM * 18 + NT - 1) / NT;       // 16-byte weight pieces per thread per K step
+template <int BM, int MODE, int BNP>
+__global__ __launch_bounds__(BNP * 2) void conv3_direct_kernel(const DirectArgs d) {
+    constexpr int DNT = BNP * 2;                            // one wave per 32 positions: 4 waves (BNP 128) or 8 (BNP 256)
+    constexpr int WM = BM / 32, PX = 48, PA = 304, SPAN_MAX = BNP + 52;
+    constexpr int A_PIECES = (BM * 18 + DNT - 1) / DNT;       // 16-byte weight pieces per thread per K step
     constexpr int X_ITEMS = (SPAN_MAX / 4 + 1) * 8;         // (quad of positions, channel pair) items per K step, upper bound
-    constexpr int X_ITERS = (X_ITEMS + NT - 1) / NT;
+    constexpr int X_ITERS = (X_ITEMS + DNT - 1) / DNT;
     __shared__ __attribute__((aligned(16))) unsigned char smA[2][BM * PA];
     __shared__ __attribute__((aligned(16))) unsigned char smX[2][SPAN_MAX * PX];
     const ConvArgs& a = d.c;
@@ -1565,9 +1566,9 @@ __global__ __launch_bounds__(NT) void conv3_direct_kernel(const DirectArgs d) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileId tile = xcd_tile(true);
-    const int m0 = tile.y * BM, n0 = tile.x * 128;
+    const int m0 = tile.y * BM, n0 = tile.x * BNP;
     const int W = g.Wi, HW = g.Hi * g.Wi;
-    const int span = 128 + 2 * W + 2, nq = (span + 3) >> 2;
+    const int span = BNP + 2 * W + 2, nq = (span + 3) >> 2;
     const float* src = MODE == MODE_FWD ? a.x : a.dy;
     const int64_t sbs = MODE == MODE_FWD ? g.x_bs : g.y_bs, scs = MODE == MODE_FWD ? g.x_cs : g.y_cs;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)a.src_bytes, 0x00020000);
@@ -1597,7 +1598,7 @@ __global__ __launch_bounds__(NT) void conv3_direct_kernel(const DirectArgs d) {
     int xlds[X_ITERS];
 #pragma unroll
     for (int i = 0; i < X_ITERS; ++i) {
-        const int item = tid + NT * i;
+        const int item = tid + DNT * i;
         const int cp = item & 7, q = item >> 3;            // channel pair fastest: consecutive lanes write consecutive LDS dwords
         const bool used = q < nq;
         xvo[i] = used ? tile_off + (unsigned)((2 * cp * scs + 4 * q) * 4) : 0xffffffffu;
@@ -1606,7 +1607,7 @@ __global__ __launch_bounds__(NT) void conv3_direct_kernel(const DirectArgs d) {
     unsigned avo[A_PIECES];
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) {
-        const int p = tid + NT * j;
+        const int p = tid + DNT * j;
         avo[j] = (unsigned)(((m0 + p / 18) * d.Ktot * 2) + (p % 18) * 16);
     }
     unsigned rx[X_ITERS][2][4];
@@ -1628,7 +1629,7 @@ __global__ __launch_bounds__(NT) void conv3_direct_kernel(const DirectArgs d) {
     auto load_a = [&](int s) {
 #pragma unroll
         for (int j = 0; j < A_PIECES; ++j)
-            if ((BM * 18) % NT == 0 || tid + NT * j < BM * 18)
+            if ((BM * 18) % DNT == 0 || tid + DNT * j < BM * 18)
                 ra[j] = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rw, avo[j], s * 288, 0));
     };
     auto store = [&](int buf, int s) {
@@ -1658,8 +1659,8 @@ __global__ __launch_bounds__(NT) void conv3_direct_kernel(const DirectArgs d) {
         }
 #pragma unroll
         for (int j = 0; j < A_PIECES; ++j) {
-            const int p = tid + NT * j;
-            if ((BM * 18) % NT == 0 || p < BM * 18) *reinterpret_cast<Words4*>(smA[buf] + (p / 18) * PA + (p % 18) * 16) = ra[j];
+            const int p = tid + DNT * j;
+            if ((BM * 18) % DNT == 0 || p < BM * 18) *reinterpret_cast<Words4*>(smA[buf] + (p / 18) * PA + (p % 18) * 16) = ra[j];
         }
     };
 
@@ -1966,10 +1967,10 @@ static inline bool direct_eligible(const ConvGeom& g, int mode, int prec, int M)
     if (g.To != g.Ti || g.Ho != g.Hi || g.Wo != g.Wi || g.Wi > 24) return false;
     const int P = conv_out_positions(g);
     const int C = mode == MODE_FWD ? g.Cin : g.Cout;
-    if (P % 128 || C % 16 || !direct_bm(M)) return false;
+    if (P % 256 || C % 16 || !direct_bm(M)) return false;
     const int BM = direct_bm(M);
-    static const int min_tiles = getenv("OTAL_CONV_DIRECT_MINTILES") ? atoi(getenv("OTAL_CONV_DIRECT_MINTILES")) : 256;
-    if ((int64_t)((M + BM - 1) / BM) * ((int64_t)g.B * P / 128) < min_tiles) return false;  // no split-K on this path
+    static const int min_tiles = getenv("OTAL_CONV_DIRECT_MINTILES") ? atoi(getenv("OTAL_CONV_DIRECT_MINTILES")) : 192;
+    if ((int64_t)((M + BM - 1) / BM) * ((int64_t)g.B * P / 256) < min_tiles) return false;  // no split-K on this path
     const int64_t ext = gather_extent_bytes(g, mode);
     return ext > 0 && ext < (1LL << 31);
 }
@@ -2000,9 +2001,9 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     d.c = a;
     d.wp = reinterpret_cast<const unsigned short*>(ws);
     d.C = C; d.Ktot = C * 27; d.wp_bytes = (unsigned)wb;
-    const dim3 grid(a.N / 128, tm, 1);
-    if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE>), grid, dim3(NT), 0, st, d);
-    else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE>), grid, dim3(NT), 0, st, d);
+    const dim3 grid(a.N / 256, tm, 1);
+    if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256>), grid, dim3(512), 0, st, d);
+    else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 256>), grid, dim3(512), 0, st, d);
     return otal_launch_status();
 }
 
