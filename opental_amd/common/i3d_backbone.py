@@ -172,6 +172,23 @@ class InceptionI3d(nn.Module):
         raise NotImplementedError("classification logits are not part of the detection path; use extract_features")
 
 
+_FUSED_AFFINE = {}
+
+
+def _fused_affine(scale, shift, offs, w0):
+    """Folded-BN scale / shift of the fused 1x1 launch of a module, in its channel order [b1a | b2a | b0] (constants)."""
+    key = (scale.data_ptr(), shift.data_ptr(), w0)
+    hit = _FUSED_AFFINE.get(key)
+    if hit is None:
+        pick = lambda t, i: t[offs[i]:offs[i + 1]]
+        hit = (torch.cat([pick(scale, w0 + 1), pick(scale, w0 + 3), pick(scale, w0)]),
+               torch.cat([pick(shift, w0 + 1), pick(shift, w0 + 3), pick(shift, w0)]))
+        if len(_FUSED_AFFINE) > 256:
+            _FUSED_AFFINE.clear()
+        _FUSED_AFFINE[key] = hit
+    return hit
+
+
 class I3DFeaturesFunction(Function):
     """Forward + hand-written backward tape of the whole backbone.
 
@@ -205,20 +222,25 @@ class I3DFeaturesFunction(Function):
                 _, w0, oc, _ = step
                 B, _, T, H, W = cur.shape
                 ctot = oc[0] + oc[2] + oc[4] + oc[5]
-                Y = torch.empty((B, ctot, T, H, W), dtype=cur.dtype, device=cur.device)
+                # One buffer Z = [h1 | h2 | Y]: the three 1x1 convolutions that read the module input (b1a, b2a, b0) run as
+                # ONE GEMM whose output range ends exactly at Y's first slice, so the input is read once instead of three
+                # times (forward, weight gradient) and its gradient is written once instead of accumulated three times.
+                o1, o13 = oc[1], oc[1] + oc[3]
+                Z = torch.empty((B, o13 + ctot, T, H, W), dtype=cur.dtype, device=cur.device)
+                h1, h2, Y = Z[:, :o1], Z[:, o1:o13], Z[:, o13:]
                 c1, c2, c3 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
-                ops.conv_forward(cur, weights[w0], ONE, ONE, scale=sc(w0), shift=sh(w0), relu=True, out=Y[:, :c1])
-                h1 = ops.conv_forward(cur, weights[w0 + 1], ONE, ONE, scale=sc(w0 + 1), shift=sh(w0 + 1), relu=True)
+                wf = torch.cat([weights[w0 + 1], weights[w0 + 3], weights[w0]], 0)
+                scf, shf = _fused_affine(scale, shift, offs, w0)
+                ops.conv_forward(cur, wf, ONE, ONE, scale=scf, shift=shf, relu=True, out=Z[:, :o13 + c1])
                 ops.conv_forward(h1, weights[w0 + 2], THREE, ONE, scale=sc(w0 + 2), shift=sh(w0 + 2), relu=True,
                                  out=Y[:, c1:c2])
-                h2 = ops.conv_forward(cur, weights[w0 + 3], ONE, ONE, scale=sc(w0 + 3), shift=sh(w0 + 3), relu=True)
                 ops.conv_forward(h2, weights[w0 + 4], THREE, ONE, scale=sc(w0 + 4), shift=sh(w0 + 4), relu=True,
                                  out=Y[:, c2:c3])
                 pm, argm = ops.maxpool3d_forward(cur, THREE, ONE)
                 ops.conv_forward(pm, weights[w0 + 5], ONE, ONE, scale=sc(w0 + 5), shift=sh(w0 + 5), relu=True,
                                  out=Y[:, c3:])
                 out_scale = torch.cat([sc(w0), sc(w0 + 2), sc(w0 + 4), sc(w0 + 5)])
-                tape.append(("mixed", w0, (c1, c2, c3), cur, h1, h2, pm, argm, Y, cur_scale, out_scale))
+                tape.append(("mixed", w0, (c1, c2, c3), cur, h1, h2, pm, argm, Y, cur_scale, (wf, o1, o13), out_scale))
                 cur, cur_scale = Y, out_scale
             if name in endpoints:
                 found[name] = (cur, len(tape))
@@ -249,11 +271,31 @@ class I3DFeaturesFunction(Function):
             else:
                 g = g.contiguous().clone()
             pending[pos] = pending[pos] + g if pos in pending else g
+        zg = {}                     # gradient buffers [dh1 | dh2 | dY] of the mixed steps, keyed by tape position
+
+        def out_grad_buffer(p, shape, like):
+            """Where the gradient w.r.t. the OUTPUT of tape step p (1-based; 0 = the network input) is written.  For a
+            mixed step it is the tail of a larger buffer, so that the fused 1x1 backward reads one channel range."""
+            if p >= 1 and tape[p - 1][0] == "mixed":
+                o13 = tape[p - 1][10][2]
+                B, ct, T, H, W = shape
+                buf = torch.empty((B, o13 + ct, T, H, W), dtype=like.dtype, device=like.device)
+                zg[p] = buf
+                return buf[:, o13:]
+            return torch.empty(tuple(shape), dtype=like.dtype, device=like.device)
+
         dcur = None
         for pos in range(len(tape), 0, -1):
             if pos in pending:
                 ext = pending.pop(pos)
-                dcur = ext if dcur is None else dcur.add_(ext)
+                if dcur is None:
+                    if tape[pos - 1][0] == "mixed":
+                        dcur = out_grad_buffer(pos, ext.shape, ext)
+                        dcur.copy_(ext)
+                    else:
+                        dcur = ext
+                else:
+                    dcur.add_(ext)
             if dcur is None:
                 continue
             step = tape[pos - 1]
@@ -264,28 +306,27 @@ class I3DFeaturesFunction(Function):
                 if first and not need_dx:
                     dcur = None
                 else:
-                    dcur = ops.conv_dgrad(dcur, weights[wi], xin.shape, k, s,
+                    dcur = ops.conv_dgrad(dcur, weights[wi], xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, dcur),
                                           out_mask=xin if in_scale is not None else None, out_scale=in_scale)
             elif step[0] == "pool":
                 _, k, s, xin, arg, in_scale, _ = step
-                dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s,
+                dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, dcur),
                                               out_mask=xin if in_scale is not None else None, out_scale=in_scale)
             else:
-                _, w0, (c1, c2, c3), xin, h1, h2, pm, argm, Y, in_scale, _ = step
-                dY = dcur
-                dX = torch.empty_like(xin)
+                _, w0, (c1, c2, c3), xin, h1, h2, pm, argm, Y, in_scale, (wf, o1, o13), _ = step
+                Zg = zg.pop(pos)            # [dh1 | dh2 | dY]; dcur is its tail
+                dY = Zg[:, o13:]
+                dX = out_grad_buffer(pos - 1, xin.shape, dcur)
                 xm = xin if in_scale is not None else None
                 sl = (slice(0, c1), slice(c1, c2), slice(c2, c3), slice(c3, Y.shape[1]))
-                g0 = dY[:, sl[0]]
-                dws[w0] = ops.conv_wgrad(xin, g0, weights[w0].shape, ONE, ONE)
-                ops.conv_dgrad(g0, weights[w0], xin.shape, ONE, ONE, out=dX, out_mask=xm, out_scale=in_scale)
-                for a, b, hid, sli in ((w0 + 1, w0 + 2, h1, sl[1]), (w0 + 3, w0 + 4, h2, sl[2])):
+                for a, b, hid, sli, dst in ((w0 + 1, w0 + 2, h1, sl[1], Zg[:, :o1]), (w0 + 3, w0 + 4, h2, sl[2], Zg[:, o1:o13])):
                     g = dY[:, sli]
                     dws[b] = ops.conv_wgrad(hid, g, weights[b].shape, THREE, ONE)
-                    dh = ops.conv_dgrad(g, weights[b], hid.shape, THREE, ONE, out_mask=hid, out_scale=sc(a))
-                    dws[a] = ops.conv_wgrad(xin, dh, weights[a].shape, ONE, ONE)
-                    ops.conv_dgrad(dh, weights[a], xin.shape, ONE, ONE, out=dX, accumulate=True,
-                                   out_mask=xm, out_scale=in_scale)
+                    ops.conv_dgrad(g, weights[b], hid.shape, THREE, ONE, out=dst, out_mask=hid, out_scale=sc(a))
+                gf = Zg[:, :o13 + c1]       # gradients of the fused 1x1 outputs: dh1, dh2, dY[:, :c1]
+                dwf = ops.conv_wgrad(xin, gf, wf.shape, ONE, ONE)
+                dws[w0 + 1], dws[w0 + 3], dws[w0] = dwf[:o1], dwf[o1:o13], dwf[o13:]
+                ops.conv_dgrad(gf, wf, xin.shape, ONE, ONE, out=dX, out_mask=xm, out_scale=in_scale)
                 g3 = dY[:, sl[3]]
                 dws[w0 + 5] = ops.conv_wgrad(pm, g3, weights[w0 + 5].shape, ONE, ONE)
                 dpm = ops.conv_dgrad(g3, weights[w0 + 5], pm.shape, ONE, ONE)

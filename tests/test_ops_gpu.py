@@ -324,3 +324,41 @@ def test_conv_bf16_vector_starting_before_tensor(shape, cout, k, s):
     close(y, yr)
     close(dx, xr.grad)
     close(dw, wr.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [0, 1])
+def test_fused_1x1_launches_match_separate_ones(prec):
+    """The backbone runs the three 1x1 convolutions that read a module's input (b1a, b2a, b0) as ONE launch over a shared
+    buffer [h1 | h2 | Y] (common/i3d_backbone.py).  Weight gradient and data gradient of the fused launch against
+    separate launches and against fp64: exact in fp32 (1e-6), bit-identical in bf16 mode."""
+    from opental_amd.common import ops
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = prec
+    try:
+        torch.manual_seed(3)
+        B, Cin, T, H, W = 1, 48, 16, 12, 12
+        o1, o3, c0, ctot = 32, 16, 24, 96
+        x = torch.randn(B, Cin, T, H, W, device="cuda")
+        Zg = torch.randn(B, o1 + o3 + ctot, T, H, W, device="cuda") * 0.1
+        gf = Zg[:, :o1 + o3 + c0]
+        wshape = (o1 + o3 + c0, Cin, 1, 1, 1)
+        dwf = ops.conv_wgrad(x, gf, wshape, (1, 1, 1), (1, 1, 1))
+        sep = torch.cat([ops.conv_wgrad(x, Zg[:, lo:hi].contiguous(), (hi - lo, Cin, 1, 1, 1), (1, 1, 1), (1, 1, 1))
+                         for lo, hi in ((0, o1), (o1, o1 + o3), (o1 + o3, o1 + o3 + c0))], 0)
+        ref = torch.einsum("bcthw,bkthw->kc", x.double(), gf.double()).view(wshape)
+        tol = 2e-6 if prec == 0 else 1e-2
+        assert float((dwf.double() - ref).abs().max()) <= tol * float(ref.abs().max())
+        assert float((dwf - sep).abs().max()) <= 2e-6 * float(ref.abs().max())
+        wf = torch.randn(*wshape, device="cuda") * 0.05
+        dx = ops.conv_dgrad(gf, wf, x.shape, (1, 1, 1), (1, 1, 1))
+        dref = torch.einsum("bkthw,kc->bcthw", gf.double(), wf.double().view(wshape[0], Cin))
+        assert float((dx.double() - dref).abs().max()) <= tol * float(dref.abs().max())
+        # forward into the shared buffer: the fused output range ends inside Y
+        Z = torch.zeros(B, o1 + o3 + ctot, T, H, W, device="cuda")
+        ops.conv_forward(x, wf, (1, 1, 1), (1, 1, 1), out=Z[:, :o1 + o3 + c0])
+        yref = torch.einsum("bcthw,kc->bkthw", x.double(), wf.double().view(wshape[0], Cin))
+        assert float((Z[:, :o1 + o3 + c0].double() - yref).abs().max()) <= tol * float(yref.abs().max())
+        assert float(Z[:, o1 + o3 + c0:].abs().max()) == 0.0
+    finally:
+        ops.CONV_PRECISION = old
