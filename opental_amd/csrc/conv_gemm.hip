@@ -1498,16 +1498,22 @@ int choose_bm(int M, int tall = 0) {
 }
 
 // choose split-K so that the grid fills the chip (256 CUs) without shredding K
-int choose_splits(int tiles, int K, int prec = 1) {
-    static const int target = getenv("OTAL_CONV_SPLIT_BLOCKS") ? atoi(getenv("OTAL_CONV_SPLIT_BLOCKS")) : 512;
+int choose_splits(int tiles, int K, int prec = 1, bool wgrad = false) {
+    static const int target_env = getenv("OTAL_CONV_SPLIT_BLOCKS") ? atoi(getenv("OTAL_CONV_SPLIT_BLOCKS")) : 0;
     // bf16: >= 8 K steps of 32 per split (fewer, larger slabs: measured +4 % step throughput over 4);
     // fp32 parity path: 128 k per split as in the version the gradient-parity fixtures were validated with
     static const int minsteps_env = getenv("OTAL_CONV_SPLIT_MINSTEPS") ? atoi(getenv("OTAL_CONV_SPLIT_MINSTEPS")) : 0;
-    const int minsteps = minsteps_env ? minsteps_env : (prec ? 8 : 4);
-    static const int cap = getenv("OTAL_CONV_MAXSPLIT") ? atoi(getenv("OTAL_CONV_MAXSPLIT")) : 384;
+    static const int cap_env = getenv("OTAL_CONV_MAXSPLIT") ? atoi(getenv("OTAL_CONV_MAXSPLIT")) : 0;
+    // The vector weight-gradient kernel keeps 4 workgroups per CU resident and its K is huge (all positions): it wants two
+    // full waves of workgroups (2048; 512 left it at 2 waves per SIMD, 61 % of wave time parked) but long splits (>= 48 K
+    // steps) so that the tiny 1x1 layers are not shredded.  Forward / data gradient keep the 512-workgroup target.
+    const bool wv = wgrad && prec;
+    const int target = target_env ? target_env : (wv ? 2048 : 512);
+    const int minsteps = minsteps_env ? minsteps_env : (wv ? 48 : (prec ? 8 : 4));
+    const int cap = cap_env ? cap_env : (wv ? 1024 : 384);
     if (tiles >= target * 3 / 4) return 1;
-    int want = (target + tiles - 1) / tiles;   // two resident workgroups per CU are enough to hide the tails
-    int maxs = K / (minsteps * 32);            // at least `minsteps` (bf16) / 2x (fp32) K-steps per split
+    int want = (target + tiles - 1) / tiles;
+    int maxs = K / (minsteps * 32);
     if (maxs < 1) maxs = 1;
     int s = want < maxs ? want : maxs;
     return s < 1 ? 1 : (s > cap ? cap : s);
@@ -1914,7 +1920,7 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
         ws_bytes -= tb;
     }
     a.ptab = ptab;
-    int splits = choose_splits(tm * tn, a.K);
+    int splits = choose_splits(tm * tn, a.K, 1, true);
     if (splits > 1) {
         const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
         if (ws_bytes < need) {
@@ -2108,7 +2114,8 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
     const int BMsel = choose_bm((int)M);
     const int BN = 128;
     const int tiles = (int)(((M + BMsel - 1) / BMsel) * ((N + BN - 1) / BN));
-    const int s = choose_splits(tiles, (int)K, 0);      // the fp32 rule splits finer: size for it
+    int s = choose_splits(tiles, (int)K, 0);            // the fp32 rule splits finer: size for it
+    if (mode == MODE_WGRAD) { const int sw = choose_splits(tiles, (int)K, 1, true); if (sw > s) s = sw; }
     // precision is not an argument here: size for whichever path needs more (generic tap table vs chunk table + packed weights)
     size_t front = mode == MODE_WGRAD ? ptab_bytes(g, 2) : tab_bytes((int)K);
     if (mode != MODE_WGRAD) {
