@@ -447,7 +447,8 @@ int fwd_planes(const PoolGeom& g, size_t& lds) {
 }
 // input planes per block (backward) + the largest number of output planes a block stages
 int bwd_planes(const PoolGeom& g, int& tlo_max, size_t& lds) {
-    int ti = 4096 / (g.Hi * g.Wi);
+    static const int tile_elems = getenv("OTAL_POOL_TILE_G") ? atoi(getenv("OTAL_POOL_TILE_G")) : 4096;
+    int ti = tile_elems / (g.Hi * g.Wi);
     if (ti < 1) ti = 1;
     if (ti > g.Ti) ti = g.Ti;
     const int ct = (g.kt + g.st - 1) / g.st;
