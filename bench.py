@@ -33,26 +33,46 @@ PEAK_TFLOPS = {"f32": 157.3,     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfm
                "bf16": 2500.0}   # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), not the 2:1-sparsity headline
 
 
-def synth_batch(batch, seed, device):
-    """Synthetic clips / targets of the THUMOS14 shape (no dataset in the container)."""
+def synth_batch(batch, seed, device, frames=256, classes=15, score_rows=2):
+    """Synthetic clips / targets of the THUMOS14 shape (no dataset in the container); frames=768, classes=150,
+    score_rows=3 ([action, start, end], AFSD/common/anet_dataset.py:250-255) for the ActivityNet recipe."""
     rs = np.random.RandomState(seed)
     g = torch.Generator(device=device).manual_seed(seed)
-    clips = torch.randint(0, 256, (batch, 3, 256, 96, 96), device=device, generator=g, dtype=torch.uint8)
+    clips = torch.randint(0, 256, (batch, 3, frames, 96, 96), device=device, generator=g, dtype=torch.uint8)
     clips = (clips.float() / 255.0) * 2.0 - 1.0
-    targets, scores = [], np.zeros((batch, 2, 256), np.float32)
+    targets, scores = [], np.zeros((batch, score_rows, frames), np.float32)
     for i in range(batch):
         rows = []
         for _ in range(rs.randint(1, 4)):
-            length = rs.uniform(8.0 / 256, 0.6)
+            length = rs.uniform(8.0 / frames, 0.6)
             start = rs.uniform(0.0, 1.0 - length)
-            rows.append([start, start + length, float(rs.randint(1, 16))])
-            s_f, e_f = start * 256, (start + length) * 256
+            rows.append([start, start + length, float(rs.randint(1, classes + 1))])
+            s_f, e_f = start * frames, (start + length) * frames
             d = max((e_f - s_f) / 10.0, 2.0)
-            for ch, c in ((0, s_f), (1, e_f)):
-                lo = int(np.clip(int(round(c - d / 2)), 0, 255)); hi = int(np.clip(int(round(c + d / 2)), 0, 255)) + 1
+            for ch, c in ((score_rows - 2, s_f), (score_rows - 1, e_f)):
+                lo = int(np.clip(int(round(c - d / 2)), 0, frames - 1)); hi = int(np.clip(int(round(c + d / 2)), 0, frames - 1)) + 1
                 scores[i, ch, lo:hi] = 1.0
+            if score_rows == 3:
+                scores[i, 0, int(s_f):int(np.ceil(e_f))] = 1.0
         targets.append(torch.tensor(rows, dtype=torch.float32, device=device))
     return clips, targets, torch.from_numpy(scores).to(device)
+
+
+def build_anet_trainer(device, seed=2020, force_collectives=False):
+    """BASELINE configs[3]: configs/anet_opental.yaml (768-frame clips, 150 classes, lr 1e-4 / backbone 1e-5, wd 1e-4),
+    flags of AFSD/anet/README.md:61 (--lw=1 --cw=1 --piou=0.6)."""
+    from opental_amd.anet.BDNet import BDNet
+    from opental_amd.anet.multisegment_loss import MultiSegmentLoss
+    from opental_amd.anet.train import make_trainer
+    torch.manual_seed(seed)
+    net = BDNet(in_channels=3, training=False, use_edl=True)
+    net.backbone._model.apply(BDNet.weight_init)
+    net = net.to(device).train()
+    edl = dict(evidence='exp', loss_type='log', iou_aware=True, with_ibm=True, ibm_start=10, momentum=0.99, num_bins=50)
+    crit = MultiSegmentLoss(150, 0.6, 1.0, cls_loss_type='edl', edl_config=edl, os_head=True).to(device)
+    crit.cls_loss.epoch = 12
+    return make_trainer(net, crit, dict(lw=1.0, cw=1.0, ctw=1.0, actw=1.0, ssl=0.1), learning_rate=1e-4, weight_decay=1e-4,
+                        force_collectives=force_collectives)
 
 
 def build_trainer(device, seed=2020, force_collectives=False):
@@ -115,7 +135,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="clips per GPU (configs[2]: batch 8/GPU)")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default 8: configs[2] batch 8/GPU; anet: 2, the yaml's)")
+    ap.add_argument("--recipe", choices=["thumos14", "anet"], default="thumos14",
+                    help="thumos14 = the headline workload (BASELINE configs[1]/[2]); anet = configs[3], 768-frame clips")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
                     help="arithmetic type of the convolution GEMMs (BASELINE.json configs[1]: bf16); f32 = parity path")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
@@ -123,6 +145,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    anet = args.recipe == "anet"
+    if args.batch is None:
+        args.batch = 2 if anet else 8
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -139,8 +164,12 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
     from opental_amd.common import ops as _ops
     _ops.CONV_PRECISION = 1 if args.dtype == "bf16" else 0
-    trainer = build_trainer(device, force_collectives=force_dist)
-    clips, targets, scores = synth_batch(args.batch, 1000 + rank, device)
+    if anet:
+        trainer = build_anet_trainer(device, force_collectives=force_dist)
+        clips, targets, scores = synth_batch(args.batch, 1000 + rank, device, frames=768, classes=150, score_rows=3)
+    else:
+        trainer = build_trainer(device, force_collectives=force_dist)
+        clips, targets, scores = synth_batch(args.batch, 1000 + rank, device)
 
     def barrier():
         if world > 1 or force_dist:
@@ -202,17 +231,20 @@ def main():
                     "conv_time_ms_per_step": round(tot_t / 2 * 1e3, 2),
                     "by_mode_TFLOPs": {k: round(e[0] / e[1] / 1e12, 2) for k, e in by.items()}}
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not anet:
         cpu = cpu_baseline()
     if world > 1:
         dist.barrier()
     if rank == 0:
         print(json.dumps({
-            "metric": "clips/sec training step, 256-frame THUMOS14 clips", "value": round(value, 3),
+            "metric": "clips/sec training step, 768-frame ActivityNet1.3 clips" if anet else
+                      "clips/sec training step, 256-frame THUMOS14 clips", "value": round(value, 3),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "OpenTAL THUMOS14 split_0 training step (configs/thumos14_opental_final.yaml, "
+            "config": {"workload": "OpenTAL ActivityNet1.3 training step (configs/anet_opental.yaml, EDL+IBM loss, per-sample "
+                                   "normalisation, ssl branch off), 768x3x96x96 clips, random-init weights" if anet else
+                                   "OpenTAL THUMOS14 split_0 training step (configs/thumos14_opental_final.yaml, "
                                    "EDL+IBM loss, ssl branch off), 256x3x96x96 clips, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "grad_allreduce": "RCCL, flat-arena buckets overlapped with backward",

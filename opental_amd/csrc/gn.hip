@@ -137,6 +137,17 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
     }
 }
 
+// gfx950 has 160 KB of LDS per CU and one workgroup may own all of it; allocations above the 64 KB default need the
+// kernel's dynamic-LDS cap raised once (the 768-frame ActivityNet maps: 16 channels x 768 x 2 arrays = 96 KB).
+constexpr size_t LDS_MAX = 160 * 1024;
+template <typename K> int allow_large_lds(K kernel, size_t lds, bool& done) {
+    if (lds <= 64 * 1024 || done) return 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_MAX) != hipSuccess) { (void)hipGetLastError(); return OTAL_E_UNSUPPORTED; }
+    done = true;
+    return 0;
+}
+
 int fill_levels(GnLevels& L, int T, int nlev, const int* lev) {
     if (nlev <= 1 || !lev) { L.nlev = 1; L.lev[0] = 0; for (int i = 1; i <= OTAL_MAX_LEVELS; ++i) L.lev[i] = T; return 0; }
     if (nlev > OTAL_MAX_LEVELS || lev[0] != 0 || lev[nlev] != T) return OTAL_E_LEVELS;
@@ -156,7 +167,9 @@ extern "C" int otal_gn_relu_fwd(const float* x, const float* gamma, const float*
     GnLevels L;
     if (int e = fill_levels(L, T, nlev, lev)) return e;
     const size_t lds = (size_t)(C / G) * T * 4 + 64;
-    if (lds > 64 * 1024) return OTAL_E_UNSUPPORTED;
+    if (lds > LDS_MAX) return OTAL_E_UNSUPPORTED;
+    static bool large_ok = false;
+    if (int e = allow_large_lds(gn_relu_fwd_kernel, lds, large_ok)) return e;
     hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G), dim3(256), lds, (hipStream_t)stream,
                        x, gamma, beta, y, stats, C, T, G, eps, relu, L);
     return otal_launch_status();
@@ -170,7 +183,9 @@ extern "C" int otal_gn_relu_bwd(const float* dy, const float* x, const float* ga
     GnLevels L;
     if (int e = fill_levels(L, T, nlev, lev)) return e;
     const size_t lds = (size_t)(C / G) * T * 8 + 64;
-    if (lds > 64 * 1024) return OTAL_E_UNSUPPORTED;
+    if (lds > LDS_MAX) return OTAL_E_UNSUPPORTED;
+    static bool large_ok = false;
+    if (int e = allow_large_lds(gn_relu_bwd_kernel, lds, large_ok)) return e;
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(256), lds, (hipStream_t)stream,
                        dy, x, gamma, beta, stats, dx, partial, C, T, G, relu, L);
     return otal_launch_status();

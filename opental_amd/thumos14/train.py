@@ -111,13 +111,20 @@ class FlatArena:
 
 class DetectorTrainer:
     def __init__(self, net, criterion, loss_weights, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8,
-                 process_group=None, bucket_mb=48, distributed=None, force_collectives=False):
+                 process_group=None, bucket_mb=48, distributed=None, force_collectives=False, param_groups=None,
+                 forward_fn=None):
+        """`param_groups`: [(parameters, lr), ...] in the order the reference hands them to torch.optim.Adam (the
+        ActivityNet recipe trains the backbone at lr/10, anet/train.py:304-312); default one group = net.parameters().
+        `forward_fn`: the recipe's forward_one_epoch (default: this module's, the THUMOS14 one)."""
         self.net, self.criterion, self.w = net, criterion, dict(loss_weights)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.distributed = dist.is_available() and dist.is_initialized() if distributed is None else distributed
         self.group = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self.forward_fn = forward_one_epoch if forward_fn is None else forward_fn
         self.arena = FlatArena(list(net.parameters()), bucket_mb << 20)
+        self.param_groups = [(list(net.parameters()), lr)] if param_groups is None else [(list(ps), g_lr) for ps, g_lr in param_groups]
+        self._group_ranges = self._arena_ranges()
         self.step_count = 0
         self._pending, self._works = None, []
         lo = self.arena.flat.data_ptr()
@@ -128,6 +135,24 @@ class DetectorTrainer:
         self._flushed = None
         for i, p in enumerate(self.arena.params):
             p.register_post_accumulate_grad_hook(self._make_hook(self.arena.bucket_of[i]))
+
+    def _arena_ranges(self):
+        """[(lo, hi, lr)]: each optimizer group must own ONE contiguous slice of the flat arena (module-aligned groups
+        do: the arena is net.parameters() reversed), so that Adam stays one launch per group."""
+        where = {id(p): (off, p.numel()) for p, off in zip(self.arena.params, self.arena.offsets)}
+        out, covered = [], 0
+        for ps, g_lr in self.param_groups:
+            spans = sorted(where[id(p)] for p in ps if id(p) in where)
+            if not spans:
+                continue
+            lo, hi = spans[0][0], spans[-1][0] + spans[-1][1]
+            if sum(n for _, n in spans) != hi - lo:
+                raise ValueError("an optimizer group is not contiguous in the flat arena")
+            out.append((lo, hi, g_lr))
+            covered += hi - lo
+        if covered != self.arena.numel:
+            raise ValueError("optimizer groups must cover every trainable parameter exactly once")
+        return out
 
     # ---- gradients -> flat arena (+ all-reduce), bucket by bucket, overlapped with backward
     # Parameters enter backward with .grad = None, so autograd ADOPTS each incoming gradient tensor instead of
@@ -191,10 +216,10 @@ class DetectorTrainer:
 
     # ---- one optimisation step
     def compute_cost(self, clips, targets, scores, ssl_clips=None, ssl_targets=None):
-        losses = forward_one_epoch(self.net, self.criterion, clips, targets, scores, training=True, ssl=False)
+        losses = self.forward_fn(self.net, self.criterion, clips, targets, scores, training=True, ssl=False)
         cost = total_cost(losses, self.w)
         if ssl_clips is not None:
-            trip = forward_one_epoch(self.net, self.criterion, ssl_clips, ssl_targets, training=True, ssl=True)
+            trip = self.forward_fn(self.net, self.criterion, ssl_clips, ssl_targets, training=True, ssl=True)
             cost = cost + trip * self.w['ssl']
         return cost, losses
 
@@ -215,8 +240,10 @@ class DetectorTrainer:
 
     def optimizer_update(self):
         """Adam (L2 weight decay in the gradient, train.py:321-323) on the flat arena: one launch."""
-        ops.adam_flat(self.arena.flat, self.arena.grad, self.arena.m, self.arena.v, self.step_count, self.lr,
-                      self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
+        a = self.arena
+        for lo, hi, g_lr in self._group_ranges:
+            ops.adam_flat(a.flat[lo:hi], a.grad[lo:hi], a.m[lo:hi], a.v[lo:hi], self.step_count, g_lr,
+                          self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
 
     # ---- the same step as ONE HIP graph: ~1500 launches per step are replayed without host involvement
     def _graph_body(self, clips, targets, scores):
@@ -228,8 +255,10 @@ class DetectorTrainer:
             self.end_backward()
         finally:
             ops.deactivate_prologues()
-        ops.adam_flat_dev(self.arena.flat, self.arena.grad, self.arena.m, self.arena.v, self._bias_corr, self.lr,
-                          self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
+        a = self.arena
+        for lo, hi, g_lr in self._group_ranges:
+            ops.adam_flat_dev(a.flat[lo:hi], a.grad[lo:hi], a.m[lo:hi], a.v[lo:hi], self._bias_corr, g_lr,
+                              self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
         return cost.detach(), losses
 
     def capture_step(self, clips, targets, scores, warmup=2):
@@ -293,7 +322,7 @@ class DetectorTrainer:
         """The Adam state as `torch.optim.Adam(net.parameters(), ...).state_dict()` would hold it (the reference's
         optimizer, train.py:321-323): per-parameter `step` / `exp_avg` / `exp_avg_sq`, indices in net.parameters() order
         (frozen parameters are listed in the group but carry no state)."""
-        allp = list(self.net.parameters())
+        allp = [p for ps, _ in self.param_groups for p in ps]
         index = {id(p): i for i, p in enumerate(allp)}
         state = {}
         if self.step_count > 0:
@@ -302,13 +331,16 @@ class DetectorTrainer:
                 state[index[id(p)]] = {'step': torch.tensor(float(self.step_count)),
                                        'exp_avg': self.arena.m[off:off + k].view(p.shape).clone(),
                                        'exp_avg_sq': self.arena.v[off:off + k].view(p.shape).clone()}
-        group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.wd, 'amsgrad': False,
-                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
-                 'params': list(range(len(allp)))}
-        return {'state': state, 'param_groups': [group]}
+        groups, first = [], 0
+        for ps, g_lr in self.param_groups:
+            groups.append({'lr': g_lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.wd,
+                           'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False,
+                           'differentiable': False, 'fused': None, 'params': list(range(first, first + len(ps)))})
+            first += len(ps)
+        return {'state': state, 'param_groups': groups}
 
     def load_optimizer_state_dict(self, sd):
-        allp = list(self.net.parameters())
+        allp = [p for ps, _ in self.param_groups for p in ps]
         where = {id(p): (off, p) for p, off in zip(self.arena.params, self.arena.offsets)}
         steps = set()
         self.arena.m.zero_(); self.arena.v.zero_()
@@ -324,8 +356,12 @@ class DetectorTrainer:
         if len(steps) > 1:
             raise RuntimeError("per-parameter step counts differ; the flat Adam keeps one")
         self.step_count = steps.pop() if steps else 0
-        g = sd['param_groups'][0]
+        if len(sd['param_groups']) != len(self.param_groups):
+            raise RuntimeError("optimizer state has a different number of parameter groups")
+        g = sd['param_groups'][-1]          # the detection-head group carries the base learning rate
         self.lr, self.betas, self.eps, self.wd = g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']
+        self.param_groups = [(ps, sg['lr']) for (ps, _), sg in zip(self.param_groups, sd['param_groups'])]
+        self._group_ranges = self._arena_ranges()
         self._graph = None
 
     def save_model(self, epoch, checkpoint_path, train_state_path):

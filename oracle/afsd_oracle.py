@@ -209,7 +209,11 @@ def proposal_windows(loc, t, frame_num):
 
 
 def priors_all(cfg=arch.THUMOS):
-    """CoarsePyramid.priors concatenated (BDNet.py:285-293, :415)."""
+    """CoarsePyramid.priors concatenated (BDNet.py:285-293, :415); the ActivityNet variant carries the level id
+    in a second column (anet/BDNet.py:262-269)."""
+    if cfg.get("fpn_strides"):
+        return torch.cat([torch.Tensor([[(c + 0.5) / t, i] for c in range(t)]).view(-1, 2)
+                          for i, t in enumerate(arch.level_lengths(cfg))], 0)
     return torch.cat([torch.Tensor([[(c + 0.5) / t] for c in range(t)]).view(-1, 1)
                       for t in arch.level_lengths(cfg)], 0)
 
@@ -230,19 +234,26 @@ def _head(P, name, x):
 
 
 def coarse_pyramid(P, f4, f5, cfg=arch.THUMOS, compat=False, keep=None):
-    """CoarsePyramid.forward, THUMOS14 variant (BDNet.py:295-432), os_head=True."""
+    """CoarsePyramid.forward, os_head=True: THUMOS14 variant (BDNet.py:295-432) or, with cfg=arch.ANET, the
+    ActivityNet variant (anet/BDNet.py:271-391; f4 is unused there)."""
     Q = "coarse_pyramid_detection"
     frame_num = cfg["frame_num"]
-    b = f4.shape[0]
-    # pyramids[0], [1]: Unit3D 'spatial_valid' (temporal k=1 -> no pad) + GN + ReLU (BDNet.py:129-155)
-    x0 = F.conv3d(f4, P[f"{Q}.pyramids.0.0.conv3d.weight"], P[f"{Q}.pyramids.0.0.conv3d.bias"])
-    x0 = gn_relu(x0.squeeze(-1).squeeze(-1), P[f"{Q}.pyramids.0.1.weight"], P[f"{Q}.pyramids.0.1.bias"])
-    x1 = F.conv3d(f5, P[f"{Q}.pyramids.1.0.conv3d.weight"], P[f"{Q}.pyramids.1.0.conv3d.bias"])
-    x1 = gn_relu(x1.squeeze(-1).squeeze(-1), P[f"{Q}.pyramids.1.1.weight"], P[f"{Q}.pyramids.1.1.bias"])
-    x0 = x0 + F.interpolate(x1, x0.shape[2:], mode="nearest")   # BDNet.py:316-319
-    feats = [x0, x1]
-    x = x1
-    for i in range(2, cfg["layer_num"]):
+    strides = cfg.get("fpn_strides")
+    if cfg.get("two_projections", True):
+        # pyramids[0], [1]: Unit3D 'spatial_valid' (temporal k=1 -> no pad) + GN + ReLU (BDNet.py:129-155)
+        x0 = F.conv3d(f4, P[f"{Q}.pyramids.0.0.conv3d.weight"], P[f"{Q}.pyramids.0.0.conv3d.bias"])
+        x0 = gn_relu(x0.squeeze(-1).squeeze(-1), P[f"{Q}.pyramids.0.1.weight"], P[f"{Q}.pyramids.0.1.bias"])
+        x1 = F.conv3d(f5, P[f"{Q}.pyramids.1.0.conv3d.weight"], P[f"{Q}.pyramids.1.0.conv3d.bias"])
+        x1 = gn_relu(x1.squeeze(-1).squeeze(-1), P[f"{Q}.pyramids.1.1.weight"], P[f"{Q}.pyramids.1.1.bias"])
+        x0 = x0 + F.interpolate(x1, x0.shape[2:], mode="nearest")   # BDNet.py:316-319
+        feats = [x0, x1]
+        x = x1
+    else:
+        # anet/BDNet.py:130-142,:284-290: one projection of Mixed_5c
+        x = F.conv3d(f5, P[f"{Q}.pyramids.0.0.conv3d.weight"], P[f"{Q}.pyramids.0.0.conv3d.bias"])
+        x = gn_relu(x.squeeze(-1).squeeze(-1), P[f"{Q}.pyramids.0.1.weight"], P[f"{Q}.pyramids.0.1.bias"])
+        feats = [x]
+    for i in range(len(feats), cfg["layer_num"]):
         x = block1d(P, f"{Q}.pyramids.{i}", x, stride=2)
         feats.append(x)
     # frame-level branch (BDNet.py:324-331)
@@ -266,6 +277,8 @@ def coarse_pyramid(P, f4, f5, cfg=arch.THUMOS, compat=False, keep=None):
             lf = block1d(P, f"{Q}.loc_tower.{j}", lf)
             cf = block1d(P, f"{Q}.conf_tower.{j}", cf)
         loc = tr(torch.exp(_head(P, f"{Q}.loc_head", lf) * P[f"{Q}.loc_heads.{i}.scale"]))  # ScaleExp :55-61
+        if strides:
+            loc = loc * strides[i]      # anet/BDNet.py:307-311
         locs.append(loc)
         confs.append(tr(_head(P, f"{Q}.conf_head", cf)))
         acts.append(tr(_head(P, f"{Q}.actionness_head", cf)))
@@ -507,6 +520,109 @@ def multisegment_loss(out, targets, cfg=arch.THUMOS, piou=0.5, cls_loss_type="ed
     if cls_loss_type == "edl":  # iou_aware (multisegment_loss.py:234-236, :249-250)
         loss_pc = loss_pc + iou_calibration_mean(pconf.reshape(-1, K), iou_pred.view(-1), K)
     return (loss_l / n, loss_c / n, loss_pl / pn, loss_pc, loss_ct / n, loss_act / an, loss_pact / pan)
+
+
+# --------------------------------------------------------------------------- ActivityNet losses (config 4)
+def evidence_loss_sum_anet(logit, target, epoch, ibm_start=10, coeff=10.0, num_cls=150):
+    """anet EvidenceLoss.forward -> edl_loss, loss_type='log', evidence='exp', with_ibm (anet/cls_loss.py:115-148,
+    :190-239): the influence-balanced weight is the closed form 1 / (|z|_1 * exp(coeff * g) + 1e-10) (no EMA bins),
+    and -- unlike the THUMOS14 file -- |z|_1 is NOT detached (:137, :229)."""
+    y = torch.eye(num_cls)[target]
+    alpha = torch.exp(torch.clamp(logit, -10, 10)) + 1
+    S = alpha.sum(1, keepdim=True)
+    per = (y * (torch.log(S) - torch.log(alpha))).sum(1)
+    if epoch >= ibm_start:
+        a = alpha.detach().clone()
+        u = num_cls / a.sum(-1, keepdim=True)
+        gnorm = (torch.abs(1 / a - u) * y).sum(1)
+        w = 1.0 / (logit.abs().sum(1).reshape(-1) * torch.exp(coeff * gnorm) + 1e-10)
+        per = w * per
+    return per.sum()
+
+
+def multisegment_loss_anet(out, targets, cfg=arch.ANET, piou=0.5, epoch=0, ibm_start=10, act_weight=0.1):
+    """anet MultiSegmentLoss.forward, edl + os_head (anet/multisegment_loss.py:106-301): every term is computed PER
+    SAMPLE with its own normalisers and the batch mean is returned; anchors only regress ground truths whose
+    larger extent lies inside their level's bounds (:69-84, :156-166); the refined-stage IoU threshold drops to the
+    best IoU among the positives when none reaches piou (:178-184); smooth-L1 for the refinement (:206)."""
+    K = cfg["num_classes"]
+    clip = cfg["frame_num"]
+    priors = out["priors"]
+    lb = torch.tensor([cfg["bounds"][int(l)][0] for l in priors[:, 1]], dtype=torch.float32).unsqueeze(1)
+    rb = torch.tensor([cfg["bounds"][int(l)][1] for l in priors[:, 1]], dtype=torch.float32).unsqueeze(1)
+    acc = [[] for _ in range(7)]
+    big = clip * 2
+    for i in range(out["loc"].shape[0]):
+        loc, conf, ploc, pconf = out["loc"][i], out["conf"][i], out["prop_loc"][i], out["prop_conf"][i]
+        center, act, pact = out["center"][i], out["act"][i], out["prop_act"][i]
+        with torch.no_grad():
+            gt, lab = targets[i][:, :-1], targets[i][:, -1]
+            c = priors[:, 0:1]
+            left = (c - gt[:, 0][None, :]) * clip
+            right = (gt[:, 1][None, :] - c) * clip
+            far = torch.max(left, right)
+            area = left + right
+            area[left < 0] = big
+            area[right < 0] = big
+            area[far <= lb.expand_as(far)] = big
+            area[far > rb.expand_as(far)] = big
+            best_area, best = area.min(1)
+            loc_t = torch.stack([(priors[:, 0] - gt[best, 0]) * clip, (gt[best, 1] - priors[:, 0]) * clip], 1)
+            conf_t = lab[best].clone()
+            conf_t[best_area >= big] = 0
+            conf_t = conf_t.long()
+            iou = tiou(loc, loc_t)
+            iou_pred = iou.clone()
+            thr = piou
+            if int((conf_t > 0).sum()) > 0:
+                thr = min(piou, float(iou[conf_t > 0].max()))
+            pconf_t = conf_t.clone()
+            pconf_t[iou < thr] = 0
+            w = loc[:, 0] + loc[:, 1]
+            ploc_t = torch.stack([(loc_t[:, 0] - loc[:, 0]) / (0.5 * w), (loc_t[:, 1] - loc[:, 1]) / (0.5 * w)], 1)
+        pos, ppos = conf_t > 0, pconf_t > 0
+        lp, lt = loc[pos], loc_t[pos]
+        loss_l = giou_loss_sum(lp, lt) if lp.numel() > 0 else lp.sum()
+        pp, pt = ploc[ppos], ploc_t[ppos]
+        loss_pl = F.smooth_l1_loss(pp, pt, reduction="sum") if pp.numel() > 0 else pp.sum()
+        if lp.numel() > 0:
+            ww = (lp[:, 0] + lp[:, 1]).unsqueeze(-1)
+            cur = 0.5 * ww * ploc[pos] + lp
+            q = tiou(cur, lt).clamp(min=0)
+            loss_ct = F.binary_cross_entropy_with_logits(center[pos].view(-1), q, reduction="sum")
+        else:
+            loss_ct = lp.sum()
+        loss_c = evidence_loss_sum_anet(conf[pos], conf_t[pos] - 1, epoch, ibm_start, num_cls=K) \
+            if int(pos.sum()) > 0 else torch.tensor(0.0)
+        loss_act, an = actionness_loss(act.reshape(-1, 1), pos.float(), act_weight)
+        loss_pc = evidence_loss_sum_anet(pconf[ppos], pconf_t[ppos] - 1, epoch, ibm_start, num_cls=K) \
+            if int(ppos.sum()) > 0 else torch.tensor(0.0)
+        loss_pact, pan = actionness_loss(pact.reshape(-1, 1), ppos.float(), act_weight)
+        n = max(int(pos.sum()), 1)
+        pn = max(int(ppos.sum()), 1)
+        loss_pc = loss_pc / pn + iou_calibration_mean(pconf.reshape(-1, K), iou_pred, K)
+        for lst, v in zip(acc, (loss_l / n, loss_c / n, loss_pl / pn, loss_pc, loss_ct / n,
+                                loss_act / an, loss_pact / pan)):
+            lst.append(v)
+    b = out["loc"].shape[0]
+    return tuple(sum(lst) / b for lst in acc)
+
+
+def train_cost_anet(out, targets, scores, cfg=arch.ANET, lw=1.0, cw=1.0, ctw=1.0, actw=1.0, piou=0.5, epoch=0):
+    """anet forward_one_epoch(ssl=False) + the weighted sum of run_one_epoch (anet/train.py:136-224): the boundary
+    masks are rows 1 / 2 of the (b,3,T) scores, the level-0 masks are every 8th frame."""
+    l, c, pl, pc, ct, la, pla = multisegment_loss_anet(out, targets, cfg, piou, epoch)
+    se = scores[:, 1:3]
+    ls, le = boundary_bce(out["start"], out["end"], se)
+    se8 = se[:, :, ::8]
+    a, b = boundary_bce(out["start_loc_prop"], out["end_loc_prop"], se8)
+    c2, d = boundary_bce(out["start_conf_prop"], out["end_conf_prop"], se8)
+    ls = ls + 0.1 * (a + c2)
+    le = le + 0.1 * (b + d)
+    parts = dict(loss_l=l * lw, loss_c=c * cw, loss_prop_l=pl * lw, loss_prop_c=pc * cw,
+                 loss_ct=ct * ctw, loss_start=ls, loss_end=le, loss_act=la * actw,
+                 loss_prop_act=pla * actw)
+    return sum(parts.values()), parts
 
 
 def boundary_bce(start, end, scores):

@@ -43,7 +43,15 @@ MIXED_BRANCH_CONVS = [  # (sub-name, cin source, cout index, kernel)
 
 THUMOS = dict(name="thumos14", frame_num=256, feat_t=64, layer_num=6, num_classes=15,
               feat_channels=(832, 1024), conv_channels=512, two_projections=True,
-              proj_kernels=((1, 6, 6), (1, 3, 3)))
+              proj_kernels=((1, 6, 6), (1, 3, 3)), fpn_strides=None, loc_bias=(0.5, 3.5))
+
+# ActivityNet1.3 variant (configs/anet_opental.yaml, AFSD/anet/BDNet.py:13-33,:120-269): 768 frames, ONE
+# projection (Mixed_5c, [1,3,3]) to t = 96, five stride-2 levels after it, loc in frames = exp(.) * fpn_stride,
+# priors carry the level id in a second column, per-level regression bounds (anet/multisegment_loss.py:69).
+ANET = dict(name="anet", frame_num=768, feat_t=96, layer_num=6, num_classes=150,
+            feat_channels=(1024,), conv_channels=512, two_projections=False,
+            proj_kernels=((1, 3, 3),), fpn_strides=(4, 8, 16, 32, 64, 128), loc_bias=(0.0, 1.5),
+            bounds=((0, 30), (15, 60), (30, 120), (60, 240), (96, 768), (256, 768)))
 
 
 def level_lengths(cfg=THUMOS):
@@ -86,7 +94,7 @@ def param_spec(cfg=THUMOS, in_channels=3):
         spec += [(f"{P}.pyramids.{i}.0.conv3d.weight", (C, fc) + tuple(kk)),
                  (f"{P}.pyramids.{i}.0.conv3d.bias", (C,)),
                  (f"{P}.pyramids.{i}.1.weight", (C,)), (f"{P}.pyramids.{i}.1.bias", (C,))]
-    for i in range(2, cfg["layer_num"]):
+    for i in range(len(cfg["proj_kernels"]), cfg["layer_num"]):
         spec += _unit1d_gn(f"{P}.pyramids.{i}", C, C, 3)
     for i in range(cfg["layer_num"]):
         spec.append((f"{P}.loc_heads.{i}.scale", (1,)))
@@ -145,7 +153,8 @@ def make_params(seed=2020, cfg=THUMOS, in_channels=3, randomize_affine=True, gai
         elif key.endswith(".loc_head.conv1d.bias") and randomize_affine:
             # loc = exp(scale * conv): a bias in [0.5, 3.5] spreads predicted half-lengths over
             # ~2..60 frames so the pooling windows of the fixtures are not all 1-2 frames wide
-            out[key] = rs.uniform(0.5, 3.5, size=shape).astype(np.float32)
+            lo, hi = cfg.get("loc_bias", (0.5, 3.5))
+            out[key] = rs.uniform(lo, hi, size=shape).astype(np.float32)
         elif key.endswith("conv1d.bias") or key.endswith("conv3d.bias"):
             out[key] = (rs.uniform(-0.1, 0.1, size=shape) if randomize_affine
                         else np.zeros(shape)).astype(np.float32)
@@ -180,6 +189,17 @@ def make_targets(seed, batch, num_classes=15, clip_length=256):
             rows.append([start, start + length, float(rs.randint(1, num_classes + 1))])
         out.append(np.asarray(rows, np.float32))
     return out
+
+
+def make_scores_anet(targets, clip_length=768):
+    """(b,3,T) [action, start, end] masks in the layout of AFSD/common/anet_dataset.py:250-255 (rows 1 and 2 are
+    the ones the training step reads, anet/train.py:136-144); bands as in make_scores."""
+    se = make_scores(targets, clip_length)
+    act = np.zeros((len(targets), 1, clip_length), np.float32)
+    for i, t in enumerate(targets):
+        for s, e, _ in t:
+            act[i, 0, int(float(s) * clip_length):int(np.ceil(float(e) * clip_length))] = 1.0
+    return np.concatenate([act, se], 1)
 
 
 def make_scores(targets, clip_length=256):

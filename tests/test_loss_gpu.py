@@ -47,7 +47,7 @@ def test_fused_loss_matches_torch_formulation(B, n_gt, epoch):
             w = [1.0, 10.0, 1.0, 10.0, 1.0, 1.0, 1.0]
             sum(l * wi for l, wi in zip(losses, w)).backward()
             grads = {k: v.grad.clone() for k, v in out.items() if v.requires_grad}
-            res.append(([float(l) for l in losses], grads, crit.cls_loss.weight_accum.clone()))
+            res.append(([float(l.detach()) for l in losses], grads, crit.cls_loss.weight_accum.clone()))
         finally:
             M.FUSED = True
     (l0, g0, w0), (l1, g1, w1) = res
