@@ -1505,11 +1505,14 @@ int choose_splits(int tiles, int K, int prec = 1, bool wgrad = false) {
     static const int minsteps_env = getenv("OTAL_CONV_SPLIT_MINSTEPS") ? atoi(getenv("OTAL_CONV_SPLIT_MINSTEPS")) : 0;
     static const int cap_env = getenv("OTAL_CONV_MAXSPLIT") ? atoi(getenv("OTAL_CONV_MAXSPLIT")) : 0;
     // The vector weight-gradient kernel keeps 4 workgroups per CU resident and its K is huge (all positions): it wants two
-    // full waves of workgroups (2048; 512 left it at 2 waves per SIMD, 61 % of wave time parked) but long splits (>= 48 K
-    // steps) so that the tiny 1x1 layers are not shredded.  Forward / data gradient keep the 512-workgroup target.
+    // full waves of workgroups (2048; 512 left it at 2 waves per SIMD, 61 % of wave time parked).  Splits of >= 16 K steps:
+    // a K step is latency-bound (~1 us) when few workgroups are resident, so the small 1x1 / 1-D layers (18 k or 1 k
+    // positions, a handful of tiles) finish sooner as many short splits than as a few long ones (measured per step:
+    // 48 steps 407.6 clips/s, 24: 419.0, 12: 420.1, 6: 416.2).  Forward / data gradient keep the 512-workgroup target.
     const bool wv = wgrad && prec;
     const int target = target_env ? target_env : (wv ? 2048 : 512);
-    const int minsteps = minsteps_env ? minsteps_env : (wv ? 48 : (prec ? 8 : 4));
+    static const int wg_minsteps_env = getenv("OTAL_WGRAD_MINSTEPS") ? atoi(getenv("OTAL_WGRAD_MINSTEPS")) : 0;
+    const int minsteps = (wv && wg_minsteps_env) ? wg_minsteps_env : minsteps_env ? minsteps_env : (wv ? 16 : (prec ? 8 : 4));
     const int cap = cap_env ? cap_env : (wv ? 1024 : 384);
     if (tiles >= target * 3 / 4) return 1;
     int want = (target + tiles - 1) / tiles;
