@@ -144,6 +144,8 @@ def main():
                     help="replay the training step from one captured HIP graph (auto: fall back to eager launches if capture fails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-hbm-kernels", action="store_true",
+                    help="skip the achieved-GB/s table of the HBM-bound kernel classes (tools/bench_hbm_kernels.py)")
     args = ap.parse_args()
     anet = args.recipe == "anet"
     if args.batch is None:
@@ -230,6 +232,18 @@ def main():
                     "launches_per_step": tot_n // 2, "avg_launch_us": round(tot_t / tot_n * 1e6, 1),
                     "conv_time_ms_per_step": round(tot_t / 2 * 1e3, 2),
                     "by_mode_TFLOPs": {k: round(e[0] / e[1] / 1e12, 2) for k, e in by.items()}}
+    hbm = None
+    if rank == 0 and world == 1 and not args.no_hbm_kernels and not anet:
+        # the bandwidth-bound kernel classes in isolation, at the shapes of this step: algorithmic bytes / launch time
+        # (HIP events around a graph replay of back-to-back launches) against the 8 TB/s HBM peak
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        from bench_hbm_kernels import measure as measure_hbm_kernels
+        from opental_amd.common import ops as _o
+        saved_prec = _o.CONV_PRECISION
+        hbm = {k: {f: v[f] for f in ("us", "algorithmic_MB", "GB/s", "frac_of_8TBps", "resident_in_infinity_cache")}
+               for k, v in measure_hbm_kernels(args.batch).items()}
+        _o.CONV_PRECISION = saved_prec
+        torch.cuda.empty_cache()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not anet:
         cpu = cpu_baseline()
@@ -249,7 +263,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "grad_allreduce": "RCCL, flat-arena buckets overlapped with backward",
                        "launch": "one captured HIP graph per step" if graphed else "eager launches"},
-            "roofline": roofline, "cpu_baseline": cpu}))
+            "roofline": roofline, "hbm_kernels": hbm, "cpu_baseline": cpu}))
     if world > 1 or force_dist:
         dist.destroy_process_group()
 

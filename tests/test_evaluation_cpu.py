@@ -1,0 +1,116 @@
+"""CPU: opental_amd/evaluation against the reference's own evaluator (results committed by oracle/pin_evaluation.py,
+which imports AFSD/evaluation/eval_detection.py from /root/reference): closed-set AP matrix / mAP, the open-set
+AUROC / AUPR / FAR@95 / OSDR for every OOD scoring rule, the thresholded open-set AP -- and the numpy curve metrics
+against scikit-learn on random data with ties."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+TIOUS = [0.3, 0.4, 0.5, 0.6, 0.7]
+
+
+@pytest.fixture(scope="module")
+def paths(golden_dir):
+    return {k: os.path.join(golden_dir, k) for k in ("eval_classes.txt", "eval_gt_open.json", "eval_gt_closed.json",
+                                                      "eval_pred.json", "eval_expected.json")}
+
+
+def detector(paths, gt, **kw):
+    from opental_amd.evaluation.eval_detection import ANETdetection
+    return ANETdetection(ground_truth_filename=paths[gt], prediction_filename=paths["eval_pred.json"],
+                         cls_idx_detection=paths["eval_classes.txt"], subset=["test"], tiou_thresholds=TIOUS,
+                         dataset="thumos14", **kw)
+
+
+def test_closed_set_map_equals_the_reference(paths):
+    want = json.load(open(paths["eval_expected.json"]))["closed"]
+    mAP, avg, ap = detector(paths, "eval_gt_closed.json", openset=False).evaluate(type="AP")
+    assert np.abs(ap - np.array(want["ap"])).max() < 1e-12
+    assert np.abs(mAP - np.array(want["mAP"])).max() < 1e-12 and abs(avg - want["average_mAP"]) < 1e-12
+
+
+@pytest.mark.parametrize("scoring", ["uncertainty", "confidence", "uncertainty_actionness", "a_by_inv_u", "u_by_inv_a", "half_au"])
+def test_open_set_metrics_equal_the_reference(paths, scoring):
+    want = json.load(open(paths["eval_expected.json"]))["open"][scoring]
+    det = detector(paths, "eval_gt_open.json", openset=True, ood_scoring=scoring)
+    det.pre_evaluate()
+    roc, pr, far = det.evaluate(type="AUC")
+    osdr = det.evaluate(type="OSDR")
+    n_fg = [len(det.eval_data[0][t]["known"]) + len(det.eval_data[0][t]["unknown"]) for t in range(len(TIOUS))]
+    assert n_fg == want["matched_foreground"]
+    for got, key in ((roc, "auc_roc"), (pr, "auc_pr"), (far, "far_95"), (osdr, "osdr")):
+        assert got.dtype == np.float32
+        assert np.abs(got - np.array(want[key], np.float32)).max() < 1e-6, key
+
+
+def test_open_set_ap_with_rejection_threshold(paths):
+    want = json.load(open(paths["eval_expected.json"]))["open_ap_threshold_0.3"]
+    mAP, _, ap = detector(paths, "eval_gt_open.json", openset=True, ood_scoring="uncertainty", ood_threshold=0.3).evaluate(type="AP")
+    assert ap.shape == (5, 16)                     # 15 known classes + '__unknown__' in the last column
+    assert np.abs(mAP - np.array(want["mAP"])).max() < 1e-12
+    assert np.abs(ap[:, -1] - np.array(want["ap_unknown_column"])).max() < 1e-12
+
+
+def test_curve_metrics_match_scikit_learn():
+    sk = pytest.importorskip("sklearn.metrics")
+    from opental_amd.evaluation import utils_eval as U
+    rs = np.random.RandomState(0)
+    for n, levels in ((50, None), (400, 12), (1000, None), (3, None)):
+        labels = rs.randint(0, 2, n)
+        labels[:2] = (0, 1)
+        scores = rs.rand(n) if levels is None else rs.randint(0, levels, n) / levels       # ties
+        assert abs(U.roc_auc_score(labels, scores) - sk.roc_auc_score(labels, scores)) < 1e-12
+        assert abs(U.average_precision_score(labels, scores) - sk.average_precision_score(labels, scores)) < 1e-12
+        fpr, tpr, _ = U.roc_curve(labels, scores)
+        f2, t2, _ = sk.roc_curve(labels, scores, pos_label=1)
+        assert np.array_equal(fpr, f2) and np.array_equal(tpr, t2)
+
+
+def test_open_set_detection_rate_small_cases():
+    from opental_amd.evaluation.utils_eval import open_set_detection_rate
+
+    def slow(preds, pred_cls, gt_cls):             # the reference's loop, restated for the check
+        x1, x2 = preds[gt_cls > 0], preds[gt_cls == 0]
+        m = (pred_cls[gt_cls > 0] == gt_cls[gt_cls > 0]).astype(float)
+        k_t = np.concatenate((m, np.zeros(len(x2)))); u_t = np.concatenate((np.zeros(len(x1)), np.ones(len(x2))))
+        idx = np.concatenate((x1, x2)).argsort(); n = len(preds)
+        sk_, su = k_t[idx], u_t[idx]
+        C, F = [0.0] * (n + 2), [0.0] * (n + 2)
+        for k in range(n - 1):
+            C[k] = sk_[k + 1:].sum() / len(x1) if len(x1) > 0 else 1.0
+            F[k] = su[k:].sum() / len(x2) if len(x2) > 0 else 0.0
+        C[n + 1] = F[n + 1] = 1.0
+        roc = sorted(zip(F, C), reverse=True)
+        return sum((roc[j][0] - roc[j + 1][0]) * (roc[j][1] + roc[j + 1][1]) / 2.0 for j in range(n + 1))
+    rs = np.random.RandomState(1)
+    for n in (1, 2, 5, 40):
+        for _ in range(5):
+            preds, pc, gc = rs.rand(n), rs.randint(1, 4, n), rs.randint(0, 4, n)
+            assert abs(open_set_detection_rate(preds, pc, gc)[0] - slow(preds, pc, gc)) < 1e-12
+    preds, pc = rs.rand(6), rs.randint(1, 4, 6)           # no known sample at all / no unknown sample at all
+    for gc in (np.zeros(6, int), pc.copy()):
+        assert abs(open_set_detection_rate(preds, pc, gc)[0] - slow(preds, pc, gc)) < 1e-12
+
+
+def test_driver_writes_the_reference_text_files(paths, tmp_path):
+    import shutil
+    from opental_amd.thumos14 import eval_open
+    pred = tmp_path / "split_0" / "detection_results.json"
+    pred.parent.mkdir()
+    shutil.copy(paths["eval_pred.json"], pred)
+    res = eval_open.main([str(tmp_path / "split_{id:d}" / "detection_results.json"), paths["eval_gt_open.json"],
+                          "--cls_idx_known", paths["eval_classes.txt"], "--all_splits", "0", "--open_set",
+                          "--ood_scoring", "uncertainty"])
+    want = json.load(open(paths["eval_expected.json"]))["open"]["uncertainty"]
+    assert np.abs(res[0]["osdr"] - np.array(want["osdr"], np.float32)).max() < 1e-6
+    lines = open(pred.parent / "eval_open.txt").read().splitlines()
+    assert lines[0] == (f"tIoU=0.3: far@95={want['far_95'][0]:.5f}, auc_roc={want['auc_roc'][0]:.5f}, "
+                        f"auc_pr={want['auc_pr'][0]:.5f}, osdr={want['osdr'][0]:.5f}")
+    assert lines[-1].startswith("Average FAR@95: ") and len(lines) == 6
+    res = eval_open.main([str(tmp_path / "split_{id:d}" / "detection_results.json"), paths["eval_gt_closed.json"],
+                          "--cls_idx_known", paths["eval_classes.txt"], "--all_splits", "0"])
+    want = json.load(open(paths["eval_expected.json"]))["closed"]
+    assert abs(res[0]["average_mAP"] - want["average_mAP"]) < 1e-12
+    assert open(pred.parent / "eval.txt").read().splitlines()[-1] == f"Average mAP: {want['average_mAP']:.5f}"
