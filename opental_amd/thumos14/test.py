@@ -132,3 +132,33 @@ def detect_batch(net, videos, sample_fps, clip_length=256, stride=128, conf_thre
               for k in ('loc', 'conf', 'prop_loc', 'prop_conf', 'center', 'act', 'prop_act', 'priors')}
     dec = decode_clips(merged, offsets, fps, clip_length, conf_thresh)
     return softnms_classes(dec, clip_start, top_k, nms_sigma) + (dec,)
+
+
+# ----------------------------------------------------------------------------- result files (test.py:246-252, threshold.py:128-150)
+OOD_SCORES = {
+    'uncertainty': lambda p: p['uncertainty'],
+    'confidence': lambda p: 1 - p['score'],
+    'uncertainty_actionness': lambda p: p['uncertainty'] * p['actionness'],
+    'a_by_inv_u': lambda p: p['actionness'] / (1 - p['uncertainty'] + 1e-6),
+    'u_by_inv_a': lambda p: p['uncertainty'] / (1 - p['actionness'] + 1e-6),
+    'half_au': lambda p: 0.5 * (p['actionness'] + 1) * p['uncertainty'],
+}
+
+
+def results_json(result_dict, threshold=None, version="THUMOS14"):
+    """The result-file layout AFSD/evaluation reads: {'version', 'results': {video: [proposal, ...]}, 'external_data'}."""
+    ext = {} if threshold is None else {'threshold': float(threshold)}
+    return {"version": version, "results": dict(result_dict), "external_data": ext}
+
+
+def ood_threshold(result_dict, scoring='uncertainty'):
+    """The known/unknown operating point of AFSD/thumos14/threshold.py:128-150: run the detector over the TRAINING
+    videos, turn every detection into a known-ness score (1 - its OOD score) and take the value that 95 % of the
+    detections exceed."""
+    import numpy as np
+    score = OOD_SCORES[scoring]
+    all_scores = [1 - score(p) for props in result_dict.values() for p in props]
+    n = len(all_scores)
+    if n == 0:
+        raise ValueError("no detections to threshold")
+    return float(np.sort(all_scores)[n - int(n * 0.95) - 1])

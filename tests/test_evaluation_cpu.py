@@ -114,3 +114,16 @@ def test_driver_writes_the_reference_text_files(paths, tmp_path):
     want = json.load(open(paths["eval_expected.json"]))["closed"]
     assert abs(res[0]["average_mAP"] - want["average_mAP"]) < 1e-12
     assert open(pred.parent / "eval.txt").read().splitlines()[-1] == f"Average mAP: {want['average_mAP']:.5f}"
+
+
+def test_ood_threshold_is_the_5th_percentile_of_knownness(paths):
+    from opental_amd.thumos14.test import ood_threshold, results_json
+    results = json.load(open(paths["eval_pred.json"]))["results"]
+    for scoring, f in (("uncertainty", lambda p: 1 - p["uncertainty"]), ("confidence", lambda p: p["score"]),
+                       ("uncertainty_actionness", lambda p: 1 - p["uncertainty"] * p["actionness"]),
+                       ("half_au", lambda p: 1 - 0.5 * (p["actionness"] + 1) * p["uncertainty"])):
+        scores = np.sort([f(p) for v in results.values() for p in v])       # threshold.py:128-148, literally
+        n = len(scores)
+        assert abs(ood_threshold(results, scoring) - scores[n - int(n * 0.95) - 1]) < 1e-12
+    out = results_json(results, threshold=0.25)
+    assert set(out) == {"version", "results", "external_data"} and out["external_data"] == {"threshold": 0.25}
