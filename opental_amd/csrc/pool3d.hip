@@ -427,6 +427,272 @@ int fill(PoolGeom& g, const int* d, const int64_t* s) {
     return 0;
 }
 
+// ---- the same nine pools, SEPARABLE.  max over the 3x3x3 window = max_dt PM[t+dt-1][h][w], PM[t'][h][w] = max_dh
+// RM[t'][h+dh-1][w], RM[t'][h''][w] = max_dw x[t'][h''][w+dw-1] (zero halo everywhere): three 1-D maxima of three values
+// instead of 27 compare/select pairs per output (the flat kernels are VALU-bound: 156 us for the 254 MB of Mixed_3b's
+// pool, a third of the HBM rate).  Taking the FIRST maximum at every stage selects the lexicographically first
+// (dt,dh,dw) among the window's maxima -- exactly the flat scan's winner.  Each stage's tap is a property of its own
+// cell, so the byte of position p holds tapW of RM[p] (bits 1:0), tapH of PM[p] (3:2) and tapT of out[p] (5:4), and the
+// backward pass routes gradients back through the three stages: 9 candidate reads per input element instead of 27,
+// summed in ascending tap order per stage (deterministic; association differs from a flat scan by fp32 rounding only).
+__device__ __forceinline__ void first_max3(float a, float b, float c, float& v, int& k) {
+    v = a; k = 0;
+    if (b > v || b != b) { v = b; k = 1; }
+    if (c > v || c != c) { v = c; k = 2; }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void maxpool333_sep_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 unsigned char* __restrict__ arg, PoolGeom g, int TT) {
+    extern __shared__ float sm[];
+    constexpr int Q = P + 2, PL = Q * Q, PP = P * P, CR = Q * P;
+    const int tid = threadIdx.x;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    const int to0 = blockIdx.x * TT;
+    const int tt = min(TT, g.To - to0);
+    const int TL = tt + 2;
+    float* xs = sm;                                              // [TL][Q][Q] input with zero halo; later pm [TL][P][P]
+    float* rm = sm + (TT + 2) * PL;                              // [TL][Q][P] row maxima
+    unsigned char* tw = reinterpret_cast<unsigned char*>(rm + (TT + 2) * CR);   // [TL][Q][P]
+    unsigned char* th = tw + (TT + 2) * CR;                      // [TL][P][P]
+    const float* xb = x + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs;
+    for (int i = tid; i < TL * PL; i += 256) {
+        const int tl = i / PL, r = i - tl * PL, hl = r / Q, wl = r - hl * Q;
+        const int ti = to0 - 1 + tl, hi = hl - 1, wi = wl - 1;
+        const bool in = (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)P && (unsigned)wi < (unsigned)P;
+        const float v = xb[in ? (ti * P + hi) * P + wi : 0];
+        xs[i] = in ? v : 0.f;
+    }
+    __syncthreads();
+    {   // rows: one thread per (row, column) of a plane, walking the planes
+        constexpr int G = 256 / CR;
+        const int grp = tid / CR, cell = tid - grp * CR;
+        const int hl = cell / P, w = cell - hl * P;
+        if (grp < G)
+            for (int tl = grp; tl < TL; tl += G) {
+                const float* r = xs + (tl * Q + hl) * Q + w;
+                float v; int k;
+                first_max3(r[0], r[1], r[2], v, k);
+                rm[(tl * Q + hl) * P + w] = v;
+                tw[(tl * Q + hl) * P + w] = (unsigned char)k;
+            }
+    }
+    __syncthreads();
+    constexpr int G2 = 256 / PP;
+    const int grp = tid / PP, cell = tid - grp * PP;
+    const int h = cell / P, w = cell - h * P;
+    float* pm = xs;
+    if (grp < G2)
+        for (int tl = grp; tl < TL; tl += G2) {
+            const float* r = rm + (tl * Q + h) * P + w;
+            float v; int k;
+            first_max3(r[0], r[P], r[2 * P], v, k);
+            pm[tl * PP + cell] = v;
+            th[tl * PP + cell] = (unsigned char)k;
+        }
+    __syncthreads();
+    const int Pn = g.To * PP;
+    if (grp < G2)
+        for (int tq = grp; tq < tt; tq += G2) {
+            const float* r = pm + tq * PP + cell;
+            float v; int k;
+            first_max3(r[0], r[PP], r[2 * PP], v, k);
+            const int p = (to0 + tq) * PP + cell;
+            y[(int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p] = v;
+            arg[(int64_t)bc * Pn + p] = (unsigned char)(tw[((tq + 1) * Q + h + 1) * P + w] | (th[(tq + 1) * PP + cell] << 2) | (k << 4));
+        }
+}
+
+constexpr int POOL_SEP_ELEMS = 1152;     // input elements per backward workgroup (8 planes of 12x12, 32 of 6x6, 128 of 3x3)
+template <int P>
+__global__ __launch_bounds__(256) void maxpool333_sep_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                                 float* __restrict__ dx, PoolGeom g, int accumulate,
+                                                                 const float* __restrict__ emask, const float* __restrict__ escale) {
+    extern __shared__ float sm[];
+    constexpr int PP = P * P, TI = POOL_SEP_ELEMS / PP, J = (POOL_SEP_ELEMS + 255) / 256;
+    const int tid = threadIdx.x;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    const int ti0 = blockIdx.x * TI;
+    const int tin = min(TI, g.Ti - ti0);
+    const int n = tin * PP;
+    float* dys = sm;                                             // [tin + 2][PP]: dy of output planes ti0-1 .. ti0+tin
+    float* gp = dys + (TI + 2) * PP;                             // [tin][PP] gradient w.r.t. the plane maxima
+    float* gr = gp + TI * PP;                                    // [tin][PP] gradient w.r.t. the row maxima
+    unsigned char* tp = reinterpret_cast<unsigned char*>(gr + TI * PP);         // [tin + 2][PP] tap bytes (0xff: no plane)
+    const float* dyb = dy + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs;
+    const unsigned char* ab = arg + (int64_t)bc * g.To * PP;
+    const int64_t xoff = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ti0 * PP;
+    // epilogue operands first: their latency hides behind the three LDS stages
+    float mk[J], old[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int i = min(tid + 256 * j, n - 1);
+        mk[j] = emask ? emask[xoff + i] : 1.f;
+        old[j] = accumulate ? dx[xoff + i] : 0.f;
+    }
+    const int first = (ti0 - 1) * PP, total = g.To * PP;
+    for (int i = tid; i < (tin + 2) * PP; i += 256) {
+        const int o = first + i;
+        const bool in = o >= 0 && o < total;
+        dys[i] = in ? dyb[in ? o : 0] : 0.f;
+        tp[i] = in ? ab[in ? o : 0] : (unsigned char)0xff;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {                         // through the t stage: out planes t+1-dt, dt = 0, 1, 2
+        float s = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int j = i + (2 - dt) * PP;
+            s += ((tp[j] >> 4) & 3) == dt ? dys[j] : 0.f;
+        }
+        gp[i] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {                         // through the h stage: plane-max cells h+1-dh of the same plane
+        const int r = i % PP, h2 = r / P;
+        float s = 0.f;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hh = h2 + 1 - dh;
+            const int j = i + (1 - dh) * P;
+            if ((unsigned)hh < (unsigned)P) s += ((tp[j + PP] >> 2) & 3) == dh ? gp[j] : 0.f;
+        }
+        gr[i] = s;
+    }
+    __syncthreads();
+    const float esc = emask ? escale[c] : 1.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {                                // through the w stage: row-max cells w+1-dw of the same row
+        const int i = tid + 256 * j;
+        if (i >= n) break;
+        const int w_in = i % P;
+        float s = 0.f;
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+            const int ww = w_in + 1 - dw;
+            const int q = i + (1 - dw);
+            if ((unsigned)ww < (unsigned)P) s += (tp[q + PP] & 3) == dw ? gr[q] : 0.f;
+        }
+        if (emask) s = mk[j] > 0.f ? s * esc : 0.f;              // ReLU/BN backward of the pooled layer
+        dx[xoff + i] = old[j] + s;
+    }
+}
+
+// ---- MaxPool3d_2a / 3a: kernel (1,3,3), stride (1,2,2), SAME padding = one zero row / column at the END of each axis,
+// planes with even height and a width that is a multiple of 4.  The generic kernels issue one dword load per tap (9 per
+// output, every second one wasted by the stride): texture-addresser-bound at 3 of 8 TB/s.  Here a thread owns TWO
+// neighbouring outputs and reads each of its three input rows as one aligned float4 + one dword (forward), or owns a
+// 2 x 4 block of inputs and reads the six outputs that can point into it (backward); results are identical to the
+// generic kernels (same scan order, same first-maximum rule, padding zeros take part, winner-is-padding = 255).
+__device__ __forceinline__ void scan_tap(float v, bool in, int tap, bool first, float& best, int& win) {
+    if (first || v > best || v != v) { best = v; win = in ? tap : 255; }
+}
+
+__global__ __launch_bounds__(256) void maxpool133_s122_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  unsigned char* __restrict__ arg, PoolGeom g, FastDiv fW2) {
+    const int W2 = g.Wo >> 1;
+    const int p2 = blockIdx.x * 256 + threadIdx.x;
+    if (p2 >= g.To * g.Ho * W2) return;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    const uint32_t q = fd_div(fW2, p2);
+    const int m = p2 - q * W2;
+    const uint32_t t = fd_div(g.fHo, q);
+    const int ho = q - t * g.Ho;
+    const float* xr = x + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)t * g.Hi + 2 * ho) * g.Wi + 4 * m;
+    const bool cin = 4 * m + 4 < g.Wi;                 // the fifth column exists (else it is the zero pad)
+    float4 v[3];
+    float e[3];
+    bool rin[3];
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+        rin[dh] = 2 * ho + dh < g.Hi;
+        v[dh] = rin[dh] ? *reinterpret_cast<const float4*>(xr + dh * g.Wi) : make_float4(0.f, 0.f, 0.f, 0.f);
+        e[dh] = (rin[dh] && cin) ? xr[dh * g.Wi + 4] : 0.f;
+    }
+    float b0 = 0.f, b1 = 0.f;
+    int w0 = 255, w1 = 255;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+        scan_tap(v[dh].x, rin[dh], dh * 3 + 0, dh == 0, b0, w0);
+        scan_tap(v[dh].y, rin[dh], dh * 3 + 1, false, b0, w0);
+        scan_tap(v[dh].z, rin[dh], dh * 3 + 2, false, b0, w0);
+        scan_tap(v[dh].z, rin[dh], dh * 3 + 0, dh == 0, b1, w1);
+        scan_tap(v[dh].w, rin[dh], dh * 3 + 1, false, b1, w1);
+        scan_tap(e[dh], rin[dh] && cin, dh * 3 + 2, false, b1, w1);
+    }
+    const int p = ((int)t * g.Ho + ho) * g.Wo + 2 * m;
+    *reinterpret_cast<float2*>(y + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p) = make_float2(b0, b1);
+    *reinterpret_cast<unsigned short*>(arg + (int64_t)bc * g.To * g.Ho * g.Wo + p) = (unsigned short)(w0 | (w1 << 8));
+}
+
+__global__ __launch_bounds__(256) void maxpool133_s122_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                                  float* __restrict__ dx, PoolGeom g, int accumulate,
+                                                                  const float* __restrict__ emask, const float* __restrict__ escale,
+                                                                  FastDiv fW4, FastDiv fH2) {
+    const int W4 = g.Wi >> 2, H2 = g.Hi >> 1;
+    const int p4 = blockIdx.x * 256 + threadIdx.x;
+    if (p4 >= g.Ti * H2 * W4) return;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    const uint32_t q = fd_div(fW4, p4);
+    const int m = p4 - q * W4;
+    const uint32_t t = fd_div(fH2, q);
+    const int a = q - t * H2;
+    const int64_t xo = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)t * g.Hi + 2 * a) * g.Wi + 4 * m;
+    float4 mk[2], old[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        mk[i] = emask ? *reinterpret_cast<const float4*>(emask + xo + i * g.Wi) : make_float4(1.f, 1.f, 1.f, 1.f);
+        old[i] = accumulate ? *reinterpret_cast<const float4*>(dx + xo + i * g.Wi) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // D[r][k], A[r][k]: output rows a-1 (r = 0) and a (r = 1), output columns 2m-1, 2m, 2m+1
+    const float* dyb = dy + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + (int64_t)t * g.Ho * g.Wo;
+    const unsigned char* ab = arg + ((int64_t)bc * g.To + t) * g.Ho * g.Wo;
+    float D[2][3];
+    int A[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int ho = a - 1 + r, wo = 2 * m - 1 + k;
+            const bool in = ho >= 0 && wo >= 0;
+            const int o = in ? ho * g.Wo + wo : 0;
+            const float d = dyb[o];
+            const int t_ = ab[o];
+            D[r][k] = in ? d : 0.f;
+            A[r][k] = in ? t_ : 255;
+        }
+    auto hit = [&](int r, int k, int tap) { return A[r][k] == tap ? D[r][k] : 0.f; };
+    float4 s0, s1;                                  // ascending tap order per input element
+    s0.x = ((hit(1, 1, 0) + hit(1, 0, 2)) + hit(0, 1, 6)) + hit(0, 0, 8);
+    s0.y = hit(1, 1, 1) + hit(0, 1, 7);
+    s0.z = ((hit(1, 2, 0) + hit(1, 1, 2)) + hit(0, 2, 6)) + hit(0, 1, 8);
+    s0.w = hit(1, 2, 1) + hit(0, 2, 7);
+    s1.x = hit(1, 1, 3) + hit(1, 0, 5);
+    s1.y = hit(1, 1, 4);
+    s1.z = hit(1, 2, 3) + hit(1, 1, 5);
+    s1.w = hit(1, 2, 4);
+    if (emask) {
+        const float esc = escale[c];
+        s0.x = mk[0].x > 0.f ? s0.x * esc : 0.f; s0.y = mk[0].y > 0.f ? s0.y * esc : 0.f;
+        s0.z = mk[0].z > 0.f ? s0.z * esc : 0.f; s0.w = mk[0].w > 0.f ? s0.w * esc : 0.f;
+        s1.x = mk[1].x > 0.f ? s1.x * esc : 0.f; s1.y = mk[1].y > 0.f ? s1.y * esc : 0.f;
+        s1.z = mk[1].z > 0.f ? s1.z * esc : 0.f; s1.w = mk[1].w > 0.f ? s1.w * esc : 0.f;
+    }
+    *reinterpret_cast<float4*>(dx + xo) = make_float4(old[0].x + s0.x, old[0].y + s0.y, old[0].z + s0.z, old[0].w + s0.w);
+    *reinterpret_cast<float4*>(dx + xo + g.Wi) = make_float4(old[1].x + s1.x, old[1].y + s1.y, old[1].z + s1.z, old[1].w + s1.w);
+}
+
+static inline bool is_133_s122(const PoolGeom& g, const void* x, const void* y) {
+    return g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 2 && g.sw == 2 && g.pt == 0 && g.ph == 0 && g.pw == 0 &&
+           g.Hi % 2 == 0 && g.Wi % 4 == 0 && g.To == g.Ti && g.Ho == g.Hi / 2 && g.Wo == g.Wi / 2 &&
+           g.x_bs % 4 == 0 && g.x_cs % 4 == 0 && g.y_bs % 2 == 0 && g.y_cs % 2 == 0 &&
+           (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 && !getenv("OTAL_POOL_NO133");
+}
+
 constexpr size_t POOL_LDS_BUDGET = 48 * 1024;
 // the Inception branch pools: 3x3x3, stride 1, pad 1, square planes of side 12 / 6 / 3 with T unchanged
 static inline bool is_333_s1(const PoolGeom& g) {
@@ -478,6 +744,26 @@ extern "C" int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
+    if (is_133_s122(g, x, y)) {
+        const int n2 = g.To * g.Ho * (g.Wo / 2);
+        hipLaunchKernelGGL(maxpool133_s122_fwd_kernel, dim3((n2 + 255) / 256, g.B * g.C), dim3(256), 0, st_, x, y, argtap, g,
+                           make_fastdiv((uint32_t)(g.Wo / 2)));
+        return otal_launch_status();
+    }
+    static const bool separable = !getenv("OTAL_POOL_SEP") || atoi(getenv("OTAL_POOL_SEP")) != 0;
+    if (is_333_s1(g) && separable && !getenv("OTAL_POOL_NOLDS")) {
+        static const int tile_elems = getenv("OTAL_POOL_TILE") ? atoi(getenv("OTAL_POOL_TILE")) : 1152;
+        const int P = g.Hi, Q = P + 2;
+        int tt = tile_elems / (P * P);
+        tt = tt < 1 ? 1 : (tt > g.To ? g.To : tt);
+        auto need = [&](int t) { return (size_t)(t + 2) * (Q * Q + Q * P) * sizeof(float) + (size_t)(t + 2) * (Q * P + P * P); };
+        while (tt > 1 && need(tt) > POOL_LDS_BUDGET) --tt;
+        const dim3 grid((g.To + tt - 1) / tt, g.B * g.C);
+        if (P == 12) hipLaunchKernelGGL(maxpool333_sep_fwd_kernel<12>, grid, dim3(256), need(tt), st_, x, y, argtap, g, tt);
+        else if (P == 6) hipLaunchKernelGGL(maxpool333_sep_fwd_kernel<6>, grid, dim3(256), need(tt), st_, x, y, argtap, g, tt);
+        else hipLaunchKernelGGL(maxpool333_sep_fwd_kernel<3>, grid, dim3(256), need(tt), st_, x, y, argtap, g, tt);
+        return otal_launch_status();
+    }
     if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
         static const int tile_elems = getenv("OTAL_POOL_TILE") ? atoi(getenv("OTAL_POOL_TILE")) : 4096;
         int tt = tile_elems / (g.Hi * g.Wi);
@@ -513,6 +799,22 @@ extern "C" int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
+    if (is_133_s122(g, dx, dy) && (!out_mask || (reinterpret_cast<uintptr_t>(out_mask) & 15) == 0)) {
+        const int n4 = g.Ti * (g.Hi / 2) * (g.Wi / 4);
+        hipLaunchKernelGGL(maxpool133_s122_bwd_kernel, dim3((n4 + 255) / 256, g.B * g.C), dim3(256), 0, st_, dy, argtap, dx, g,
+                           accumulate, out_mask, out_scale, make_fastdiv((uint32_t)(g.Wi / 4)), make_fastdiv((uint32_t)(g.Hi / 2)));
+        return otal_launch_status();
+    }
+    static const bool separable = !getenv("OTAL_POOL_SEP") || atoi(getenv("OTAL_POOL_SEP")) != 0;
+    if (is_333_s1(g) && separable && !getenv("OTAL_POOL_NOLDS")) {
+        const int PP = g.Hi * g.Wi, ti = POOL_SEP_ELEMS / PP;
+        const size_t l3 = (size_t)((ti + 2) * PP + 2 * ti * PP) * sizeof(float) + (size_t)(ti + 2) * PP;
+        const dim3 grid((g.Ti + ti - 1) / ti, g.B * g.C);
+        if (g.Hi == 12) hipLaunchKernelGGL(maxpool333_sep_bwd_kernel<12>, grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale);
+        else if (g.Hi == 6) hipLaunchKernelGGL(maxpool333_sep_bwd_kernel<6>, grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale);
+        else hipLaunchKernelGGL(maxpool333_sep_bwd_kernel<3>, grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale);
+        return otal_launch_status();
+    }
     if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
         // smaller t-tiles than the forward: ~16 KB of LDS per workgroup keeps 8 of them resident per CU, so one
         // workgroup's staging overlaps the others' gather (measured: 1152 elements 245 us, 4096 elements 310 us on 3c)

@@ -362,3 +362,38 @@ def test_fused_1x1_launches_match_separate_ones(prec):
         assert float(Z[:, o1 + o3 + c0:].abs().max()) == 0.0
     finally:
         ops.CONV_PRECISION = old
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 5, 48, 48), (1, 2, 3, 24, 24), (1, 1, 2, 2, 4)])
+def test_strided_pool_fast_path_equals_generic_kernels(shape, monkeypatch):
+    """MaxPool3d_2a / 3a (kernel (1,3,3), stride (1,2,2)): the float4 kernels against the generic ones -- outputs and
+    winner taps bit for bit, the fused mask / scale / accumulate backward within fp32 add order; dx may be a channel
+    slice of a larger buffer."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(21)
+    k, s = (1, 3, 3), (1, 2, 2)
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).clamp(min=0).cuda()        # zeros tie with the padding
+    x[0, 0, 0] = -1.0                                                                   # a plane where the zero padding wins
+    y1, a1 = ops.maxpool3d_forward(x, k, s)
+    monkeypatch.setenv("OTAL_POOL_NO133", "1")
+    y0, a0 = ops.maxpool3d_forward(x, k, s)
+    monkeypatch.delenv("OTAL_POOL_NO133")
+    assert torch.equal(y0, y1) and torch.equal(a0, a1)
+    dy = torch.from_numpy(rs.randn(*y0.shape).astype(np.float32)).cuda()
+    sc = torch.from_numpy(rs.uniform(0.5, 1.5, shape[1]).astype(np.float32)).cuda()
+    big = torch.from_numpy(rs.randn(shape[0], shape[1] + 4, *shape[2:]).astype(np.float32)).cuda()
+    outs = []
+    for generic in (True, False):
+        if generic:
+            monkeypatch.setenv("OTAL_POOL_NO133", "1")
+        else:
+            monkeypatch.delenv("OTAL_POOL_NO133", raising=False)
+        buf = big.clone()
+        xm = torch.zeros_like(big)
+        xm[:, 4:] = x                                   # the mask source shares dx's (sliced) layout, as in the backbone
+        ops.maxpool3d_backward(dy, a0, x.shape, k, s, out=buf[:, 4:], accumulate=True, out_mask=xm[:, 4:], out_scale=sc)
+        plain = ops.maxpool3d_backward(dy, a0, x.shape, k, s)
+        outs.append((buf, plain))
+    assert torch.equal(outs[0][0][:, :4], outs[1][0][:, :4])
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-6, atol=1e-6)
