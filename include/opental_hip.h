@@ -152,7 +152,11 @@ int otal_gn_relu_bwd(const float* dy, const float* x, const float* gamma, const 
 
 /* ------------------------------------------------------------------ MaxPool3dSamePadding ----
  * geom: 17 ints B,C, Ti,Hi,Wi, To,Ho,Wo, kt,kh,kw, st,sh,sw, pt,ph,pw (front pads; ZERO padding);
- * strides as for the convolution.  argtap: (B,C,To,Ho,Wo) uint8 winner tap (255 = padded zero).
+ * strides as for the convolution.  argtap: (B,C,To,Ho,Wo) uint8, OPAQUE to the caller: written by _fwd, consumed by
+ * _bwd with the same geometry.  (Content: the winner's tap index (dt*kh+dh)*kw+dw, 255 = a padded zero won; for the
+ * 3x3x3 / stride 1 / pad 1 pools on 12x12, 6x6 and 3x3 planes the maximum is taken separably and the byte of position p
+ * holds three 2-bit axis taps: w stage bits 1:0, h stage 3:2, t stage 5:4 -- see csrc/pool3d.hip.)  In every case the
+ * winner is the FIRST maximum in (dt,dh,dw) scan order with the zero padding taking part.
  * Replaces MaxPool3dSamePadding.forward (AFSD/common/layers.py:9-35) and its autograd backward. */
 int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const float* x, float* y,
                        unsigned char* argtap, void* stream);

@@ -280,132 +280,6 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_lds_kernel(const float* __r
     }
 }
 
-// ---- 3x3x3 / stride 1 / pad 1 on P x P planes (the nine Inception branch pools: P = 12, 6, 3): plane size as a
-// template constant, so every tap offset is an LDS immediate and the index decode is shifts/multiplies.  The generic
-// LDS kernels spent most of their time on per-tap address arithmetic (VALU-bound: 140 us for a 151 MB tensor).
-template <int P>
-__global__ __launch_bounds__(256) void maxpool333_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                             unsigned char* __restrict__ arg, PoolGeom g, int TT) {
-    extern __shared__ float sm[];
-    constexpr int Q = P + 2, PL = Q * Q, PP = P * P;
-    const int bc = blockIdx.y;
-    const int b = bc / g.C, c = bc - b * g.C;
-    const int to0 = blockIdx.x * TT;
-    const int tt = min(TT, g.To - to0);
-    const int TL = tt + 2;
-    const float* xb = x + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs;
-    for (int i = threadIdx.x; i < TL * PL; i += 256) {
-        const int tl = i / PL, r = i - tl * PL, hl = r / Q, wl = r - hl * Q;
-        const int ti = to0 - 1 + tl, hi = hl - 1, wi = wl - 1;
-        const bool in = (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)P && (unsigned)wi < (unsigned)P;
-        const float v = xb[in ? (ti * P + hi) * P + wi : 0];
-        sm[i] = in ? v : 0.f;
-    }
-    __syncthreads();
-    const int Pn = g.To * PP;
-    for (int i = threadIdx.x; i < tt * PP; i += 256) {
-        const int tq = i / PP, r = i - tq * PP, ho = r / P, wo = r - ho * P;
-        const float* base = sm + (tq * Q + ho) * Q + wo;
-        float best = 0.f;
-        int win = 0;
-#pragma unroll
-        for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-            for (int dh = 0; dh < 3; ++dh)
-#pragma unroll
-                for (int dw = 0; dw < 3; ++dw) {
-                    const float v = base[(dt * Q + dh) * Q + dw];
-                    if ((dt | dh | dw) == 0 || v > best || v != v) { best = v; win = (dt * 3 + dh) * 3 + dw; }
-                }
-        const int wdt = win / 9, wr = win - wdt * 9, wdh = wr / 3, wdw = wr - wdh * 3;
-        const int ti = to0 + tq - 1 + wdt, hi = ho - 1 + wdh, wi = wo - 1 + wdw;
-        const bool in = (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)P && (unsigned)wi < (unsigned)P;
-        const int p = to0 * PP + i;
-        y[(int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p] = best;
-        arg[(int64_t)bc * Pn + p] = (unsigned char)(in ? win : 255);
-    }
-}
-
-template <int P>
-__global__ __launch_bounds__(256) void maxpool333_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
-                                                             float* __restrict__ dx, PoolGeom g, int accumulate,
-                                                             const float* __restrict__ emask, const float* __restrict__ escale,
-                                                             int TI) {
-    extern __shared__ float2 sm2[];             // {dy, winner tap as int bits}; halo: {0, 255}
-    constexpr int Q = P + 2, PL = Q * Q, PP = P * P;
-    const int bc = blockIdx.y;
-    const int b = bc / g.C, c = bc - b * g.C;
-    const int ti0 = blockIdx.x * TI;
-    const int tin = min(TI, g.Ti - ti0);
-    const int TLo = tin + 2;                    // output planes ti0-1 .. ti0+tin
-    const float* dyb = dy + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs;
-    const unsigned char* ab = arg + (int64_t)bc * g.To * PP;
-#ifndef OTAL_POOL_U
-#define OTAL_POOL_U 8       // measured on MI355X (tools/micro_pool.py): 8 staged loads in flight, output loop unbatched
-#endif
-#ifndef OTAL_POOL_UO
-#define OTAL_POOL_UO 1
-#endif
-    constexpr int U = OTAL_POOL_U;              // staging loads in flight per thread
-    for (int i0 = threadIdx.x; i0 < TLo * PL; i0 += 256 * U) {
-        float d[U];
-        int a[U];
-        bool in[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + 256 * u;
-            const int tl = i / PL, r = i - tl * PL, hl = r / Q, wl = r - hl * Q;
-            const int to = ti0 - 1 + tl, ho = hl - 1, wo = wl - 1;
-            in[u] = i < TLo * PL && (unsigned)to < (unsigned)g.To && (unsigned)ho < (unsigned)P && (unsigned)wo < (unsigned)P;
-            const int o = in[u] ? (to * P + ho) * P + wo : 0;
-            d[u] = dyb[o];
-            a[u] = ab[o];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (i0 + 256 * u < TLo * PL) sm2[i0 + 256 * u] = make_float2(in[u] ? d[u] : 0.f, __int_as_float(in[u] ? a[u] : 255));
-    }
-    __syncthreads();
-    constexpr int UO = OTAL_POOL_UO;
-    const float esc = emask ? escale[c] : 1.f;
-    for (int i0 = threadIdx.x; i0 < tin * PP; i0 += 256 * UO) {
-        float acc[UO], mk[UO], old[UO];
-        int64_t off[UO];
-#pragma unroll
-        for (int u = 0; u < UO; ++u) {
-            const int i = min(i0 + 256 * u, tin * PP - 1);
-            off[u] = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ti0 * PP + i;
-            mk[u] = emask ? emask[off[u]] : 1.f;
-            old[u] = accumulate ? dx[off[u]] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < UO; ++u) {
-            const int i = min(i0 + 256 * u, tin * PP - 1);
-            const int tq = i / PP, r = i - tq * PP, hi = r / P, wi = r - hi * P;
-            // input (ti,hi,wi) is tap (dt,dh,dw) of output (ti+1-dt, hi+1-dh, wi+1-dw); LDS index of output o is o+1 per axis
-            const float2* base = sm2 + ((tq + 2) * Q + (hi + 2)) * Q + (wi + 2);
-            float s_ = 0.f;
-#pragma unroll
-            for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-                for (int dh = 0; dh < 3; ++dh)
-#pragma unroll
-                    for (int dw = 0; dw < 3; ++dw) {
-                        const float2 e = base[-((dt * Q + dh) * Q + dw)];
-                        s_ += __float_as_int(e.y) == (dt * 3 + dh) * 3 + dw ? e.x : 0.f;     // ascending tap order: deterministic
-                    }
-            acc[u] = s_;
-        }
-#pragma unroll
-        for (int u = 0; u < UO; ++u) {
-            if (i0 + 256 * u >= tin * PP) continue;
-            float v = acc[u];
-            if (emask) v = mk[u] > 0.f ? v * esc : 0.f;         // ReLU/BN backward of the pooled layer
-            dx[off[u]] = old[u] + v;
-        }
-    }
-}
-
 int fill(PoolGeom& g, const int* d, const int64_t* s) {
     // d: B,C, Ti,Hi,Wi, To,Ho,Wo, kt,kh,kw, st,sh,sw, pt,ph,pw
     g.B = d[0]; g.C = d[1]; g.Ti = d[2]; g.Hi = d[3]; g.Wi = d[4]; g.To = d[5]; g.Ho = d[6]; g.Wo = d[7];
@@ -427,7 +301,7 @@ int fill(PoolGeom& g, const int* d, const int64_t* s) {
     return 0;
 }
 
-// ---- the same nine pools, SEPARABLE.  max over the 3x3x3 window = max_dt PM[t+dt-1][h][w], PM[t'][h][w] = max_dh
+// ---- 3x3x3 / stride 1 / pad 1 on P x P planes (the nine Inception branch pools: P = 12, 6, 3), SEPARABLE.  max over the 3x3x3 window = max_dt PM[t+dt-1][h][w], PM[t'][h][w] = max_dh
 // RM[t'][h+dh-1][w], RM[t'][h''][w] = max_dw x[t'][h''][w+dw-1] (zero halo everywhere): three 1-D maxima of three values
 // instead of 27 compare/select pairs per output (the flat kernels are VALU-bound: 156 us for the 254 MB of Mixed_3b's
 // pool, a third of the HBM rate).  Taking the FIRST maximum at every stage selects the lexicographically first
@@ -750,8 +624,7 @@ extern "C" int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const
                            make_fastdiv((uint32_t)(g.Wo / 2)));
         return otal_launch_status();
     }
-    static const bool separable = !getenv("OTAL_POOL_SEP") || atoi(getenv("OTAL_POOL_SEP")) != 0;
-    if (is_333_s1(g) && separable && !getenv("OTAL_POOL_NOLDS")) {
+    if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
         static const int tile_elems = getenv("OTAL_POOL_TILE") ? atoi(getenv("OTAL_POOL_TILE")) : 1152;
         const int P = g.Hi, Q = P + 2;
         int tt = tile_elems / (P * P);
@@ -762,18 +635,6 @@ extern "C" int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const
         if (P == 12) hipLaunchKernelGGL(maxpool333_sep_fwd_kernel<12>, grid, dim3(256), need(tt), st_, x, y, argtap, g, tt);
         else if (P == 6) hipLaunchKernelGGL(maxpool333_sep_fwd_kernel<6>, grid, dim3(256), need(tt), st_, x, y, argtap, g, tt);
         else hipLaunchKernelGGL(maxpool333_sep_fwd_kernel<3>, grid, dim3(256), need(tt), st_, x, y, argtap, g, tt);
-        return otal_launch_status();
-    }
-    if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
-        static const int tile_elems = getenv("OTAL_POOL_TILE") ? atoi(getenv("OTAL_POOL_TILE")) : 4096;
-        int tt = tile_elems / (g.Hi * g.Wi);
-        tt = tt < 1 ? 1 : (tt > g.To ? g.To : tt);
-        while (tt > 1 && (size_t)(tt + 2) * (g.Hi + 2) * (g.Wi + 2) * sizeof(float) > POOL_LDS_BUDGET) --tt;
-        const size_t l3 = (size_t)(tt + 2) * (g.Hi + 2) * (g.Wi + 2) * sizeof(float);
-        const dim3 grid((g.To + tt - 1) / tt, g.B * g.C);
-        if (g.Hi == 12) hipLaunchKernelGGL(maxpool333_fwd_kernel<12>, grid, dim3(256), l3, st_, x, y, argtap, g, tt);
-        else if (g.Hi == 6) hipLaunchKernelGGL(maxpool333_fwd_kernel<6>, grid, dim3(256), l3, st_, x, y, argtap, g, tt);
-        else hipLaunchKernelGGL(maxpool333_fwd_kernel<3>, grid, dim3(256), l3, st_, x, y, argtap, g, tt);
         return otal_launch_status();
     }
     size_t lds = 0;
@@ -805,28 +666,13 @@ extern "C" int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const
                            accumulate, out_mask, out_scale, make_fastdiv((uint32_t)(g.Wi / 4)), make_fastdiv((uint32_t)(g.Hi / 2)));
         return otal_launch_status();
     }
-    static const bool separable = !getenv("OTAL_POOL_SEP") || atoi(getenv("OTAL_POOL_SEP")) != 0;
-    if (is_333_s1(g) && separable && !getenv("OTAL_POOL_NOLDS")) {
+    if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
         const int PP = g.Hi * g.Wi, ti = POOL_SEP_ELEMS / PP;
         const size_t l3 = (size_t)((ti + 2) * PP + 2 * ti * PP) * sizeof(float) + (size_t)(ti + 2) * PP;
         const dim3 grid((g.Ti + ti - 1) / ti, g.B * g.C);
         if (g.Hi == 12) hipLaunchKernelGGL(maxpool333_sep_bwd_kernel<12>, grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale);
         else if (g.Hi == 6) hipLaunchKernelGGL(maxpool333_sep_bwd_kernel<6>, grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale);
         else hipLaunchKernelGGL(maxpool333_sep_bwd_kernel<3>, grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale);
-        return otal_launch_status();
-    }
-    if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
-        // smaller t-tiles than the forward: ~16 KB of LDS per workgroup keeps 8 of them resident per CU, so one
-        // workgroup's staging overlaps the others' gather (measured: 1152 elements 245 us, 4096 elements 310 us on 3c)
-        static const int tile_elems = getenv("OTAL_POOL_TILE") ? atoi(getenv("OTAL_POOL_TILE")) : 1152;
-        int ti = tile_elems / (g.Hi * g.Wi);
-        ti = ti < 1 ? 1 : (ti > g.Ti ? g.Ti : ti);
-        while (ti > 1 && (size_t)(ti + 2) * (g.Hi + 2) * (g.Wi + 2) * sizeof(float2) > POOL_LDS_BUDGET) --ti;
-        const size_t l3 = (size_t)(ti + 2) * (g.Hi + 2) * (g.Wi + 2) * sizeof(float2);
-        const dim3 grid((g.Ti + ti - 1) / ti, g.B * g.C);
-        if (g.Hi == 12) hipLaunchKernelGGL(maxpool333_bwd_kernel<12>, grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, ti);
-        else if (g.Hi == 6) hipLaunchKernelGGL(maxpool333_bwd_kernel<6>, grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, ti);
-        else hipLaunchKernelGGL(maxpool333_bwd_kernel<3>, grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, ti);
         return otal_launch_status();
     }
     size_t lds = 0;
