@@ -454,18 +454,21 @@ __global__ __launch_bounds__(256) void maxpool333_sep_bwd_kernel(const float* __
     }
 }
 
-// ---- MaxPool3d_2a / 3a: kernel (1,3,3), stride (1,2,2), SAME padding = one zero row / column at the END of each axis,
-// planes with even height and a width that is a multiple of 4.  The generic kernels issue one dword load per tap (9 per
-// output, every second one wasted by the stride): texture-addresser-bound at 3 of 8 TB/s.  Here a thread owns TWO
-// neighbouring outputs and reads each of its three input rows as one aligned float4 + one dword (forward), or owns a
-// 2 x 4 block of inputs and reads the six outputs that can point into it (backward); results are identical to the
-// generic kernels (same scan order, same first-maximum rule, padding zeros take part, winner-is-padding = 255).
+// ---- MaxPool3d_2a / 3a (kernel (1,3,3), stride (1,2,2)) and MaxPool3d_4a ((3,3,3) / (2,2,2)): SAME padding = one zero
+// plane / row / column at the END of each strided axis, planes with even height and a width that is a multiple of 4.
+// The generic kernels issue one dword load per tap (9 or 27 per output, every second one wasted by the stride):
+// texture-addresser-bound at 3 of 8 TB/s.  Here a thread owns TWO neighbouring outputs and reads each of its input rows
+// as one aligned float4 + one dword (forward), or owns a 2 x 4 block of inputs and reads the outputs that can point into
+// it (backward: 6 per candidate output plane); results are identical to the generic kernels (same scan order, same
+// first-maximum rule, padding zeros take part, winner-is-padding = 255).  KT = 1 (stride 1 in t) or 3 (stride 2 in t).
 __device__ __forceinline__ void scan_tap(float v, bool in, int tap, bool first, float& best, int& win) {
     if (first || v > best || v != v) { best = v; win = in ? tap : 255; }
 }
 
-__global__ __launch_bounds__(256) void maxpool133_s122_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                  unsigned char* __restrict__ arg, PoolGeom g, FastDiv fW2) {
+template <int KT>
+__global__ __launch_bounds__(256) void maxpoolk33_s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                unsigned char* __restrict__ arg, PoolGeom g, FastDiv fW2) {
+    constexpr int ST = KT == 3 ? 2 : 1;
     const int W2 = g.Wo >> 1;
     const int p2 = blockIdx.x * 256 + threadIdx.x;
     if (p2 >= g.To * g.Ho * W2) return;
@@ -475,37 +478,45 @@ __global__ __launch_bounds__(256) void maxpool133_s122_fwd_kernel(const float* _
     const int m = p2 - q * W2;
     const uint32_t t = fd_div(g.fHo, q);
     const int ho = q - t * g.Ho;
-    const float* xr = x + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)t * g.Hi + 2 * ho) * g.Wi + 4 * m;
+    const float* xr = x + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)t * ST * g.Hi + 2 * ho) * g.Wi + 4 * m;
     const bool cin = 4 * m + 4 < g.Wi;                 // the fifth column exists (else it is the zero pad)
-    float4 v[3];
-    float e[3];
-    bool rin[3];
+    float4 v[KT][3];
+    float e[KT][3];
+    bool rin[KT][3];
 #pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-        rin[dh] = 2 * ho + dh < g.Hi;
-        v[dh] = rin[dh] ? *reinterpret_cast<const float4*>(xr + dh * g.Wi) : make_float4(0.f, 0.f, 0.f, 0.f);
-        e[dh] = (rin[dh] && cin) ? xr[dh * g.Wi + 4] : 0.f;
-    }
+    for (int dt = 0; dt < KT; ++dt)
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            rin[dt][dh] = (int)t * ST + dt < g.Ti && 2 * ho + dh < g.Hi;
+            const float* r = xr + ((int64_t)dt * g.Hi + dh) * g.Wi;
+            v[dt][dh] = rin[dt][dh] ? *reinterpret_cast<const float4*>(r) : make_float4(0.f, 0.f, 0.f, 0.f);
+            e[dt][dh] = (rin[dt][dh] && cin) ? r[4] : 0.f;
+        }
     float b0 = 0.f, b1 = 0.f;
     int w0 = 255, w1 = 255;
 #pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-        scan_tap(v[dh].x, rin[dh], dh * 3 + 0, dh == 0, b0, w0);
-        scan_tap(v[dh].y, rin[dh], dh * 3 + 1, false, b0, w0);
-        scan_tap(v[dh].z, rin[dh], dh * 3 + 2, false, b0, w0);
-        scan_tap(v[dh].z, rin[dh], dh * 3 + 0, dh == 0, b1, w1);
-        scan_tap(v[dh].w, rin[dh], dh * 3 + 1, false, b1, w1);
-        scan_tap(e[dh], rin[dh] && cin, dh * 3 + 2, false, b1, w1);
-    }
+    for (int dt = 0; dt < KT; ++dt)
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int tap = (dt * 3 + dh) * 3;
+            const bool first = dt == 0 && dh == 0, in = rin[dt][dh];
+            scan_tap(v[dt][dh].x, in, tap + 0, first, b0, w0);
+            scan_tap(v[dt][dh].y, in, tap + 1, false, b0, w0);
+            scan_tap(v[dt][dh].z, in, tap + 2, false, b0, w0);
+            scan_tap(v[dt][dh].z, in, tap + 0, first, b1, w1);
+            scan_tap(v[dt][dh].w, in, tap + 1, false, b1, w1);
+            scan_tap(e[dt][dh], in && cin, tap + 2, false, b1, w1);
+        }
     const int p = ((int)t * g.Ho + ho) * g.Wo + 2 * m;
     *reinterpret_cast<float2*>(y + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p) = make_float2(b0, b1);
     *reinterpret_cast<unsigned short*>(arg + (int64_t)bc * g.To * g.Ho * g.Wo + p) = (unsigned short)(w0 | (w1 << 8));
 }
 
-__global__ __launch_bounds__(256) void maxpool133_s122_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
-                                                                  float* __restrict__ dx, PoolGeom g, int accumulate,
-                                                                  const float* __restrict__ emask, const float* __restrict__ escale,
-                                                                  FastDiv fW4, FastDiv fH2) {
+template <int KT>
+__global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                                float* __restrict__ dx, PoolGeom g, int accumulate,
+                                                                const float* __restrict__ emask, const float* __restrict__ escale,
+                                                                FastDiv fW4, FastDiv fH2) {
     const int W4 = g.Wi >> 2, H2 = g.Hi >> 1;
     const int p4 = blockIdx.x * 256 + threadIdx.x;
     if (p4 >= g.Ti * H2 * W4) return;
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(256) void maxpool133_s122_bwd_kernel(const float* _
     const int b = bc / g.C, c = bc - b * g.C;
     const uint32_t q = fd_div(fW4, p4);
     const int m = p4 - q * W4;
-    const uint32_t t = fd_div(fH2, q);
+    const int t = (int)fd_div(fH2, q);
     const int a = q - t * H2;
     const int64_t xo = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)t * g.Hi + 2 * a) * g.Wi + 4 * m;
     float4 mk[2], old[2];
@@ -522,33 +533,47 @@ __global__ __launch_bounds__(256) void maxpool133_s122_bwd_kernel(const float* _
         mk[i] = emask ? *reinterpret_cast<const float4*>(emask + xo + i * g.Wi) : make_float4(1.f, 1.f, 1.f, 1.f);
         old[i] = accumulate ? *reinterpret_cast<const float4*>(dx + xo + i * g.Wi) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // D[r][k], A[r][k]: output rows a-1 (r = 0) and a (r = 1), output columns 2m-1, 2m, 2m+1
-    const float* dyb = dy + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + (int64_t)t * g.Ho * g.Wo;
-    const unsigned char* ab = arg + ((int64_t)bc * g.To + t) * g.Ho * g.Wo;
-    float D[2][3];
-    int A[2][3];
+    // candidate output planes, ascending tap (dt) order: KT = 1: plane t (dt 0);  KT = 3, stride 2: plane t/2 with
+    // dt = t & 1, then -- for even t -- plane t/2 - 1 with dt = 2
+    constexpr int NP = KT == 3 ? 2 : 1;
+    float D[NP][2][3];
+    int A[NP][2][3];
+    int base[NP];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int pl = 0; pl < NP; ++pl) {
+        const int to = KT == 1 ? t : (t >> 1) - pl;
+        const bool pin = KT == 1 || (pl == 0 ? true : ((t & 1) == 0 && to >= 0));
+        base[pl] = KT == 1 ? 0 : 9 * (pl == 0 ? (t & 1) : 2);
+        const float* dyb = dy + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + (int64_t)(pin ? to : 0) * g.Ho * g.Wo;
+        const unsigned char* ab = arg + ((int64_t)bc * g.To + (pin ? to : 0)) * g.Ho * g.Wo;
+        // D[r][k], A[r][k]: output rows a-1 (r = 0) and a (r = 1), output columns 2m-1, 2m, 2m+1
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int ho = a - 1 + r, wo = 2 * m - 1 + k;
-            const bool in = ho >= 0 && wo >= 0;
-            const int o = in ? ho * g.Wo + wo : 0;
-            const float d = dyb[o];
-            const int t_ = ab[o];
-            D[r][k] = in ? d : 0.f;
-            A[r][k] = in ? t_ : 255;
-        }
-    auto hit = [&](int r, int k, int tap) { return A[r][k] == tap ? D[r][k] : 0.f; };
-    float4 s0, s1;                                  // ascending tap order per input element
-    s0.x = ((hit(1, 1, 0) + hit(1, 0, 2)) + hit(0, 1, 6)) + hit(0, 0, 8);
-    s0.y = hit(1, 1, 1) + hit(0, 1, 7);
-    s0.z = ((hit(1, 2, 0) + hit(1, 1, 2)) + hit(0, 2, 6)) + hit(0, 1, 8);
-    s0.w = hit(1, 2, 1) + hit(0, 2, 7);
-    s1.x = hit(1, 1, 3) + hit(1, 0, 5);
-    s1.y = hit(1, 1, 4);
-    s1.z = hit(1, 2, 3) + hit(1, 1, 5);
-    s1.w = hit(1, 2, 4);
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int ho = a - 1 + r, wo = 2 * m - 1 + k;
+                const bool in = pin && ho >= 0 && wo >= 0;
+                const int o = in ? ho * g.Wo + wo : 0;
+                const float d = dyb[o];
+                const int t_ = ab[o];
+                D[pl][r][k] = in ? d : 0.f;
+                A[pl][r][k] = in ? t_ : 255;
+            }
+    }
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;   // ascending tap order per input element
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+        const int tb = base[pl];
+        auto hit = [&](int r, int k, int tap) { return A[pl][r][k] == tb + tap ? D[pl][r][k] : 0.f; };
+        s0.x += ((hit(1, 1, 0) + hit(1, 0, 2)) + hit(0, 1, 6)) + hit(0, 0, 8);
+        s0.y += hit(1, 1, 1) + hit(0, 1, 7);
+        s0.z += ((hit(1, 2, 0) + hit(1, 1, 2)) + hit(0, 2, 6)) + hit(0, 1, 8);
+        s0.w += hit(1, 2, 1) + hit(0, 2, 7);
+        s1.x += hit(1, 1, 3) + hit(1, 0, 5);
+        s1.y += hit(1, 1, 4);
+        s1.z += hit(1, 2, 3) + hit(1, 1, 5);
+        s1.w += hit(1, 2, 4);
+    }
     if (emask) {
         const float esc = escale[c];
         s0.x = mk[0].x > 0.f ? s0.x * esc : 0.f; s0.y = mk[0].y > 0.f ? s0.y * esc : 0.f;
@@ -560,11 +585,16 @@ __global__ __launch_bounds__(256) void maxpool133_s122_bwd_kernel(const float* _
     *reinterpret_cast<float4*>(dx + xo + g.Wi) = make_float4(old[1].x + s1.x, old[1].y + s1.y, old[1].z + s1.z, old[1].w + s1.w);
 }
 
-static inline bool is_133_s122(const PoolGeom& g, const void* x, const void* y) {
-    return g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 2 && g.sw == 2 && g.pt == 0 && g.ph == 0 && g.pw == 0 &&
-           g.Hi % 2 == 0 && g.Wi % 4 == 0 && g.To == g.Ti && g.Ho == g.Hi / 2 && g.Wo == g.Wi / 2 &&
-           g.x_bs % 4 == 0 && g.x_cs % 4 == 0 && g.y_bs % 2 == 0 && g.y_cs % 2 == 0 &&
-           (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 && !getenv("OTAL_POOL_NO133");
+// 1: the (1,3,3)/(1,2,2) pools, 3: the (3,3,3)/(2,2,2) pool, 0: not one of them (or misaligned operands)
+static inline int strided_k33_kind(const PoolGeom& g, const void* x, const void* y) {
+    if (!(g.kh == 3 && g.kw == 3 && g.sh == 2 && g.sw == 2 && g.pt == 0 && g.ph == 0 && g.pw == 0 && g.Hi % 2 == 0 &&
+          g.Wi % 4 == 0 && g.Ho == g.Hi / 2 && g.Wo == g.Wi / 2 && g.x_bs % 4 == 0 && g.x_cs % 4 == 0 && g.y_bs % 2 == 0 &&
+          g.y_cs % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0) ||
+        getenv("OTAL_POOL_NO133"))
+        return 0;
+    if (g.kt == 1 && g.st == 1 && g.To == g.Ti) return 1;
+    if (g.kt == 3 && g.st == 2 && g.Ti % 2 == 0 && g.To == g.Ti / 2) return 3;
+    return 0;
 }
 
 constexpr size_t POOL_LDS_BUDGET = 48 * 1024;
@@ -618,10 +648,12 @@ extern "C" int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
-    if (is_133_s122(g, x, y)) {
+    if (const int kind = strided_k33_kind(g, x, y)) {
         const int n2 = g.To * g.Ho * (g.Wo / 2);
-        hipLaunchKernelGGL(maxpool133_s122_fwd_kernel, dim3((n2 + 255) / 256, g.B * g.C), dim3(256), 0, st_, x, y, argtap, g,
-                           make_fastdiv((uint32_t)(g.Wo / 2)));
+        const dim3 grid((n2 + 255) / 256, g.B * g.C);
+        const FastDiv fW2 = make_fastdiv((uint32_t)(g.Wo / 2));
+        if (kind == 1) hipLaunchKernelGGL(maxpoolk33_s2_fwd_kernel<1>, grid, dim3(256), 0, st_, x, y, argtap, g, fW2);
+        else hipLaunchKernelGGL(maxpoolk33_s2_fwd_kernel<3>, grid, dim3(256), 0, st_, x, y, argtap, g, fW2);
         return otal_launch_status();
     }
     if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
@@ -660,10 +692,13 @@ extern "C" int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
-    if (is_133_s122(g, dx, dy) && (!out_mask || (reinterpret_cast<uintptr_t>(out_mask) & 15) == 0)) {
+    const int kind = (!out_mask || (reinterpret_cast<uintptr_t>(out_mask) & 15) == 0) ? strided_k33_kind(g, dx, dy) : 0;
+    if (kind) {
         const int n4 = g.Ti * (g.Hi / 2) * (g.Wi / 4);
-        hipLaunchKernelGGL(maxpool133_s122_bwd_kernel, dim3((n4 + 255) / 256, g.B * g.C), dim3(256), 0, st_, dy, argtap, dx, g,
-                           accumulate, out_mask, out_scale, make_fastdiv((uint32_t)(g.Wi / 4)), make_fastdiv((uint32_t)(g.Hi / 2)));
+        const dim3 grid((n4 + 255) / 256, g.B * g.C);
+        const FastDiv fW4 = make_fastdiv((uint32_t)(g.Wi / 4)), fH2 = make_fastdiv((uint32_t)(g.Hi / 2));
+        if (kind == 1) hipLaunchKernelGGL(maxpoolk33_s2_bwd_kernel<1>, grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2);
+        else hipLaunchKernelGGL(maxpoolk33_s2_bwd_kernel<3>, grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2);
         return otal_launch_status();
     }
     if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {

@@ -364,14 +364,14 @@ def test_fused_1x1_launches_match_separate_ones(prec):
         ops.CONV_PRECISION = old
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 5, 48, 48), (1, 2, 3, 24, 24), (1, 1, 2, 2, 4)])
-def test_strided_pool_fast_path_equals_generic_kernels(shape, monkeypatch):
-    """MaxPool3d_2a / 3a (kernel (1,3,3), stride (1,2,2)): the float4 kernels against the generic ones -- outputs and
-    winner taps bit for bit, the fused mask / scale / accumulate backward within fp32 add order; dx may be a channel
-    slice of a larger buffer."""
+@pytest.mark.parametrize("k,s", [((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2))])
+@pytest.mark.parametrize("shape", [(2, 3, 6, 48, 48), (1, 2, 4, 24, 24), (1, 5, 8, 12, 12), (1, 1, 2, 2, 4)])
+def test_strided_pool_fast_path_equals_generic_kernels(shape, k, s, monkeypatch):
+    """MaxPool3d_2a / 3a (kernel (1,3,3), stride (1,2,2)) and 4a ((3,3,3) / (2,2,2)): the float4 kernels against the
+    generic ones -- outputs and winner taps bit for bit, the fused mask / scale / accumulate backward within fp32 add
+    order; dx may be a channel slice of a larger buffer."""
     from opental_amd.common import ops
     rs = np.random.RandomState(21)
-    k, s = (1, 3, 3), (1, 2, 2)
     x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).clamp(min=0).cuda()        # zeros tie with the padding
     x[0, 0, 0] = -1.0                                                                   # a plane where the zero padding wins
     y1, a1 = ops.maxpool3d_forward(x, k, s)
