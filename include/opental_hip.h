@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 8
+#define OTAL_ABI_VERSION 9
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -144,7 +144,7 @@ int otal_conv_pack_wt(const float* w, float* wt, int Cout, int Cin, int kvol, vo
  * (AFSD/thumos14/BDNet.py:67-103,:129-203,:274-284). */
 int otal_gn_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
                      int B, int C, int T, int G, float eps, int relu, int nlev, const int* lev, void* stream);
-/* dx and per-(sample,channel) partial sums partial[(b*C+c)*3 + {0,1,2}] = {d_gamma, d_beta, sum_t dx}
+/* dx and per-(sample,channel) partial sums partial[(b*3 + {0,1,2})*C + c] = {d_gamma, d_beta, sum_t dx}
  * (sum over b by the caller; sum_t dx is the gradient of the preceding convolution's bias). */
 int otal_gn_relu_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
                      const float* stats, float* dx, float* partial, int B, int C, int T, int G,

@@ -267,7 +267,7 @@ class I3DFeaturesFunction(Function):
                 continue
             zs = tape[pos - 1][-1]
             if zs is not None:
-                g = g * (z > 0) * zs.view(1, -1, 1, 1, 1)
+                g = torch.ops.aten.threshold_backward(g, z, 0.0) * zs.view(1, -1, 1, 1, 1)     # g * (z > 0) * scale
             else:
                 g = g.contiguous().clone()
             pending[pos] = pending[pos] + g if pos in pending else g

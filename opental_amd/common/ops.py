@@ -355,12 +355,12 @@ def gn_relu_backward(dy, x, gamma, beta, stats, groups=32, relu=True, levels=Non
     B, C, T = x.shape
     nlev, lev = _lev_arg(levels)
     dx = torch.empty_like(x)
-    partial = torch.empty((B, C, 3), dtype=torch.float32, device=x.device)
+    partial = torch.empty((B, 3, C), dtype=torch.float32, device=x.device)
     L.check(L.lib().otal_gn_relu_bwd(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.ptr(dx),
                                      L.ptr(partial), B, C, T, groups, int(relu), nlev, lev, L.stream()),
             "otal_gn_relu_bwd")
-    red = partial.sum(0)            # (C,3): d_gamma, d_beta, d_conv_bias
-    return dx, red[:, 0].contiguous(), red[:, 1].contiguous(), red[:, 2].contiguous()
+    red = partial.sum(0)            # (3,C): d_gamma, d_beta, d_conv_bias -- three contiguous rows, no copies
+    return dx, red[0], red[1], red[2]
 
 
 # ----------------------------------------------------------------------------- MaxPool3d (SAME, zero pad)

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
     }
 }
 
-// dx: (B,C,T); partial: (B,C,3) = {sum dyh*xhat, sum dyh, sum dx}
+// dx: (B,C,T); partial: (B,3,C) = {sum dyh*xhat, sum dyh, sum dx} (channel-contiguous rows: summing over b leaves
+// d_gamma, d_beta and the bias gradient as three contiguous vectors)
 __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ stats, float* __restrict__ dx,
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
         }
         a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
         if (lane == 0) {
-            float* p = partial + ((int64_t)b * C + ch) * 3;
-            p[0] = a0; p[1] = a1; p[2] = a2;
+            float* p = partial + (int64_t)b * 3 * C + ch;
+            p[0] = a0; p[C] = a1; p[2 * C] = a2;
         }
     }
 }

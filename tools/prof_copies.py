@@ -1,4 +1,4 @@
-"""Which Python source lines issue the device copies (aten::copy_ / cat / clone) of one training step."""
+"""Shapes of the device copies (aten::copy_ / cat / contiguous / clone) of one training step, by count and time."""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -11,14 +11,13 @@ for _ in range(3):
     tr.step(clips, targets, scores)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     tr.step(clips, targets, scores)
     torch.cuda.synchronize()
 acc = collections.defaultdict(lambda: [0, 0.0])
 for e in prof.events():
-    if e.name in ("aten::copy_", "aten::cat", "aten::add", "aten::add_", "aten::sum", "aten::mul", "aten::fill_", "aten::zero_") and e.device_time_total > 0:
-        where = next((s for s in e.stack if "/repo/" in s and "tools/" not in s), None) or next(iter(e.stack), "?")
-        k = (e.name, where.strip()[-110:])
+    if e.name in ("aten::copy_", "aten::cat", "aten::add", "aten::add_", "aten::sum", "aten::mul", "aten::fill_", "aten::zero_", "aten::_foreach_copy_") and e.device_time_total > 0:
+        k = (e.name, str(e.input_shapes)[:110])
         acc[k][0] += 1; acc[k][1] += e.device_time_total
-for (name, where), (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:45]:
-    print(f"{t/1e3:7.3f} ms n={n:3d} {name:12s} {where}")
+for (name, shp), (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f"{t/1e3:7.3f} ms n={n:3d} {name:12s} {shp}")
