@@ -1,0 +1,82 @@
+"""Inference path of the ActivityNet1.3 recipe on MI355X, with the reference's function names (AFSD/anet/test.py):
+prepare_clip (:83-92), decode_prediction (:95-132), filtering (:135-156), get_video_prediction (:159-200).
+
+A video is ONE 768-frame clip here (the data is resampled to the clip length, anet/test.py:71-80), so a batch of videos
+is a batch of clips: the network runs on them together and the same two launches as THUMOS14 finish the job --
+otal_decode_clips (refine + decode + Dirichlet scores + thresholds, for every clip) and otal_softnms_classes (one
+workgroup per (video, class)).  Differences from the THUMOS14 file that are kept: short videos are padded with 127.5
+(mid-grey), the confidence threshold is 0.001, proposals are clipped to [0, duration] and empty ones dropped.
+"""
+import torch
+
+from ..thumos14 import test as _t
+
+CLIP_LENGTH = 768
+
+
+def prepare_clip(data, offset, clip_length=CLIP_LENGTH, crop_size=96):
+    """uint8 (C,T,H,W) device tensor -> (1,C,clip_length,H,W) float in [-1,1]; the tail is padded with 127.5 -> 0.0."""
+    clip = data[:, offset: offset + clip_length].float()
+    if clip.size(1) < clip_length:
+        pad = torch.full([clip.size(0), clip_length - clip.size(1), crop_size, crop_size], 127.5, device=clip.device)
+        clip = torch.cat([clip, pad], dim=1)
+    return ((clip / 255.0) * 2.0 - 1.0).unsqueeze(0)
+
+
+def _heads(output_dict):
+    """The ActivityNet priors carry the level id in a second column (anet/BDNet.py:262-269); decoding uses the centres."""
+    d = dict(output_dict)
+    if d['priors'].dim() == 2 and d['priors'].shape[1] > 1:
+        d['priors'] = d['priors'][:, 0].contiguous()
+    return d
+
+
+def decode_clips(output_dict, fps, clip_length=CLIP_LENGTH, conf_thresh=0.001):
+    """Batched decode_prediction + the threshold masks of filtering for n videos (offset 0)."""
+    n = output_dict['loc'].shape[0]
+    return _t.decode_clips(_heads(output_dict), [0.0] * n, fps, clip_length, conf_thresh)
+
+
+def decode_prediction(output_dict, idx=0, sample_fps=1.0, clip_length=CLIP_LENGTH):
+    """Single-clip view: decoded_segments (A,2) in SECONDS (the reference divides by fps in filtering), conf_scores
+    (K,A), uncertainty (A,), actionness (A,)."""
+    return _t.decode_predictions(_heads(output_dict), idx, 0.0, sample_fps, clip_length)
+
+
+def filtering(decoded_segments, conf_score_cls, uncertainty, actionness, conf_thresh=0.001):
+    return _t.filtering(decoded_segments, conf_score_cls, uncertainty, actionness, conf_thresh)
+
+
+def get_video_prediction(rows, counts, duration, idx_to_class=None):
+    """anet/test.py:159-200: the proposal list of one video from its suppressed rows (K,top_k,5), clipped to
+    [0, duration]; proposals that end before they start are dropped."""
+    rows, counts = rows.cpu().numpy(), counts.cpu().numpy()
+    proposal_list = []
+    for cl in range(rows.shape[0]):
+        name = idx_to_class[cl + 1] if idx_to_class is not None else cl + 1
+        for i in range(int(counts[cl])):
+            r = rows[cl, i]
+            if not r[2] > 0:
+                continue
+            start, end = max(0, float(r[0])), min(duration, float(r[1]))
+            if end <= start:
+                continue
+            proposal_list.append({'label': name, 'score': float(r[2]), 'segment': [start, end],
+                                  'uncertainty': float(r[3]), 'actionness': float(r[4])})
+    return proposal_list
+
+
+@torch.no_grad()
+def detect_batch(net, videos, sample_fps, durations, idx_to_class=None, clip_length=CLIP_LENGTH, conf_thresh=0.001,
+                 top_k=5000, nms_sigma=0.85, batch_clips=4):
+    """videos: list of uint8 (C,T,96,96) device tensors (centre-cropped).  Returns {index: proposal list}."""
+    outs = []
+    for i in range(0, len(videos), batch_clips):
+        batch = torch.cat([prepare_clip(v, 0, clip_length, v.shape[-1]) for v in videos[i:i + batch_clips]], 0)
+        outs.append(net(batch))
+    merged = {k: (torch.cat([o[k] for o in outs], 0) if k != 'priors' else outs[0][k])
+              for k in ('loc', 'conf', 'prop_loc', 'prop_conf', 'center', 'act', 'prop_act', 'priors')}
+    fps = [float(f) for f in sample_fps]
+    dec = decode_clips(merged, fps, clip_length, conf_thresh)
+    rows, counts, _ = _t.softnms_classes(dec, list(range(len(videos) + 1)), top_k, nms_sigma)
+    return {v: get_video_prediction(rows[v], counts[v], durations[v], idx_to_class) for v in range(len(videos))}

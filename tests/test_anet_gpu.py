@@ -140,3 +140,32 @@ def test_one_step_with_the_two_learning_rates(golden_dir):
         O.adam_step(want, p.grad.cpu().clone(), torch.zeros_like(want), torch.zeros_like(want), 1, lr, 1e-4)
         moved = float((want - before[k].cpu()).abs().max())
         assert float((p.detach().cpu() - want).abs().max()) <= 1e-3 * moved + 1e-9, k
+
+
+def test_inference_postprocessing_equals_the_reference(golden_dir):
+    """decode + thresholds + Soft-NMS + clipping of three one-clip videos against the proposal lists the reference's
+    AFSD/anet/test.py produced for the same seeded head outputs (oracle/pin_anet_inference.py)."""
+    from oracle.pin_anet_inference import VIDEOS, synthetic_heads
+    from opental_amd.anet import test as T
+    from opental_amd.thumos14.test import softnms_classes
+    fx = np.load(os.path.join(golden_dir, "anet_inference.npz"))
+    heads = [synthetic_heads(seed, cm) for _, seed, _, _, cm in VIDEOS]
+    merged = {k: (torch.cat([h[k] for h in heads], 0).cuda() if k != 'priors' else heads[0][k].cuda()) for k in heads[0]}
+    dec = T.decode_clips(merged, [v[2] for v in VIDEOS])
+    rows, counts, _ = softnms_classes(dec, list(range(len(VIDEOS) + 1)), 5000, 0.85)
+    for v, (name, _, _, duration, _) in enumerate(VIDEOS):
+        got = T.get_video_prediction(rows[v], counts[v], duration)
+        want_cls, want = fx[name + "_class"], fx[name + "_rows"]
+        assert [p['label'] for p in got] == want_cls.tolist(), name           # same kept set, same order
+        have = np.array([[p['segment'][0], p['segment'][1], p['score'], p['uncertainty'], p['actionness']] for p in got])
+        assert np.abs(have - want).max() < 2e-4 * max(1.0, np.abs(want).max()), name
+        assert all(0 <= p['segment'][0] < p['segment'][1] <= duration for p in got)
+
+
+def test_short_video_is_padded_with_mid_grey():
+    from opental_amd.anet.test import prepare_clip
+    data = torch.randint(0, 256, (3, 100, 96, 96), dtype=torch.uint8, device="cuda")
+    clip = prepare_clip(data, 0)
+    assert tuple(clip.shape) == (1, 3, 768, 96, 96)
+    assert torch.equal(clip[0, :, :100], (data.float() / 255.0) * 2.0 - 1.0)
+    assert float(clip[0, :, 100:].abs().max()) == 0.0          # 127.5 / 255 * 2 - 1 == 0
