@@ -397,3 +397,26 @@ def test_strided_pool_fast_path_equals_generic_kernels(shape, k, s, monkeypatch)
     assert torch.equal(outs[0][0][:, :4], outs[1][0][:, :4])
     assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-6)
     assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape,cout", [((2, 3, 8, 96, 96), 64), ((1, 3, 12, 20, 96), 64), ((1, 3, 4, 8, 96), 96)])
+def test_conv1a_direct_kernel_matches_the_gather_kernel(shape, cout, monkeypatch):
+    """Conv3d_1a_7x7 (7x7x7, stride 2, 3 channels, 96-wide planes): the LDS-patch kernel against the kw-vector gather
+    kernel (same bf16-rounded operands, fp32 accumulation in a different order) and against torch on the rounded
+    operands; scale / shift / ReLU epilogue included."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(41)
+    k, s = (7, 7, 7), (2, 2, 2)
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    w = torch.from_numpy((rs.randn(cout, 3, 7, 7, 7) / 30).astype(np.float32)).cuda()
+    sc = torch.from_numpy(rs.uniform(0.5, 1.5, cout).astype(np.float32)).cuda()
+    sh = torch.from_numpy(rs.uniform(-0.3, 0.3, cout).astype(np.float32)).cuda()
+    monkeypatch.setattr(ops, "CONV_PRECISION", 1)
+    y1 = ops.conv_forward(x, w, k, s, scale=sc, shift=sh, relu=True)
+    monkeypatch.setenv("OTAL_CONV_NO1A", "1")
+    y0 = ops.conv_forward(x, w, k, s, scale=sc, shift=sh, relu=True)
+    monkeypatch.delenv("OTAL_CONV_NO1A")
+    assert float((y1 - y0).abs().max()) <= 2e-5 * float(y0.abs().max())
+    xr, wr = x.to(torch.bfloat16).float().cpu(), w.to(torch.bfloat16).float().cpu()
+    ref = F.conv3d(F.pad(xr, [2, 3, 2, 3, 2, 3]), wr, stride=2) * sc.cpu().view(1, -1, 1, 1, 1) + sh.cpu().view(1, -1, 1, 1, 1)
+    close(y1, ref.clamp(min=0))
