@@ -142,6 +142,9 @@ def main():
                     help="arithmetic type of the convolution GEMMs (BASELINE.json configs[1]: bf16); f32 = parity path")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the training step from one captured HIP graph (auto: fall back to eager launches if capture fails)")
+    ap.add_argument("--ssl", action="store_true",
+                    help="also run the self-supervised triplet branch every step (train.py:237-242 runs it when flags[0]): a second "
+                         "backbone pass on the spliced clip + 3 BoundaryMaxPooling calls + triplet losses; eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hbm-kernels", action="store_true",
@@ -173,6 +176,16 @@ def main():
         trainer = build_trainer(device, force_collectives=force_dist)
         clips, targets, scores = synth_batch(args.batch, 1000 + rank, device)
 
+    ssl_args = ()
+    if args.ssl:
+        ssl_clips, _, _ = synth_batch(args.batch, 2000 + rank, device, frames=768 if anet else 256, classes=150 if anet else 15,
+                                      score_rows=3 if anet else 2)
+        frames = 768 if anet else 256
+        # anchor / positive / negative segments in frames, as the datasets' augment() emits them (thumos_dataset.py:160-237)
+        ssl_targets = [torch.tensor([[0.30, 0.55], [0.32, 0.52], [0.70, 0.90]], device=device) * frames for _ in range(args.batch)]
+        ssl_args = (ssl_clips, ssl_targets)
+        args.graph = "off"
+
     def barrier():
         if world > 1 or force_dist:
             dist.barrier()
@@ -193,11 +206,11 @@ def main():
             if rank == 0:
                 print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {str(e)[:200]}); eager launches", file=sys.stderr)
     for _ in range(args.warmup):
-        trainer.step(clips, targets, scores)
+        trainer.step(clips, targets, scores, *ssl_args)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.step(clips, targets, scores)
+        trainer.step(clips, targets, scores, *ssl_args)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1 or force_dist:
@@ -257,11 +270,12 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "OpenTAL ActivityNet1.3 training step (configs/anet_opental.yaml, EDL+IBM loss, per-sample "
-                                   "normalisation, ssl branch off), 768x3x96x96 clips, random-init weights" if anet else
+                                   "normalisation, ssl branch " + ("ON" if args.ssl else "off") + "), 768x3x96x96 clips, random-init weights" if anet else
                                    "OpenTAL THUMOS14 split_0 training step (configs/thumos14_opental_final.yaml, "
-                                   "EDL+IBM loss, ssl branch off), 256x3x96x96 clips, random-init weights",
+                                   "EDL+IBM loss, ssl branch " + ("ON" if args.ssl else "off") + "), 256x3x96x96 clips, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "grad_allreduce": "RCCL, flat-arena buckets overlapped with backward",
+                       "ssl_branch": bool(args.ssl),
                        "launch": "one captured HIP graph per step" if graphed else "eager launches"},
             "roofline": roofline, "hbm_kernels": hbm, "cpu_baseline": cpu}))
     if world > 1 or force_dist:
