@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 9
+#define OTAL_ABI_VERSION 10
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -164,6 +164,22 @@ int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const float* x, 
 int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const float* dy,
                        const unsigned char* argtap, float* dx, int accumulate,
                        const float* out_mask, const float* out_scale, void* stream);
+
+/* ------------------------------------------------------------------ head output tails ----
+ * Everything between the head convolutions and CoarsePyramid's outputs (AFSD/thumos14/BDNet.py:337-353,:399-412,:538-556;
+ * AFSD/anet/BDNet.py:307-320,:366-376) for n_items <= 8 maps at once: raw[i] (B, channels[i], N) -> out[i] (B, N, channels[i]),
+ *   modes[i] 0: the permute(0,2,1).contiguous() only;
+ *            1: ScaleExp per pyramid level, exp(scales[l] * x) * level_strides[l] (level_strides null = 1: THUMOS14);
+ *            2: permute + DirichletLayer.compute_uncertainty with evidence 'exp' into unct[i] (B, N).
+ * lev[0..nlev]: anchor ranges of the levels along N.  _bwd: draw[i] (B, C, N) from dout[i] (B, N, C) and dunct[i] (B, N)
+ * (either may be null = zero) and dscales[nlev] (deterministic single-workgroup reduction). */
+int otal_head_outputs_fwd(int n_items, const int* channels, const int* modes, const float* const* raw, float* const* out,
+                          float* const* unct, const float* scales, int B, int N, int nlev, const int* lev,
+                          const float* level_strides, void* stream);
+int otal_head_outputs_bwd(int n_items, const int* channels, const int* modes, const float* const* raw,
+                          const float* const* out, const float* const* unct, const float* const* dout,
+                          const float* const* dunct, float* const* draw, const float* scales, float* dscales, int B,
+                          int N, int nlev, const int* lev, const float* level_strides, void* stream);
 
 /* ------------------------------------------------------------------ proposal window indices ----
  * loc (B,Ntot,2) -> level-space windows seg (B,Ntot,4) and frame-space windows frame_seg (B,Ntot,4)

@@ -72,6 +72,7 @@ class BDNet(_thumos.BDNet):
         self.evidence = cfg['evidence']
         if self.use_edl:
             self.out_layer = DirichletLayer(self.evidence, dim=-1)
+        self.coarse_pyramid_detection.dirichlet_exp = bool(self.use_edl and self.evidence == 'exp')
         self.use_rpl = False
 
     @staticmethod

@@ -490,3 +490,51 @@ class DetectionLossFunction(torch.autograd.Function):
         dcen, dact, dpact = take(A, (B, K)), take(A, (B, K)), take(A, (B, K))
         return (dloc_l * g_l + dloc_ct * g_ct, dconf * g_c, dpl_pl * g_pl + dpl_ct * g_ct, dpconf * g_pc,
                 dcen * g_ct, dact * g_a, dpact * g_pa) + (None,) * 10
+
+
+# ----------------------------------------------------------------------------- head output tails
+class HeadOutputsFunction(torch.autograd.Function):
+    """permute / ScaleExp / Dirichlet uncertainty of all detection-head maps in one launch (csrc/heads.hip).
+
+    apply(scales, levels, level_strides, modes, *raws): raws[i] (B,C_i,N) -> outs[i] (B,N,C_i) for every item, followed by
+    the uncertainty maps (B,N) of the mode-2 items.  scales: the per-level ScaleExp parameters (nlev,) for mode 1."""
+
+    @staticmethod
+    def forward(ctx, scales, levels, level_strides, modes, *raws):
+        raws = [r.contiguous() for r in raws]
+        L.require_device(scales, *raws)
+        B, _, N = raws[0].shape
+        n = len(raws)
+        outs = [torch.empty((B, N, r.shape[1]), dtype=torch.float32, device=r.device) for r in raws]
+        uncts = [torch.empty((B, N), dtype=torch.float32, device=raws[0].device) if m == 2 else None for m in modes]
+        VP = ctypes.c_void_p * n
+        arr = lambda ts: VP(*[None if t is None else t.data_ptr() for t in ts])
+        strides = None if level_strides is None else (ctypes.c_float * len(level_strides))(*level_strides)
+        meta = (L.int_array([r.shape[1] for r in raws]), L.int_array(list(modes)), len(levels) - 1, L.int_array(list(levels)), strides, B, N, n)
+        L.check(L.lib().otal_head_outputs_fwd(n, meta[0], meta[1], arr(raws), arr(outs), arr(uncts), L.ptr(scales), B, N, meta[2],
+                                              meta[3], strides, L.stream()), "otal_head_outputs_fwd")
+        ctx.meta, ctx.modes = meta, tuple(modes)
+        ctx.save_for_backward(scales, *raws, *outs, *[u for u in uncts if u is not None])
+        return tuple(outs) + tuple(u for u in uncts if u is not None)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        chans, modes_a, nlev, lev, strides, B, N, n = ctx.meta
+        saved = ctx.saved_tensors
+        scales, raws, outs, us = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n], list(saved[1 + 2 * n:])
+        uncts, dunct, k = [], [], 0
+        for m in ctx.modes:
+            if m == 2:
+                uncts.append(us[k]); dunct.append(grads[n + k]); k += 1
+            else:
+                uncts.append(None); dunct.append(None)
+        douts = [None if g is None else g.contiguous() for g in grads[:n]]
+        dunct = [None if g is None else g.contiguous() for g in dunct]
+        draws = [torch.empty_like(r) for r in raws]
+        dscales = torch.zeros_like(scales)
+        VP = ctypes.c_void_p * n
+        arr = lambda ts: VP(*[None if t is None else t.data_ptr() for t in ts])
+        L.check(L.lib().otal_head_outputs_bwd(n, chans, modes_a, arr(raws), arr(outs), arr(uncts), arr(douts), arr(dunct), arr(draws),
+                                              L.ptr(scales), L.ptr(dscales), B, N, nlev, lev, strides, L.stream()),
+                "otal_head_outputs_bwd")
+        return (dscales, None, None, None) + tuple(draws)

@@ -136,6 +136,7 @@ class CoarsePyramid(nn.Module):
         self.num_classes = num_cls
         self.os_head = os_head
         self.fpn_strides = fpn_strides
+        self.dirichlet_exp = False      # set by BDNet: uncertainty maps come out of the head-tail launch (evidence 'exp')
         self.projection_inputs = tuple(ep for ep, _ in projections)
         self.pyramids = nn.ModuleList()
         self.loc_heads = nn.ModuleList()
@@ -232,12 +233,18 @@ class CoarsePyramid(nn.Module):
         packed = torch.cat(feats, dim=2)                                    # (B,512,126)
         loc_feat = self.loc_tower[1](self.loc_tower[0](packed, lev), lev)
         conf_feat = self.conf_tower[1](self.conf_tower[0](packed, lev), lev)
-        scale_cols = torch.cat([self.loc_heads[i].scale.expand(t) for i, t in enumerate(self.level_lengths)])
-        loc = tr(torch.exp(self.loc_head(loc_feat, lev) * scale_cols))      # ScaleExp per level
-        if self.fpn_strides is not None:                                    # anet/BDNet.py:307-311: loc in frames
-            loc = loc * self._stride_cols(loc.device).view(1, -1, 1)
-        conf = tr(self.conf_head(self._drop(conf_feat), lev))
-        act = tr(self.actionness_head(conf_feat, lev)) if self.os_head else None
+        # Head convolutions are level-batched GEMM launches; their tails -- ScaleExp (x fpn stride in the ActivityNet model),
+        # the permute(0,2,1).contiguous() of every map and the Dirichlet uncertainty -- are one launch per stage
+        # (csrc/heads.hip): the coarse stage here, the refined stage after the proposal branches.
+        scales = torch.cat([h.scale for h in self.loc_heads])
+        um = 2 if self.dirichlet_exp else 0
+        raws = [self.loc_head(loc_feat, lev), self.conf_head(self._drop(conf_feat), lev)]
+        if self.os_head:
+            raws.append(self.actionness_head(conf_feat, lev))
+        res = ops.HeadOutputsFunction.apply(scales, tuple(lev), self.fpn_strides, (1, um, 0)[:len(raws)], *raws)
+        loc, conf = res[0], res[1]
+        act = res[2] if self.os_head else None
+        unct = res[len(raws)] if self.dirichlet_exp else None
         with torch.no_grad():
             segments, frame_segments = ops.proposal_windows(loc.detach(), lev, float(self.frame_num))
         loc_prop_feat, loc_lr = self.loc_proposal_branch(loc_feat, frame_level_feat, segments, frame_segments, lev)
@@ -248,10 +255,13 @@ class CoarsePyramid(nn.Module):
         ndim = loc_lr.size(1) // 2
         start_loc_prop, end_loc_prop = tr(loc_lr[:, :ndim, :t0]), tr(loc_lr[:, ndim:, :t0])
         start_conf_prop, end_conf_prop = tr(conf_lr[:, :ndim, :t0]), tr(conf_lr[:, ndim:, :t0])
-        prop_loc = tr(self.prop_loc_head(loc_prop_feat))
-        prop_conf = tr(self.prop_conf_head(self._drop(conf_prop_feat)))
-        prop_act = tr(self.prop_actionness_head(conf_prop_feat)) if self.os_head else None
-        center = tr(self.center_head(loc_prop_feat, lev))
+        raws = [self.prop_loc_head(loc_prop_feat), self.prop_conf_head(self._drop(conf_prop_feat)), self.center_head(loc_prop_feat, lev)]
+        if self.os_head:
+            raws.append(self.prop_actionness_head(conf_prop_feat))
+        res = ops.HeadOutputsFunction.apply(scales, tuple(lev), None, (0, um, 0, 0)[:len(raws)], *raws)
+        prop_loc, prop_conf, center = res[0], res[1], res[2]
+        prop_act = res[3] if self.os_head else None
+        self._last_unct = (unct, res[len(raws)]) if self.dirichlet_exp else None
         priors = self._priors_on(loc.device)
         outs = (loc, conf, prop_loc, prop_conf, center, priors, start, end,
                 start_loc_prop, end_loc_prop, start_conf_prop, end_conf_prop, act, prop_act)
@@ -293,6 +303,7 @@ class BDNet(nn.Module):
         self.evidence = cfg['evidence']
         if self.use_edl:
             self.out_layer = DirichletLayer(self.evidence, dim=-1)
+        self.coarse_pyramid_detection.dirichlet_exp = bool(self.use_edl and self.evidence == 'exp')
         self.use_rpl = use_rpl
 
     @staticmethod
@@ -340,8 +351,12 @@ class BDNet(nn.Module):
                     'end_loc_prop': end_loc_prop, 'start_conf_prop': start_conf_prop,
                     'end_conf_prop': end_conf_prop, 'act': act, 'prop_act': prop_act}
         if self.use_edl:
-            out_dict.update({'unct': self.out_layer.compute_uncertainty(conf),
-                             'prop_unct': self.out_layer.compute_uncertainty(prop_conf)})
+            fused = getattr(self.coarse_pyramid_detection, '_last_unct', None)
+            if fused is not None:
+                out_dict.update({'unct': fused[0], 'prop_unct': fused[1]})
+            else:
+                out_dict.update({'unct': self.out_layer.compute_uncertainty(conf),
+                                 'prop_unct': self.out_layer.compute_uncertainty(prop_conf)})
         if get_feat and not self.training:
             out_dict.update({'conf_feat': ctr_feat, 'prop_conf_feat': prop_ctr_feat})
         return out_dict

@@ -420,3 +420,43 @@ def test_conv1a_direct_kernel_matches_the_gather_kernel(shape, cout, monkeypatch
     xr, wr = x.to(torch.bfloat16).float().cpu(), w.to(torch.bfloat16).float().cpu()
     ref = F.conv3d(F.pad(xr, [2, 3, 2, 3, 2, 3]), wr, stride=2) * sc.cpu().view(1, -1, 1, 1, 1) + sh.cpu().view(1, -1, 1, 1, 1)
     close(y1, ref.clamp(min=0))
+
+
+@pytest.mark.parametrize("lev,strides,K", [((0, 64, 96, 112, 120, 124, 126), None, 15), ((0, 96, 144, 168, 180, 186, 189), (4, 8, 16, 32, 64, 128), 150)])
+def test_head_output_tails_match_the_torch_formulation(lev, strides, K):
+    """ScaleExp (per level, x fpn stride), permute(0,2,1).contiguous() and Dirichlet uncertainty of the head maps in one
+    launch against the reference's op sequence (BDNet.py:337-353,:538-556), forward and backward incl. d scale."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(51)
+    B, N = 3, lev[-1]
+    mk = lambda c, sd: torch.from_numpy((rs.randn(B, c, N) * sd).astype(np.float32))
+    raws = [mk(2, 1.0), mk(K, 4.0), mk(1, 1.0)]                      # logits beyond +-10 exercise the clamp
+    scales = torch.from_numpy(rs.uniform(0.8, 1.2, len(lev) - 1).astype(np.float32))
+    # reference formulation
+    rl = [r.clone().requires_grad_(True) for r in raws]
+    sl = scales.clone().requires_grad_(True)
+    cols = torch.cat([sl[i].expand(lev[i + 1] - lev[i]) for i in range(len(lev) - 1)])
+    loc = torch.exp(rl[0] * cols).permute(0, 2, 1).contiguous()
+    if strides is not None:
+        loc = loc * torch.cat([torch.full((lev[i + 1] - lev[i],), float(s)) for i, s in enumerate(strides)]).view(1, -1, 1)
+    conf = rl[1].permute(0, 2, 1).contiguous()
+    act = rl[2].permute(0, 2, 1).contiguous()
+    unct = K / (torch.exp(torch.clamp(conf, -10, 10)) + 1).sum(-1)
+    gs = [torch.from_numpy(rs.randn(*t.shape).astype(np.float32)) for t in (loc, conf, act, unct)]
+    (loc * gs[0]).sum().add((conf * gs[1]).sum()).add((act * gs[2]).sum()).add((unct * gs[3]).sum()).backward()
+    # HIP
+    rd = [r.clone().cuda().requires_grad_(True) for r in raws]
+    sd = scales.clone().cuda().requires_grad_(True)
+    o = ops.HeadOutputsFunction.apply(sd, tuple(lev), strides, (1, 2, 0), *rd)
+    for got, want in zip(o, (loc, conf, act, unct)):
+        close(got, want.detach(), tol=2e-6)
+    sum((a * g.cuda()).sum() for a, g in zip(o, gs)).backward()
+    for a, b_ in zip(rd, rl):
+        close(a.grad, b_.grad, tol=2e-5)
+    close(sd.grad, sl.grad, tol=2e-5)
+    # gradients that never arrive (uncertainty is not part of the training loss) are zeros, not garbage
+    rd2 = [r.clone().cuda().requires_grad_(True) for r in raws]
+    o2 = ops.HeadOutputsFunction.apply(sd.detach().requires_grad_(True), tuple(lev), strides, (1, 2, 0), *rd2)
+    o2[1].sum().backward()
+    assert float(rd2[0].grad.abs().max()) == 0.0 and float(rd2[2].grad.abs().max()) == 0.0
+    assert torch.equal(rd2[1].grad, torch.ones_like(rd2[1].grad))
