@@ -192,9 +192,26 @@ def main():
         torch.cuda.synchronize()
 
     graphed = False
-    # auto: capture only on a single rank -- multi-rank capture of the RCCL hooks could not be exercised on the 1-GPU
-    # development boxes (the single-rank forced-collective capture works); N > 1 runs use the eager path unless --graph on
-    if args.graph == "on" or (args.graph == "auto" and world == 1):
+    launch_probe = None
+    # Launch mode.  The step is GPU-bound since the loss / gradient hand-over stopped issuing ~800 tiny kernels, and ROCm 7.2
+    # replays this ~1000-node graph a few per cent SLOWER than a fast host enqueues it (measured 436 vs 454 clips/s).  So
+    # `auto` first checks whether the host has slack: if issuing the launches of a step takes < 90 % of the step, eager
+    # launches it is; only a host-bound step is captured into one HIP graph.  (auto never captures on N > 1 ranks: multi-rank
+    # capture of the RCCL hooks could not be exercised on the 1-GPU development boxes; --graph on forces it.)
+    want_graph = args.graph == "on"
+    if args.graph == "auto" and world == 1 and not args.ssl:
+        for _ in range(3):
+            trainer.step(clips, targets, scores)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(6):
+            trainer.step(clips, targets, scores)
+        t_issue = time.perf_counter() - t
+        torch.cuda.synchronize()
+        t_total = time.perf_counter() - t
+        launch_probe = {"eager_ms": round(t_total / 6 * 1e3, 3), "host_issue_ms": round(t_issue / 6 * 1e3, 3)}
+        want_graph = t_issue > 0.9 * t_total
+    if want_graph:
         try:
             trainer.capture_step(clips, targets, scores)
             graphed = True
@@ -275,7 +292,7 @@ def main():
                                    "EDL+IBM loss, ssl branch " + ("ON" if args.ssl else "off") + "), 256x3x96x96 clips, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "grad_allreduce": "RCCL, flat-arena buckets overlapped with backward",
-                       "ssl_branch": bool(args.ssl),
+                       "ssl_branch": bool(args.ssl), "launch_probe": launch_probe,
                        "launch": "one captured HIP graph per step" if graphed else "eager launches"},
             "roofline": roofline, "hbm_kernels": hbm, "cpu_baseline": cpu}))
     if world > 1 or force_dist:

@@ -496,12 +496,16 @@ class DetectionLossFunction(torch.autograd.Function):
 class HeadOutputsFunction(torch.autograd.Function):
     """permute / ScaleExp / Dirichlet uncertainty of all detection-head maps in one launch (csrc/heads.hip).
 
-    apply(scales, levels, level_strides, modes, *raws): raws[i] (B,C_i,N) -> outs[i] (B,N,C_i) for every item, followed by
-    the uncertainty maps (B,N) of the mode-2 items.  scales: the per-level ScaleExp parameters (nlev,) for mode 1."""
+    apply(levels, level_strides, modes, *scales_then_raws): the nlev one-element ScaleExp parameters (separate tensors, so
+    that each receives its own 16-byte-aligned gradient: a 4-byte-offset view would push the trainer's whole multi-tensor
+    gradient copy onto its unvectorised path), then raws[i] (B,C_i,N) -> outs[i] (B,N,C_i) for every item, followed by
+    the uncertainty maps (B,N) of the mode-2 items."""
 
     @staticmethod
-    def forward(ctx, scales, levels, level_strides, modes, *raws):
-        raws = [r.contiguous() for r in raws]
+    def forward(ctx, levels, level_strides, modes, *tensors):
+        nlev_ = len(levels) - 1
+        scales = torch.cat([t.detach().reshape(1) for t in tensors[:nlev_]])
+        raws = [r.contiguous() for r in tensors[nlev_:]]
         L.require_device(scales, *raws)
         B, _, N = raws[0].shape
         n = len(raws)
@@ -537,4 +541,6 @@ class HeadOutputsFunction(torch.autograd.Function):
         L.check(L.lib().otal_head_outputs_bwd(n, chans, modes_a, arr(raws), arr(outs), arr(uncts), arr(douts), arr(dunct), arr(draws),
                                               L.ptr(scales), L.ptr(dscales), B, N, nlev, lev, strides, L.stream()),
                 "otal_head_outputs_bwd")
-        return (dscales, None, None, None) + tuple(draws)
+        aligned = torch.zeros((nlev, 4), dtype=dscales.dtype, device=dscales.device)
+        aligned[:, 0] = dscales
+        return (None, None, None) + tuple(aligned[l, :1] for l in range(nlev)) + tuple(draws)

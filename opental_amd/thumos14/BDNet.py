@@ -236,12 +236,12 @@ class CoarsePyramid(nn.Module):
         # Head convolutions are level-batched GEMM launches; their tails -- ScaleExp (x fpn stride in the ActivityNet model),
         # the permute(0,2,1).contiguous() of every map and the Dirichlet uncertainty -- are one launch per stage
         # (csrc/heads.hip): the coarse stage here, the refined stage after the proposal branches.
-        scales = torch.cat([h.scale for h in self.loc_heads])
+        scales = [h.scale for h in self.loc_heads]
         um = 2 if self.dirichlet_exp else 0
         raws = [self.loc_head(loc_feat, lev), self.conf_head(self._drop(conf_feat), lev)]
         if self.os_head:
             raws.append(self.actionness_head(conf_feat, lev))
-        res = ops.HeadOutputsFunction.apply(scales, tuple(lev), self.fpn_strides, (1, um, 0)[:len(raws)], *raws)
+        res = ops.HeadOutputsFunction.apply(tuple(lev), self.fpn_strides, (1, um, 0)[:len(raws)], *scales, *raws)
         loc, conf = res[0], res[1]
         act = res[2] if self.os_head else None
         unct = res[len(raws)] if self.dirichlet_exp else None
@@ -258,7 +258,7 @@ class CoarsePyramid(nn.Module):
         raws = [self.prop_loc_head(loc_prop_feat), self.prop_conf_head(self._drop(conf_prop_feat)), self.center_head(loc_prop_feat, lev)]
         if self.os_head:
             raws.append(self.prop_actionness_head(conf_prop_feat))
-        res = ops.HeadOutputsFunction.apply(scales, tuple(lev), None, (0, um, 0, 0)[:len(raws)], *raws)
+        res = ops.HeadOutputsFunction.apply(tuple(lev), None, (0, um, 0, 0)[:len(raws)], *[h.detach() for h in scales], *raws)
         prop_loc, prop_conf, center = res[0], res[1], res[2]
         prop_act = res[3] if self.os_head else None
         self._last_unct = (unct, res[len(raws)]) if self.dirichlet_exp else None

@@ -446,17 +446,18 @@ def test_head_output_tails_match_the_torch_formulation(lev, strides, K):
     (loc * gs[0]).sum().add((conf * gs[1]).sum()).add((act * gs[2]).sum()).add((unct * gs[3]).sum()).backward()
     # HIP
     rd = [r.clone().cuda().requires_grad_(True) for r in raws]
-    sd = scales.clone().cuda().requires_grad_(True)
-    o = ops.HeadOutputsFunction.apply(sd, tuple(lev), strides, (1, 2, 0), *rd)
+    sds = [scales[i:i + 1].clone().cuda().requires_grad_(True) for i in range(len(lev) - 1)]
+    o = ops.HeadOutputsFunction.apply(tuple(lev), strides, (1, 2, 0), *sds, *rd)
     for got, want in zip(o, (loc, conf, act, unct)):
         close(got, want.detach(), tol=2e-6)
     sum((a * g.cuda()).sum() for a, g in zip(o, gs)).backward()
     for a, b_ in zip(rd, rl):
         close(a.grad, b_.grad, tol=2e-5)
-    close(sd.grad, sl.grad, tol=2e-5)
+    close(torch.cat([t.grad for t in sds]), sl.grad, tol=2e-5)
+    assert all(t.grad.data_ptr() % 16 == 0 for t in sds)          # aligned: keeps multi-tensor gradient copies vectorised
     # gradients that never arrive (uncertainty is not part of the training loss) are zeros, not garbage
     rd2 = [r.clone().cuda().requires_grad_(True) for r in raws]
-    o2 = ops.HeadOutputsFunction.apply(sd.detach().requires_grad_(True), tuple(lev), strides, (1, 2, 0), *rd2)
+    o2 = ops.HeadOutputsFunction.apply(tuple(lev), strides, (1, 2, 0), *[t.detach() for t in sds], *rd2)
     o2[1].sum().backward()
     assert float(rd2[0].grad.abs().max()) == 0.0 and float(rd2[2].grad.abs().max()) == 0.0
     assert torch.equal(rd2[1].grad, torch.ones_like(rd2[1].grad))
