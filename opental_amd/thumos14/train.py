@@ -273,6 +273,8 @@ class DetectorTrainer:
         self._bias_corr = torch.zeros(2, dtype=torch.float32, device=dev)
         clone = lambda t: None if t is None else ([u.clone() for u in t] if isinstance(t, (list, tuple)) else t.clone())
         static = tuple(clone(t) for t in (clips, targets, scores))
+        # (the warm-up steps run on a side stream on purpose: the AccumulateGrad stream-mismatch warning is noise here)
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
