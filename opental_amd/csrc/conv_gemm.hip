@@ -1748,7 +1748,7 @@ __global__ __launch_bounds__(256) void pack_direct_kernel(unsigned* __restrict__
 // channels (+ one all-zero eighth tap) are 32 consecutive k, and for an output position they are 64 CONTIGUOUS bytes of
 // the patch starting at pixel 2 wo -- so the im2col operand of every MFMA is one aligned ds_read_b128, with no address
 // tables, no masks (the zero padding is in the patch) and no per-element VALU work.  Weights: [Mpad][49 rows][32 k] bf16,
-// zero where ci = 3 or dw = 7, one 4 KB slice per K step through a three-slot LDS ring.
+// zero where ci = 3 or dw = 7, one 4 KB slice per K step through two LDS slots.
 // Measured (b = 8, 310 GFLOP): 0.84 ms against 0.95 ms of the gather kernel (tools/micro_conv.py 1a fwd).  Ablation: the
 // epilogue + 49 barriers alone 0.29 ms (604 MB of output in 384-byte runs), staging 0.13, weight ring 0.07, LDS operand
 // reads + MFMA 0.12 -- the phases of a workgroup run back to back and only two workgroups fit a CU (77 KB of LDS), so they
@@ -1778,7 +1778,7 @@ __global__ __launch_bounds__(256) void pack_conv1a_kernel(unsigned* __restrict__
 __global__ __launch_bounds__(C1_NT) void conv1a_direct_fwd_kernel(const Conv1aArgs d) {
     constexpr int BM = 64, WM = 2;
     __shared__ __attribute__((aligned(16))) unsigned char patch[C1_NPL * C1_NR * C1_PITCH];
-    __shared__ __attribute__((aligned(16))) unsigned char smA[3][BM * C1_PA];      // ring of three K-step slices
+    __shared__ __attribute__((aligned(16))) unsigned char smA[2][BM * C1_PA];      // two K-step slices (+ patch = 77.6 KB: two workgroups per CU)
     const ConvArgs& a = d.c;
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1854,12 +1854,13 @@ __global__ __launch_bounds__(C1_NT) void conv1a_direct_fwd_kernel(const Conv1aAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
     // Software pipeline: the operands of step s+1 are read from LDS while the MFMAs of step s run (the patch is static and
-    // slice s+1 of the weight ring became visible at the previous barrier); slice s+2 travels global -> registers -> ring.
+    // weight slice s+1 became visible at the previous barrier).  Slice s+2 travels global -> registers -> the slot that held
+    // slice s: its operands were read into registers during step s-1 and those reads retired before the last barrier.
     bf16x8 av[2][2][WM], bv[2][2];
     auto read_ops = [&](int set, int s) {
         const int dt = s / 7, dh = s - dt * 7;
         const unsigned char* xrow = patch + xbase + (dt * C1_NR + dh) * C1_PITCH;
-        const unsigned char* arow = smA[s % 3] + abase;
+        const unsigned char* arow = smA[s & 1] + abase;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -1878,7 +1879,7 @@ __global__ __launch_bounds__(C1_NT) void conv1a_direct_fwd_kernel(const Conv1aAr
 #pragma unroll
             for (int i = 0; i < WM; ++i)
                 acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[set][kk][i], bv[set][kk], acc[i][0], 0, 0, 0);
-        if (s + 2 < C1_STEPS) store_a((s + 2) % 3);
+        if (s + 2 < C1_STEPS) store_a(s & 1);
         __syncthreads();
     }
     // this wave's 32 positions are consecutive in the output: rows ho0, ho0+1 of plane to0 + lt
