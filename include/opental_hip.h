@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 10
+#define OTAL_ABI_VERSION 11
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -164,6 +164,16 @@ int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const float* x, 
 int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const float* dy,
                        const unsigned char* argtap, float* dx, int accumulate,
                        const float* out_mask, const float* out_scale, void* stream);
+/* The same pair with the producer's ReLU mask carried as SIGN BITS of the pool input instead of re-reading the fp32
+ * activations in the backward pass (604 MB -> 19 MB for MaxPool3d_2a): _fwd_signbits also writes signbits
+ * (otal_maxpool3d_signbits_bytes(), opaque), _bwd_signbits applies (bit set) * out_scale[c].  Strided 3x3 pools
+ * ((1,3,3)/(1,2,2), (3,3,3)/(2,2,2)) only: _signbits_bytes returns 0 elsewhere and the calls OTAL_E_UNSUPPORTED. */
+size_t otal_maxpool3d_signbits_bytes(const int* geom, const int64_t* strides);
+int otal_maxpool3d_fwd_signbits(const int* geom, const int64_t* strides, const float* x, float* y,
+                                unsigned char* argtap, unsigned char* signbits, void* stream);
+int otal_maxpool3d_bwd_signbits(const int* geom, const int64_t* strides, const float* dy, const unsigned char* argtap,
+                                float* dx, int accumulate, const unsigned char* signbits, const float* out_scale,
+                                void* stream);
 
 /* ------------------------------------------------------------------ head output tails ----
  * Everything between the head convolutions and CoarsePyramid's outputs (AFSD/thumos14/BDNet.py:337-353,:399-412,:538-556;

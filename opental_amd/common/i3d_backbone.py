@@ -215,8 +215,10 @@ class I3DFeaturesFunction(Function):
                 cur, cur_scale = y, sc(wi)
             elif kind == "pool":
                 _, k, s, _ = step
-                y, arg = ops.maxpool3d_forward(cur, k, s)
-                tape.append(("pool", k, s, cur, arg, cur_scale, None))
+                # a pool behind a conv + ReLU: let the forward kernel keep that layer's ReLU mask as sign bits, so that the
+                # backward pass does not re-read the 4-byte activations only for their sign
+                y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=cur_scale is not None)
+                tape.append(("pool", k, s, cur, (arg, bits), cur_scale, None))
                 cur, cur_scale = y, None
             else:
                 _, w0, oc, _ = step
@@ -309,9 +311,10 @@ class I3DFeaturesFunction(Function):
                     dcur = ops.conv_dgrad(dcur, weights[wi], xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, dcur),
                                           out_mask=xin if in_scale is not None else None, out_scale=in_scale)
             elif step[0] == "pool":
-                _, k, s, xin, arg, in_scale, _ = step
+                _, k, s, xin, (arg, bits), in_scale, _ = step
                 dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, dcur),
-                                              out_mask=xin if in_scale is not None else None, out_scale=in_scale)
+                                              out_mask=xin if (in_scale is not None and bits is None) else None,
+                                              out_scale=in_scale, out_signbits=bits)
             else:
                 _, w0, (c1, c2, c3), xin, h1, h2, pm, argm, Y, in_scale, (wf, o1, o13), _ = step
                 Zg = zg.pop(pos)            # [dh1 | dh2 | dY]; dcur is its tail

@@ -376,7 +376,9 @@ def _pool_geom(x5, k, s):
     return [B, C, Ti, Hi, Wi, *outs, *k, *s, *pads], tuple(outs)
 
 
-def maxpool3d_forward(x, k, s, out=None):
+def maxpool3d_forward(x, k, s, out=None, signbits=False):
+    """(y, winner bytes) -- with signbits=True (y, winner bytes, sign bits of x or None): the strided 3x3 pools can hand
+    the ReLU mask of their input to the backward pass as one bit per element (maxpool3d_backward(out_signbits=...))."""
     x5 = _as5(x)
     g, outn = _pool_geom(x5, k, s)
     B, C = x5.shape[:2]
@@ -385,11 +387,20 @@ def maxpool3d_forward(x, k, s, out=None):
     arg = torch.empty((B, C) + outn, dtype=torch.uint8, device=x.device)
     _check(x5, "x"); _check(out, "y")
     ga, sa = _geom_arrays(g, x5, out)
+    if signbits:
+        lib = L.lib()
+        lib.otal_maxpool3d_signbits_bytes.restype = ctypes.c_size_t
+        nbytes = int(lib.otal_maxpool3d_signbits_bytes(ga, sa))
+        if nbytes and x5.data_ptr() % 16 == 0 and out.data_ptr() % 8 == 0:
+            bits = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            L.check(lib.otal_maxpool3d_fwd_signbits(ga, sa, L.ptr(x5), L.ptr(out), L.ptr(arg), L.ptr(bits), L.stream()),
+                    "otal_maxpool3d_fwd_signbits")
+            return out, arg, bits
     L.check(L.lib().otal_maxpool3d_fwd(ga, sa, L.ptr(x5), L.ptr(out), L.ptr(arg), L.stream()), "otal_maxpool3d_fwd")
-    return out, arg
+    return (out, arg, None) if signbits else (out, arg)
 
 
-def maxpool3d_backward(dy, arg, x_shape, k, s, out=None, accumulate=False, out_mask=None, out_scale=None):
+def maxpool3d_backward(dy, arg, x_shape, k, s, out=None, accumulate=False, out_mask=None, out_scale=None, out_signbits=None):
     if out is None:
         if accumulate:
             raise RuntimeError("accumulate needs an existing buffer")
@@ -399,6 +410,12 @@ def maxpool3d_backward(dy, arg, x_shape, k, s, out=None, accumulate=False, out_m
     if tuple(dy.shape[2:]) != outn or not arg.is_contiguous():
         raise RuntimeError("maxpool3d_backward: shape mismatch")
     ga, sa = _geom_arrays(g, out, dy)
+    if out_signbits is not None:
+        if out.data_ptr() % 16 or dy.data_ptr() % 8:
+            raise RuntimeError("maxpool3d_backward: the sign-bit path needs 16-byte aligned dx")
+        L.check(L.lib().otal_maxpool3d_bwd_signbits(ga, sa, L.ptr(dy), L.ptr(arg), L.ptr(out), int(accumulate), L.ptr(out_signbits),
+                                                    L.ptr(out_scale), L.stream()), "otal_maxpool3d_bwd_signbits")
+        return out
     if out_mask is not None and (tuple(out_mask.shape) != tuple(out.shape) or out_mask.stride() != out.stride()):
         raise RuntimeError("out_mask must share dx's shape and layout")
     L.check(L.lib().otal_maxpool3d_bwd(ga, sa, L.ptr(dy), L.ptr(arg), L.ptr(out), int(accumulate),

@@ -465,9 +465,13 @@ __device__ __forceinline__ void scan_tap(float v, bool in, int tap, bool first, 
     if (first || v > best || v != v) { best = v; win = in ? tap : 255; }
 }
 
+// signbits (optional): one byte per 2 x 4 block of INPUT elements -- bit i*4+j = (x[row 2a+i][col 4m+j] > 0) -- at
+// ((bc*Ti + t)*(Hi/2) + a)*(Wi/4) + m: the ReLU mask of the producing layer, which the backward kernel then reads as one
+// byte per thread instead of two float4 of the 4-byte activations (604 MB -> 19 MB for MaxPool3d_2a).
 template <int KT>
 __global__ __launch_bounds__(256) void maxpoolk33_s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                unsigned char* __restrict__ arg, PoolGeom g, FastDiv fW2) {
+                                                                unsigned char* __restrict__ arg, PoolGeom g, FastDiv fW2,
+                                                                unsigned char* __restrict__ signbits) {
     constexpr int ST = KT == 3 ? 2 : 1;
     const int W2 = g.Wo >> 1;
     const int p2 = blockIdx.x * 256 + threadIdx.x;
@@ -510,13 +514,26 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_fwd_kernel(const float* __r
     const int p = ((int)t * g.Ho + ho) * g.Wo + 2 * m;
     *reinterpret_cast<float2*>(y + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p) = make_float2(b0, b1);
     *reinterpret_cast<unsigned short*>(arg + (int64_t)bc * g.To * g.Ho * g.Wo + p) = (unsigned short)(w0 | (w1 << 8));
+    if (signbits) {             // this thread read the input planes t*ST .. t*ST + ST - 1, rows 2 ho and 2 ho + 1, columns 4m .. 4m+3 in full
+#pragma unroll
+        for (int dt = 0; dt < ST; ++dt) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 r = v[dt][i];
+                bits |= (unsigned)(r.x > 0.f) << (i * 4) | (unsigned)(r.y > 0.f) << (i * 4 + 1) | (unsigned)(r.z > 0.f) << (i * 4 + 2) |
+                        (unsigned)(r.w > 0.f) << (i * 4 + 3);
+            }
+            signbits[(((int64_t)bc * g.Ti + (int)t * ST + dt) * (g.Hi >> 1) + ho) * (g.Wi >> 2) + m] = (unsigned char)bits;
+        }
+    }
 }
 
 template <int KT>
 __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
                                                                 float* __restrict__ dx, PoolGeom g, int accumulate,
                                                                 const float* __restrict__ emask, const float* __restrict__ escale,
-                                                                FastDiv fW4, FastDiv fH2) {
+                                                                FastDiv fW4, FastDiv fH2, const unsigned char* __restrict__ signbits) {
     const int W4 = g.Wi >> 2, H2 = g.Hi >> 1;
     const int p4 = blockIdx.x * 256 + threadIdx.x;
     if (p4 >= g.Ti * H2 * W4) return;
@@ -528,9 +545,16 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __r
     const int a = q - t * H2;
     const int64_t xo = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)t * g.Hi + 2 * a) * g.Wi + 4 * m;
     float4 mk[2], old[2];
+    if (signbits) {             // the producer's ReLU mask as one byte per thread (written by the forward kernel)
+        const unsigned bits = signbits[(((int64_t)bc * g.Ti + t) * H2 + a) * W4 + m];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            mk[i] = make_float4((float)((bits >> (i * 4)) & 1u), (float)((bits >> (i * 4 + 1)) & 1u), (float)((bits >> (i * 4 + 2)) & 1u),
+                                (float)((bits >> (i * 4 + 3)) & 1u));
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        mk[i] = emask ? *reinterpret_cast<const float4*>(emask + xo + i * g.Wi) : make_float4(1.f, 1.f, 1.f, 1.f);
+        if (!signbits) mk[i] = emask ? *reinterpret_cast<const float4*>(emask + xo + i * g.Wi) : make_float4(1.f, 1.f, 1.f, 1.f);
         old[i] = accumulate ? *reinterpret_cast<const float4*>(dx + xo + i * g.Wi) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // candidate output planes, ascending tap (dt) order: KT = 1: plane t (dt 0);  KT = 3, stride 2: plane t/2 with
@@ -548,17 +572,20 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __r
         const unsigned char* ab = arg + ((int64_t)bc * g.To + (pin ? to : 0)) * g.Ho * g.Wo;
         // D[r][k], A[r][k]: output rows a-1 (r = 0) and a (r = 1), output columns 2m-1, 2m, 2m+1
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int ho = a - 1 + r, wo = 2 * m - 1 + k;
-                const bool in = pin && ho >= 0 && wo >= 0;
-                const int o = in ? ho * g.Wo + wo : 0;
-                const float d = dyb[o];
-                const int t_ = ab[o];
-                D[pl][r][k] = in ? d : 0.f;
-                A[pl][r][k] = in ? t_ : 255;
-            }
+        for (int r = 0; r < 2; ++r) {
+            // columns 2m, 2m+1 as one aligned float2 / ushort, column 2m-1 on its own: 4 loads per row instead of 6
+            const int ho = a - 1 + r;
+            const bool rin = pin && ho >= 0;
+            const int o = rin ? ho * g.Wo + 2 * m : 0;
+            const float2 d2 = *reinterpret_cast<const float2*>(dyb + o);
+            const unsigned t2 = *reinterpret_cast<const unsigned short*>(ab + o);
+            const bool lin = rin && m > 0;
+            const float d0 = dyb[lin ? o - 1 : o];
+            const int t0 = ab[lin ? o - 1 : o];
+            D[pl][r][0] = lin ? d0 : 0.f;  A[pl][r][0] = lin ? t0 : 255;
+            D[pl][r][1] = rin ? d2.x : 0.f; A[pl][r][1] = rin ? (int)(t2 & 255u) : 255;
+            D[pl][r][2] = rin ? d2.y : 0.f; A[pl][r][2] = rin ? (int)(t2 >> 8) : 255;
+        }
     }
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;   // ascending tap order per input element
 #pragma unroll
@@ -574,7 +601,7 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __r
         s1.z += hit(1, 2, 3) + hit(1, 1, 5);
         s1.w += hit(1, 2, 4);
     }
-    if (emask) {
+    if (emask || signbits) {
         const float esc = escale[c];
         s0.x = mk[0].x > 0.f ? s0.x * esc : 0.f; s0.y = mk[0].y > 0.f ? s0.y * esc : 0.f;
         s0.z = mk[0].z > 0.f ? s0.z * esc : 0.f; s0.w = mk[0].w > 0.f ? s0.w * esc : 0.f;
@@ -642,18 +669,19 @@ int bwd_planes(const PoolGeom& g, int& tlo_max, size_t& lds) {
 
 }  // namespace
 
-extern "C" int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const float* x, float* y,
-                                  unsigned char* argtap, void* stream) {
+static int pool_fwd(const int* geom, const int64_t* strides, const float* x, float* y, unsigned char* argtap,
+                    unsigned char* signbits, void* stream) {
     if (!geom || !strides || !x || !y || !argtap) return OTAL_E_NULL;
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
+    if (signbits && !strided_k33_kind(g, x, y)) return OTAL_E_UNSUPPORTED;
     if (const int kind = strided_k33_kind(g, x, y)) {
         const int n2 = g.To * g.Ho * (g.Wo / 2);
         const dim3 grid((n2 + 255) / 256, g.B * g.C);
         const FastDiv fW2 = make_fastdiv((uint32_t)(g.Wo / 2));
-        if (kind == 1) hipLaunchKernelGGL(maxpoolk33_s2_fwd_kernel<1>, grid, dim3(256), 0, st_, x, y, argtap, g, fW2);
-        else hipLaunchKernelGGL(maxpoolk33_s2_fwd_kernel<3>, grid, dim3(256), 0, st_, x, y, argtap, g, fW2);
+        if (kind == 1) hipLaunchKernelGGL(maxpoolk33_s2_fwd_kernel<1>, grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
+        else hipLaunchKernelGGL(maxpoolk33_s2_fwd_kernel<3>, grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
         return otal_launch_status();
     }
     if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
@@ -684,21 +712,22 @@ extern "C" int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const
     return otal_launch_status();
 }
 
-extern "C" int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const float* dy,
-                                  const unsigned char* argtap, float* dx, int accumulate,
-                                  const float* out_mask, const float* out_scale, void* stream) {
+static int pool_bwd(const int* geom, const int64_t* strides, const float* dy, const unsigned char* argtap, float* dx,
+                    int accumulate, const float* out_mask, const float* out_scale, const unsigned char* signbits, void* stream) {
     if (!geom || !strides || !dy || !dx || !argtap) return OTAL_E_NULL;
-    if ((out_mask == nullptr) != (out_scale == nullptr)) return OTAL_E_NULL;
+    if (((out_mask == nullptr) && (signbits == nullptr)) != (out_scale == nullptr)) return OTAL_E_NULL;
+    if (out_mask && signbits) return OTAL_E_NULL;
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
     const int kind = (!out_mask || (reinterpret_cast<uintptr_t>(out_mask) & 15) == 0) ? strided_k33_kind(g, dx, dy) : 0;
+    if (signbits && !kind) return OTAL_E_UNSUPPORTED;
     if (kind) {
         const int n4 = g.Ti * (g.Hi / 2) * (g.Wi / 4);
         const dim3 grid((n4 + 255) / 256, g.B * g.C);
         const FastDiv fW4 = make_fastdiv((uint32_t)(g.Wi / 4)), fH2 = make_fastdiv((uint32_t)(g.Hi / 2));
-        if (kind == 1) hipLaunchKernelGGL(maxpoolk33_s2_bwd_kernel<1>, grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2);
-        else hipLaunchKernelGGL(maxpoolk33_s2_bwd_kernel<3>, grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2);
+        if (kind == 1) hipLaunchKernelGGL(maxpoolk33_s2_bwd_kernel<1>, grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
+        else hipLaunchKernelGGL(maxpoolk33_s2_bwd_kernel<3>, grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
         return otal_launch_status();
     }
     if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
@@ -721,4 +750,33 @@ extern "C" int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const
         OTAL_POOL_DISPATCH(maxpool3d_bwd_kernel, grid, 0, dy, argtap, dx, g, accumulate, out_mask, out_scale);
     }
     return otal_launch_status();
+}
+
+extern "C" int otal_maxpool3d_fwd(const int* geom, const int64_t* strides, const float* x, float* y,
+                                  unsigned char* argtap, void* stream) {
+    return pool_fwd(geom, strides, x, y, argtap, nullptr, stream);
+}
+extern "C" int otal_maxpool3d_bwd(const int* geom, const int64_t* strides, const float* dy,
+                                  const unsigned char* argtap, float* dx, int accumulate,
+                                  const float* out_mask, const float* out_scale, void* stream) {
+    return pool_bwd(geom, strides, dy, argtap, dx, accumulate, out_mask, out_scale, nullptr, stream);
+}
+// The producing layer's ReLU mask as sign bits (strided 3x3 pools only): bytes the _signbits entry points need, 0 = unsupported
+extern "C" size_t otal_maxpool3d_signbits_bytes(const int* geom, const int64_t* strides) {
+    if (!geom || !strides) return 0;
+    PoolGeom g;
+    if (fill(g, geom, strides)) return 0;
+    if (!strided_k33_kind(g, nullptr, nullptr)) return 0;
+    return (size_t)g.B * g.C * g.Ti * (g.Hi / 2) * (g.Wi / 4);
+}
+extern "C" int otal_maxpool3d_fwd_signbits(const int* geom, const int64_t* strides, const float* x, float* y,
+                                           unsigned char* argtap, unsigned char* signbits, void* stream) {
+    if (!signbits) return OTAL_E_NULL;
+    return pool_fwd(geom, strides, x, y, argtap, signbits, stream);
+}
+extern "C" int otal_maxpool3d_bwd_signbits(const int* geom, const int64_t* strides, const float* dy, const unsigned char* argtap,
+                                           float* dx, int accumulate, const unsigned char* signbits, const float* out_scale,
+                                           void* stream) {
+    if (!signbits || !out_scale) return OTAL_E_NULL;
+    return pool_bwd(geom, strides, dy, argtap, dx, accumulate, nullptr, out_scale, signbits, stream);
 }

@@ -397,6 +397,14 @@ def test_strided_pool_fast_path_equals_generic_kernels(shape, k, s, monkeypatch)
     assert torch.equal(outs[0][0][:, :4], outs[1][0][:, :4])
     assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-6)
     assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-6, atol=1e-6)
+    # the ReLU mask carried as sign bits by the forward kernel instead of re-read from the activations: identical dx
+    y2, a2, bits = ops.maxpool3d_forward(x, k, s, signbits=True)
+    assert torch.equal(y2, y0) and torch.equal(a2, a0)
+    if shape[-1] % 4 == 0:
+        assert bits is not None and bits.numel() == x.numel() // 8
+        d_bits = ops.maxpool3d_backward(dy, a0, x.shape, k, s, out_scale=sc, out_signbits=bits)
+        d_mask = ops.maxpool3d_backward(dy, a0, x.shape, k, s, out_mask=x, out_scale=sc)
+        assert torch.equal(d_bits, d_mask)
 
 
 @pytest.mark.parametrize("shape,cout", [((2, 3, 8, 96, 96), 64), ((1, 3, 12, 20, 96), 64), ((1, 3, 4, 8, 96), 96)])

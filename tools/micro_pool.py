@@ -38,4 +38,10 @@ for name in names:
     tb = timeit(lambda: ops.maxpool3d_backward(dy, arg, x.shape, k, s, out=dx, out_mask=x, out_scale=sc), iters)
     bf = (x.numel() * 4 + y.numel() * 5) / tf / 1e12
     bb = (y.numel() * 5 + x.numel() * 8) / tb / 1e12
-    print(f"{name:4s} fwd {tf*1e6:7.1f} us {bf:5.2f} TB/s | bwd(+mask) {tb*1e6:7.1f} us {bb:5.2f} TB/s", flush=True)
+    extra = ""
+    y2, a2, bits = ops.maxpool3d_forward(x, k, s, signbits=True)
+    if bits is not None:
+        tfb = timeit(lambda: ops.maxpool3d_forward(x, k, s, signbits=True), iters)
+        tbb = timeit(lambda: ops.maxpool3d_backward(dy, arg, x.shape, k, s, out=dx, out_scale=sc, out_signbits=bits), iters)
+        extra = f" | with sign bits: fwd {tfb*1e6:7.1f} us, bwd {tbb*1e6:7.1f} us"
+    print(f"{name:4s} fwd {tf*1e6:7.1f} us {bf:5.2f} TB/s | bwd(+mask) {tb*1e6:7.1f} us {bb:5.2f} TB/s{extra}", flush=True)
