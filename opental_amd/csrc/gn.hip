@@ -46,22 +46,47 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
     const int n = cpg * T;
     for (int i = tid; i < n; i += 256) buf[i] = x[base + i];
     __syncthreads();
-#pragma unroll 1
-    for (int l = 0; l < L.nlev; ++l) {
-        const int lo = L.lev[l], len = L.lev[l + 1] - lo;
-        const int cnt = cpg * len;
+    if (L.nlev == 1) {          // one level: the whole workgroup reduces it
+        const int cnt = n;
         float s = 0.f;
-        for (int i = tid; i < cnt; i += 256) { const int c = i / len, t = i - c * len; s += buf[c * T + lo + t]; }
+        for (int i = tid; i < cnt; i += 256) s += buf[i];
         const float mean = block_sum(s, red, tid) / (float)cnt;
         float q = 0.f;
-        for (int i = tid; i < cnt; i += 256) { const int c = i / len, t = i - c * len; const float d = buf[c * T + lo + t] - mean; q += d * d; }
+        for (int i = tid; i < cnt; i += 256) { const float d = buf[i] - mean; q += d * d; }
         const float var = block_sum(q, red, tid) / (float)cnt;
         const float rstd = 1.0f / sqrtf(var + eps);
         if (tid == 0) {
+            stats[((int64_t)b * G + g) * 2 + 0] = mean;
+            stats[((int64_t)b * G + g) * 2 + 1] = rstd;
+        }
+        for (int i = tid; i < cnt; i += 256) {
+            const int ch = g * cpg + i / T;
+            float v = (buf[i] - mean) * rstd * gamma[ch] + beta[ch];
+            if (relu) v = fmaxf(v, 0.f);
+            y[base + i] = v;
+        }
+        return;
+    }
+    // level-packed maps: one WAVE per level (levels l = wave, wave + 4, ...), wave-local reductions only -- the 12
+    // block-wide reductions of the six-level map (two barriers each) were most of this latency-bound kernel (one workgroup
+    // per (sample, group), 2016 elements)
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll 1
+    for (int l = wave; l < L.nlev; l += 4) {
+        const int lo = L.lev[l], len = L.lev[l + 1] - lo;
+        const int cnt = cpg * len;
+        float s = 0.f;
+        for (int i = lane; i < cnt; i += 64) { const int c = i / len, t = i - c * len; s += buf[c * T + lo + t]; }
+        const float mean = __shfl(wave_sum(s), 0, 64) / (float)cnt;
+        float q = 0.f;
+        for (int i = lane; i < cnt; i += 64) { const int c = i / len, t = i - c * len; const float d = buf[c * T + lo + t] - mean; q += d * d; }
+        const float var = __shfl(wave_sum(q), 0, 64) / (float)cnt;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        if (lane == 0) {
             stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 0] = mean;
             stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 1] = rstd;
         }
-        for (int i = tid; i < cnt; i += 256) {
+        for (int i = lane; i < cnt; i += 64) {
             const int c = i / len, t = i - c * len;
             const int ch = g * cpg + c;
             float v = (buf[c * T + lo + t] - mean) * rstd * gamma[ch] + beta[ch];
@@ -89,14 +114,18 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
     const int n = cpg * T;
     for (int i = tid; i < n; i += 256) { xb[i] = x[base + i]; gb[i] = dy[base + i]; }
     __syncthreads();
+    // level l is handled by the whole workgroup when it is the only one, else by wave l % 4 on its own (see the forward)
+    const bool solo = L.nlev == 1;
+    const int wv = tid >> 6, ln = tid & 63;
+    const int first = solo ? tid : ln, stride = solo ? 256 : 64;
 #pragma unroll 1
-    for (int l = 0; l < L.nlev; ++l) {
+    for (int l = solo ? 0 : wv; l < L.nlev; l += solo ? 1 : 4) {
         const int lo = L.lev[l], len = L.lev[l + 1] - lo;
         const int cnt = cpg * len;
         const float mean = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 0];
         const float rstd = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 1];
         float s1 = 0.f, s2 = 0.f;
-        for (int i = tid; i < cnt; i += 256) {
+        for (int i = first; i < cnt; i += stride) {
             const int c = i / len, t = i - c * len, ch = g * cpg + c, p = c * T + lo + t;
             const float xh = (xb[p] - mean) * rstd;
             float d = gb[p];
@@ -107,18 +136,21 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
             s1 += dg;
             s2 += dg * xh;
         }
-        const float m1 = block_sum(s1, red, tid) / (float)cnt;
-        const float m2 = block_sum(s2, red, tid) / (float)cnt;
-        // block_sum's barriers also make every thread's xb/gb writes visible
-        for (int i = tid; i < cnt; i += 256) {
+        float m1, m2;
+        if (solo) {
+            m1 = block_sum(s1, red, tid) / (float)cnt;
+            m2 = block_sum(s2, red, tid) / (float)cnt;       // block_sum's barriers also make every thread's xb/gb writes visible
+        } else {
+            m1 = __shfl(wave_sum(s1), 0, 64) / (float)cnt;   // a wave re-reads only what it wrote itself
+            m2 = __shfl(wave_sum(s2), 0, 64) / (float)cnt;
+        }
+        for (int i = first; i < cnt; i += stride) {
             const int c = i / len, t = i - c * len, ch = g * cpg + c, p = c * T + lo + t;
             const float v = rstd * (gb[p] * gamma[ch] - m1 - xb[p] * m2);
             dx[base + (int64_t)c * T + lo + t] = v;
-            // keep dyh in gb for the per-channel sums below; stash dx in the (now free) dy slot? no:
-            // per-channel sums need dyh, xhat and dx -> recompute dx there.
         }
-        __syncthreads();
     }
+    __syncthreads();            // xb / gb of every level (and the dx stores the sums below re-read) are complete
     // per-channel sums over all t (all levels), fixed order: one wave per channel, lanes stride t
     const int wave = tid >> 6, lane = tid & 63;
     for (int c = wave; c < cpg; c += 4) {
