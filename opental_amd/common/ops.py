@@ -295,14 +295,15 @@ def conv_dgrad_collapse(dy, w, x_shape):
 
     Every input element (ci, t, h, w) is reached by exactly one tap, so the generic data-gradient
     gather would visit kh*kw taps to find it (36x redundant work for the [1,6,6] projection).
-    Instead: dx[b, (ci,hw), t] = sum_co W[co, (ci,hw)] * dy[b, co, t] -- the data gradient of a 1x1 convolution
-    with Cin*kh*kw input channels, whose forward-layout weight is just a VIEW of w (no transposed copy of the 61 MB
-    [1,6,6] projection: the launch's own prologue packs W^T, in bf16, into its persistent region), then
-    (ci,hw,t) -> (ci,t,hw)."""
+    Instead: dx[b, (ci,hw), t] = sum_co W[co, (ci,hw)] * dy[b, co, t] -- a forward-mode 1x1 GEMM
+    with M = Cin*kh*kw, K = Cout on the transposed weights, then (ci,hw,t) -> (ci,t,hw).
+    (Handing the launch a view of w as the natural weight of a 1x1 data gradient instead of the transposed copy was
+    measured: the prologue's strided bf16 pack of the 15.3 M weights costs 0.19 ms against 0.12 ms for this copy.)"""
     B, Cin, T, H, W = x_shape
     Cout = w.shape[0]
+    wt = w.reshape(Cout, Cin * H * W).t().contiguous().view(Cin * H * W, Cout, 1)
     dy3 = dy.reshape(B, Cout, T)
-    dxp = conv_dgrad(dy3, w.view(Cout, Cin * H * W, 1), (B, Cin * H * W, T), 1, 1)     # (B, Cin*H*W, T)
+    dxp = conv_forward(dy3, wt, 1, 1)                                   # (B, Cin*H*W, T)
     return dxp.view(B, Cin, H * W, T).permute(0, 1, 3, 2).contiguous().view(B, Cin, T, H, W)
 
 
