@@ -75,6 +75,12 @@ class InceptionModule(nn.Module):
     def units(self):
         return [self.b0, self.b1a, self.b1b, self.b2a, self.b2b, self.b3b]
 
+    def fused_1x1_weights(self):
+        """The three 1x1 weights that read the module input, in the channel order of the fused launch [b1a | b2a | b0]:
+        a trainer that homes parameters in a flat arena keeps them ADJACENT in this order (FlatArena), so that the fused
+        weight is a zero-copy view and its packed form can live in a persistent prologue region."""
+        return [self.b1a.conv3d.weight, self.b2a.conv3d.weight, self.b0.conv3d.weight]
+
 
 # endpoint table (i3d_backbone.py:194-296)
 _ENDPOINTS = (
@@ -175,6 +181,31 @@ class InceptionI3d(nn.Module):
 _FUSED_AFFINE = {}
 
 
+def _fused_weight(w_b1a, w_b2a, w_b0):
+    """[b1a | b2a | b0] along the output channels: a view when the three live back to back in one storage, else a copy."""
+    n1, n2 = w_b1a.numel(), w_b2a.numel()
+    es = w_b1a.element_size()
+    if (w_b1a.is_contiguous() and w_b2a.is_contiguous() and w_b0.is_contiguous()
+            and w_b2a.data_ptr() == w_b1a.data_ptr() + n1 * es and w_b0.data_ptr() == w_b2a.data_ptr() + n2 * es
+            and w_b1a.untyped_storage().data_ptr() == w_b0.untyped_storage().data_ptr()):
+        rows = w_b1a.shape[0] + w_b2a.shape[0] + w_b0.shape[0]
+        return w_b1a.as_strided((rows,) + tuple(w_b1a.shape[1:]), w_b1a.stride(), w_b1a.storage_offset())
+    return torch.cat([w_b1a, w_b2a, w_b0], 0)
+
+
+def _cat_cached(cache, key, parts):
+    hit = cache.get(key)
+    if hit is None:
+        hit = torch.cat(parts)
+        if len(cache) > 256:
+            cache.clear()
+        cache[key] = hit
+    return hit
+
+
+_OUT_SCALE = {}
+
+
 def _fused_affine(scale, shift, offs, w0):
     """Folded-BN scale / shift of the fused 1x1 launch of a module, in its channel order [b1a | b2a | b0] (constants)."""
     key = (scale.data_ptr(), shift.data_ptr(), w0)
@@ -231,7 +262,7 @@ class I3DFeaturesFunction(Function):
                 Z = torch.empty((B, o13 + ctot, T, H, W), dtype=cur.dtype, device=cur.device)
                 h1, h2, Y = Z[:, :o1], Z[:, o1:o13], Z[:, o13:]
                 c1, c2, c3 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
-                wf = torch.cat([weights[w0 + 1], weights[w0 + 3], weights[w0]], 0)
+                wf = _fused_weight(weights[w0 + 1].detach(), weights[w0 + 3].detach(), weights[w0].detach())
                 scf, shf = _fused_affine(scale, shift, offs, w0)
                 ops.conv_forward(cur, wf, ONE, ONE, scale=scf, shift=shf, relu=True, out=Z[:, :o13 + c1])
                 ops.conv_forward(h1, weights[w0 + 2], THREE, ONE, scale=sc(w0 + 2), shift=sh(w0 + 2), relu=True,
@@ -241,7 +272,7 @@ class I3DFeaturesFunction(Function):
                 pm, argm = ops.maxpool3d_forward(cur, THREE, ONE)
                 ops.conv_forward(pm, weights[w0 + 5], ONE, ONE, scale=sc(w0 + 5), shift=sh(w0 + 5), relu=True,
                                  out=Y[:, c3:])
-                out_scale = torch.cat([sc(w0), sc(w0 + 2), sc(w0 + 4), sc(w0 + 5)])
+                out_scale = _cat_cached(_OUT_SCALE, (scale.data_ptr(), w0), [sc(w0), sc(w0 + 2), sc(w0 + 4), sc(w0 + 5)])
                 tape.append(("mixed", w0, (c1, c2, c3), cur, h1, h2, pm, argm, Y, cur_scale, (wf, o1, o13), out_scale))
                 cur, cur_scale = Y, out_scale
             if name in endpoints:

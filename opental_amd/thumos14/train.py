@@ -69,11 +69,21 @@ def total_cost(losses, w):
 class FlatArena:
     """Trainable parameters re-homed into one contiguous fp32 buffer (+ parallel grad / m / v)."""
 
-    def __init__(self, params, bucket_bytes):
+    def __init__(self, params, bucket_bytes, adjacent=()):
+        """`adjacent`: groups of parameters that must sit back to back, in the given order (e.g. the three 1x1 weights of
+        an Inception module that one fused launch reads as a single matrix, InceptionModule.fused_1x1_weights)."""
         self.params = [p for p in params if p.requires_grad]
         # arena order = expected gradient-completion order: autograd finishes the heads / pyramid
         # first and the (single-node) backbone last, i.e. reverse registration order
         self.params = list(reversed(self.params))
+        for group in adjacent:
+            ids = {id(p) for p in group}
+            if not all(any(q is p for q in self.params) for p in group):
+                continue
+            first = min(i for i, q in enumerate(self.params) if id(q) in ids)
+            rest = [q for q in self.params if id(q) not in ids]
+            first -= sum(1 for q in self.params[:first] if id(q) in ids)
+            self.params = rest[:first] + list(group) + rest[first:]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
@@ -122,7 +132,8 @@ class DetectorTrainer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
         self.forward_fn = forward_one_epoch if forward_fn is None else forward_fn
-        self.arena = FlatArena(list(net.parameters()), bucket_mb << 20)
+        adjacent = [m.fused_1x1_weights() for m in net.modules() if hasattr(m, 'fused_1x1_weights')]
+        self.arena = FlatArena(list(net.parameters()), bucket_mb << 20, adjacent)
         self.param_groups = [(list(net.parameters()), lr)] if param_groups is None else [(list(ps), g_lr) for ps, g_lr in param_groups]
         self._group_ranges = self._arena_ranges()
         self.step_count = 0

@@ -157,3 +157,31 @@ def test_checkpoint_round_trip_and_reference_optimizer_format(tmp_path):
     for i, p in enumerate(net3.parameters()):
         off = tr3.arena.offsets[[id(q) for q in tr3.arena.params].index(id(p))]
         assert torch.equal(opt.state[list(ref_net.parameters())[i]]['exp_avg'].reshape(-1), tr3.arena.m[off:off + p.numel()])
+
+
+def test_fused_1x1_weights_are_adjacent_arena_views():
+    """FlatArena keeps [b1a | b2a | b0] of every Inception module back to back, so the fused 1x1 weight is a zero-copy view."""
+    from opental_amd.common.i3d_backbone import InceptionModule, _fused_weight
+    from opental_amd.thumos14.train import FlatArena
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.head = nn.Linear(4, 4)
+            self.m1 = InceptionModule(8, (4, 6, 8, 2, 4, 4), 'm1')
+            self.m2 = InceptionModule(20, (8, 4, 8, 4, 4, 4), 'm2')
+    net = Net()
+    loose = _fused_weight(*[w.detach() for w in net.m1.fused_1x1_weights()])
+    want = torch.cat([w.detach() for w in net.m1.fused_1x1_weights()], 0).clone()
+    assert torch.equal(loose, want)                                   # not adjacent yet: a copy
+    adjacent = [m.fused_1x1_weights() for m in net.modules() if hasattr(m, 'fused_1x1_weights')]
+    arena = FlatArena(list(net.parameters()), 1 << 20, adjacent)
+    assert arena.numel == sum(p.numel() for p in net.parameters() if p.requires_grad)
+    assert len({id(p) for p in arena.params}) == len(arena.params)
+    for m in (net.m1, net.m2):
+        ws = [w.detach() for w in m.fused_1x1_weights()]
+        wf = _fused_weight(*ws)
+        assert wf.data_ptr() == ws[0].data_ptr() and wf.shape[0] == sum(w.shape[0] for w in ws)
+        assert torch.equal(wf, torch.cat(ws, 0))
+        wf[0, 0, 0, 0, 0] = 123.0                                     # a view: writes land in the parameter
+        assert float(m.b1a.conv3d.weight.detach()[0, 0, 0, 0, 0]) == 123.0
