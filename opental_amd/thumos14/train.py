@@ -56,14 +56,23 @@ def forward_one_epoch(net, criterion, clips, targets, scores=None, training=True
     return loss_l, loss_c, loss_prop_l, loss_prop_c, loss_ct, loss_start, loss_end, loss_act, loss_prop_act
 
 
+_COST_WEIGHTS = {}
+
+
 def total_cost(losses, w):
-    """The weighted sum of run_one_epoch (train.py:226-235)."""
+    """The weighted sum of run_one_epoch (train.py:226-235) as one stack + one dot product (the reference's nine scalar
+    multiplies and eight adds are ~20 one-element kernels, forward and backward)."""
     loss_l, loss_c, loss_prop_l, loss_prop_c, loss_ct, loss_start, loss_end, loss_act, loss_prop_act = losses
-    cost = loss_l * w['lw'] + loss_c * w['cw'] + loss_prop_l * w['lw'] + loss_prop_c * w['cw'] + \
-        loss_ct * w['ctw'] + loss_start + loss_end
+    parts = [loss_l, loss_c, loss_prop_l, loss_prop_c, loss_ct, loss_start, loss_end]
+    weights = [w['lw'], w['cw'], w['lw'], w['cw'], w['ctw'], 1.0, 1.0]
     if loss_act is not None:
-        cost = cost + loss_act * w['actw'] + loss_prop_act * w['actw']
-    return cost
+        parts += [loss_act, loss_prop_act]
+        weights += [w['actw'], w['actw']]
+    key = (tuple(weights), parts[0].device)
+    wv = _COST_WEIGHTS.get(key)
+    if wv is None:
+        wv = _COST_WEIGHTS[key] = torch.tensor(weights, dtype=torch.float32, device=parts[0].device)
+    return torch.dot(torch.stack([p.reshape(()) for p in parts]), wv)
 
 
 class FlatArena:
