@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 11
+#define OTAL_ABI_VERSION 12
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -190,6 +190,16 @@ int otal_head_outputs_bwd(int n_items, const int* channels, const int* modes, co
                           const float* const* out, const float* const* unct, const float* const* dout,
                           const float* const* dunct, float* const* draw, const float* scales, float* dscales, int B,
                           int N, int nlev, const int* lev, const float* level_strides, void* stream);
+
+/* ------------------------------------------------------------------ boundary (start / end) losses ----
+ * calc_bce_loss (AFSD/thumos14/train.py:152-161; anet/train.py:136-144) on both channel halves of a boundary feature
+ * map x (B, C, T) read in place through its batch / channel strides (time stride 1): half h in {0, 1},
+ * m = mean over the half's channels of tanh(x), loss_h = mean over (b, t) of BCE(m, mask[b, mask_row0 + h, t * mask_step]).
+ * terms (B, 2, T): the per-(b, t) BCE values (loss_h = sum / (B T)); dx (B, C, T) contiguous: d loss_h / d x for the
+ * channels of half h (scale each half by the incoming gradient of its loss). */
+int otal_boundary_bce(const float* x, int64_t x_batch_stride, int64_t x_channel_stride, const float* mask,
+                      int64_t mask_batch_stride, int64_t mask_row_stride, int mask_row0, int mask_step, float* terms,
+                      float* dx, int B, int C, int T, void* stream);
 
 /* ------------------------------------------------------------------ proposal window indices ----
  * loc (B,Ntot,2) -> level-space windows seg (B,Ntot,4) and frame-space windows frame_seg (B,Ntot,4)

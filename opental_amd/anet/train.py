@@ -36,10 +36,18 @@ def forward_one_epoch(net, criterion, clips, targets, scores=None, training=True
     loss_l, loss_c, loss_prop_l, loss_prop_c, loss_ct, loss_act, loss_prop_act = criterion(
         [output_dict['loc'], output_dict['conf'], output_dict['prop_loc'], output_dict['prop_conf'],
          output_dict['center'], output_dict['priors'], output_dict['act'], output_dict['prop_act']], targets)
-    loss_start, loss_end = calc_bce_loss(output_dict['start'], output_dict['end'], scores)
-    scores_ = scores[:, :, ::8]     # F.interpolate(scale_factor=1/8), nearest (anet/train.py:174-178)
-    a, b = calc_bce_loss(output_dict['start_loc_prop'], output_dict['end_loc_prop'], scores_)
-    c, d = calc_bce_loss(output_dict['start_conf_prop'], output_dict['end_conf_prop'], scores_)
+    src = getattr(getattr(net, 'coarse_pyramid_detection', None), '_bce_sources', None)
+    if src is not None and src[0].is_cuda and src[0].dtype == torch.float32:
+        # one launch per map: tanh, channel mean, BCE and the gradient, on the channel-major maps in place (csrc/bce.hip)
+        from ..common.ops import BoundaryBCEFunction
+        loss_start, loss_end = BoundaryBCEFunction.apply(src[0], scores, 1, 1)
+        a, b = BoundaryBCEFunction.apply(src[1], scores, 1, 8)       # F.interpolate(scale_factor=1/8), nearest
+        c, d = BoundaryBCEFunction.apply(src[2], scores, 1, 8)
+    else:
+        loss_start, loss_end = calc_bce_loss(output_dict['start'], output_dict['end'], scores)
+        scores_ = scores[:, :, ::8]     # F.interpolate(scale_factor=1/8), nearest
+        a, b = calc_bce_loss(output_dict['start_loc_prop'], output_dict['end_loc_prop'], scores_)
+        c, d = calc_bce_loss(output_dict['start_conf_prop'], output_dict['end_conf_prop'], scores_)
     loss_start = loss_start + 0.1 * (a + c)
     loss_end = loss_end + 0.1 * (b + d)
     return loss_l, loss_c, loss_prop_l, loss_prop_c, loss_ct, loss_start, loss_end, loss_act, loss_prop_act

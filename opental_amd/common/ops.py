@@ -563,3 +563,36 @@ class HeadOutputsFunction(torch.autograd.Function):
         aligned = torch.zeros((nlev, 4), dtype=dscales.dtype, device=dscales.device)
         aligned[:, 0] = dscales
         return (None, None, None) + tuple(aligned[l, :1] for l in range(nlev)) + tuple(draws)
+
+
+# ----------------------------------------------------------------------------- boundary (start / end) losses
+class BoundaryBCEFunction(torch.autograd.Function):
+    """(loss_start, loss_end) = calc_bce_loss on the two channel halves of x (B,C,T), read in place (x may be a slice along
+    T of a larger map); mask (B,R,Tm) holds the start / end rows at row0, row0+1 and is sampled every `step` frames."""
+
+    @staticmethod
+    def forward(ctx, x, mask, row0, step):
+        if not (x.is_cuda and mask.is_cuda):
+            raise RuntimeError("opental_amd ops run on the GPU only")
+        B, C, T = x.shape
+        if x.stride(2) != 1 or mask.stride(2) != 1 or x.dtype != torch.float32 or mask.dtype != torch.float32:
+            raise RuntimeError("boundary_bce: float32 maps with unit time stride")
+        if row0 + 2 > mask.shape[1] or (T - 1) * step >= mask.shape[2]:
+            raise RuntimeError("boundary_bce: mask rows / length do not cover the map")
+        terms = torch.empty((B, 2, T), dtype=torch.float32, device=x.device)
+        dx = torch.empty((B, C, T), dtype=torch.float32, device=x.device)
+        L.check(L.lib().otal_boundary_bce(L.ptr(x), ctypes.c_int64(x.stride(0)), ctypes.c_int64(x.stride(1)), L.ptr(mask),
+                                          ctypes.c_int64(mask.stride(0)), ctypes.c_int64(mask.stride(1)), int(row0), int(step),
+                                          L.ptr(terms), L.ptr(dx), B, C, T, L.stream()), "otal_boundary_bce")
+        ctx.save_for_backward(dx)
+        ctx.x_shape = tuple(x.shape)
+        losses = terms.sum(dim=(0, 2)) / float(B * T)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g_start, g_end):
+        (dx,) = ctx.saved_tensors
+        B, C, T = ctx.x_shape
+        z = dx.new_zeros(())
+        g = torch.stack([z if g_start is None else g_start.reshape(()), z if g_end is None else g_end.reshape(())])
+        return (dx.view(B, 2, C // 2, T) * g.view(1, 2, 1, 1)).view(B, C, T), None, None, None

@@ -249,12 +249,17 @@ class CoarsePyramid(nn.Module):
             segments, frame_segments = ops.proposal_windows(loc.detach(), lev, float(self.frame_num))
         loc_prop_feat, loc_lr = self.loc_proposal_branch(loc_feat, frame_level_feat, segments, frame_segments, lev)
         conf_prop_feat, conf_lr = self.conf_proposal_branch(conf_feat, frame_level_feat, segments, frame_segments, lev)
+        # The six boundary maps of the output dict are (B,T,C) VIEWS of the channel-major maps (the reference returns
+        # permuted copies, BDNet.py:328-331,:392-396; same values): their only consumer, the start / end losses of the
+        # training step, reads the channel-major maps in place (ops.BoundaryBCEFunction via _bce_sources).
+        pv = lambda y: y.permute(0, 2, 1)
         half = frame_level_feat.size(1) // 2
-        start, end = tr(frame_level_feat[:, :half]), tr(frame_level_feat[:, half:])
+        start, end = pv(frame_level_feat[:, :half]), pv(frame_level_feat[:, half:])
         t0 = self.level_lengths[0]
         ndim = loc_lr.size(1) // 2
-        start_loc_prop, end_loc_prop = tr(loc_lr[:, :ndim, :t0]), tr(loc_lr[:, ndim:, :t0])
-        start_conf_prop, end_conf_prop = tr(conf_lr[:, :ndim, :t0]), tr(conf_lr[:, ndim:, :t0])
+        start_loc_prop, end_loc_prop = pv(loc_lr[:, :ndim, :t0]), pv(loc_lr[:, ndim:, :t0])
+        start_conf_prop, end_conf_prop = pv(conf_lr[:, :ndim, :t0]), pv(conf_lr[:, ndim:, :t0])
+        self._bce_sources = (frame_level_feat, loc_lr[:, :, :t0], conf_lr[:, :, :t0])
         raws = [self.prop_loc_head(loc_prop_feat), self.prop_conf_head(self._drop(conf_prop_feat)), self.center_head(loc_prop_feat, lev)]
         if self.os_head:
             raws.append(self.prop_actionness_head(conf_prop_feat))

@@ -469,3 +469,29 @@ def test_head_output_tails_match_the_torch_formulation(lev, strides, K):
     o2[1].sum().backward()
     assert float(rd2[0].grad.abs().max()) == 0.0 and float(rd2[2].grad.abs().max()) == 0.0
     assert torch.equal(rd2[1].grad, torch.ones_like(rd2[1].grad))
+
+
+@pytest.mark.parametrize("B,C,T,Tm,row0,step", [(2, 512, 256, 256, 0, 1), (3, 1024, 64, 256, 0, 4), (2, 1024, 96, 768, 1, 8)])
+def test_boundary_bce_matches_calc_bce_loss(B, C, T, Tm, row0, step):
+    """tanh + channel mean + BCE of both halves of a boundary map in one launch, read in place from a T-slice of a wider
+    map, against calc_bce_loss (train.py:152-161) on the permuted copies; gradients included."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(61)
+    wide = torch.from_numpy(np.abs(rs.randn(B, C, T + 30)).astype(np.float32) * 0.6)      # post-ReLU features
+    mask = torch.from_numpy((rs.rand(B, row0 + 2, Tm) < 0.2).astype(np.float32))
+    xr = wide.clone().requires_grad_(True)
+    xs = xr[:, :, :T]
+    half = C // 2
+    st = torch.tanh(xs[:, :half].permute(0, 2, 1).contiguous()).mean(-1)
+    en = torch.tanh(xs[:, half:].permute(0, 2, 1).contiguous()).mean(-1)
+    ms = mask[:, :, ::step][:, :, :T]
+    ls = F.binary_cross_entropy(st.reshape(-1), ms[:, row0].contiguous().view(-1))
+    le = F.binary_cross_entropy(en.reshape(-1), ms[:, row0 + 1].contiguous().view(-1))
+    (ls * 0.7 + le * 1.3).backward()
+    xd = wide.clone().cuda().requires_grad_(True)
+    gs, ge = ops.BoundaryBCEFunction.apply(xd[:, :, :T], mask.cuda(), row0, step)
+    close(gs, ls.detach(), tol=1e-5)
+    close(ge, le.detach(), tol=1e-5)
+    (gs * 0.7 + ge * 1.3).backward()
+    close(xd.grad, xr.grad, tol=2e-5)
+    assert float(xd.grad[:, :, T:].abs().max()) == 0.0
