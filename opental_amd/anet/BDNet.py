@@ -44,7 +44,7 @@ class CoarsePyramid(_thumos.CoarsePyramid):
 
     def forward(self, feat_dict, ssl=False):
         outs = super(CoarsePyramid, self).forward(feat_dict, ssl=ssl)
-        return outs if ssl else outs[:14]          # the reference returns 14 tensors (anet/BDNet.py:384-391)
+        return outs if ssl else outs[:14] + outs[16:]   # the reference returns 14 tensors (anet/BDNet.py:384-391) [+ the extras dict]
 
 
 class BDNet(_thumos.BDNet):

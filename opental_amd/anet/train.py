@@ -36,7 +36,7 @@ def forward_one_epoch(net, criterion, clips, targets, scores=None, training=True
     loss_l, loss_c, loss_prop_l, loss_prop_c, loss_ct, loss_act, loss_prop_act = criterion(
         [output_dict['loc'], output_dict['conf'], output_dict['prop_loc'], output_dict['prop_conf'],
          output_dict['center'], output_dict['priors'], output_dict['act'], output_dict['prop_act']], targets)
-    src = getattr(getattr(net, 'coarse_pyramid_detection', None), '_bce_sources', None)
+    src = getattr(output_dict, 'boundary_maps', None)
     if src is not None and src[0].is_cuda and src[0].dtype == torch.float32:
         # one launch per map: tanh, channel mean, BCE and the gradient, on the channel-major maps in place (csrc/bce.hip)
         from ..common.ops import BoundaryBCEFunction

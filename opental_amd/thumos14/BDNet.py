@@ -251,7 +251,7 @@ class CoarsePyramid(nn.Module):
         conf_prop_feat, conf_lr = self.conf_proposal_branch(conf_feat, frame_level_feat, segments, frame_segments, lev)
         # The six boundary maps of the output dict are (B,T,C) VIEWS of the channel-major maps (the reference returns
         # permuted copies, BDNet.py:328-331,:392-396; same values): their only consumer, the start / end losses of the
-        # training step, reads the channel-major maps in place (ops.BoundaryBCEFunction via _bce_sources).
+        # training step, reads the channel-major maps in place (ops.BoundaryBCEFunction via OutputDict.boundary_maps).
         pv = lambda y: y.permute(0, 2, 1)
         half = frame_level_feat.size(1) // 2
         start, end = pv(frame_level_feat[:, :half]), pv(frame_level_feat[:, half:])
@@ -259,22 +259,32 @@ class CoarsePyramid(nn.Module):
         ndim = loc_lr.size(1) // 2
         start_loc_prop, end_loc_prop = pv(loc_lr[:, :ndim, :t0]), pv(loc_lr[:, ndim:, :t0])
         start_conf_prop, end_conf_prop = pv(conf_lr[:, :ndim, :t0]), pv(conf_lr[:, ndim:, :t0])
-        self._bce_sources = (frame_level_feat, loc_lr[:, :, :t0], conf_lr[:, :, :t0])
+        boundary_maps = (frame_level_feat, loc_lr[:, :, :t0], conf_lr[:, :, :t0])
         raws = [self.prop_loc_head(loc_prop_feat), self.prop_conf_head(self._drop(conf_prop_feat)), self.center_head(loc_prop_feat, lev)]
         if self.os_head:
             raws.append(self.prop_actionness_head(conf_prop_feat))
         res = ops.HeadOutputsFunction.apply(tuple(lev), None, (0, um, 0, 0)[:len(raws)], *[h.detach() for h in scales], *raws)
         prop_loc, prop_conf, center = res[0], res[1], res[2]
         prop_act = res[3] if self.os_head else None
-        self._last_unct = (unct, res[len(raws)]) if self.dirichlet_exp else None
+        fused_unct = (unct, res[len(raws)]) if self.dirichlet_exp else None
         priors = self._priors_on(loc.device)
         outs = (loc, conf, prop_loc, prop_conf, center, priors, start, end,
                 start_loc_prop, end_loc_prop, start_conf_prop, end_conf_prop, act, prop_act)
         ctr_feat = prop_ctr_feat = None
         if get_feat:
             ctr_feat, prop_ctr_feat = tr(conf_feat), tr(conf_prop_feat)
-        self._last_windows = (segments, frame_segments)
-        return outs + (ctr_feat, prop_ctr_feat)
+        self._last_windows = (segments, frame_segments)       # no-grad index tensors (tests / debugging)
+        # Graph-attached by-products travel with the return value, never on the module: a tensor with a grad_fn parked on
+        # `self` would keep the step's autograd graph (and its AccumulateGrad nodes, bound to the stream they were created
+        # on) alive into the next step -- which breaks a later HIP-graph capture of the step.
+        extras = {'unct': fused_unct, 'boundary_maps': boundary_maps}
+        return outs + (ctr_feat, prop_ctr_feat, extras)
+
+
+class OutputDict(dict):
+    """The reference's output dict (same keys, tensors only) + `boundary_maps`: the channel-major maps behind the six
+    boundary entries, for the fused start / end loss.  An attribute, not a key, and it dies with the dict."""
+    boundary_maps = None
 
 
 class BDNet(nn.Module):
@@ -350,13 +360,14 @@ class BDNet(nn.Module):
         outs = self.coarse_pyramid_detection(feat_dict, get_feat=True) if get_feat else self.coarse_pyramid_detection(feat_dict)
         loc, conf, prop_loc, prop_conf, center, priors, start, end, start_loc_prop, end_loc_prop, \
             start_conf_prop, end_conf_prop, act, prop_act = outs[:14]
-        ctr_feat, prop_ctr_feat = outs[14:] if len(outs) > 14 else (None, None)
-        out_dict = {'loc': loc, 'conf': conf, 'priors': priors, 'prop_loc': prop_loc, 'prop_conf': prop_conf,
+        extras = outs[-1] if isinstance(outs[-1], dict) else {}
+        ctr_feat, prop_ctr_feat = outs[14:16] if len(outs) > 15 else (None, None)
+        out_dict = OutputDict({'loc': loc, 'conf': conf, 'priors': priors, 'prop_loc': prop_loc, 'prop_conf': prop_conf,
                     'center': center, 'start': start, 'end': end, 'start_loc_prop': start_loc_prop,
                     'end_loc_prop': end_loc_prop, 'start_conf_prop': start_conf_prop,
-                    'end_conf_prop': end_conf_prop, 'act': act, 'prop_act': prop_act}
+                    'end_conf_prop': end_conf_prop, 'act': act, 'prop_act': prop_act})
         if self.use_edl:
-            fused = getattr(self.coarse_pyramid_detection, '_last_unct', None)
+            fused = extras.get('unct')
             if fused is not None:
                 out_dict.update({'unct': fused[0], 'prop_unct': fused[1]})
             else:
@@ -364,6 +375,7 @@ class BDNet(nn.Module):
                                  'prop_unct': self.out_layer.compute_uncertainty(prop_conf)})
         if get_feat and not self.training:
             out_dict.update({'conf_feat': ctr_feat, 'prop_conf_feat': prop_ctr_feat})
+        out_dict.boundary_maps = extras.get('boundary_maps')    # channel-major sources of the six boundary maps (loss input)
         return out_dict
 
 

@@ -47,7 +47,7 @@ def forward_one_epoch(net, criterion, clips, targets, scores=None, training=True
         loss_ = [nn.TripletMarginLoss()(anchor[i], positive[i], negative[i]) * weights[i] for i in range(3)]
         return torch.stack(loss_).sum(0)
     loss_l, loss_c, loss_prop_l, loss_prop_c, loss_ct, loss_act, loss_prop_act = criterion(output_dict, targets)
-    src = getattr(getattr(net, 'coarse_pyramid_detection', None), '_bce_sources', None)
+    src = getattr(output_dict, 'boundary_maps', None)
     if src is not None and src[0].is_cuda and src[0].dtype == torch.float32:
         # one launch per map: tanh, channel mean, BCE and the gradient, on the channel-major maps in place (csrc/bce.hip)
         from ..common.ops import BoundaryBCEFunction
@@ -145,6 +145,7 @@ class DetectorTrainer:
         `forward_fn`: the recipe's forward_one_epoch (default: this module's, the THUMOS14 one)."""
         self.net, self.criterion, self.w = net, criterion, dict(loss_weights)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self._base_lr = lr          # the groups' rates follow `self.lr` proportionally (a scheduler only touches self.lr)
         self.distributed = dist.is_available() and dist.is_initialized() if distributed is None else distributed
         self.group = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
@@ -270,6 +271,7 @@ class DetectorTrainer:
         """Adam (L2 weight decay in the gradient, train.py:321-323) on the flat arena: one launch."""
         a = self.arena
         for lo, hi, g_lr in self._group_ranges:
+            g_lr = g_lr * (self.lr / self._base_lr) if self._base_lr else g_lr
             ops.adam_flat(a.flat[lo:hi], a.grad[lo:hi], a.m[lo:hi], a.v[lo:hi], self.step_count, g_lr,
                           self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
 
@@ -285,6 +287,7 @@ class DetectorTrainer:
             ops.deactivate_prologues()
         a = self.arena
         for lo, hi, g_lr in self._group_ranges:
+            g_lr = g_lr * (self.lr / self._base_lr) if self._base_lr else g_lr
             ops.adam_flat_dev(a.flat[lo:hi], a.grad[lo:hi], a.m[lo:hi], a.v[lo:hi], self._bias_corr, g_lr,
                               self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
         return cost.detach(), losses
@@ -391,6 +394,7 @@ class DetectorTrainer:
         g = sd['param_groups'][-1]          # the detection-head group carries the base learning rate
         self.lr, self.betas, self.eps, self.wd = g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']
         self.param_groups = [(ps, sg['lr']) for (ps, _), sg in zip(self.param_groups, sd['param_groups'])]
+        self._base_lr = self.lr
         self._group_ranges = self._arena_ranges()
         self._graph = None
 

@@ -228,6 +228,28 @@ def test_bf16_compute_mode_stays_close_to_fp32(golden_dir):
 
 
 @pytest.mark.gpu
+def test_capture_after_eager_steps():
+    """A trainer that already ran eager steps can still be captured (bench.py --graph auto does exactly that when the host
+    turns out to be the bottleneck).  Regression: a graph-attached tensor parked on a module kept the previous step's
+    AccumulateGrad nodes -- bound to the default stream -- alive, and hipStreamEndCapture crashed."""
+    import bench
+    from opental_amd.common import ops
+    dev = torch.device("cuda", 0)
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        clips, targets, scores = bench.synth_batch(1, 78, dev)
+        tr = bench.build_trainer(dev, seed=12)
+        eager = [float(tr.step(clips, targets, scores)[0]) for _ in range(2)]
+        tr.capture_step(clips, targets, scores, warmup=1)
+        replayed = [float(tr.step(clips, targets, scores)[0].clone()) for _ in range(2)]
+        torch.cuda.synchronize()
+        assert tr.step_count == 5 and all(np.isfinite(eager + replayed))
+        assert replayed[-1] != eager[0]                       # the replays are real optimisation steps
+    finally:
+        ops.CONV_PRECISION = old
+
+
 def test_graph_replayed_step_matches_eager_steps():
     """DetectorTrainer.capture_step: forward + losses + backward + Adam replayed from one HIP graph must walk the
     same parameter trajectory as eager launches (same kernels in the same order; only Adam's bias correction is
