@@ -193,10 +193,9 @@ def main():
 
     graphed = False
     launch_probe = None
-    # Launch mode.  The step is GPU-bound since the loss / gradient hand-over stopped issuing ~800 tiny kernels, and ROCm 7.2
-    # replays this ~1000-node graph a few per cent SLOWER than a fast host enqueues it (measured 436 vs 454 clips/s).  So
-    # `auto` first checks whether the host has slack: if issuing the launches of a step takes < 90 % of the step, eager
-    # launches it is; only a host-bound step is captured into one HIP graph.  (auto never captures on N > 1 ranks: multi-rank
+    # Launch mode.  The step is GPU-bound since the loss / gradient hand-over stopped issuing ~800 tiny kernels: eager
+    # launches and a replayed HIP graph give the same throughput when the host has slack.  `auto` checks for that slack:
+    # if issuing the launches of a step takes < 90 % of the step, eager launches it is; only a host-bound step is captured.  (auto never captures on N > 1 ranks: multi-rank
     # capture of the RCCL hooks could not be exercised on the 1-GPU development boxes; --graph on forces it.)
     want_graph = args.graph == "on"
     if args.graph == "auto" and world == 1 and not args.ssl:
