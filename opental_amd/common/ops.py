@@ -101,6 +101,8 @@ _MAKE_GEOM_CACHE = {}
 
 
 def _make_geom(B, Cin, Cout, in_thw, k, s, levels, spatial_valid):
+    if levels is not None and tuple(k) == (1, 1, 1) and tuple(s) == (1, 1, 1):
+        levels = None       # a 1x1 convolution has no tap that could cross a level boundary: the plain (faster) kernels apply
     key = (B, Cin, Cout, tuple(in_thw), k, s, levels if levels is None else tuple(levels), spatial_valid)
     hit = _MAKE_GEOM_CACHE.get(key)
     if hit is None:
