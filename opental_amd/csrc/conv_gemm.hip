@@ -2243,6 +2243,17 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         a.a_vec4 = (a.K % 4 == 0) && (((uintptr_t)a.w & 15) == 0) && BMsel >= 64;
     }
     int splits = choose_splits(tm * tn, a.K, a.prec);
+    if (MODE == MODE_WGRAD && a.prec) {
+        // the generic kernel gets the weight gradients of the 1-D pyramid / head layers (126 positions per sample: no vector
+        // path): K = B * 126 positions, a few dozen tiles -- latency-bound K steps, so split down to OTAL_GWGRAD_MINSTEPS
+        static const int ms = getenv("OTAL_GWGRAD_MINSTEPS") ? atoi(getenv("OTAL_GWGRAD_MINSTEPS")) : 4;      // measured: 8 -> 474.6, 4 -> 478.3, 2 -> 478.0, 1 -> 476.3 clips/s
+        static const int tg = getenv("OTAL_GWGRAD_TARGET") ? atoi(getenv("OTAL_GWGRAD_TARGET")) : 512;
+        const int tiles = tm * tn;
+        int want = (tg + tiles - 1) / tiles, maxs = a.K / (ms * 32);
+        if (maxs < 1) maxs = 1;
+        splits = tiles >= tg * 3 / 4 ? 1 : (want < maxs ? want : maxs);
+        if (splits > 384) splits = 384;
+    }
     if (splits > 1) {
         const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
         if (!ws || ws_bytes < need) {       // shrink to what the workspace allows
