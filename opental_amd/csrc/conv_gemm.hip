@@ -1914,6 +1914,134 @@ int launch_conv1a_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st)
     return otal_launch_status();
 }
 
+// ---- weight gradient of the 1-D pyramid / head layers (H = W = 1, stride 1, k = 1 or 3, level-packed or not).
+// These 36 launches per step have 126 .. 256 positions per sample -- no vector path (P % 32 != 0, W = 1) -- and ran on the
+// generic tap-table kernel at ~30 us each for 0.5 .. 1.6 GFLOP.  But with H = W = 1 both operands are K-CONTIGUOUS rows:
+// dW[co][ci][dt] = sum_t dy[co][t] * x[ci][t + dt - pt].  A workgroup owns a 64 x 64 (co, ci) tile of one (sample,
+// 128-position chunk): both row blocks are staged once in LDS as bf16 (x with one halo element per side), every MFMA
+// operand is an aligned 16-byte LDS read, and the two shifted taps are the aligned neighbours funnel-shifted by one
+// element, with the taps that would cross a level boundary masked per position.  Partial sums go to split-K slabs
+// (split = sample x chunk), reduced in order by splitk_reduce_kernel.
+constexpr int W1_TC = 128, W1_PITCH = 304;      // positions per chunk; LDS row pitch in bytes (152 bf16: 2-way conflicts at most)
+
+template <int KT>
+__global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const ConvArgs a, int nchunks, int units, int upw) {
+    __shared__ __attribute__((aligned(16))) unsigned char sdy[64 * W1_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char sx[64 * W1_PITCH];      // element 8 + tl holds x[t0 + tl]
+    __shared__ __attribute__((aligned(16))) unsigned mstart[W1_TC / 2], mend[W1_TC / 2];   // bf16-pair masks: 0 where the tap is cut
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64, split = blockIdx.z;
+    const int T = g.Ti;
+    const int mi = wave & 1, ni = wave >> 1, h8 = (lane >> 5) * 8;
+    const unsigned char* arow = sdy + (mi * 32 + (lane & 31)) * W1_PITCH + h8 * 2;
+    const unsigned char* brow = sx + (ni * 32 + (lane & 31)) * W1_PITCH + (8 + h8) * 2;
+    f32x16 acc[KT];
+#pragma unroll
+    for (int d = 0; d < KT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+    // a workgroup walks `upw` (sample, chunk) units: fewer, fatter split-K slabs (one epilogue and one slab per upw units)
+    for (int unit = split * upw; unit < min(units, (split + 1) * upw); ++unit) {
+    const int b = unit / nchunks, t0 = (unit - b * nchunks) * W1_TC;
+    const float* dyb = a.dy + (int64_t)b * g.y_bs + t0;
+    const float* xb = a.x + (int64_t)b * g.x_bs + t0;
+    __syncthreads();            // the previous unit's operand reads are done
+    // ---- stage dy (64 rows x 128 positions) and x (+ 8 elements of left pad, of which the last is the halo x[t0 - 1])
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, tl = (idx & 63) * 2;
+        const bool rowd = co0 + r < g.Cout, rowx = ci0 + r < g.Cin;
+        const bool in0 = t0 + tl < T, in1 = t0 + tl + 1 < T;
+        float2 d = make_float2(0.f, 0.f), v = make_float2(0.f, 0.f);
+        if (rowd && in1) d = *reinterpret_cast<const float2*>(dyb + (int64_t)(co0 + r) * g.y_cs + tl);
+        else if (rowd && in0) d.x = dyb[(int64_t)(co0 + r) * g.y_cs + tl];
+        if (rowx && in1) v = *reinterpret_cast<const float2*>(xb + (int64_t)(ci0 + r) * g.x_cs + tl);
+        else if (rowx && in0) v.x = xb[(int64_t)(ci0 + r) * g.x_cs + tl];
+        *reinterpret_cast<unsigned*>(sdy + r * W1_PITCH + tl * 2) = cvt_pk_bf16(d.x, d.y);
+        *reinterpret_cast<unsigned*>(sx + r * W1_PITCH + (8 + tl) * 2) = cvt_pk_bf16(v.x, v.y);
+    }
+    if (tid < 128) {        // halo: x[t0 - 1] at element 7, x[t0 + 128] at element 136 (pairs written whole: 6|7 and 136|137)
+        const int r = tid & 63, right = tid >> 6;
+        const int u = right ? t0 + W1_TC : t0 - 1;
+        const bool ok = ci0 + r < g.Cin && u >= 0 && u < T;
+        const float v = ok ? a.x[(int64_t)b * g.x_bs + (int64_t)(ci0 + r) * g.x_cs + u] : 0.f;
+        *reinterpret_cast<unsigned*>(sx + r * W1_PITCH + (right ? 136 : 6) * 2) = right ? cvt_pk_bf16(v, 0.f) : cvt_pk_bf16(0.f, v);
+    }
+    if (tid < W1_TC / 2) {  // a tap shifted by -1 is cut where t starts a level, one shifted by +1 where t ends one
+        unsigned ms = 0xffffffffu, me = 0xffffffffu;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int t = t0 + 2 * tid + e;
+            int lo, up;
+            level_bounds(g, t < T ? t : T - 1, T, lo, up);
+            if (t == lo) ms &= e ? 0x0000ffffu : 0xffff0000u;
+            if (t + 1 == up) me &= e ? 0x0000ffffu : 0xffff0000u;
+        }
+        mstart[tid] = ms; mend[tid] = me;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int k = 0; k < W1_TC / 16; ++k) {
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + k * 32);
+        const Words4 c = *reinterpret_cast<const Words4*>(brow + k * 32);                   // x[t .. t+7]
+        if constexpr (KT == 1) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, c), acc[0], 0, 0, 0);
+        } else {
+            const unsigned left = *reinterpret_cast<const unsigned*>(brow + k * 32 - 4);    // x[t-2], x[t-1]
+            const unsigned right = *reinterpret_cast<const unsigned*>(brow + k * 32 + 16);   // x[t+8], x[t+9]
+            const Words4 ms = *reinterpret_cast<const Words4*>(reinterpret_cast<const unsigned char*>(mstart) + k * 32 + h8 * 2);
+            const Words4 me = *reinterpret_cast<const Words4*>(reinterpret_cast<const unsigned char*>(mend) + k * 32 + h8 * 2);
+            Words4 m1, p1;                                                                   // x[t-1 .. t+6], x[t+1 .. t+8]
+            m1.a = __builtin_amdgcn_alignbit(c.a, left, 16) & ms.a; m1.b = __builtin_amdgcn_alignbit(c.b, c.a, 16) & ms.b;
+            m1.c = __builtin_amdgcn_alignbit(c.c, c.b, 16) & ms.c;  m1.d = __builtin_amdgcn_alignbit(c.d, c.c, 16) & ms.d;
+            p1.a = __builtin_amdgcn_alignbit(c.b, c.a, 16) & me.a;  p1.b = __builtin_amdgcn_alignbit(c.c, c.b, 16) & me.b;
+            p1.c = __builtin_amdgcn_alignbit(c.d, c.c, 16) & me.c;  p1.d = __builtin_amdgcn_alignbit(right, c.d, 16) & me.d;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, m1), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, c), acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, p1), acc[2], 0, 0, 0);
+        }
+    }
+    }
+    // slab[split][co][ci * KT + dt]
+    const int ci = ci0 + ni * 32 + (lane & 31);
+    float* slab = a.slab + (int64_t)split * a.M * a.N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < g.Cout && ci < g.Cin) {
+#pragma unroll
+            for (int d = 0; d < KT; ++d) slab[(int64_t)co * a.N + ci * KT + d] = acc[d][r];
+        }
+    }
+}
+
+static inline int wgrad1d_chunks(const ConvGeom& g) { return (g.Ti + W1_TC - 1) / W1_TC; }
+static inline bool wgrad1d_eligible(const ConvGeom& g, int prec, const void* x, const void* dy) {
+    if (!prec || getenv("OTAL_CONV_NOW1D")) return false;
+    if (g.Hi != 1 || g.Wi != 1 || g.Ho != 1 || g.Wo != 1 || g.kh != 1 || g.kw != 1 || g.st != 1 || g.To != g.Ti) return false;
+    if (!((g.kt == 1 && g.pt == 0) || (g.kt == 3 && g.pt == 1))) return false;
+    if (g.Cin % 64 || (g.x_bs | g.x_cs | g.y_bs | g.y_cs) & 1) return false;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 7) return false;
+    return (int64_t)g.B * wgrad1d_chunks(g) <= 1024;
+}
+
+int launch_wgrad1d(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    static const int upw_env = getenv("OTAL_W1D_UPW") ? atoi(getenv("OTAL_W1D_UPW")) : 0;
+    const int nchunks = wgrad1d_chunks(a.g), units = a.g.B * nchunks;
+    const int tiles = ((a.g.Cout + 63) / 64) * (a.g.Cin / 64);
+    const int upw = upw_env > 0 ? upw_env : 1;      // units per workgroup: measured 1 -> 478.4, 2 -> 475.8, 4 -> 465.7 clips/s
+    (void)tiles;
+    const int splits = (units + upw - 1) / upw;
+    const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
+    if (!ws || ws_bytes < need) return OTAL_E_UNSUPPORTED;
+    a.splits = splits; a.k_per_split = 0; a.slab = reinterpret_cast<float*>(ws);
+    const dim3 grid((a.g.Cout + 63) / 64, a.g.Cin / 64, splits);
+    if (a.g.kt == 1) hipLaunchKernelGGL(conv_wgrad1d_kernel<1>, grid, dim3(256), 0, st, a, nchunks, units, upw);
+    else hipLaunchKernelGGL(conv_wgrad1d_kernel<3>, grid, dim3(256), 0, st, a, nchunks, units, upw);
+    if (int e = otal_launch_status()) return e;
+    return launch_splitk_reduce<MODE_WGRAD>(a, st);
+}
+
 // ---- chunked bf16 path: eligibility, workspace layout [chunk table][packed bf16 weights][split-K slabs]
 constexpr int CHUNK_PAD = 16;       // table entries readable past Kp/8 (two K steps of prefetch)
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -2195,6 +2323,10 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if constexpr (MODE == MODE_WGRAD) {
         if (wgrad_pair_mode(a.g, a.prec)) return launch_wgrad_vector(a, 8, ws, ws_bytes, st);
         if (const int cw = wgrad_vector_width(a.g, a.prec)) return launch_wgrad_vector(a, cw, ws, ws_bytes, st);
+        if (wgrad1d_eligible(a.g, a.prec, a.x, a.dy)) {
+            const int e = launch_wgrad1d(a, ws, ws_bytes, st);
+            if (e != OTAL_E_UNSUPPORTED) return e;          // workspace too small for the slabs: the generic kernel below
+        }
     }
     if constexpr (MODE == MODE_FWD) {
         if (conv1a_direct_eligible(a.g, MODE, a.prec, a.x)) return launch_conv1a_direct(a, ws, ws_bytes, st);

@@ -495,3 +495,28 @@ def test_boundary_bce_matches_calc_bce_loss(B, C, T, Tm, row0, step):
     (gs * 0.7 + ge * 1.3).backward()
     close(xd.grad, xr.grad, tol=2e-5)
     assert float(xd.grad[:, :, T:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,k,lev", [(2, 64, 64, 126, 3, LEV), (3, 128, 15, 126, 3, LEV), (2, 192, 96, 126, 1, None),
+                                                  (2, 64, 128, 256, 3, None), (1, 64, 2, 189, 3, [0, 96, 144, 168, 180, 186, 189]),
+                                                  (2, 64, 64, 130, 3, None)])
+def test_wgrad_1d_kernel_matches_torch(B, Cin, Cout, T, k, lev, monkeypatch):
+    """Weight gradient of the 1-D pyramid / head layers (H = W = 1): the K-contiguous LDS kernel against torch on the
+    bf16-rounded operands (per level when level-packed) and against the generic tap-table kernel."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(71)
+    x = torch.from_numpy(rs.randn(B, Cin, T).astype(np.float32))
+    dy = torch.from_numpy(rs.randn(B, Cout, T).astype(np.float32))
+    monkeypatch.setattr(ops, "CONV_PRECISION", 1)
+    got = ops.conv_wgrad(x.cuda(), dy.cuda(), (Cout, Cin, k), k, 1, levels=lev)
+    monkeypatch.setenv("OTAL_CONV_NOW1D", "1")
+    old = ops.conv_wgrad(x.cuda(), dy.cuda(), (Cout, Cin, k), k, 1, levels=lev)
+    monkeypatch.delenv("OTAL_CONV_NOW1D")
+    xr, dr = x.to(torch.bfloat16).float(), dy.to(torch.bfloat16).float()
+    w = torch.zeros(Cout, Cin, k, requires_grad=True)
+    bounds = lev if lev is not None else [0, T]
+    for i in range(len(bounds) - 1):
+        lo, hi = bounds[i], bounds[i + 1]
+        F.conv1d(xr[:, :, lo:hi], w, padding=k // 2).backward(dr[:, :, lo:hi])
+    close(got, w.grad, tol=2e-5)
+    close(got, old, tol=2e-5)
