@@ -2190,6 +2190,9 @@ static inline int wgrad_vector_width(const ConvGeom& g, int prec) {
     const int64_t ex = 4 * ((int64_t)(g.B - 1) * g.x_bs + (int64_t)(g.Cin - 1) * g.x_cs + conv_in_positions(g));
     const int64_t ey = 4 * ((int64_t)(g.B - 1) * g.y_bs + (int64_t)(g.Cout - 1) * g.y_cs + conv_out_positions(g));
     if (ex <= 0 || ey <= 0 || ex >= (int64_t)0xfffffff0u || ey >= (int64_t)0xfffffff0u) return 0;
+    // a 1x1x1 kernel has no shifted tap: any 8 consecutive positions of a sample are one contiguous vector, whatever the row
+    // length (6x6 planes were on 2-element vectors, 3x3 planes on the generic kernel)
+    if (g.kt == 1 && g.kh == 1 && g.kw == 1 && !getenv("OTAL_CONV_NO1X1V8")) return 8;
     if (g.Wi % 8 == 0) return 8;
     if (g.Wi % 4 == 0) return 4;
     if (g.Wi % 2 == 0) return 2;

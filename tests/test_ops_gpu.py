@@ -258,6 +258,8 @@ BF16_CASES = [((1, 3, 16, 24, 24), 64, (7, 7, 7), (2, 2, 2), False), ((1, 64, 6,
               # vector-gather paths: 4 positions per load (W % 4 == 0) and 2 (W % 2 == 0), batch > 1, 1x1x1 and 3x1x1 taps
               ((2, 16, 3, 24, 24), 40, (3, 3, 3), (1, 1, 1), False), ((2, 24, 5, 6, 6), 64, (3, 3, 3), (1, 1, 1), False),
               ((2, 64, 4, 12, 12), 96, (1, 1, 1), (1, 1, 1), False), ((1, 32, 6, 8, 8), 48, (3, 1, 1), (1, 1, 1), False),
+              # 1x1x1 weight gradients on 8-position vectors that cross row ends (W = 6 and W = 3 planes)
+              ((2, 64, 8, 6, 6), 80, (1, 1, 1), (1, 1, 1), False), ((2, 96, 32, 3, 3), 64, (1, 1, 1), (1, 1, 1), False),
               # direct 3x3x3 kernel (P % 256 == 0, channels % 16 == 0): W = 8 / 12 / 24 / 6, BM 96 / 64 / padded rows, batch 2
               ((2, 16, 4, 8, 8), 96, (3, 3, 3), (1, 1, 1), False), ((1, 32, 16, 12, 12), 64, (3, 3, 3), (1, 1, 1), False),
               ((1, 64, 4, 24, 24), 192, (3, 3, 3), (1, 1, 1), False), ((2, 48, 64, 6, 6), 112, (3, 3, 3), (1, 1, 1), False)]
