@@ -2069,6 +2069,9 @@ static inline int chunk_vector_width(const ConvGeom& g) {
     if (const char* e = getenv("OTAL_CONV_CW")) { if (atoi(e) == 1) return 1; }
     if (g.st != 1 || g.sh != 1 || g.sw != 1 || g.nlev > 1) return 1;
     if (g.Wo != g.Wi || (g.kw != 1 && g.kw != 3) || g.pw != (g.kw - 1) / 2) return 1;
+    // 1x1x1: no shifted tap, so 4 consecutive positions of a sample are contiguous across row ends as well
+    if (g.kt == 1 && g.kh == 1 && g.kw == 1 && g.To == g.Ti && g.Ho == g.Hi && conv_out_positions(g) % 4 == 0 &&
+        !getenv("OTAL_CONV_NO1X1V4")) return 4;
     if (g.Wi % 4 == 0) return 4;
     if (g.Wi % 2 == 0) return 2;
     return 1;
