@@ -97,8 +97,11 @@ def softnms_classes(dec, clip_start, top_k=5000, sigma=0.5, score_threshold=0.00
     return out, counts, index
 
 
-def get_video_detections(rows, counts, idx_to_class=None, top_k=5000):
-    """test.py:165-200: per-video proposal list from the suppressed rows of one video (K,top_k,5)."""
+def get_video_detections(rows, counts, idx_to_class=None, top_k=5000, duration=None, drop_empty=False):
+    """test.py:165-200: per-video proposal list from the suppressed rows of one video (K,top_k,5).
+    With `duration` (seconds) the cross-dataset variant, test_cross_data.py:178-215: segments are clipped to
+    [0, duration] and the ones left empty are dropped (`drop_empty` alone: that script's THUMOS14 leg, which passes
+    no duration but still drops empty segments)."""
     rows, counts = rows.cpu().numpy(), counts.cpu().numpy()
     proposal_list = []
     for cl in range(rows.shape[0]):
@@ -106,7 +109,12 @@ def get_video_detections(rows, counts, idx_to_class=None, top_k=5000):
         for i in range(int(counts[cl])):
             r = rows[cl, i]
             if r[2] > 0:
-                proposal_list.append({'label': name, 'score': float(r[2]), 'segment': [float(r[0]), float(r[1])],
+                start, end = float(r[0]), float(r[1])
+                if duration is not None or drop_empty:
+                    start, end = max(0, start), (min(duration, end) if duration is not None else end)
+                    if end <= start:
+                        continue
+                proposal_list.append({'label': name, 'score': float(r[2]), 'segment': [start, end],
                                       'uncertainty': float(r[3]), 'actionness': float(r[4])})
     return proposal_list
 

@@ -1,0 +1,87 @@
+"""Cross-dataset open-set inference driver (AFSD/thumos14/test_cross_data.py): host logic on CPU,
+and on the GPU the batched driver against the reference's per-video, per-window order of operations."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_anet_padding_equals_the_thumos_padding():
+    """127.5 padded before normalisation (test_cross_data.py:80-89) is bit-for-bit the 0.0 padded after it
+    (test.py:67-76): the batched windows of detect_batch serve both datasets."""
+    from opental_amd.thumos14 import test as T, test_cross_data as X
+    rs = np.random.RandomState(0)
+    data = torch.from_numpy(rs.randint(0, 256, size=(3, 300, 8, 8)).astype(np.uint8))
+    for off in (0, 44, 256):
+        assert torch.equal(X.prepare_anet_clip(data, off, 256, 8), T.prepare_clip(data, off, 256))
+    assert X.prepare_anet_clip(data, 256, 256, 8).shape == (1, 3, 256, 8, 8)
+    assert float(X.prepare_anet_clip(data, 256, 256, 8)[0, :, 44:].abs().max()) == 0.0
+
+
+def test_duration_clipping_and_empty_segments():
+    from opental_amd.thumos14 import test as T
+    rows = torch.zeros(2, 3, 5)
+    rows[0, 0] = torch.tensor([1.0, 9.0, 0.9, 0.2, 0.7])
+    rows[0, 1] = torch.tensor([7.5, 12.0, 0.5, 0.3, 0.6])     # clipped to the duration
+    rows[1, 0] = torch.tensor([8.5, 11.0, 0.4, 0.1, 0.8])     # starts past the duration: dropped
+    rows[1, 1] = torch.tensor([3.0, 3.0, 0.3, 0.1, 0.8])      # empty: dropped only by the cross-dataset variants
+    counts = torch.tensor([2, 2])
+    names = {1: 'A', 2: 'B'}
+    plain = T.get_video_detections(rows, counts, names)
+    assert [p['segment'] for p in plain] == [[1.0, 9.0], [7.5, 12.0], [8.5, 11.0], [3.0, 3.0]]
+    cross = T.get_video_detections(rows, counts, names, duration=8.0)
+    assert [(p['label'], p['segment']) for p in cross] == [('A', [1.0, 8.0]), ('A', [7.5, 8.0])]
+    thumos_leg = T.get_video_detections(rows, counts, names, drop_empty=True)
+    assert [p['segment'] for p in thumos_leg] == [[1.0, 9.0], [7.5, 12.0], [8.5, 11.0]]
+
+
+def test_exclude_overlapping_and_merge():
+    from opental_amd.thumos14 import test as T, test_cross_data as X
+    infos = {'v_a': {'annotations': [{'label': 'Long jump'}, {'label': 'Knitting'}]},
+             'v_b': {'annotations': [{'label': 'Knitting'}]},
+             'v_c': {'annotations': []}}
+    anet = T.results_json({'a': [{'label': 'x'}], 'b': [{'label': 'y'}], 'c': []})
+    kept = X.exclude_overlapping(anet, infos, ['Long jump\n', 'Shot put\n'])
+    assert sorted(kept['results']) == ['b', 'c'] and kept['version'] == 'THUMOS14' and kept['external_data'] == {}
+    thumos = T.results_json({'video_test_0000004': [{'label': 'z'}], 'b': [{'label': 'old'}]})
+    merged = X.merge_results(thumos, kept)
+    assert sorted(merged['results']) == ['b', 'c', 'video_test_0000004']
+    assert merged['results']['b'] == [{'label': 'y'}]          # dict.update semantics of the reference's merge
+    assert thumos['results']['b'] == [{'label': 'old'}]        # inputs untouched
+
+
+@pytest.mark.gpu
+def test_test_anet_matches_per_window_order(golden_dir):
+    """The batched driver (videos batched, all windows decoded and suppressed in two launches) against the reference's
+    order: per video, per window at b=1 with prepare_anet_clip, then decode, Soft-NMS, duration clipping."""
+    import os
+    from oracle import arch
+    from opental_amd.thumos14 import test as T, test_cross_data as X
+    from opental_amd.thumos14.BDNet import BDNet
+    fx = np.load(os.path.join(golden_dir, "thumos_b1.npz"))
+    net = BDNet(training=False, use_edl=True)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in arch.make_params(int(fx["param_seed"])).items()})
+    net = net.cuda().eval()
+    rs = np.random.RandomState(3)
+    frames = {'v_one': 300, 'v_two': 200, 'v_gone': 256}
+    videos = {n: torch.from_numpy(rs.randint(0, 256, size=(3, t, 96, 96)).astype(np.uint8)).cuda() for n, t in frames.items()}
+    del videos['v_gone']                                        # listed but not on disk: skipped (test_cross_data.py:268-270)
+    infos = {n: {'fps': 10.0, 'duration': 0.08 * t, 'frame_num': t} for n, t in frames.items()}
+    out = X.test_anet(net, videos, infos, batch_clips=1, conf_thresh=0.01)
+    assert sorted(out['results']) == ['one', 'two'] and out['version'] == 'THUMOS14'
+    total = 0
+    for name in ('v_one', 'v_two'):
+        data, t = videos[name], frames[name]
+        offs = T.get_offsets(t, 256, 128)
+        assert offs == ([0, 44] if t == 300 else [0])
+        with torch.no_grad():
+            outs = [net(X.prepare_anet_clip(data, o, 256, 96)) for o in offs]
+        merged = {k: (torch.cat([o[k] for o in outs], 0) if k != 'priors' else outs[0][k])
+                  for k in ('loc', 'conf', 'prop_loc', 'prop_conf', 'center', 'act', 'prop_act', 'priors')}
+        dec = T.decode_clips(merged, [float(o) for o in offs], [10.0] * len(offs), 256, 0.01)
+        rows, counts, _ = T.softnms_classes(dec, [0, len(offs)], 5000, 0.5)
+        ref = T.get_video_detections(rows[0], counts[0], None, 5000, duration=infos[name]['duration'])
+        got = out['results'][name[2:]]
+        assert got == ref
+        assert all(0.0 <= p['segment'][0] < p['segment'][1] <= infos[name]['duration'] for p in got)
+        total += len(got)
+    assert total > 0
