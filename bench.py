@@ -257,10 +257,19 @@ def main():
                                if args.dtype == "bf16" else "conv_gemm_kernel") +
                               f": implicit-GEMM convolution, {args.dtype} MFMA operands, fp32 accumulate; per-op time incl. prologue and split-K reduce",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": None,      # PMC counters cannot be read from inside the run:
                     "launches_per_step": tot_n // 2, "avg_launch_us": round(tot_t / tot_n * 1e6, 1),
                     "conv_time_ms_per_step": round(tot_t / 2 * 1e3, 2),
                     "by_mode_TFLOPs": {k: round(e[0] / e[1] / 1e12, 2) for k, e in by.items()}}
+        # ... the committed rocprofv3 --pmc passes over this very command (tools/pmc_step.sh) supply it for the default workload
+        pmc = os.path.join(REPO, "profiles", "r01_pmc_step_traffic.json")
+        if os.path.exists(pmc) and args.dtype == "bf16" and not anet and args.batch == 8 and not args.ssl:
+            with open(pmc) as f:
+                t = json.load(f)
+            roofline["traffic"] = int(t["conv_traffic_MB_per_launch"] * 1e6)
+            roofline["traffic_note"] = ("bytes of HBM traffic per convolution launch, FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 "
+                                        "--pmc passes over this command (profiles/r01_pmc_step_traffic.txt); whole step "
+                                        f"{t['step_traffic_MB'] / 1e3:.1f} GB")
     hbm = None
     if rank == 0 and world == 1 and not args.no_hbm_kernels and not anet:
         # the bandwidth-bound kernel classes in isolation, at the shapes of this step: algorithmic bytes / launch time
