@@ -39,7 +39,8 @@ class ConvSameFunction(Function):
         if ctx.needs_input_grad[0]:
             dx = (ops.conv_dgrad_collapse(dy, w, x.shape) if ops.is_full_collapse(x.shape, k, s, sv)
                   else ops.conv_dgrad(dy, w, x.shape, k, s, spatial_valid=sv, levels=lev))
-        dw = ops.conv_wgrad(x, dy, w.shape, k, s, spatial_valid=sv, levels=lev) if ctx.needs_input_grad[1] else None
+        dw = (ops.conv_wgrad(x, dy, w.shape, k, s, spatial_valid=sv, levels=lev, out=ops.grad_slot(w))
+              if ctx.needs_input_grad[1] else None)
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=[0] + list(range(2, dy.dim())))
@@ -70,7 +71,7 @@ class ConvGNReLUFunction(Function):
         if ctx.needs_input_grad[0]:
             dx = (ops.conv_dgrad_collapse(dc5, w, x.shape) if ops.is_full_collapse(x.shape, k, s, sv)
                   else ops.conv_dgrad(dc5, w, x.shape, k, s, spatial_valid=sv, levels=lev))
-        dw = ops.conv_wgrad(x, dc5, w.shape, k, s, spatial_valid=sv, levels=lev)
+        dw = ops.conv_wgrad(x, dc5, w.shape, k, s, spatial_valid=sv, levels=lev, out=ops.grad_slot(w))
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 

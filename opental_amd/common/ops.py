@@ -5,7 +5,9 @@ Tensors may be channel slices of a larger contiguous buffer (``buf[:, c0:c1]``):
 channel strides are passed to the kernels, which is how Inception concatenation is written
 in place instead of through torch.cat.
 """
+import bisect
 import ctypes
+import os
 
 import torch
 
@@ -307,6 +309,49 @@ def conv_dgrad_collapse(dy, w, x_shape):
     dy3 = dy.reshape(B, Cout, T)
     dxp = conv_forward(dy3, wt, 1, 1)                                   # (B, Cin*H*W, T)
     return dxp.view(B, Cin, H * W, T).permute(0, 1, 3, 2).contiguous().view(B, Cin, T, H, W)
+
+
+class GradSlots:
+    """Address map from a flat parameter arena to its flat gradient arena: while a trainer's backward runs, a weight
+    gradient is computed straight into its parameter's slice of the gradient arena instead of a fresh tensor that is
+    copied there afterwards (179 MB read + written per step).  A slot is handed out once per step: a weight used twice
+    (self-supervised branch) gets a fresh tensor the second time and autograd adds it in."""
+
+    def __init__(self, flat, grad, offsets, numels):
+        self.base, self.n, self.grad = flat.data_ptr(), flat.numel(), grad
+        self.offsets, self.numels = list(offsets), list(numels)
+        self.written = [False] * len(self.offsets)
+
+    def reset(self):
+        self.written = [False] * len(self.offsets)
+
+    def take(self, w):
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            return None
+        off = w.data_ptr() - self.base
+        if off < 0 or off % 4 or off // 4 + w.numel() > self.n:
+            return None
+        off //= 4
+        i = bisect.bisect_left(self.offsets, off)
+        if i == len(self.offsets) or self.offsets[i] != off:
+            return None
+        j, cur, end = i, off, off + w.numel()          # w may span several adjacent parameters (fused 1x1 weights)
+        while j < len(self.offsets) and cur < end:
+            cur += self.numels[j]
+            j += 1
+        if cur != end or any(self.written[i:j]):
+            return None
+        for q in range(i, j):
+            self.written[q] = True
+        return self.grad[off:end].view(w.shape)
+
+
+GRAD_SLOTS = None       # the running trainer's GradSlots (DetectorTrainer.begin_backward / end_backward)
+
+
+def grad_slot(w):
+    """Destination of `w`'s gradient in the running trainer's arena, or None (no trainer, foreign weight, slot taken)."""
+    return GRAD_SLOTS.take(w) if GRAD_SLOTS is not None and not os.environ.get("OTAL_NO_GRAD_SLOTS") else None
 
 
 def conv_wgrad(x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None, accumulate=False):

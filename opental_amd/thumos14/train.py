@@ -162,6 +162,7 @@ class DetectorTrainer:
         self._bias_corr = None      # 2-float device tensor: Adam bias corrections of the step being run
         self.collectives = self.distributed and (self.world > 1 or force_collectives)   # force: 1-rank RCCL smoke test
         self._flushed = None
+        self._slots = ops.GradSlots(self.arena.flat, self.arena.grad, self.arena.offsets, [p.numel() for p in self.arena.params])
         for i, p in enumerate(self.arena.params):
             p.register_post_accumulate_grad_hook(self._make_hook(self.arena.bucket_of[i]))
 
@@ -221,10 +222,13 @@ class DetectorTrainer:
             p.grad = None
         self._pending = list(self.arena.bucket_size)
         self._flushed = [False] * len(self.arena.buckets)
+        self._slots.reset()
+        ops.GRAD_SLOTS = self._slots                # weight gradients are written straight into the arena
 
     def end_backward(self):
         """Call after cost.backward(): flush the buckets that did not complete (unused parameters), wait for the
         all-reduces, and leave every .grad aliasing its arena slice."""
+        ops.GRAD_SLOTS = None
         for b in range(len(self.arena.buckets)):
             self._flush_bucket(b)
         self._pending = None
@@ -263,6 +267,7 @@ class DetectorTrainer:
             self.end_backward()
         finally:
             ops.deactivate_prologues()
+            ops.GRAD_SLOTS = None
         self.step_count += 1
         self.optimizer_update()
         return cost.detach(), losses
@@ -285,6 +290,7 @@ class DetectorTrainer:
             self.end_backward()
         finally:
             ops.deactivate_prologues()
+            ops.GRAD_SLOTS = None
         a = self.arena
         for lo, hi, g_lr in self._group_ranges:
             g_lr = g_lr * (self.lr / self._base_lr) if self._base_lr else g_lr
