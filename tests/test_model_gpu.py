@@ -322,3 +322,42 @@ def test_persistent_prologues_do_not_change_the_trajectory():
         assert hi - lo == 4 * b.arena.numel
     finally:
         ops.CONV_PRECISION = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ssl", [False, True])
+def test_weight_gradients_written_into_the_arena_match_the_copied_ones(ssl, monkeypatch):
+    """ops.GradSlots: during a trainer's backward the weight-gradient launches write into the gradient arena directly.
+    The arena must hold bit-for-bit what the hand-over copy used to put there -- also when the self-supervised branch
+    uses every backbone weight twice (slot handed out once, second gradient added by autograd)."""
+    import bench
+    from opental_amd.common import ops
+    dev = torch.device("cuda", 0)
+    clips, targets, scores = bench.synth_batch(1, 31, dev)
+    extra = ()
+    if ssl:
+        ssl_clips, _, _ = bench.synth_batch(1, 32, dev)
+        extra = (ssl_clips, [torch.tensor([[0.30, 0.55], [0.32, 0.52], [0.70, 0.90]], device=dev) * 256])
+    grads, copied = [], []
+    orig = torch._foreach_copy_
+    for slots in (True, False):
+        if slots:
+            monkeypatch.delenv("OTAL_NO_GRAD_SLOTS", raising=False)
+        else:
+            monkeypatch.setenv("OTAL_NO_GRAD_SLOTS", "1")
+        n = [0]
+
+        def counting(dst, src, n=n):
+            n[0] += sum(d.numel() for d in dst)
+            return orig(dst, src)
+        monkeypatch.setattr(torch, "_foreach_copy_", counting)
+        tr = bench.build_trainer(dev, seed=12)
+        tr.step(clips, targets, scores, *extra)
+        grads.append(tr.arena.grad.clone())
+        copied.append(n[0])
+        assert ops.GRAD_SLOTS is None
+    assert torch.equal(grads[0], grads[1])
+    assert float(grads[0].abs().max()) > 0
+    assert copied[1] > 0.9 * grads[0].numel()
+    if not ssl:                 # (a weight used twice is summed by autograd into a new tensor, which is copied as before)
+        assert copied[0] < 0.01 * grads[0].numel(), copied
