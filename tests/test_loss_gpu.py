@@ -21,16 +21,20 @@ def _inputs(B, seed, n_gt, dev):
     out = dict(loc=loc, conf=t(B, K, C, scale=2.0), prop_loc=t(B, K, 2, scale=0.3), prop_conf=t(B, K, C, scale=2.0),
                center=t(B, K, 1), priors=priors, act=t(B, K, 1), prop_act=t(B, K, 1))
     targets = []
-    for _ in range(B):
+    for i in range(B):
         rows = []
-        for _ in range(n_gt):
+        for _ in range(n_gt[i] if isinstance(n_gt, (list, tuple)) else (0 if n_gt == "between" else n_gt)):
             ln = rs.uniform(0.05, 0.5); st = rs.uniform(0, 1 - ln)
             rows.append([st, st + ln, float(rs.randint(1, 16))])
+        if n_gt == "between":       # a segment that contains no anchor centre of any level: a batch without positives
+            rows = [[0.2505, 0.2575, 3.0]]
         targets.append(torch.tensor(rows, dtype=torch.float32, device=dev).reshape(-1, 3))
     return out, targets
 
 
-@pytest.mark.parametrize("B,n_gt,epoch", [(1, 2, 0), (2, 3, 12), (8, 2, 12), (3, 1, 12)])
+@pytest.mark.parametrize("B,n_gt,epoch", [(1, 2, 0), (2, 3, 12), (8, 2, 12), (3, 1, 12),
+                                          (4, [1, 5, 2, 3], 12),        # ragged: per-sample target counts differ (padded + masked)
+                                          (2, "between", 0), (2, "between", 12)])   # no positive anchor at all
 def test_fused_loss_matches_torch_formulation(B, n_gt, epoch):
     from opental_amd.thumos14 import multisegment_loss as M
     dev = torch.device("cuda", 0)
@@ -42,6 +46,8 @@ def test_fused_loss_matches_torch_formulation(B, n_gt, epoch):
             crit.cls_loss.epoch = epoch
             crit.cls_loss.weight_accum.copy_(torch.linspace(0.5, 1.5, 50))
             out, targets = _inputs(B, 7 + B, n_gt, dev)
+            if n_gt == "between":
+                assert int(crit.match(out['loc'].detach(), out['priors'], targets)[1].sum()) == 0
             losses = crit(out, targets)
             assert ('DetectionLossFunction' in type(losses[0].grad_fn).__name__) == fused, type(losses[0].grad_fn).__name__
             w = [1.0, 10.0, 1.0, 10.0, 1.0, 1.0, 1.0]
@@ -56,4 +62,4 @@ def test_fused_loss_matches_torch_formulation(B, n_gt, epoch):
     for k in g0:
         scale = float(g0[k].abs().max())
         assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * max(scale, 1e-6), (k, scale)
-        assert scale > 0
+        assert scale > 0 or (n_gt == "between" and k not in ('act', 'prop_act'))   # only actionness sees the negatives
