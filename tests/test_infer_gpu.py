@@ -125,3 +125,28 @@ def test_full_size_properties():
     idx = index.long()
     inc = (idx[..., 1:] > idx[..., :-1]) | ~kept[..., 1:]
     assert bool(inc.all())                                                     # original index order
+
+
+def test_no_candidate_passes_the_threshold():
+    """A video whose windows produce no candidate (and a batch where only some (video, class) problems are empty):
+    Soft-NMS keeps nothing, the proposal list is empty, nothing is read out of range."""
+    from opental_amd.thumos14 import test as T
+    g = torch.Generator(device="cuda").manual_seed(1)
+    V, C, A, K = 3, 2, 126, 15
+    n = V * C
+    ctr = torch.rand(n, A, device="cuda", generator=g) * 100
+    dec = dict(seg=torch.stack([ctr - 2, ctr + 2], -1).contiguous(), score=torch.rand(n, K, A, device="cuda", generator=g),
+               unct=torch.rand(n, A, device="cuda", generator=g), actn=torch.rand(n, A, device="cuda", generator=g))
+    flag = torch.zeros(n, K, A, dtype=torch.uint8, device="cuda")
+    flag[2:4, 4, :50] = 1                                   # only video 1, class index 4 has candidates
+    dec["flag"] = flag
+    rows, counts, _ = T.softnms_classes(dec, [0, 2, 4, 6], top_k=5000, sigma=0.5)
+    c = counts.cpu()
+    assert int(c[0].sum()) == 0 and int(c[2].sum()) == 0
+    assert int(c[1, 4]) > 0 and int(c[1].sum()) == int(c[1, 4])
+    assert T.get_video_detections(rows[0], counts[0]) == [] and T.get_video_detections(rows[2], counts[2]) == []
+    got = T.get_video_detections(rows[1], counts[1])
+    assert len(got) > 0 and all(p['label'] == 5 for p in got)
+    dec["flag"] = torch.zeros_like(flag)
+    rows, counts, _ = T.softnms_classes(dec, [0, 2, 4, 6], top_k=5000, sigma=0.5)
+    assert int(counts.sum()) == 0 and float(rows.abs().max()) == 0.0
