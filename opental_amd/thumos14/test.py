@@ -121,7 +121,7 @@ def get_video_detections(rows, counts, idx_to_class=None, top_k=5000, duration=N
 
 @torch.no_grad()
 def detect_batch(net, videos, sample_fps, clip_length=256, stride=128, conf_thresh=0.01, top_k=5000, nms_sigma=0.5,
-                 batch_clips=16):
+                 batch_clips=32):
     """videos: list of uint8 (C,T,96,96) device tensors (already centre-cropped).  Returns the
     per-video rows/counts of Soft-NMS.  test.py:203-252 without the JSON dump."""
     clips, offsets, fps, clip_start = [], [], [], [0]
@@ -133,6 +133,9 @@ def detect_batch(net, videos, sample_fps, clip_length=256, stride=128, conf_thre
         fps += [float(sample_fps[v] if hasattr(sample_fps, '__len__') else sample_fps)] * len(offs)
         clip_start.append(clip_start[-1] + len(offs))
     outs = []
+    # 32 windows per forward pass: past that the first feature maps leave the 32-bit buffer offsets of the vector-gather
+    # kernels (64 windows: Conv3d_1a's output is 4.8 GB) and the generic kernels take over at half the speed
+    batch_clips = max(1, min(int(batch_clips), 32))
     for i in range(0, len(clips), batch_clips):
         batch = torch.cat([prepare_clip(videos[v], o, clip_length) for v, o in clips[i:i + batch_clips]], 0)
         outs.append(net(batch))

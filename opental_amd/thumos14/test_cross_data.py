@@ -25,7 +25,7 @@ def prepare_anet_clip(data, offset, clip_length, crop_size):
 
 @torch.no_grad()
 def test_anet(net, videos, video_infos, idx_to_class=None, clip_length=256, stride=128, conf_thresh=0.01, top_k=5000,
-              nms_sigma=0.5, batch_clips=16, batch_videos=8):
+              nms_sigma=0.5, batch_clips=32, batch_videos=8):
     """videos: {name: uint8 (C,T,96,96) device tensor, centre-cropped}; video_infos[name] holds 'fps', 'duration'
     and 'frame_num' (the ActivityNet video_info_train_val.json rows).  Returns the result dict of
     test_cross_data.py:265-312 (keys without the "v_" prefix)."""

@@ -12,6 +12,8 @@ from opental_amd.thumos14.BDNet import BDNet
 
 def main():
     nvid = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    from opental_amd.common import ops
+    ops.CONV_PRECISION = 1 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else 0      # default: the exact-fp32 parity path
     dev = torch.device("cuda", 0)
     rs = np.random.RandomState(0)
     torch.manual_seed(0)
@@ -22,13 +24,13 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     videos = [torch.randint(0, 256, (3, int(f), 96, 96), device=dev, generator=g, dtype=torch.uint8) for f in frames]
     nclips = sum(len(T.get_offsets(int(f), 256, 128)) for f in frames)
-    T.detect_batch(net, videos[:2], 10.0, batch_clips=16)          # warm-up
+    T.detect_batch(net, videos[:2], 10.0, batch_clips=32)          # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rows, counts, index, dec = T.detect_batch(net, videos, 10.0, batch_clips=16)
+    rows, counts, index, dec = T.detect_batch(net, videos, 10.0, batch_clips=32)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    res = {"videos": nvid, "clips": nclips, "end_to_end_s": round(dt, 4),
+    res = {"conv_operands": "bf16 (fp32 accumulate)" if ops.CONV_PRECISION else "f32 (parity path)", "videos": nvid, "clips": nclips, "end_to_end_s": round(dt, 4),
            "proposals_per_s": round(126 * nclips / dt, 1), "kept": int(counts.sum())}
     # post-processing alone on synthetic head outputs with realistic overlap
     V, C, A, K = 213, 24, 126, 15
