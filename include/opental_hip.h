@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 12
+#define OTAL_ABI_VERSION 13
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -268,6 +268,16 @@ int otal_detection_loss(const float* loc, const float* conf, const float* prop_l
  * = 24 bytes each (8-byte aligned); the random decisions are taken on the host exactly as the reference takes them. */
 int otal_prepare_clips(const unsigned char* frames, const void* params, float* out, int B, int T, int Hs, int Ws,
                        int Ho, int Wo, void* stream);
+
+/* Sliding windows of the inference path: B windows cut out of planar uint8 videos (C,Tv,H,W) resident on the device
+ * -> normalised fp32 batch (B,C,T,H,W) in one pass.  Replaces AFSD/thumos14/test.py:67-76 prepare_clip per window
+ * (float(), (x/255)*2-1 as torch evaluates it on the GPU: x times the fp32 reciprocal of 255; zero padding of a short
+ * last window AFTER normalisation, unsqueeze) and the torch.cat of the
+ * batch; test_cross_data.py:80-89 prepare_anet_clip gives the same values (127.5 padded before normalisation = 0.0).
+ * params: device array of B records {uint64 src (device address of frame `offset`, channel 0, of the window's video),
+ * int32 chan_stride4 (Tv*H*W/4), int32 valid_t (frames available from `offset`, <= T)} = 16 bytes each; H*W % 4 == 0
+ * and 4-byte aligned videos (else OTAL_E_UNSUPPORTED). */
+int otal_prepare_windows(const void* params, float* out, int B, int C, int T, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -47,7 +47,53 @@ __global__ __launch_bounds__(256) void prepare_clips_kernel(const unsigned char*
     }
 }
 
+struct WindowParams {    // one per inference window, device array (16 bytes)
+    unsigned long long src;  // device address of frame `offset` of channel 0 of the window's video (planar uint8 (C,Tv,H,W))
+    int chan_stride4;        // Tv * H * W / 4: distance between the channels of that video, in 4-byte words
+    int valid_t;             // frames available from `offset`; the rest of the window is 0.0 (zero padding AFTER normalisation)
+};
+
+// 4 pixels per thread: one dword load, one 16-byte store
+__global__ __launch_bounds__(256) void prepare_windows_kernel(const WindowParams* __restrict__ params, float4* __restrict__ out,
+                                                              int C, int T, int plane4) {
+    const int b = blockIdx.y;
+    const WindowParams p = params[b];
+    const long long vol4 = (long long)T * plane4;
+    const unsigned* src = reinterpret_cast<const unsigned*>(p.src);
+    const long long valid4 = (long long)p.valid_t * plane4;
+    for (int c = 0; c < C; ++c) {
+        float4* ob = out + ((long long)b * C + c) * vol4;
+        const unsigned* sc = src + (long long)c * p.chan_stride4;
+        for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < vol4; idx += (long long)gridDim.x * 256) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < valid4) {
+                const unsigned w = sc[idx];
+                // the reference normalises the windows ON THE GPU (test.py:67-76 on a cuda tensor), where torch divides by a
+                // scalar as a multiplication by its fp32 reciprocal -- unlike the training transforms, which run in numpy
+                const float inv = 1.0f / 255.0f;
+                v.x = ((float)(w & 0xffu) * inv) * 2.0f - 1.0f;
+                v.y = ((float)((w >> 8) & 0xffu) * inv) * 2.0f - 1.0f;
+                v.z = ((float)((w >> 16) & 0xffu) * inv) * 2.0f - 1.0f;
+                v.w = ((float)(w >> 24) * inv) * 2.0f - 1.0f;
+            }
+            ob[idx] = v;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int otal_prepare_windows(const void* params, float* out, int B, int C, int T, int H, int W, void* stream) {
+    if (!params || !out) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || H <= 0 || W <= 0) return OTAL_E_SHAPE;
+    if (B > 65535 || ((long long)H * W) % 4) return OTAL_E_UNSUPPORTED;
+    const int plane4 = H * W / 4;
+    const long long vol4 = (long long)T * plane4;
+    const int bx = (int)((vol4 + 255) / 256 < 2048 ? (vol4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(prepare_windows_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const WindowParams*>(params), reinterpret_cast<float4*>(out), C, T, plane4);
+    return otal_launch_status();
+}
 
 extern "C" int otal_prepare_clips(const unsigned char* frames, const void* params, float* out, int B, int T, int Hs,
                                   int Ws, int Ho, int Wo, void* stream) {

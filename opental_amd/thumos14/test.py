@@ -36,6 +36,33 @@ def prepare_clip(data, offset, clip_length):
     return clip.unsqueeze(0)
 
 
+_WINDOW_DTYPE = None
+
+
+def prepare_windows(videos, windows, clip_length):
+    """All windows of one forward pass in ONE launch (otal_prepare_windows): videos = uint8 (C,Tv,H,W) device tensors,
+    windows = [(video index, offset)].  Bit-identical to torch.cat([prepare_clip(videos[v], o, clip_length) ...])."""
+    import numpy as np
+    global _WINDOW_DTYPE
+    if _WINDOW_DTYPE is None:
+        _WINDOW_DTYPE = np.dtype([("src", "<u8"), ("chan_stride4", "<i4"), ("valid_t", "<i4")])
+    C, _, H, W = videos[windows[0][0]].shape
+    recs = np.zeros(len(windows), _WINDOW_DTYPE)
+    for i, (v, o) in enumerate(windows):
+        d = videos[v]
+        if d.dtype != torch.uint8 or not d.is_cuda or not d.is_contiguous() or tuple(d.shape[2:]) != (H, W) or d.shape[0] != C:
+            raise RuntimeError("videos must be contiguous uint8 (C,T,H,W) device tensors of one frame size")
+        if (H * W) % 4 or d.data_ptr() % 4 or not 0 <= o < d.shape[1]:
+            raise RuntimeError("otal_prepare_windows needs H*W % 4 == 0, 4-byte aligned videos and offsets inside the video")
+        recs[i] = (d.data_ptr() + o * H * W, d.shape[1] * H * W // 4, min(clip_length, d.shape[1] - o))
+    dev = videos[windows[0][0]].device
+    params = torch.from_numpy(recs.view(np.uint8).copy()).to(dev, non_blocking=True)
+    out = torch.empty((len(windows), C, clip_length, H, W), dtype=torch.float32, device=dev)
+    L.check(L.lib().otal_prepare_windows(L.ptr(params), L.ptr(out), len(windows), C, clip_length, H, W, L.stream()),
+            "otal_prepare_windows")
+    return out
+
+
 def decode_clips(output_dict, offsets, fps, clip_length=256, conf_thresh=0.01):
     """Batched parse_output + decode_predictions + threshold masks.  output_dict: model outputs for
     `n` clips; offsets/fps: per-clip tensors or lists.  Returns dict(seg, score, unct, actn, flag)."""
@@ -137,8 +164,7 @@ def detect_batch(net, videos, sample_fps, clip_length=256, stride=128, conf_thre
     # kernels (64 windows: Conv3d_1a's output is 4.8 GB) and the generic kernels take over at half the speed
     batch_clips = max(1, min(int(batch_clips), 32))
     for i in range(0, len(clips), batch_clips):
-        batch = torch.cat([prepare_clip(videos[v], o, clip_length) for v, o in clips[i:i + batch_clips]], 0)
-        outs.append(net(batch))
+        outs.append(net(prepare_windows(videos, clips[i:i + batch_clips], clip_length)))
     merged = {k: (torch.cat([o[k] for o in outs], 0) if k != 'priors' else outs[0][k])
               for k in ('loc', 'conf', 'prop_loc', 'prop_conf', 'center', 'act', 'prop_act', 'priors')}
     dec = decode_clips(merged, offsets, fps, clip_length, conf_thresh)

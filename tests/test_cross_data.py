@@ -85,3 +85,23 @@ def test_test_anet_matches_per_window_order(golden_dir):
         assert all(0.0 <= p['segment'][0] < p['segment'][1] <= infos[name]['duration'] for p in got)
         total += len(got)
     assert total > 0
+
+
+@pytest.mark.gpu
+def test_prepare_windows_is_bit_identical_to_prepare_clip():
+    """otal_prepare_windows (one launch per forward pass) against the reference's per-window preparation: full windows,
+    a short last window (zero padded after normalisation), a video shorter than the window, both datasets' variants."""
+    from opental_amd.thumos14 import test as T, test_cross_data as X
+    rs = np.random.RandomState(11)
+    videos = [torch.from_numpy(rs.randint(0, 256, size=(3, t, 96, 96)).astype(np.uint8)).cuda() for t in (300, 200, 513)]
+    windows = [(v, o) for v, d in enumerate(videos) for o in T.get_offsets(d.shape[1], 256, 128)] + [(2, 400), (0, 299)]
+    got = T.prepare_windows(videos, windows, 256)
+    ref = torch.cat([T.prepare_clip(videos[v], o, 256) for v, o in windows], 0)
+    assert got.shape == ref.shape == (len(windows), 3, 256, 96, 96)
+    assert torch.equal(got, ref)
+    assert torch.equal(got, torch.cat([X.prepare_anet_clip(videos[v], o, 256, 96) for v, o in windows], 0))
+    assert float(got[-1, :, 1:].abs().max()) == 0.0 and float(got[-1, :, 0].abs().max()) > 0
+    with pytest.raises(RuntimeError):
+        T.prepare_windows(videos, [(0, 300)], 256)               # offset past the end
+    with pytest.raises(RuntimeError):
+        T.prepare_windows([videos[0].float()], [(0, 0)], 256)    # not uint8
