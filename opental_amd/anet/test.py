@@ -72,7 +72,8 @@ def detect_batch(net, videos, sample_fps, durations, idx_to_class=None, clip_len
     """videos: list of uint8 (C,T,96,96) device tensors (centre-cropped).  Returns {index: proposal list}."""
     outs = []
     for i in range(0, len(videos), batch_clips):
-        batch = torch.cat([prepare_clip(v, 0, clip_length, v.shape[-1]) for v in videos[i:i + batch_clips]], 0)
+        # one launch per forward pass; same values as prepare_clip per video (127.5 padded before the normalisation IS 0.0)
+        batch = _t.prepare_windows(videos, [(j, 0) for j in range(i, min(i + batch_clips, len(videos)))], clip_length)
         outs.append(net(batch))
     merged = {k: (torch.cat([o[k] for o in outs], 0) if k != 'priors' else outs[0][k])
               for k in ('loc', 'conf', 'prop_loc', 'prop_conf', 'center', 'act', 'prop_act', 'priors')}
