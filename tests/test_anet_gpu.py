@@ -169,3 +169,28 @@ def test_short_video_is_padded_with_mid_grey():
     assert tuple(clip.shape) == (1, 3, 768, 96, 96)
     assert torch.equal(clip[0, :, :100], (data.float() / 255.0) * 2.0 - 1.0)
     assert float(clip[0, :, 100:].abs().max()) == 0.0          # 127.5 / 255 * 2 - 1 == 0
+
+
+def test_detect_batch_equals_the_per_video_order(golden_dir):
+    """anet.test.detect_batch (windows of a pass prepared by one launch, all videos decoded and suppressed together)
+    against the reference's order of operations: per video prepare_clip -> net -> decode -> Soft-NMS -> duration clip."""
+    from opental_amd.anet import test as A
+    from opental_amd.thumos14 import test as T
+    fx = np.load(os.path.join(golden_dir, "anet_b1.npz"))
+    net = build(fx).eval()
+    rs = np.random.RandomState(5)
+    videos = [torch.from_numpy(rs.randint(0, 256, size=(3, t, 96, 96)).astype(np.uint8)).cuda() for t in (768, 500, 90)]
+    batch = T.prepare_windows(videos, [(0, 0), (1, 0), (2, 0)], 768)
+    assert torch.equal(batch, torch.cat([A.prepare_clip(v, 0) for v in videos], 0))
+    fps, durations = [4.0, 5.0, 6.0], [190.0, 99.0, 14.0]
+    got = A.detect_batch(net, videos, fps, durations, batch_clips=1)
+    total = 0
+    for v, data in enumerate(videos):
+        with torch.no_grad():
+            out = net(A.prepare_clip(data, 0))
+        dec = A.decode_clips(out, [fps[v]])
+        rows, counts, _ = T.softnms_classes(dec, [0, 1], 5000, 0.85)
+        ref = A.get_video_prediction(rows[0], counts[0], durations[v])
+        assert got[v] == ref
+        total += len(ref)
+    assert total > 0
