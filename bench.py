@@ -240,12 +240,14 @@ def main():
     if rank == 0 and not args.no_roofline:
         from opental_amd.common import ops
         saved_graph, trainer._graph = trainer._graph, None      # per-launch HIP events need eager launches
+        # rank 0 runs these two profiling steps ALONE: no gradient all-reduce in them (the other ranks are not there to join)
+        saved_coll, trainer.collectives = trainer.collectives, False
         ops.CONV_PROFILE = []
         for _ in range(2):
             trainer.step(clips, targets, scores)
         torch.cuda.synchronize()
         prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-        trainer._graph = saved_graph
+        trainer._graph, trainer.collectives = saved_graph, saved_coll
         by = {}
         for mode, flops, a, b in prof:
             e = by.setdefault(mode, [0.0, 0.0, 0])
@@ -304,6 +306,7 @@ def main():
                        "launch": "one captured HIP graph per step" if graphed else "eager launches"},
             "roofline": roofline, "hbm_kernels": hbm, "cpu_baseline": cpu}))
     if world > 1 or force_dist:
+        dist.barrier()              # every rank leaves together (rank 0 was busy with the roofline steps)
         dist.destroy_process_group()
 
 
