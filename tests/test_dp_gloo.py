@@ -66,6 +66,16 @@ def _worker(rank, world, port, q):
         for step in range(3):
             tr.step(xs[rank, step], ys[rank, step], None)
         q.put((rank, tr.arena.flat.clone(), tr.arena.grad.clone()))
+        # what bench.py does after the timed region: rank 0 profiles two more steps ALONE, without the all-reduce (a
+        # collective issued here would never complete: the other ranks are already waiting at the final barrier)
+        if rank == 0:
+            assert tr.collectives
+            saved, tr.collectives = tr.collectives, False
+            before = tr.arena.flat.clone()
+            tr.step(xs[0, 0], ys[0, 0], None)
+            tr.collectives = saved
+            assert not torch.equal(before, tr.arena.flat)
+        dist.barrier()
     finally:
         dist.destroy_process_group()
 
