@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int NT = 256, BK_MIN = 16;
+constexpr int NT = 256;
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 enum { EPI_RELU = 1, EPI_ACCUM = 2, DBG_NOLOAD = 4, DBG_NOSTORE = 8, DBG_NOBARRIER = 16, EPI_NPAD8 = 32 };   // DBG_*: ablation only (OTAL_CONV_DEBUG)
 
@@ -2101,12 +2101,10 @@ static void launch_prep(const PrepDesc& d, hipStream_t st) {
 template <int MODE>
 int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int C = MODE == MODE_FWD ? a.g.Cin : a.g.Cout;
-    const int kvol = conv_kvol(a.g);
     const bool kwv = MODE == MODE_FWD && (C % 8) != 0;
     if (kwv) a.K = a.g.Cin * a.g.kt * a.g.kh * 8;          // kw padded to 8 taps per (ci, dt, dh) row
     const int BMsel = choose_bm(a.M, kwv ? 0 : 1);
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + 127) / 128;
-    const int Mpad = tm * BMsel;
     a.Kp = chunk_kp(a.K);
     const size_t tb = chunk_tab_bytes(a.K), wb = chunk_wp_bytes(a.M, BMsel, a.K);
     int2* ctab;
