@@ -5,6 +5,7 @@ kernels are not involved; the optimizer update is overridden with the oracle's A
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -195,3 +196,34 @@ def test_fused_1x1_weights_are_adjacent_arena_views():
         assert torch.equal(wf, torch.cat(ws, 0))
         wf[0, 0, 0, 0, 0] = 123.0                                     # a view: writes land in the parameter
         assert float(m.b1a.conv3d.weight.detach()[0, 0, 0, 0, 0]) == 123.0
+
+
+def test_grad_slots_address_map():
+    """ops.GradSlots (host logic, CPU tensors): a weight's gradient slot is its slice of the gradient arena; a tensor
+    spanning several adjacent parameters (fused 1x1 weights) gets the spanning slice; every slot is handed out once per
+    step; anything that is not exactly a run of whole parameters gets none."""
+    from opental_amd.common import ops
+    shapes = [(4, 3, 1, 1, 1), (2, 3, 1, 1, 1), (6, 2, 3), (5,)]
+    numels = [int(np.prod(s)) for s in shapes]
+    offsets = [int(v) for v in np.cumsum([0] + numels[:-1])]
+    flat, grad = torch.zeros(sum(numels)), torch.zeros(sum(numels))
+    params = [flat[o:o + n].view(s) for o, n, s in zip(offsets, numels, shapes)]
+    slots = ops.GradSlots(flat, grad, offsets, numels)
+    g2 = slots.take(params[2])
+    assert g2.shape == params[2].shape and g2.data_ptr() == grad.data_ptr() + 4 * offsets[2]
+    assert slots.take(params[2]) is None                                   # second use in the same step: autograd adds it in
+    assert slots.take(params[2].view(6, 2, 3, 1, 1)).__class__ is type(None)
+    fused = flat[:numels[0] + numels[1]].view(6, 3, 1, 1, 1)               # the first two weights seen as one
+    gf = slots.take(fused)
+    assert gf.shape == fused.shape and gf.data_ptr() == grad.data_ptr()
+    assert slots.take(params[0]) is None and slots.take(params[1]) is None  # both covered by the fused slot
+    assert slots.take(flat[offsets[3] + 1:offsets[3] + 3]) is None          # not at a parameter start
+    assert slots.take(flat[offsets[3]:offsets[3] + 3]) is None              # not a whole parameter
+    assert slots.take(torch.zeros(5)) is None                               # foreign tensor
+    assert slots.take(params[3].double()) is None
+    slots.reset()
+    g0 = slots.take(params[0])
+    g0.fill_(7.0)
+    assert float(grad[:numels[0]].min()) == 7.0 and float(grad[numels[0]:].abs().max()) == 0.0
+    assert slots.take(fused) is None                                        # part of its span is taken
+    assert ops.grad_slot(params[1]) is None                                 # no trainer backward running
