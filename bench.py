@@ -154,11 +154,27 @@ def main():
     if args.batch is None:
         args.batch = 2 if anet else 8
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher of N ranks (one process per GPU) and exit with their
+        # status; the ranks re-enter this file with RANK / LOCAL_RANK / WORLD_SIZE set (as under torch.distributed.run).
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s)")
+        import socket
+        import subprocess
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if world != args.gpus and not os.environ.get("OTAL_FORCE_DIST"):
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N does it by itself)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     force_dist = bool(os.environ.get("OTAL_FORCE_DIST"))      # exercise the RCCL path on a single rank
@@ -167,6 +183,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
+        if dist.get_world_size() != world:
+            raise SystemExit(f"RCCL reports {dist.get_world_size()} ranks, expected {world}")
     from opental_amd.common import ops as _ops
     _ops.CONV_PRECISION = 1 if args.dtype == "bf16" else 0
     if anet:
@@ -187,52 +205,73 @@ def main():
         args.graph = "off"
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     graphed = False
     launch_probe = None
+    multi = world > 1 or force_dist
     # Launch mode.  The step is GPU-bound since the loss / gradient hand-over stopped issuing ~800 tiny kernels: eager
-    # launches and a replayed HIP graph give the same throughput when the host has slack.  `auto` checks for that slack:
-    # if issuing the launches of a step takes < 90 % of the step, eager launches it is; only a host-bound step is captured.  (auto never captures on N > 1 ranks: multi-rank
-    # capture of the RCCL hooks could not be exercised on the 1-GPU development boxes; --graph on forces it.)
+    # launches and a replayed HIP graph give the same throughput when the host has slack.  `auto` checks for that slack on
+    # every rank (the probe steps are ordinary data-parallel steps, all ranks take part): if issuing the launches of a step
+    # takes < 90 % of the step on the SLOWEST host thread, eager launches it is; only a host-bound step is captured.  The
+    # decision and the outcome of the capture are agreed between the ranks (MAX / MIN all-reduce), so all ranks replay or
+    # none does.
     want_graph = args.graph == "on"
-    if args.graph == "auto" and world == 1 and not args.ssl:
+    if args.graph == "auto" and not args.ssl:
         for _ in range(3):
             trainer.step(clips, targets, scores)
-        torch.cuda.synchronize()
+        barrier()
         t = time.perf_counter()
         for _ in range(6):
             trainer.step(clips, targets, scores)
         t_issue = time.perf_counter() - t
         torch.cuda.synchronize()
         t_total = time.perf_counter() - t
+        if multi:
+            tt = torch.tensor([t_issue, t_total], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_issue, t_total = float(tt[0]), float(tt[1])
         launch_probe = {"eager_ms": round(t_total / 6 * 1e3, 3), "host_issue_ms": round(t_issue / 6 * 1e3, 3)}
         want_graph = t_issue > 0.9 * t_total
     if want_graph:
+        ok = 1
         try:
             trainer.capture_step(clips, targets, scores)
-            graphed = True
         except Exception as e:                      # noqa: BLE001 -- any capture failure means eager launches
             if args.graph == "on":
                 raise
-            trainer._graph = None
+            ok = 0
             torch.cuda.synchronize()
-            if rank == 0:
-                print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {str(e)[:200]}); eager launches", file=sys.stderr)
+            print(f"[bench] rank {rank}: HIP graph capture unavailable ({type(e).__name__}: {str(e)[:200]}); eager launches", file=sys.stderr)
+        if multi:
+            okt = torch.tensor([ok], device=device, dtype=torch.int32)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            ok = int(okt)
+        graphed = bool(ok)
+        if not graphed:
+            trainer._graph = None
     for _ in range(args.warmup):
         trainer.step(clips, targets, scores, *ssl_args)
+    trainer.measure_exposed = multi and not graphed      # HIP events around the wait for the gradient all-reduces
+    trainer.exposed_events = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.step(clips, targets, scores, *ssl_args)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1 or force_dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+    trainer.measure_exposed = False
+    exposed_ms = None
+    if trainer.exposed_events:
+        exposed_ms = sum(a.elapsed_time(b) for a, b in trainer.exposed_events) / len(trainer.exposed_events)
+    if multi:
+        t = torch.tensor([dt, exposed_ms if exposed_ms is not None else -1.0], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        dt = float(t[0])
+        exposed_ms = float(t[1]) if float(t[1]) >= 0 else None
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
 
@@ -301,7 +340,11 @@ def main():
                                    "OpenTAL THUMOS14 split_0 training step (configs/thumos14_opental_final.yaml, "
                                    "EDL+IBM loss, ssl branch " + ("ON" if args.ssl else "off") + "), 256x3x96x96 clips, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "grad_allreduce": "RCCL, flat-arena buckets overlapped with backward",
+                       "parallelism": f"dp{world}", "rccl_ranks": dist.get_world_size() if (world > 1 or force_dist) else 1,
+                       "grad_allreduce": "RCCL sum over xGMI of the flat fp32 gradient arena in %d contiguous buckets, issued from inside "
+                                         "the backward pass (the backbone hands its finished layers over while it runs); "
+                                         "exposed = compute-stream wait for the collectives after backward" % len(trainer.arena.buckets),
+                       "allreduce_exposed_ms": None if exposed_ms is None else round(exposed_ms, 3),
                        "ssl_branch": bool(args.ssl), "launch_probe": launch_probe,
                        "launch": "one captured HIP graph per step" if graphed else "eager launches"},
             "roofline": roofline, "hbm_kernels": hbm, "cpu_baseline": cpu}))

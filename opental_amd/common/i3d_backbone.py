@@ -193,14 +193,17 @@ def _fused_weight(w_b1a, w_b2a, w_b0):
     return torch.cat([w_b1a, w_b2a, w_b0], 0)
 
 
-def _cat_cached(cache, key, parts):
+def _cat_cached(cache, owner, tag, parts):
+    """torch.cat(parts), cached per (owner storage, tag); the entry keeps `owner` alive, so its address cannot be handed to
+    another tensor while the key exists (a refold after load_state_dict / a second model gets its own entries)."""
+    key = (owner.data_ptr(), owner._version, tag)
     hit = cache.get(key)
     if hit is None:
-        hit = torch.cat(parts)
+        hit = (torch.cat(parts), owner)
         if len(cache) > 256:
             cache.clear()
         cache[key] = hit
-    return hit
+    return hit[0]
 
 
 _OUT_SCALE = {}
@@ -208,16 +211,18 @@ _OUT_SCALE = {}
 
 def _fused_affine(scale, shift, offs, w0):
     """Folded-BN scale / shift of the fused 1x1 launch of a module, in its channel order [b1a | b2a | b0] (constants)."""
-    key = (scale.data_ptr(), shift.data_ptr(), w0)
+    # the entry holds the folded tensors, so their addresses cannot be recycled under the key: a refold after
+    # load_state_dict, or a second model in the process, gets a new entry
+    key = (scale.data_ptr(), shift.data_ptr(), scale._version, w0)
     hit = _FUSED_AFFINE.get(key)
     if hit is None:
         pick = lambda t, i: t[offs[i]:offs[i + 1]]
         hit = (torch.cat([pick(scale, w0 + 1), pick(scale, w0 + 3), pick(scale, w0)]),
-               torch.cat([pick(shift, w0 + 1), pick(shift, w0 + 3), pick(shift, w0)]))
+               torch.cat([pick(shift, w0 + 1), pick(shift, w0 + 3), pick(shift, w0)]), scale, shift)
         if len(_FUSED_AFFINE) > 256:
             _FUSED_AFFINE.clear()
         _FUSED_AFFINE[key] = hit
-    return hit
+    return hit[0], hit[1]
 
 
 class I3DFeaturesFunction(Function):
@@ -272,7 +277,7 @@ class I3DFeaturesFunction(Function):
                 pm, argm = ops.maxpool3d_forward(cur, THREE, ONE)
                 ops.conv_forward(pm, weights[w0 + 5], ONE, ONE, scale=sc(w0 + 5), shift=sh(w0 + 5), relu=True,
                                  out=Y[:, c3:])
-                out_scale = _cat_cached(_OUT_SCALE, (scale.data_ptr(), w0), [sc(w0), sc(w0 + 2), sc(w0 + 4), sc(w0 + 5)])
+                out_scale = _cat_cached(_OUT_SCALE, scale, w0, [sc(w0), sc(w0 + 2), sc(w0 + 4), sc(w0 + 5)])
                 tape.append(("mixed", w0, (c1, c2, c3), cur, h1, h2, pm, argm, Y, cur_scale, (wf, o1, o13), out_scale))
                 cur, cur_scale = Y, out_scale
             if name in endpoints:
@@ -336,6 +341,7 @@ class I3DFeaturesFunction(Function):
             if step[0] == "conv":
                 _, wi, k, s, xin, y, in_scale, _ = step
                 dws[wi] = ops.conv_wgrad(xin, dcur, weights[wi].shape, k, s, out=ops.grad_slot(weights[wi]))
+                ops.grads_ready([(weights[wi], dws[wi])])
                 if first and not need_dx:
                     dcur = None
                 else:
@@ -363,6 +369,7 @@ class I3DFeaturesFunction(Function):
                 ops.conv_dgrad(gf, wf, xin.shape, ONE, ONE, out=dX, out_mask=xm, out_scale=in_scale)
                 g3 = dY[:, sl[3]]
                 dws[w0 + 5] = ops.conv_wgrad(pm, g3, weights[w0 + 5].shape, ONE, ONE, out=ops.grad_slot(weights[w0 + 5]))
+                ops.grads_ready([(weights[w0 + q], dws[w0 + q]) for q in range(6)])      # this module's six weights are final
                 dpm = ops.conv_dgrad(g3, weights[w0 + 5], pm.shape, ONE, ONE)
                 ops.maxpool3d_backward(dpm, argm, xin.shape, THREE, ONE, out=dX, accumulate=True,
                                        out_mask=xm, out_scale=in_scale)

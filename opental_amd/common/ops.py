@@ -347,6 +347,15 @@ class GradSlots:
 
 
 GRAD_SLOTS = None       # the running trainer's GradSlots (DetectorTrainer.begin_backward / end_backward)
+GRAD_READY = None       # the running trainer's callback for weight gradients that are final before their node returns
+
+
+def grads_ready(pairs):
+    """A multi-layer autograd node (the I3D backbone) announces (weight, gradient) pairs as soon as they are final, so a
+    data-parallel trainer can hand the finished arena range to RCCL while the node's remaining layers still run."""
+    cb = GRAD_READY
+    if cb is not None:
+        cb(pairs)
 
 
 def grad_slot(w):

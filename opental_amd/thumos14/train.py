@@ -86,9 +86,11 @@ def total_cost(losses, w):
 class FlatArena:
     """Trainable parameters re-homed into one contiguous fp32 buffer (+ parallel grad / m / v)."""
 
-    def __init__(self, params, bucket_bytes, adjacent=()):
+    def __init__(self, params, bucket_bytes, adjacent=(), split_key=None):
         """`adjacent`: groups of parameters that must sit back to back, in the given order (e.g. the three 1x1 weights of
-        an Inception module that one fused launch reads as a single matrix, InceptionModule.fused_1x1_weights)."""
+        an Inception module that one fused launch reads as a single matrix, InceptionModule.fused_1x1_weights).
+        `split_key`: function parameter -> hashable; a new bucket starts wherever the key changes along the arena (the
+        trainer separates the backbone's buckets from the pyramid's: they complete at different times of backward)."""
         self.params = [p for p in params if p.requires_grad]
         # arena order = expected gradient-completion order: autograd finishes the heads / pyramid
         # first and the (single-node) backbone last, i.e. reverse registration order
@@ -121,11 +123,12 @@ class FlatArena:
         # buckets: contiguous [lo,hi) ranges of about bucket_bytes
         self.buckets, self.bucket_of = [], []
         lo, cur = 0, 0
+        key = split_key if split_key is not None else (lambda q: 0)
         for i, p in enumerate(self.params):
             self.bucket_of.append(len(self.buckets))
             cur += p.numel() * 4
             last = i == len(self.params) - 1
-            if cur >= bucket_bytes or last:
+            if cur >= bucket_bytes or last or key(self.params[i + 1]) != key(p):
                 hi = self.offsets[i] + p.numel()
                 self.buckets.append((lo, hi))
                 lo, cur = hi, 0
@@ -138,7 +141,7 @@ class FlatArena:
 
 class DetectorTrainer:
     def __init__(self, net, criterion, loss_weights, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8,
-                 process_group=None, bucket_mb=48, distributed=None, force_collectives=False, param_groups=None,
+                 process_group=None, bucket_mb=16, distributed=None, force_collectives=False, param_groups=None,
                  forward_fn=None):
         """`param_groups`: [(parameters, lr), ...] in the order the reference hands them to torch.optim.Adam (the
         ActivityNet recipe trains the backbone at lr/10, anet/train.py:304-312); default one group = net.parameters().
@@ -151,7 +154,23 @@ class DetectorTrainer:
         self.world = dist.get_world_size(process_group) if self.distributed else 1
         self.forward_fn = forward_one_epoch if forward_fn is None else forward_fn
         adjacent = [m.fused_1x1_weights() for m in net.modules() if hasattr(m, 'fused_1x1_weights')]
-        self.arena = FlatArena(list(net.parameters()), bucket_mb << 20, adjacent)
+        # The backbone is ONE autograd node that finishes last; it announces its weight gradients layer by layer while it
+        # runs (ops.GRAD_READY), so its buckets are kept apart from the pyramid's and go to RCCL from inside its backward.
+        backbone = getattr(net, 'backbone', None)
+        late = {id(p) for p in backbone.parameters()} if isinstance(backbone, nn.Module) else set()
+        # ... and the weight whose gradient is computed LAST (the first trainable backbone parameter: Conv3d_1a) gets a
+        # bucket of its own: the only all-reduce that cannot hide under later backward work is then a 260 KB one
+        last = next((id(p) for p in (backbone.parameters() if late else ()) if p.requires_grad), None)
+        self.arena = FlatArena(list(net.parameters()), bucket_mb << 20, adjacent,
+                               split_key=lambda p: 2 if id(p) == last else int(id(p) in late))
+        a = self.arena
+        # Collectives are ISSUED in one fixed order on every rank -- the pyramid / head buckets (complete first), then the
+        # backbone's -- whatever order the gradients happen to arrive in: a rank whose batch leaves a parameter unused
+        # would otherwise issue its all-reduces in a different order than its peers (mismatched collectives hang).
+        is_late = [id(a.params[a.bucket_members[b][0]]) in late for b in range(len(a.buckets))]
+        self.late_buckets = [b for b in range(len(a.buckets)) if is_late[b]]
+        self._flush_order = sorted(range(len(a.buckets)), key=lambda b: (is_late[b], b))
+        self._index_of = {p.data_ptr(): i for i, p in enumerate(a.params)}
         self.param_groups = [(list(net.parameters()), lr)] if param_groups is None else [(list(ps), g_lr) for ps, g_lr in param_groups]
         self._group_ranges = self._arena_ranges()
         self.step_count = 0
@@ -159,12 +178,19 @@ class DetectorTrainer:
         lo = self.arena.flat.data_ptr()
         self._prologues = ops.PrologueCache((lo, lo + 4 * self.arena.numel))   # per-layer tables + bf16 weights, refreshed once per step
         self._graph = None          # (CUDAGraph, static inputs, static outputs) once capture_step() succeeded
+        self._graph_key = None      # the host scalars baked into the capture
+        self._graph_keepalive = None
         self._bias_corr = None      # 2-float device tensor: Adam bias corrections of the step being run
         self.collectives = self.distributed and (self.world > 1 or force_collectives)   # force: 1-rank RCCL smoke test
         self._flushed = None
+        self._skipped = []          # arena indices of parameters that received no gradient in the current step
+        self._early = True          # the backbone may hand finished weight gradients over from inside its backward
+        self.measure_exposed = False    # bench.py: record HIP events around the wait for the all-reduces
+        self.exposed_events = []
+        self._ibm_work = None
         self._slots = ops.GradSlots(self.arena.flat, self.arena.grad, self.arena.offsets, [p.numel() for p in self.arena.params])
         for i, p in enumerate(self.arena.params):
-            p.register_post_accumulate_grad_hook(self._make_hook(self.arena.bucket_of[i]))
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     def _arena_ranges(self):
         """[(lo, hi, lr)]: each optimizer group must own ONE contiguous slice of the flat arena (module-aligned groups
@@ -186,17 +212,48 @@ class DetectorTrainer:
 
     # ---- gradients -> flat arena (+ all-reduce), bucket by bucket, overlapped with backward
     # Parameters enter backward with .grad = None, so autograd ADOPTS each incoming gradient tensor instead of
-    # launching `arena_view += grad` per parameter (~190 tiny kernels per step + a 179 MB zero fill); when the last
-    # gradient of a bucket has arrived, one multi-tensor copy moves the bucket into the arena and, in data-parallel
-    # runs, its all-reduce starts.
-    def _make_hook(self, b):
+    # launching `arena_view += grad` per parameter (~190 tiny kernels per step + a 179 MB zero fill).  A gradient is
+    # "done" either when autograd has accumulated it (post-accumulate hook) or -- backbone weights, whose gradients the
+    # weight-gradient launches write straight into the arena -- when the backbone's backward announces it
+    # (ops.GRAD_READY), long before that node returns.  When the last gradient of a bucket is done, one multi-tensor copy
+    # moves the stragglers into the arena and, in data-parallel runs, the bucket's all-reduce is issued (in
+    # self._flush_order).
+    def _make_hook(self, i):
         def hook(_param):
-            if self._pending is None:
+            if self._pending is None or self._done[i]:
                 return
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._flush_bucket(b)
+            self._mark(i)
         return hook
+
+    def _mark(self, i):
+        self._done[i] = True
+        b = self.arena.bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._ready[b] = True
+            self._drain()
+
+    def _grads_ready(self, pairs):
+        """Called from inside the backbone's backward (common/i3d_backbone.py) with (weight, gradient) pairs whose
+        gradient is final.  Only gradients that already sit in their arena slice count (ops.grad_slot)."""
+        if self._pending is None or not self._early:
+            return
+        a = self.arena
+        for w, g in pairs:
+            i = self._index_of.get(w.data_ptr())
+            if i is None or g is None or self._done[i] or g.data_ptr() != a.grad_views[i].data_ptr():
+                continue
+            self._in_arena[i] = True
+            self._mark(i)
+
+    def _drain(self, force=False):
+        order = self._flush_order
+        while self._cursor < len(order):
+            b = order[self._cursor]
+            if not (self._ready[b] or force):
+                break
+            self._flush_bucket(b)
+            self._cursor += 1
 
     def _flush_bucket(self, b):
         if self._flushed[b]:
@@ -205,9 +262,12 @@ class DetectorTrainer:
         a = self.arena
         dst, src = [], []
         for i in a.bucket_members[b]:
+            if self._in_arena[i]:
+                continue                                # written in place and announced by the backbone
             g = a.params[i].grad
             if g is None:
-                a.grad_views[i].zero_()                 # parameter unused this step
+                a.grad_views[i].zero_()                 # parameter unused this step: no update (as torch.optim.Adam)
+                self._skipped.append(i)
             elif g.data_ptr() != a.grad_views[i].data_ptr():
                 dst.append(a.grad_views[i]); src.append(g)
         if dst:
@@ -216,21 +276,38 @@ class DetectorTrainer:
             lo, hi = a.buckets[b]
             self._works.append(dist.all_reduce(a.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def begin_backward(self):
-        """Call before cost.backward(): gradients start undefined, buckets open."""
-        for p in self.arena.params:
+    def begin_backward(self, early=True):
+        """Call before cost.backward(): gradients start undefined, buckets open.  `early=False` (a step that runs the
+        backbone twice, i.e. the ssl branch): gradients are only final when autograd has accumulated them."""
+        a = self.arena
+        for p in a.params:
             p.grad = None
-        self._pending = list(self.arena.bucket_size)
-        self._flushed = [False] * len(self.arena.buckets)
+        self._pending = list(a.bucket_size)
+        self._flushed = [False] * len(a.buckets)
+        self._ready = [False] * len(a.buckets)
+        self._done = [False] * len(a.params)
+        self._in_arena = [False] * len(a.params)
+        self._skipped = []
+        self._cursor = 0
+        self._early = early
         self._slots.reset()
         ops.GRAD_SLOTS = self._slots                # weight gradients are written straight into the arena
+        ops.GRAD_READY = self._grads_ready
+        if self.collectives and self._ibm_state() is not None:
+            # the loss kernel updated the IBM EMA in the forward pass: its 50-float average travels under the backward
+            self._ibm_work = dist.all_reduce(self._ibm_state(), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _ibm_state(self):
+        if getattr(self.criterion, 'cls_loss_type', None) == 'edl' and getattr(self.criterion.cls_loss, 'with_ibm', False):
+            return self.criterion.cls_loss.weight_accum
+        return None
 
     def end_backward(self):
         """Call after cost.backward(): flush the buckets that did not complete (unused parameters), wait for the
         all-reduces, and leave every .grad aliasing its arena slice."""
         ops.GRAD_SLOTS = None
-        for b in range(len(self.arena.buckets)):
-            self._flush_bucket(b)
+        ops.GRAD_READY = None
+        self._drain(force=True)
         self._pending = None
         for p, v in zip(self.arena.params, self.arena.grad_views):
             p.grad = v
@@ -239,13 +316,21 @@ class DetectorTrainer:
     def _finish_allreduce(self):
         if not self.collectives:
             return
+        ev = None
+        if self.measure_exposed:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
         for w in self._works:
             w.wait()
         self._works = []
-        if getattr(self.criterion, 'cls_loss_type', None) == 'edl' and self.criterion.cls_loss.with_ibm:
-            acc = self.criterion.cls_loss.weight_accum
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
-            acc.div_(self.world)
+        if self._ibm_work is not None:
+            self._ibm_work.wait()
+            self._ibm_work = None
+            self._ibm_state().div_(self.world)
+        if ev is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            self.exposed_events.append((ev, end))
 
     # ---- one optimisation step
     def compute_cost(self, clips, targets, scores, ssl_clips=None, ssl_targets=None):
@@ -257,28 +342,73 @@ class DetectorTrainer:
         return cost, losses
 
     def step(self, clips, targets, scores, ssl_clips=None, ssl_targets=None):
+        stale = False
         if self._graph is not None and ssl_clips is None:
-            return self._replay(clips, targets, scores)
-        ops.activate_prologues(self._prologues)        # ONE launch re-packs the weights of every known conv layer
+            if self._graph_key == self._capture_key():
+                return self._replay(clips, targets, scores)
+            stale = True            # a baked-in host scalar changed (learning rate, IBM switch): eager now, capture again
+            self._graph = None
+        # an eager step next to a captured graph (ssl branch) must not touch the descriptor buffers the graph replays
+        # from: it works on its own prologue cache
+        cache = self._prologues if self._graph is None else self._eager_prologues()
+        ops.activate_prologues(cache)                  # ONE launch re-packs the weights of every known conv layer
         try:
             cost, losses = self.compute_cost(clips, targets, scores, ssl_clips, ssl_targets)
-            self.begin_backward()
+            self.begin_backward(early=ssl_clips is None)
             cost.backward()
             self.end_backward()
         finally:
             ops.deactivate_prologues()
             ops.GRAD_SLOTS = None
+            ops.GRAD_READY = None
         self.step_count += 1
         self.optimizer_update()
+        if stale:
+            self.capture_step(clips, targets, scores, warmup=0)
         return cost.detach(), losses
+
+    def _eager_prologues(self):
+        c = getattr(self, '_prologues_eager', None)
+        if c is None:
+            lo = self.arena.flat.data_ptr()
+            c = self._prologues_eager = ops.PrologueCache((lo, lo + 4 * self.arena.numel))
+        return c
+
+    def _capture_key(self):
+        """Every host scalar a captured step bakes into its launches."""
+        cl = getattr(self.criterion, 'cls_loss', None)
+        ibm = None
+        if cl is not None and hasattr(cl, 'epoch'):
+            ibm = (bool(getattr(cl, 'with_ibm', False)), int(cl.epoch) >= int(getattr(cl, 'ibm_start', 0)),
+                   float(getattr(cl, 'annealing_coef', 0.0)) if hasattr(cl, 'annealing_coef') else None)
+        return (float(self.lr), float(self._base_lr), tuple(float(g) for _, _, g in self._group_ranges), float(self.wd),
+                tuple(self.betas), float(self.eps), self.world, bool(self.collectives), ibm,
+                tuple(sorted((k, float(v)) for k, v in self.w.items())))
 
     def optimizer_update(self):
         """Adam (L2 weight decay in the gradient, train.py:321-323) on the flat arena: one launch."""
         a = self.arena
+        keep = self._stash_skipped()
         for lo, hi, g_lr in self._group_ranges:
             g_lr = g_lr * (self.lr / self._base_lr) if self._base_lr else g_lr
             ops.adam_flat(a.flat[lo:hi], a.grad[lo:hi], a.m[lo:hi], a.v[lo:hi], self.step_count, g_lr,
                           self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
+        self._restore_skipped(keep)
+
+    # torch.optim.Adam leaves a parameter whose .grad is None alone (no weight decay, moments untouched); the flat launch
+    # covers the whole arena, so the (rare) parameters without a gradient are put back afterwards.
+    def _stash_skipped(self):
+        a = self.arena
+        keep = []
+        for i in self._skipped:
+            sl = slice(a.offsets[i], a.offsets[i] + a.params[i].numel())
+            keep.append((sl, a.flat[sl].clone(), a.m[sl].clone(), a.v[sl].clone()))
+        return keep
+
+    def _restore_skipped(self, keep):
+        a = self.arena
+        for sl, p, m, v in keep:
+            a.flat[sl].copy_(p); a.m[sl].copy_(m); a.v[sl].copy_(v)
 
     # ---- the same step as ONE HIP graph: ~1500 launches per step are replayed without host involvement
     def _graph_body(self, clips, targets, scores):
@@ -291,11 +421,14 @@ class DetectorTrainer:
         finally:
             ops.deactivate_prologues()
             ops.GRAD_SLOTS = None
+            ops.GRAD_READY = None
         a = self.arena
+        keep = self._stash_skipped()
         for lo, hi, g_lr in self._group_ranges:
             g_lr = g_lr * (self.lr / self._base_lr) if self._base_lr else g_lr
             ops.adam_flat_dev(a.flat[lo:hi], a.grad[lo:hi], a.m[lo:hi], a.v[lo:hi], self._bias_corr, g_lr,
                               self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
+        self._restore_skipped(keep)
         return cost.detach(), losses
 
     def capture_step(self, clips, targets, scores, warmup=2):
@@ -330,6 +463,9 @@ class DetectorTrainer:
             out = self._graph_body(*static)
         self.step_count += 0        # capture does not execute
         self._graph = (graph, static, out)
+        self._graph_key = self._capture_key()
+        # the captured prologue launch reads these descriptor buffers by raw pointer: they live as long as the graph
+        self._graph_keepalive = (self._prologues.dev_descs, self._prologues.dev_starts)
         return self
 
     def _set_bias(self, step):

@@ -227,3 +227,134 @@ def test_grad_slots_address_map():
     assert float(grad[:numels[0]].min()) == 7.0 and float(grad[numels[0]:].abs().max()) == 0.0
     assert slots.take(fused) is None                                        # part of its span is taken
     assert ops.grad_slot(params[1]) is None                                 # no trainer backward running
+
+
+# ----------------------------------------------------------------------------- the REAL arena at world size 2
+class _FakeBackboneFn(torch.autograd.Function):
+    """Follows I3DFeaturesFunction.backward's hand-over protocol on CPU tensors: one node for every backbone weight, whose
+    backward writes each weight gradient into its arena slot (ops.grad_slot) layer by layer, LAST layer first, and
+    announces it (ops.grads_ready) before moving on."""
+
+    @staticmethod
+    def forward(ctx, seed, log, *weights):
+        ctx.seed, ctx.log, ctx.weights = seed, log, weights
+        return torch.stack([w.reshape(-1)[0] for w in weights]).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        from opental_amd.common import ops
+        gen = torch.Generator().manual_seed(ctx.seed)
+        grads = [None] * len(ctx.weights)
+        for i in range(len(ctx.weights) - 1, -1, -1):
+            w = ctx.weights[i]
+            slot = ops.grad_slot(w)
+            val = torch.randn(w.shape, generator=gen)
+            if slot is not None:
+                slot.copy_(val)
+                grads[i] = slot
+            else:
+                grads[i] = val
+            ops.grads_ready([(w, grads[i])])
+            ctx.log.append(("layer", i))
+        ctx.log.append(("backbone-node-returns",))
+        return (None, None) + tuple(grads)
+
+
+def _real_worker(rank, world, port, q, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from opental_amd.thumos14.BDNet import BDNet
+        from opental_amd.thumos14.train import DetectorTrainer
+        torch.manual_seed(0)
+        net = BDNet(in_channels=3, training=False, use_edl=True).train()
+        log = []
+
+        class T(DetectorTrainer):
+            def compute_cost(self, clips, targets, scores, ssl_clips=None, ssl_targets=None):
+                bb = [p for p in self.net.backbone.parameters() if p.requires_grad]
+                gen = torch.Generator().manual_seed(1000 + rank)
+                cost = _FakeBackboneFn.apply(2000 + rank, log, *bb)
+                skip = self.net.coarse_pyramid_detection.center_head.conv1d.bias if rank == 1 else None
+                for p in self.net.coarse_pyramid_detection.parameters():
+                    if p is skip:
+                        continue            # rank 1 leaves one parameter unused: the issue order must not change
+                    cost = cost + (p * torch.randn(p.shape, generator=gen)).sum()
+                return cost, (cost,)
+
+            def _flush_bucket(self, b):
+                if not self._flushed[b]:
+                    log.append(("allreduce", b))
+                super()._flush_bucket(b)
+
+            def optimizer_update(self):
+                pass
+        tr = T(net, nn.Module(), {}, lr=1e-5, weight_decay=1e-3, distributed=True)
+        tr.step(None, None, None)
+        torch.save(tr.arena.grad, os.path.join(outdir, f"grad{rank}.pt"))       # 179 MB: through a file, not the queue
+        q.put((rank, None, log, list(tr._skipped), tr.late_buckets, list(tr._flush_order)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_real_detector_arena_two_ranks_early_handover_and_issue_order(tmp_path):
+    """World size 2 on gloo with the REAL parameter arena of BDNet (44.7 M parameters, the bucket layout the MI355X run
+    uses): summed gradients are identical on both ranks and equal the sum of the per-rank gradients; the backbone buckets'
+    all-reduces are issued from INSIDE the backbone node's backward (all but the final 260 KB one before its first
+    layer is reached); both ranks issue their collectives in the same order although rank 1 leaves a parameter unused."""
+    import queue
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_real_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    except queue.Empty:
+        res = None
+    for p in procs:
+        p.join(timeout=120)
+        if p.is_alive():
+            p.kill()
+    assert res is not None and all(p.exitcode == 0 for p in procs)
+    (_, _, log0, skipped0, late, order), (_, _, log1, skipped1, _, _) = res
+    g0, g1 = (torch.load(str(tmp_path / f"grad{r}.pt")) for r in range(world))
+    assert torch.equal(g0, g1)
+    issue0 = [e[1] for e in log0 if e[0] == "allreduce"]
+    issue1 = [e[1] for e in log1 if e[0] == "allreduce"]
+    assert issue0 == issue1 == order                    # one fixed issue order on every rank
+    assert skipped0 == [] and len(skipped1) == 1        # rank 1's unused parameter is left alone by Adam
+    # early hand-over: every backbone bucket except the last one is issued before the backbone node returns, and the
+    # first of them long before the last layer (index 0 = Conv3d_1a) is reached
+    pos = {e: i for i, e in enumerate(log0)}
+    ret = pos[("backbone-node-returns",)]
+    for b in late:
+        assert pos[("allreduce", b)] < ret
+    assert pos[("allreduce", late[0])] < pos[("layer", 20)]
+    assert pos[("allreduce", late[-1])] > pos[("layer", 1)]    # the 260 KB bucket of the weight that finishes last (layer 0)
+    # the reduced gradient really is the sum over ranks (recompute rank-local gradients here)
+    from opental_amd.thumos14.BDNet import BDNet
+    torch.manual_seed(0)
+    net = BDNet(in_channels=3, training=False, use_edl=True).train()
+    bb = [p for p in net.backbone.parameters() if p.requires_grad]
+    from opental_amd.thumos14.train import DetectorTrainer
+    tr = DetectorTrainer(net, nn.Module(), {}, lr=1e-5, weight_decay=1e-3, distributed=False)
+    want = torch.zeros_like(g0)
+    where = {id(p): (off, p.numel()) for p, off in zip(tr.arena.params, tr.arena.offsets)}
+    for rank in range(world):
+        gen_b = torch.Generator().manual_seed(2000 + rank)
+        for i in range(len(bb) - 1, -1, -1):
+            off, n = where[id(bb[i])]
+            want[off:off + n] += torch.randn(bb[i].shape, generator=gen_b).reshape(-1)
+        gen = torch.Generator().manual_seed(1000 + rank)
+        skip = net.coarse_pyramid_detection.center_head.conv1d.bias if rank == 1 else None
+        for p in net.coarse_pyramid_detection.parameters():
+            if p is skip:
+                continue
+            off, n = where[id(p)]
+            want[off:off + n] += torch.randn(p.shape, generator=gen).reshape(-1)
+    assert torch.allclose(g0, want, rtol=0, atol=1e-6)
