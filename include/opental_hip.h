@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 13
+#define OTAL_ABI_VERSION 14
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -45,6 +45,11 @@ extern "C" {
 
 int otal_abi_version(void);
 const char* otal_error_string(int code);
+/* Named integer switches that select kernel variants (A/B tests, micro-benchmarks; e.g. "OTAL_CONV_NO1A").  A switch
+ * starts from the environment variable of the same name, read once at its first use -- the launch path itself never
+ * calls getenv; otal_set_option changes it at run time, otal_get_option reads it (dflt when it was never set). */
+int otal_set_option(const char* name, int value);
+int otal_get_option(const char* name, int dflt);
 
 /* ------------------------------------------------------------------ BoundaryMaxPooling ----
  * out[n,c,k] = max_{i in [l,r]} in[n,c,i];  (l,r) = clamp(trunc(seg[n,k,2*(c>=C/2)+{0,1}]), 0, T-1);
@@ -229,6 +234,17 @@ int otal_softnms_classes(const float* seg, const float* score, const float* unct
                          const unsigned char* flag, const int* clip_start, int nvideos, int max_clips,
                          int A, int K, float sigma, int top_k, float score_threshold, float* out,
                          int* counts, int* out_index, int out_cols, void* stream);
+/* A (video, class) problem keeps its candidates in LDS (<= ~7600 rows = 60 THUMOS14 windows).  The reference's host
+ * loop has no such limit (test.py:165-200 handles a video of any length), so longer videos run from a caller-owned
+ * global scratch: otal_softnms_scratch_bytes returns its size for a batch with `total_clips` clips in all and at most
+ * `max_clips` per video (0 when every video fits LDS); otal_softnms_classes_ws = otal_softnms_classes + that scratch.
+ * otal_softnms_classes itself returns OTAL_E_UNSUPPORTED when a scratch would be needed. */
+size_t otal_softnms_scratch_bytes(int total_clips, int max_clips, int A, int K);
+int otal_softnms_classes_ws(const float* seg, const float* score, const float* unct, const float* actn,
+                            const unsigned char* flag, const int* clip_start, int nvideos, int max_clips,
+                            int A, int K, float sigma, int top_k, float score_threshold, float* out,
+                            int* counts, int* out_index, int out_cols, void* scratch, size_t scratch_bytes,
+                            int total_clips, void* stream);
 
 /* ------------------------------------------------------------------ optimizer ----
  * torch.optim.Adam with L2 weight decay (AFSD/thumos14/train.py:321-323) over one flat fp32

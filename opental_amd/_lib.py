@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTAL_LIB_PATH") or os.path.join(_HERE, "lib", "libopental_hip.so")   # override: A/B kernel builds
-ABI_VERSION = 13
+ABI_VERSION = 14
 F32, BF16 = 0, 1
 
 _lib = None
@@ -30,6 +30,12 @@ def lib():
             raise RuntimeError("libopental_hip.so ABI version mismatch; rebuild")
         _lib = L
     return _lib
+
+
+def set_option(name, value):
+    """Run-time kernel-selection switch (include/opental_hip.h: otal_set_option); the C side reads the environment
+    variable of the same name only once, at the switch's first use."""
+    check(lib().otal_set_option(name.encode(), int(value)), "otal_set_option")
 
 
 def check(rc, what):

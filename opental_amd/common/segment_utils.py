@@ -38,9 +38,14 @@ def softnms_v2(segments, sigma=0.5, top_k=1000, score_threshold=0.001, use_edl=F
     out = torch.empty((1, max(k, 1), 5), device=dev)
     counts = torch.zeros(1, dtype=torch.int32, device=dev)
     idx = torch.empty((1, max(k, 1)), dtype=torch.int32, device=dev)
-    L.check(L.lib().otal_softnms_classes(L.ptr(se), L.ptr(sc), L.ptr(c3), L.ptr(c4), L.ptr(flag), L.ptr(clip_start),
-                                         1, 1, n, 1, ctypes.c_float(sigma), max(k, 1), ctypes.c_float(score_threshold),
-                                         L.ptr(out), L.ptr(counts), L.ptr(idx), 5, L.stream()), "otal_softnms_classes")
+    lib = L.lib()
+    lib.otal_softnms_scratch_bytes.restype = ctypes.c_size_t
+    nbytes = int(lib.otal_softnms_scratch_bytes(1, 1, n, 1))          # > 0 past ~7600 candidates: global working set
+    scratch = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    L.check(lib.otal_softnms_classes_ws(L.ptr(se), L.ptr(sc), L.ptr(c3), L.ptr(c4), L.ptr(flag), L.ptr(clip_start),
+                                        1, 1, n, 1, ctypes.c_float(sigma), max(k, 1), ctypes.c_float(score_threshold),
+                                        L.ptr(out), L.ptr(counts), L.ptr(idx), 5, L.ptr(scratch), ctypes.c_size_t(nbytes), 1,
+                                        L.stream()), "otal_softnms_classes_ws")
     count = int(counts.item())
     rows = out[0, :count]
     if ncol == 3:

@@ -33,3 +33,8 @@ static inline int otal_launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 static inline int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// Named run-time switch (core.hip): first lookup reads the environment variable `name` (absent: dflt; present but not a
+// number: 1), later lookups are one load; otal_set_option() changes it.  Never getenv() on a launch path.
+int* otal_option_slot(const char* name, int dflt);
+#define OTAL_OPT(name, dflt) ([]() -> int { static int* const slot_ = otal_option_slot(name, dflt); return *slot_; }())

@@ -1484,7 +1484,7 @@ int fill_geom(ConvGeom& g, const int* d) {
 
 // tile height: least padded M, with a small penalty for the lower arithmetic intensity of short tiles
 int choose_bm(int M, int tall = 0) {
-    static const int tall_env = getenv("OTAL_CONV_TALL") ? atoi(getenv("OTAL_CONV_TALL")) : 1;    // bit0: fwd/dgrad (on: 2c fwd +16 %), bit1: wgrad (off: -9 %)
+    const int tall_env = OTAL_OPT("OTAL_CONV_TALL", 1);    // bit0: fwd/dgrad (on: 2c fwd +16 %), bit1: wgrad (off: -9 %)
     if ((tall & tall_env) && M % 192 == 0) return 192;     // one 192-row tile re-fetches the gathered operand half as often
     const int cand[4] = {128, 96, 64, 32};
     const double pen[4] = {1.00, 1.03, 1.10, 1.30};
@@ -1499,11 +1499,11 @@ int choose_bm(int M, int tall = 0) {
 
 // choose split-K so that the grid fills the chip (256 CUs) without shredding K
 int choose_splits(int tiles, int K, int prec = 1, bool wgrad = false) {
-    static const int target_env = getenv("OTAL_CONV_SPLIT_BLOCKS") ? atoi(getenv("OTAL_CONV_SPLIT_BLOCKS")) : 0;
+    const int target_env = OTAL_OPT("OTAL_CONV_SPLIT_BLOCKS", 0);
     // bf16: >= 8 K steps of 32 per split (fewer, larger slabs: measured +4 % step throughput over 4);
     // fp32 parity path: 128 k per split as in the version the gradient-parity fixtures were validated with
-    static const int minsteps_env = getenv("OTAL_CONV_SPLIT_MINSTEPS") ? atoi(getenv("OTAL_CONV_SPLIT_MINSTEPS")) : 0;
-    static const int cap_env = getenv("OTAL_CONV_MAXSPLIT") ? atoi(getenv("OTAL_CONV_MAXSPLIT")) : 0;
+    const int minsteps_env = OTAL_OPT("OTAL_CONV_SPLIT_MINSTEPS", 0);
+    const int cap_env = OTAL_OPT("OTAL_CONV_MAXSPLIT", 0);
     // The vector weight-gradient kernel keeps 4 workgroups per CU resident and its K is huge (all positions): it wants two
     // full waves of workgroups (2048; 512 left it at 2 waves per SIMD, 61 % of wave time parked).  Splits of >= 16 K steps:
     // a K step is latency-bound (~1 us) when few workgroups are resident, so the small 1x1 / 1-D layers (18 k or 1 k
@@ -1511,7 +1511,7 @@ int choose_splits(int tiles, int K, int prec = 1, bool wgrad = false) {
     // 48 steps 407.6 clips/s, 24: 419.0, 12: 420.1, 6: 416.2).  Forward / data gradient keep the 512-workgroup target.
     const bool wv = wgrad && prec;
     const int target = target_env ? target_env : (wv ? 2048 : 512);
-    static const int wg_minsteps_env = getenv("OTAL_WGRAD_MINSTEPS") ? atoi(getenv("OTAL_WGRAD_MINSTEPS")) : 0;
+    const int wg_minsteps_env = OTAL_OPT("OTAL_WGRAD_MINSTEPS", 0);
     const int minsteps = (wv && wg_minsteps_env) ? wg_minsteps_env : minsteps_env ? minsteps_env : (wv ? 16 : (prec ? 8 : 4));
     const int cap = cap_env ? cap_env : (wv ? 1024 : 384);
     if (tiles >= target * 3 / 4) return 1;
@@ -1539,9 +1539,9 @@ static void set_epilogue_extents(ConvArgs& a) {
     if (MODE == MODE_FWD) out = 4 * ((int64_t)(g.B - 1) * g.y_bs + (int64_t)(g.Cout - 1) * g.y_cs + conv_out_positions(g));
     else if (MODE == MODE_DGRAD) out = 4 * ((int64_t)(g.B - 1) * g.x_bs + (int64_t)(g.Cin - 1) * g.x_cs + conv_in_positions(g));
     else out = 4 * (int64_t)g.Cout * g.Cin * conv_kvol(g);
-    a.out_bytes = (out > 0 && out < (int64_t)0xfffffff0u && !getenv("OTAL_CONV_SLOW_EPILOGUE")) ? (unsigned)out : 0u;
+    a.out_bytes = (out > 0 && out < (int64_t)0xfffffff0u && !OTAL_OPT("OTAL_CONV_SLOW_EPILOGUE", 0)) ? (unsigned)out : 0u;
     const int64_t slab = 4 * (int64_t)a.splits * a.M * a.N;
-    a.slab_bytes = (a.splits > 1 && slab < (int64_t)0xfffffff0u && !getenv("OTAL_CONV_SLOW_EPILOGUE")) ? (unsigned)slab : 0u;
+    a.slab_bytes = (a.splits > 1 && slab < (int64_t)0xfffffff0u && !OTAL_OPT("OTAL_CONV_SLOW_EPILOGUE", 0)) ? (unsigned)slab : 0u;
 }
 
 // =================================================================================================
@@ -1888,7 +1888,7 @@ __global__ __launch_bounds__(C1_NT) void conv1a_direct_fwd_kernel(const Conv1aAr
 }
 
 static inline bool conv1a_direct_eligible(const ConvGeom& g, int mode, int prec, const void* x) {
-    if (!prec || mode != MODE_FWD || g.nlev > 1 || getenv("OTAL_CONV_NO1A")) return false;
+    if (!prec || mode != MODE_FWD || g.nlev > 1 || OTAL_OPT("OTAL_CONV_NO1A", 0)) return false;
     if (g.Cin != 3 || g.kt != 7 || g.kh != 7 || g.kw != 7 || g.st != 2 || g.sh != 2 || g.sw != 2) return false;
     if (g.pt != 2 || g.ph != 2 || g.pw != 2 || g.Wi != 96 || g.Wo != C1_WO || g.Hi != 2 * g.Ho || g.Ti != 2 * g.To) return false;
     if (g.To % C1_TT || g.Ho % C1_TR || g.x_bs % 4 || g.x_cs % 4 || (reinterpret_cast<uintptr_t>(x) & 15)) return false;
@@ -2017,7 +2017,7 @@ __global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const ConvArgs a, int
 
 static inline int wgrad1d_chunks(const ConvGeom& g) { return (g.Ti + W1_TC - 1) / W1_TC; }
 static inline bool wgrad1d_eligible(const ConvGeom& g, int prec, const void* x, const void* dy) {
-    if (!prec || getenv("OTAL_CONV_NOW1D")) return false;
+    if (!prec || OTAL_OPT("OTAL_CONV_NOW1D", 0)) return false;
     if (g.Hi != 1 || g.Wi != 1 || g.Ho != 1 || g.Wo != 1 || g.kh != 1 || g.kw != 1 || g.st != 1 || g.To != g.Ti) return false;
     if (!((g.kt == 1 && g.pt == 0) || (g.kt == 3 && g.pt == 1))) return false;
     if (g.Cin % 64 || (g.x_bs | g.x_cs | g.y_bs | g.y_cs) & 1) return false;
@@ -2026,7 +2026,7 @@ static inline bool wgrad1d_eligible(const ConvGeom& g, int prec, const void* x, 
 }
 
 int launch_wgrad1d(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
-    static const int upw_env = getenv("OTAL_W1D_UPW") ? atoi(getenv("OTAL_W1D_UPW")) : 0;
+    const int upw_env = OTAL_OPT("OTAL_W1D_UPW", 0);
     const int nchunks = wgrad1d_chunks(a.g), units = a.g.B * nchunks;
     const int tiles = ((a.g.Cout + 63) / 64) * (a.g.Cin / 64);
     const int upw = upw_env > 0 ? upw_env : 1;      // units per workgroup: measured 1 -> 478.4, 2 -> 475.8, 4 -> 465.7 clips/s
@@ -2057,21 +2057,21 @@ static inline int64_t gather_extent_bytes(const ConvGeom& g, int mode) {
 }
 static inline bool chunk_eligible(const ConvGeom& g, int mode, int prec) {
     if (!prec || mode == MODE_WGRAD) return false;
-    if (getenv("OTAL_CONV_NOCHUNK")) return false;
+    if (OTAL_OPT("OTAL_CONV_NOCHUNK", 0)) return false;
     const int C = mode == MODE_FWD ? g.Cin : g.Cout;
-    if (C % 8 && !(mode == MODE_FWD && g.kw >= 3 && !getenv("OTAL_CONV_NOKWV"))) return false;    // forward has the kw-vector mode
+    if (C % 8 && !(mode == MODE_FWD && g.kw >= 3 && !OTAL_OPT("OTAL_CONV_NOKWV", 0))) return false;    // forward has the kw-vector mode
     const int64_t ext = gather_extent_bytes(g, mode);
     return ext > 0 && ext < (int64_t)0xfffffff0u;       // 32-bit buffer offsets
 }
 
 // positions one thread may fetch with a single vector load (see conv_gemm_bf16c_kernel)
 static inline int chunk_vector_width(const ConvGeom& g) {
-    if (const char* e = getenv("OTAL_CONV_CW")) { if (atoi(e) == 1) return 1; }
+    if (OTAL_OPT("OTAL_CONV_CW", 0) == 1) return 1;
     if (g.st != 1 || g.sh != 1 || g.sw != 1 || g.nlev > 1) return 1;
     if (g.Wo != g.Wi || (g.kw != 1 && g.kw != 3) || g.pw != (g.kw - 1) / 2) return 1;
     // 1x1x1: no shifted tap, so 4 consecutive positions of a sample are contiguous across row ends as well
     if (g.kt == 1 && g.kh == 1 && g.kw == 1 && g.To == g.Ti && g.Ho == g.Hi && conv_out_positions(g) % 4 == 0 &&
-        !getenv("OTAL_CONV_NO1X1V4")) return 4;
+        !OTAL_OPT("OTAL_CONV_NO1X1V4", 0)) return 4;
     if (g.Wi % 4 == 0) return 4;
     if (g.Wi % 2 == 0) return 2;
     return 1;
@@ -2175,7 +2175,7 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 constexpr int PTAB_PAD = 64;        // entries readable past the last group (two K steps of prefetch at CW = 2 -> 32)
 // stride-2 pair mode of the vector WGRAD (Conv3d_1a): window ends must stay within 4 elements of the row
 static inline bool wgrad_pair_mode(const ConvGeom& g, int prec) {
-    if (!prec || getenv("OTAL_CONV_NOVEC_WGRAD") || g.nlev > 1) return false;
+    if (!prec || OTAL_OPT("OTAL_CONV_NOVEC_WGRAD", 0) || g.nlev > 1) return false;
     if (g.sw != 2 || g.st > 2 || g.sh > 2 || g.kw > 7 || g.pw > 3 || g.Wo % 8 || conv_out_positions(g) % 32) return false;
     if (g.Wi - (2 * (g.Wo - 8) - g.pw + 6) < 12) return false;      // last window: elements 0..11 inside the row
     const int64_t ex = 4 * ((int64_t)(g.B - 1) * g.x_bs + (int64_t)(g.Cin - 1) * g.x_cs + conv_in_positions(g));
@@ -2183,7 +2183,7 @@ static inline bool wgrad_pair_mode(const ConvGeom& g, int prec) {
     return ex > 0 && ey > 0 && ex < (int64_t)0xffffff00u && ey < (int64_t)0xfffffff0u;
 }
 static inline int wgrad_vector_width(const ConvGeom& g, int prec) {
-    if (!prec || getenv("OTAL_CONV_NOVEC_WGRAD")) return 0;
+    if (!prec || OTAL_OPT("OTAL_CONV_NOVEC_WGRAD", 0)) return 0;
     if (g.st != 1 || g.sh != 1 || g.sw != 1 || g.nlev > 1) return 0;
     if (g.To != g.Ti || g.Ho != g.Hi || g.Wo != g.Wi) return 0;
     if ((g.kw != 1 && g.kw != 3) || g.pw != (g.kw - 1) / 2) return 0;
@@ -2193,7 +2193,7 @@ static inline int wgrad_vector_width(const ConvGeom& g, int prec) {
     if (ex <= 0 || ey <= 0 || ex >= (int64_t)0xfffffff0u || ey >= (int64_t)0xfffffff0u) return 0;
     // a 1x1x1 kernel has no shifted tap: any 8 consecutive positions of a sample are one contiguous vector, whatever the row
     // length (6x6 planes were on 2-element vectors, 3x3 planes on the generic kernel)
-    if (g.kt == 1 && g.kh == 1 && g.kw == 1 && !getenv("OTAL_CONV_NO1X1V8")) return 8;
+    if (g.kt == 1 && g.kh == 1 && g.kw == 1 && !OTAL_OPT("OTAL_CONV_NO1X1V8", 0)) return 8;
     if (g.Wi % 8 == 0) return 8;
     if (g.Wi % 4 == 0) return 4;
     if (g.Wi % 2 == 0) return 2;
@@ -2276,7 +2276,7 @@ static inline int direct_bm(int M) {
     return (pad64 - M) * 5 <= M ? 64 : 0;          // accept <= 20 % padded rows
 }
 static inline bool direct_eligible(const ConvGeom& g, int mode, int prec, int M) {
-    static const bool off = getenv("OTAL_CONV_NODIRECT") != nullptr;
+    const bool off = OTAL_OPT("OTAL_CONV_NODIRECT", 0) != 0;
     if (off || !prec || mode == MODE_WGRAD || g.nlev > 1) return false;
     if (g.kt != 3 || g.kh != 3 || g.kw != 3 || g.st != 1 || g.sh != 1 || g.sw != 1 || g.pt != 1 || g.ph != 1 || g.pw != 1) return false;
     if (g.To != g.Ti || g.Ho != g.Hi || g.Wo != g.Wi || g.Wi > 24) return false;
@@ -2284,7 +2284,7 @@ static inline bool direct_eligible(const ConvGeom& g, int mode, int prec, int M)
     const int C = mode == MODE_FWD ? g.Cin : g.Cout;
     if (P % 256 || C % 16 || !direct_bm(M)) return false;
     const int BM = direct_bm(M);
-    static const int min_tiles = getenv("OTAL_CONV_DIRECT_MINTILES") ? atoi(getenv("OTAL_CONV_DIRECT_MINTILES")) : 192;
+    const int min_tiles = OTAL_OPT("OTAL_CONV_DIRECT_MINTILES", 192);
     if ((int64_t)((M + BM - 1) / BM) * ((int64_t)g.B * P / 256) < min_tiles) return false;  // no split-K on this path
     const int64_t ext = gather_extent_bytes(g, mode);
     return ext > 0 && ext < (1LL << 31);
@@ -2356,7 +2356,7 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     }
     a.zero = zero_word_address();
     if (!a.zero) return OTAL_E_UNSUPPORTED;
-    if (const char* d = getenv("OTAL_CONV_DEBUG")) a.flags |= (atoi(d) & (DBG_NOLOAD | DBG_NOSTORE | DBG_NOBARRIER));
+    a.flags |= (OTAL_OPT("OTAL_CONV_DEBUG", 0) & (DBG_NOLOAD | DBG_NOSTORE | DBG_NOBARRIER));
     if (MODE != MODE_WGRAD) {       // carve the tap table off the front of the workspace and build it
         const size_t tb = tab_bytes(a.K);
         if (!ws || ws_bytes < tb) return OTAL_E_UNSUPPORTED;
@@ -2382,8 +2382,8 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if (MODE == MODE_WGRAD && a.prec) {
         // the generic kernel gets the weight gradients of the 1-D pyramid / head layers (126 positions per sample: no vector
         // path): K = B * 126 positions, a few dozen tiles -- latency-bound K steps, so split down to OTAL_GWGRAD_MINSTEPS
-        static const int ms = getenv("OTAL_GWGRAD_MINSTEPS") ? atoi(getenv("OTAL_GWGRAD_MINSTEPS")) : 4;      // measured: 8 -> 474.6, 4 -> 478.3, 2 -> 478.0, 1 -> 476.3 clips/s
-        static const int tg = getenv("OTAL_GWGRAD_TARGET") ? atoi(getenv("OTAL_GWGRAD_TARGET")) : 512;
+        const int ms = OTAL_OPT("OTAL_GWGRAD_MINSTEPS", 4);      // measured: 8 -> 474.6, 4 -> 478.3, 2 -> 478.0, 1 -> 476.3 clips/s
+        const int tg = OTAL_OPT("OTAL_GWGRAD_TARGET", 512);
         const int tiles = tm * tn;
         int want = (tg + tiles - 1) / tiles, maxs = a.K / (ms * 32);
         if (maxs < 1) maxs = 1;

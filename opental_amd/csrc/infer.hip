@@ -79,25 +79,45 @@ __device__ __forceinline__ Best best_merge(Best a, Best b) {
     return r;
 }
 
-// One workgroup per (video, class).  LDS: ts, te, sc (float), st (int: 0 dropped, 1 done, 2 undone),
+// One workgroup per (video, class).  Working set: ts, te, sc (float), st (int: 0 dropped, 1 done, 2 undone),
 // src (int: row in the clip-major candidate space) for up to `cap` candidates.
+// BIG = false: the working set lives in LDS (`cap` = lds_cap rows); a video with more rows than that is left to the
+//              BIG launch when one follows (`defer_big`), i.e. this workgroup returns at once.
+// BIG = true : the working set lives in a caller-provided global scratch sized for every row of the video (five
+//              arrays of total_clips*K*A words; (v,k) owns rows [(clip_start[v]*K + k*clips_v)*A, +clips_v*A)), so a
+//              video of any length is handled (the reference's host loop has no limit either, test.py:165-200); only
+//              the videos the LDS launch deferred are processed.  All traffic stays inside one workgroup, whose
+//              barriers order its own global stores and loads.
+template <bool BIG>
 __global__ __launch_bounds__(NMS_THREADS) void softnms_classes_kernel(
         const float* __restrict__ seg, const float* __restrict__ score, const float* __restrict__ unct,
         const float* __restrict__ actn, const unsigned char* __restrict__ flag, const int* __restrict__ clip_start,
-        float* __restrict__ out, int* __restrict__ counts, int* __restrict__ out_index, int A, int K, int cap,
-        float sigma, int top_k, float thr, int out_cols) {
+        float* __restrict__ out, int* __restrict__ counts, int* __restrict__ out_index, int A, int K, int lds_cap,
+        float sigma, int top_k, float thr, int out_cols, float* __restrict__ scratch, long long scratch_rows, int defer_big) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ts = reinterpret_cast<float*>(smem);
-    float* te = ts + cap;
-    float* sc = te + cap;
-    int* st = reinterpret_cast<int*>(sc + cap);
-    int* src = st + cap;
     __shared__ Best red[NMS_THREADS / 64];
     __shared__ int s_n, s_scan[NMS_THREADS / 64 + 1];
     const int v = blockIdx.x / K, k = blockIdx.x % K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = clip_start[v], c1 = clip_start[v + 1];
     const int total = (c1 - c0) * A;          // rows of this video in clip-major order
+    if (BIG ? total <= lds_cap : (defer_big && total > lds_cap)) return;
+    const int cap = BIG ? total : lds_cap;
+    float* ts; float* te; float* sc; int* st; int* src;
+    if constexpr (BIG) {
+        const long long o = ((long long)c0 * K + (long long)k * (c1 - c0)) * A;
+        ts = scratch + o;
+        te = scratch + scratch_rows + o;
+        sc = scratch + 2 * scratch_rows + o;
+        st = reinterpret_cast<int*>(scratch + 3 * scratch_rows + o);
+        src = reinterpret_cast<int*>(scratch + 4 * scratch_rows + o);
+    } else {
+        ts = reinterpret_cast<float*>(smem);
+        te = ts + cap;
+        sc = te + cap;
+        st = reinterpret_cast<int*>(sc + cap);
+        src = st + cap;
+    }
     // ---- gather flagged candidates in index order (block scan over chunks of NMS_THREADS rows)
     if (tid == 0) s_n = 0;
     __syncthreads();
@@ -219,23 +239,49 @@ extern "C" int otal_decode_clips(const float* loc, const float* prop_loc, const 
     return otal_launch_status();
 }
 
+constexpr size_t NMS_LDS_LIMIT = 150 * 1024;      // working set of ~7600 candidates; beyond that the scratch path runs
+
+extern "C" size_t otal_softnms_scratch_bytes(int total_clips, int max_clips, int A, int K) {
+    if (total_clips <= 0 || max_clips <= 0 || A <= 0 || K <= 0) return 0;
+    if ((size_t)max_clips * A * 20 <= NMS_LDS_LIMIT) return 0;
+    return (size_t)total_clips * K * A * 20;
+}
+
+extern "C" int otal_softnms_classes_ws(const float* seg, const float* score, const float* unct, const float* actn,
+                                       const unsigned char* flag, const int* clip_start, int nvideos, int max_clips,
+                                       int A, int K, float sigma, int top_k, float score_threshold, float* out,
+                                       int* counts, int* out_index, int out_cols, void* scratch, size_t scratch_bytes,
+                                       int total_clips, void* stream) {
+    if (!seg || !score || !unct || !actn || !flag || !clip_start || !out || !counts) return OTAL_E_NULL;
+    if (nvideos <= 0 || max_clips <= 0 || A <= 0 || K <= 0 || top_k <= 0 || out_cols < 3 || out_cols > 5)
+        return OTAL_E_SHAPE;
+    const size_t need = otal_softnms_scratch_bytes(total_clips, max_clips, A, K);
+    const bool big = need != 0;
+    if (big && (!scratch || scratch_bytes < need)) return OTAL_E_UNSUPPORTED;   // longest video exceeds LDS: scratch required
+    const int lds_cap = big ? (int)(NMS_LDS_LIMIT / 20) : max_clips * A;
+    const size_t lds = (size_t)lds_cap * 20;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(softnms_classes_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long long rows = (long long)total_clips * K * A;
+    hipLaunchKernelGGL(softnms_classes_kernel<false>, dim3(nvideos * K), dim3(NMS_THREADS), lds, (hipStream_t)stream, seg,
+                       score, unct, actn, flag, clip_start, out, counts, out_index, A, K, lds_cap, sigma, top_k, score_threshold,
+                       out_cols, (float*)nullptr, 0LL, big ? 1 : 0);
+    if (big)
+        hipLaunchKernelGGL(softnms_classes_kernel<true>, dim3(nvideos * K), dim3(NMS_THREADS), 0, (hipStream_t)stream, seg,
+                           score, unct, actn, flag, clip_start, out, counts, out_index, A, K, lds_cap, sigma, top_k,
+                           score_threshold, out_cols, (float*)scratch, rows, 1);
+    return otal_launch_status();
+}
+
 extern "C" int otal_softnms_classes(const float* seg, const float* score, const float* unct, const float* actn,
                                     const unsigned char* flag, const int* clip_start, int nvideos, int max_clips,
                                     int A, int K, float sigma, int top_k, float score_threshold, float* out,
                                     int* counts, int* out_index, int out_cols, void* stream) {
-    if (!seg || !score || !unct || !actn || !flag || !clip_start || !out || !counts) return OTAL_E_NULL;
-    if (nvideos <= 0 || max_clips <= 0 || A <= 0 || K <= 0 || top_k <= 0 || out_cols < 3 || out_cols > 5)
-        return OTAL_E_SHAPE;
-    const int cap = max_clips * A;
-    const size_t lds = (size_t)cap * 20;
-    if (lds > 150 * 1024) return OTAL_E_UNSUPPORTED;      // > ~7600 candidates per (video, class)
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(softnms_classes_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(softnms_classes_kernel, dim3(nvideos * K), dim3(NMS_THREADS), lds, (hipStream_t)stream, seg,
-                       score, unct, actn, flag, clip_start, out, counts, out_index, A, K, cap, sigma, top_k, score_threshold,
-                       out_cols);
-    return otal_launch_status();
+    // no scratch: every video must fit the LDS working set (OTAL_E_UNSUPPORTED otherwise; use otal_softnms_classes_ws)
+    return otal_softnms_classes_ws(seg, score, unct, actn, flag, clip_start, nvideos, max_clips, A, K, sigma, top_k,
+                                   score_threshold, out, counts, out_index, out_cols, nullptr, 0,
+                                   (size_t)max_clips * A * 20 <= NMS_LDS_LIMIT ? 1 : max_clips, stream);
 }

@@ -663,7 +663,7 @@ static inline int strided_k33_kind(const PoolGeom& g, const void* x, const void*
     if (!(g.kh == 3 && g.kw == 3 && g.sh == 2 && g.sw == 2 && g.pt == 0 && g.ph == 0 && g.pw == 0 && g.Hi % 2 == 0 &&
           g.Wi % 4 == 0 && g.Ho == g.Hi / 2 && g.Wo == g.Wi / 2 && g.x_bs % 4 == 0 && g.x_cs % 4 == 0 && g.y_bs % 2 == 0 &&
           g.y_cs % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0) ||
-        getenv("OTAL_POOL_NO133"))
+        OTAL_OPT("OTAL_POOL_NO133", 0))
         return 0;
     if (g.kt == 1 && g.st == 1 && g.To == g.Ti) return 1;
     if (g.kt == 3 && g.st == 2 && g.Ti % 2 == 0 && g.To == g.Ti / 2) return 3;
@@ -690,7 +690,7 @@ int fwd_planes(const PoolGeom& g, size_t& lds) {
 }
 // input planes per block (backward) + the largest number of output planes a block stages
 int bwd_planes(const PoolGeom& g, int& tlo_max, size_t& lds) {
-    static const int tile_elems = getenv("OTAL_POOL_TILE_G") ? atoi(getenv("OTAL_POOL_TILE_G")) : 4096;
+    const int tile_elems = OTAL_OPT("OTAL_POOL_TILE_G", 4096);
     int ti = tile_elems / (g.Hi * g.Wi);
     if (ti < 1) ti = 1;
     if (ti > g.Ti) ti = g.Ti;
@@ -730,8 +730,8 @@ static int pool_fwd(const int* geom, const int64_t* strides, const float* x, flo
         else hipLaunchKernelGGL(maxpoolk33_s2_fwd_kernel<3>, grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
         return otal_launch_status();
     }
-    if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
-        static const int tile_elems = getenv("OTAL_POOL_TILE") ? atoi(getenv("OTAL_POOL_TILE")) : 1152;
+    if (is_333_s1(g) && !OTAL_OPT("OTAL_POOL_NOLDS", 0)) {
+        const int tile_elems = OTAL_OPT("OTAL_POOL_TILE", 1152);
         const int P = g.Hi, Q = P + 2;
         int tt = tile_elems / (P * P);
         tt = tt < 1 ? 1 : (tt > g.To ? g.To : tt);
@@ -748,7 +748,7 @@ static int pool_fwd(const int* geom, const int64_t* strides, const float* x, flo
     // staging pays when the taps overlap (stride 1: every input is read kvol times); the strided pools read each input
     // ~2 times and were measured faster with direct loads (r01: 230 vs 514 us for the 1x3x3 / (1,2,2) pool)
     const bool overlap = g.st == 1 && g.sh == 1 && g.sw == 1;
-    const int tt = (getenv("OTAL_POOL_NOLDS") || !overlap) ? 0 : fwd_planes(g, lds);
+    const int tt = (OTAL_OPT("OTAL_POOL_NOLDS", 0) || !overlap) ? 0 : fwd_planes(g, lds);
     if (tt > 0) {
         const dim3 grid((g.To + tt - 1) / tt, g.B * g.C);
         OTAL_POOL_DISPATCH(maxpool3d_fwd_lds_kernel, grid, lds, x, y, argtap, g, tt);
@@ -777,7 +777,7 @@ static int pool_bwd(const int* geom, const int64_t* strides, const float* dy, co
         else hipLaunchKernelGGL(maxpoolk33_s2_bwd_kernel<3>, grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
         return otal_launch_status();
     }
-    if (is_333_s1(g) && !getenv("OTAL_POOL_NOLDS")) {
+    if (is_333_s1(g) && !OTAL_OPT("OTAL_POOL_NOLDS", 0)) {
         const int PP = g.Hi * g.Wi, ti = POOL_SEP_ELEMS / PP;
         const size_t l3 = (size_t)((ti + 2) * PP + 2 * ti * PP) * sizeof(float) + (size_t)(ti + 2) * PP;
         const dim3 grid((g.Ti + ti - 1) / ti, g.B * g.C);
@@ -793,7 +793,7 @@ static int pool_bwd(const int* geom, const int64_t* strides, const float* dy, co
     }
     size_t lds = 0;
     int tlo_max = 0;
-    const int ti = getenv("OTAL_POOL_NOLDS") ? 0 : bwd_planes(g, tlo_max, lds);
+    const int ti = OTAL_OPT("OTAL_POOL_NOLDS", 0) ? 0 : bwd_planes(g, tlo_max, lds);
     if (ti > 0) {
         const dim3 grid((g.Ti + ti - 1) / ti, g.B * g.C);
         OTAL_POOL_DISPATCH(maxpool3d_bwd_lds_kernel, grid, lds, dy, argtap, dx, g, accumulate, out_mask, out_scale, ti, tlo_max);

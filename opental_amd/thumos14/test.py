@@ -117,10 +117,15 @@ def softnms_classes(dec, clip_start, top_k=5000, sigma=0.5, score_threshold=0.00
     out = torch.zeros((V, K, tk, 5), device=dev)
     counts = torch.zeros((V, K), dtype=torch.int32, device=dev)
     index = torch.zeros((V, K, tk), dtype=torch.int32, device=dev)
-    L.check(L.lib().otal_softnms_classes(L.ptr(dec['seg']), L.ptr(dec['score']), L.ptr(dec['unct']),
-                                         L.ptr(dec['actn']), L.ptr(dec['flag']), L.ptr(cs), V, max_clips, A, K,
-                                         ctypes.c_float(sigma), tk, ctypes.c_float(score_threshold), L.ptr(out),
-                                         L.ptr(counts), L.ptr(index), 5, L.stream()), "otal_softnms_classes")
+    lib = L.lib()
+    lib.otal_softnms_scratch_bytes.restype = ctypes.c_size_t
+    nbytes = int(lib.otal_softnms_scratch_bytes(int(n), int(max_clips), int(A), int(K)))   # > 0: a video exceeds the LDS working set
+    scratch = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    L.check(lib.otal_softnms_classes_ws(L.ptr(dec['seg']), L.ptr(dec['score']), L.ptr(dec['unct']),
+                                        L.ptr(dec['actn']), L.ptr(dec['flag']), L.ptr(cs), V, max_clips, A, K,
+                                        ctypes.c_float(sigma), tk, ctypes.c_float(score_threshold), L.ptr(out),
+                                        L.ptr(counts), L.ptr(index), 5, L.ptr(scratch), ctypes.c_size_t(nbytes), int(n),
+                                        L.stream()), "otal_softnms_classes_ws")
     return out, counts, index
 
 

@@ -150,3 +150,43 @@ def test_no_candidate_passes_the_threshold():
     dec["flag"] = torch.zeros_like(flag)
     rows, counts, _ = T.softnms_classes(dec, [0, 2, 4, 6], top_k=5000, sigma=0.5)
     assert int(counts.sum()) == 0 and float(rows.abs().max()) == 0.0
+
+
+def test_long_video_runs_from_the_global_working_set():
+    """A video with more windows than the LDS working set holds (> ~7600 rows: 60 THUMOS14 windows) -- the reference's
+    host loop has no length limit (test.py:165-200) -- next to short ones in the same batch: the long video's problems
+    run from the global scratch, the short ones from LDS; both must equal the C oracle's per-class Soft-NMS."""
+    from opental_amd.thumos14 import test as T
+    from opental_amd.common.segment_utils import softnms_v2
+    rs = np.random.RandomState(11)
+    A, K = 126, 3
+    clips_per_video = [2, 70, 5]                # 70 windows x 126 anchors = 8820 rows
+    clip_start = np.concatenate([[0], np.cumsum(clips_per_video)]).tolist()
+    n = clip_start[-1]
+    centres = rs.uniform(5, 900, size=(n, 6))
+    c = centres[np.arange(n)[:, None], rs.randint(0, 6, size=(n, A))] + rs.normal(0, 2.0, size=(n, A))
+    w = np.abs(rs.normal(6, 3, size=(n, A))) + 0.5
+    seg = np.stack([c - w / 2, c + w / 2], -1).astype(np.float32)
+    score = rs.beta(0.5, 2.0, size=(n, K, A)).astype(np.float32)
+    unct = rs.uniform(0, 1, size=(n, A)).astype(np.float32)
+    actn = rs.uniform(0.3, 1, size=(n, A)).astype(np.float32)
+    flag = ((score > 0.05) & (actn[:, None, :] > 0.4)).astype(np.uint8)
+    dec = {k: torch.from_numpy(v).cuda() for k, v in dict(seg=seg, score=score, unct=unct, actn=actn, flag=flag).items()}
+    rows, counts, index = T.softnms_classes(dec, clip_start, top_k=5000, sigma=0.5)
+    for v in range(3):
+        for k in range(K):
+            sel = []
+            for cidx in range(clip_start[v], clip_start[v + 1]):
+                m = flag[cidx, k].astype(bool)
+                sel.append(np.concatenate([seg[cidx][m], score[cidx, k][m, None], unct[cidx][m, None], actn[cidx][m, None]], -1))
+            cand = torch.from_numpy(np.concatenate(sel, 0))
+            r_ref, c_ref, m_ref = O.softnms_v2_c(cand)
+            assert int(counts[v, k]) == c_ref, (v, k)
+            np.testing.assert_allclose(rows[v, k, :c_ref].cpu().numpy(), r_ref.numpy(), rtol=2e-6, atol=1e-7)
+    # softnms_v2 itself past the LDS limit: 9000 candidates in one call
+    big = torch.from_numpy(np.concatenate([seg.reshape(-1, 2)[:9000], score[:, 0].reshape(-1, 1)[:9000],
+                                           unct.reshape(-1, 1)[:9000], actn.reshape(-1, 1)[:9000]], -1).astype(np.float32))
+    r_ref, c_ref, m_ref = O.softnms_v2_c(big, top_k=5000)
+    r, cnt, m = softnms_v2(big.cuda(), sigma=0.5, top_k=5000, score_threshold=0.001, use_edl=True, os_head=True, get_mask=True)
+    assert int(cnt) == c_ref and np.array_equal(m.cpu().numpy(), np.asarray(m_ref, dtype=bool))
+    np.testing.assert_allclose(r.cpu().numpy(), r_ref.numpy(), rtol=2e-6, atol=1e-7)

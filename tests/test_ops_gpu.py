@@ -6,6 +6,26 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+
+_SWITCHES = ("OTAL_POOL_NO133", "OTAL_CONV_NO1A", "OTAL_CONV_NOW1D")
+
+
+def _switch(monkeypatch, name, value):
+    """Flip a kernel-selection switch of the library (otal_set_option; reset by the fixture below)."""
+    from opental_amd import _lib as L
+    assert name in _SWITCHES
+    L.set_option(name, value)
+
+
+@pytest.fixture(autouse=True)
+def _switches_off_after_each_test():
+    yield
+    from opental_amd import _lib as L
+    if L._lib is not None:
+        for name in _SWITCHES:
+            L.set_option(name, 0)
+
+
 from oracle import afsd_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -377,9 +397,9 @@ def test_strided_pool_fast_path_equals_generic_kernels(shape, k, s, monkeypatch)
     x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).clamp(min=0).cuda()        # zeros tie with the padding
     x[0, 0, 0] = -1.0                                                                   # a plane where the zero padding wins
     y1, a1 = ops.maxpool3d_forward(x, k, s)
-    monkeypatch.setenv("OTAL_POOL_NO133", "1")
+    _switch(monkeypatch, "OTAL_POOL_NO133", 1)
     y0, a0 = ops.maxpool3d_forward(x, k, s)
-    monkeypatch.delenv("OTAL_POOL_NO133")
+    _switch(monkeypatch, "OTAL_POOL_NO133", 0)
     assert torch.equal(y0, y1) and torch.equal(a0, a1)
     dy = torch.from_numpy(rs.randn(*y0.shape).astype(np.float32)).cuda()
     sc = torch.from_numpy(rs.uniform(0.5, 1.5, shape[1]).astype(np.float32)).cuda()
@@ -387,9 +407,9 @@ def test_strided_pool_fast_path_equals_generic_kernels(shape, k, s, monkeypatch)
     outs = []
     for generic in (True, False):
         if generic:
-            monkeypatch.setenv("OTAL_POOL_NO133", "1")
+            _switch(monkeypatch, "OTAL_POOL_NO133", 1)
         else:
-            monkeypatch.delenv("OTAL_POOL_NO133", raising=False)
+            _switch(monkeypatch, "OTAL_POOL_NO133", 0)
         buf = big.clone()
         xm = torch.zeros_like(big)
         xm[:, 4:] = x                                   # the mask source shares dx's (sliced) layout, as in the backbone
@@ -423,9 +443,9 @@ def test_conv1a_direct_kernel_matches_the_gather_kernel(shape, cout, monkeypatch
     sh = torch.from_numpy(rs.uniform(-0.3, 0.3, cout).astype(np.float32)).cuda()
     monkeypatch.setattr(ops, "CONV_PRECISION", 1)
     y1 = ops.conv_forward(x, w, k, s, scale=sc, shift=sh, relu=True)
-    monkeypatch.setenv("OTAL_CONV_NO1A", "1")
+    _switch(monkeypatch, "OTAL_CONV_NO1A", 1)
     y0 = ops.conv_forward(x, w, k, s, scale=sc, shift=sh, relu=True)
-    monkeypatch.delenv("OTAL_CONV_NO1A")
+    _switch(monkeypatch, "OTAL_CONV_NO1A", 0)
     assert float((y1 - y0).abs().max()) <= 2e-5 * float(y0.abs().max())
     xr, wr = x.to(torch.bfloat16).float().cpu(), w.to(torch.bfloat16).float().cpu()
     ref = F.conv3d(F.pad(xr, [2, 3, 2, 3, 2, 3]), wr, stride=2) * sc.cpu().view(1, -1, 1, 1, 1) + sh.cpu().view(1, -1, 1, 1, 1)
@@ -511,9 +531,9 @@ def test_wgrad_1d_kernel_matches_torch(B, Cin, Cout, T, k, lev, monkeypatch):
     dy = torch.from_numpy(rs.randn(B, Cout, T).astype(np.float32))
     monkeypatch.setattr(ops, "CONV_PRECISION", 1)
     got = ops.conv_wgrad(x.cuda(), dy.cuda(), (Cout, Cin, k), k, 1, levels=lev)
-    monkeypatch.setenv("OTAL_CONV_NOW1D", "1")
+    _switch(monkeypatch, "OTAL_CONV_NOW1D", 1)
     old = ops.conv_wgrad(x.cuda(), dy.cuda(), (Cout, Cin, k), k, 1, levels=lev)
-    monkeypatch.delenv("OTAL_CONV_NOW1D")
+    _switch(monkeypatch, "OTAL_CONV_NOW1D", 0)
     xr, dr = x.to(torch.bfloat16).float(), dy.to(torch.bfloat16).float()
     w = torch.zeros(Cout, Cin, k, requires_grad=True)
     bounds = lev if lev is not None else [0, T]
