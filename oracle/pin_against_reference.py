@@ -21,7 +21,9 @@ import sys
 import types
 
 sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"       # child processes too (joblib workers of the evaluation code)
 REF = "/root/reference"
+ARGV = list(sys.argv[1:])         # our own flags (sys.argv is replaced before the reference's config module is imported)
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(REPO, "tests", "golden")
 
@@ -118,7 +120,10 @@ def main():
                 return seed, m
         raise RuntimeError("no seed with a safe rounding margin")
 
-    for batch, first, need in ((1, 11, 6e-4), (2, 500, 4e-4)):
+    only = [int(a.split("=")[1]) for a in ARGV if a.startswith("--batch=")]     # e.g. --batch=4: just that fixture
+    for batch, first, need in ((1, 11, 6e-4), (2, 500, 4e-4), (4, 900, 3e-4)):
+        if only and batch not in only:
+            continue
         tag = f"thumos_b{batch}"
         clip_seed, m0 = pick_clip_seed(batch, first, need)
         report.append(f"{tag}: clip seed {clip_seed} (rounding margin {m0:.2e})")
@@ -283,6 +288,14 @@ def main():
                       f"({names[int(fx['grad32dist_correct'].argmax())]})")
         np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **fx)
         report.append(f"{tag}: wrote tests/golden/{tag}.npz")
+
+    if only:            # a single model fixture was requested: keep the other files, append to the report
+        with open(os.path.join(GOLD, "PIN_REPORT.txt"), "a") as f:
+            f.write("\n".join(report[1:]) + "\n")
+        print("\n".join(report))
+        leftovers = [os.path.join(d, n) for d, _, fs in os.walk(REF) for n in fs if n.endswith(".pyc")]
+        assert not leftovers, leftovers
+        return
 
     # ---- 6. Soft-NMS parity + fixtures
     rs = np.random.RandomState(5)

@@ -13,6 +13,7 @@ import sys
 import types
 
 sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"       # child processes too (joblib workers of the evaluation code)
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 GOLD = os.path.join(REPO, "tests", "golden")

@@ -1,6 +1,8 @@
-"""GPU: the single-launch HIP detection loss (csrc/loss.hip) against this package's torch
-formulation of the same reference code (which is pinned to the reference through tests/golden): the seven loss
-values, every gradient and the IBM EMA state, for batches with and without positives, before and after ibm_start."""
+"""GPU: the single-launch HIP detection loss (csrc/loss.hip) against the CPU ORACLE
+(oracle/afsd_oracle.py multisegment_loss -- the restatement pinned to the imported reference, tests/golden) and
+against this package's torch formulation of the same reference code: the seven loss values, every gradient and the
+IBM EMA state, for batches up to the benchmark's b = 8, ragged target counts, batches without positives, before and
+after ibm_start."""
 import numpy as np
 import pytest
 import torch
@@ -63,3 +65,40 @@ def test_fused_loss_matches_torch_formulation(B, n_gt, epoch):
         scale = float(g0[k].abs().max())
         assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * max(scale, 1e-6), (k, scale)
         assert scale > 0 or (n_gt == "between" and k not in ('act', 'prop_act'))   # only actionness sees the negatives
+
+
+
+@pytest.mark.parametrize("B,n_gt,epoch", [(1, 2, 0), (2, 3, 12), (8, 2, 12), (8, [1, 3, 2, 1, 4, 2, 3, 1], 12), (8, 3, 0),
+                                          (4, [1, 5, 2, 3], 12), (2, "between", 0), (2, "between", 12), (8, "between", 12)])
+def test_hip_loss_matches_cpu_oracle(B, n_gt, epoch):
+    """The HIP kernel against oracle.multisegment_loss + torch-CPU autograd on the same seeded inputs: 7 losses, the
+    gradient of the weighted cost w.r.t. every head output, and the IBM EMA bins after the step."""
+    from oracle import afsd_oracle as O
+    from opental_amd.thumos14 import multisegment_loss as M
+    dev = torch.device("cuda", 0)
+    w = [1.0, 10.0, 1.0, 10.0, 1.0, 1.0, 1.0]
+    assert M.FUSED
+    crit = M.MultiSegmentLoss(15, 0.5, 1.0, cls_loss_type='edl', edl_config=EDL, os_head=True, act_config=ACT).to(dev)
+    crit.cls_loss.epoch = epoch
+    crit.cls_loss.weight_accum.copy_(torch.linspace(0.5, 1.5, 50))
+    out, targets = _inputs(B, 7 + B, n_gt, dev)
+    losses = crit(out, targets)
+    assert 'DetectionLossFunction' in type(losses[0].grad_fn).__name__
+    sum(l * wi for l, wi in zip(losses, w)).backward()
+    # the oracle on the CPU copies of the same tensors
+    cpu = {k: (v.detach().cpu().clone().requires_grad_(v.requires_grad)) for k, v in out.items()}
+    st = O.EvidenceState()
+    st.epoch = epoch
+    st.weight_accum = torch.linspace(0.5, 1.5, 50)
+    ref = O.multisegment_loss(cpu, [t.cpu() for t in targets], state=st)
+    sum(l * wi for l, wi in zip(ref, w)).backward()
+    got = [float(l.detach()) for l in losses]
+    want = [float(l.detach()) for l in ref]
+    assert np.allclose(got, want, rtol=3e-5, atol=2e-6), (got, want)
+    assert torch.allclose(crit.cls_loss.weight_accum.cpu(), st.weight_accum, rtol=2e-5, atol=1e-7)
+    for k, v in out.items():
+        if not v.requires_grad:
+            continue
+        g_ref = cpu[k].grad if cpu[k].grad is not None else torch.zeros_like(cpu[k])
+        scale = float(g_ref.abs().max())
+        assert float((v.grad.cpu() - g_ref).abs().max()) <= 3e-5 * max(scale, 1e-6) + 1e-9, (k, scale)

@@ -38,7 +38,7 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-6))
 
 
-@pytest.fixture(scope="module", params=[1, 2])
+@pytest.fixture(scope="module", params=[1, 2, 4])
 def run(request, golden_dir):
     b = request.param
     fx = np.load(os.path.join(golden_dir, f"thumos_b{b}.npz"))

@@ -39,8 +39,11 @@ def main():
     tot = sum(e[1] for e in agg.values())
     print(f"step {t0.elapsed_time(t1):.2f} ms, conv {tot:.2f} ms, {len(rows)} launches")
     print("mode   n   ms     TF/s   B Cin Cout  Ti Hi Wi -> To Ho Wo  k  s")
-    for (mode, g), e in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+    for (mode, g), e in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('OTAL_TOP', '60'))]:
         print(f"{mode:6s}{e[0]:3d} {e[1]:7.3f} {e[2]/e[1]/1e9:7.1f}  {g[0]} {g[1]:4d} {g[2]:4d}  {g[3]:3d} {g[4]:2d} {g[5]:2d} -> {g[6]:3d} {g[7]:2d} {g[8]:2d}  {g[9]}{g[10]}{g[11]} {g[12]}{g[13]}{g[14]}")
+    for name, sel in (("1-D pyramid / heads (H=W=1 outputs)", lambda g: g[7] == 1 and g[8] == 1), ("3-D backbone", lambda g: not (g[7] == 1 and g[8] == 1))):
+        t = sum(e[1] for (m, g), e in agg.items() if sel(g)); f = sum(e[2] for (m, g), e in agg.items() if sel(g)); n = sum(e[0] for (m, g), e in agg.items() if sel(g))
+        print(f"{name}: {n} launches, {t:.2f} ms, {f/t/1e9:.1f} TF/s")
     for mode in ("fwd", "dgrad", "wgrad"):
         t = sum(e[1] for (m, _), e in agg.items() if m == mode); f = sum(e[2] for (m, _), e in agg.items() if m == mode)
         print(mode, f"{t:.2f} ms {f/t/1e9:.1f} TF/s")
