@@ -507,8 +507,9 @@ class DetectorTrainer:
                                        'exp_avg': self.arena.m[off:off + k].view(p.shape).clone(),
                                        'exp_avg_sq': self.arena.v[off:off + k].view(p.shape).clone()}
         groups, first = [], 0
+        rate = (self.lr / self._base_lr) if self._base_lr else 1.0      # a scheduler moves self.lr; the groups follow
         for ps, g_lr in self.param_groups:
-            groups.append({'lr': g_lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.wd,
+            groups.append({'lr': g_lr * rate, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.wd,
                            'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False,
                            'differentiable': False, 'fused': None, 'params': list(range(first, first + len(ps)))})
             first += len(ps)
