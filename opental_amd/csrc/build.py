@@ -33,7 +33,7 @@ def build(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
-    headers = glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(REPO, "include", "*.h"))
+    headers = glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(HERE, "*.inc")) + glob.glob(os.path.join(REPO, "include", "*.h"))
     objs, procs = [], []
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")

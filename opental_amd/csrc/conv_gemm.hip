@@ -2322,9 +2322,15 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     return otal_launch_status();
 }
 
+#include "conv_wgrad_direct.inc"
+
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if constexpr (MODE == MODE_WGRAD) {
+        if (wgrad_direct_eligible(a.g, a.prec, a.x, a.dy)) {
+            const int e = launch_wgrad_direct(a, ws, ws_bytes, st);
+            if (e != OTAL_E_UNSUPPORTED) return e;          // slabs do not fit: the vector kernel below
+        }
         if (wgrad_pair_mode(a.g, a.prec)) return launch_wgrad_vector(a, 8, ws, ws_bytes, st);
         if (const int cw = wgrad_vector_width(a.g, a.prec)) return launch_wgrad_vector(a, cw, ws, ws_bytes, st);
         if (wgrad1d_eligible(a.g, a.prec, a.x, a.dy)) {

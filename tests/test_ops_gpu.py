@@ -542,3 +542,47 @@ def test_wgrad_1d_kernel_matches_torch(B, Cin, Cout, T, k, lev, monkeypatch):
         F.conv1d(xr[:, :, lo:hi], w, padding=k // 2).backward(dr[:, :, lo:hi])
     close(got, w.grad, tol=2e-5)
     close(got, old, tol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout,slices", [((1, 64, 4, 24, 24), 192, False), ((2, 96, 3, 12, 12), 128, False),
+                                               ((1, 64, 2, 24, 24), 208, True),      # Cout not a multiple of the 64-row tile
+                                               ((2, 80, 5, 12, 12), 64, True),       # Cin not a multiple of the 32-channel block
+                                               ((3, 128, 8, 12, 12), 192, False)])
+def test_direct_wgrad_3x3x3_matches_reference_and_vector_kernel(shape, cout, slices):
+    """conv3_wgrad_direct_kernel (LDS-staged receptive field, transposed LDS reads; csrc/conv_wgrad_direct.inc) on the
+    backbone's 24x24 / 12x12 layer shapes: equal to an fp32 convolution's weight gradient on the bf16-ROUNDED operands
+    (1e-4 of scale), equal to the vector kernel it replaces (same products, other summation order), with x / dy taken as
+    channel slices of larger buffers (Inception concat layout), several samples / planes (zero borders in t and h), and
+    split-K over the positions."""
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    rs = np.random.RandomState(abs(hash(str((shape, cout)))) % 10000)
+    B, Cin, T, H, W = shape
+    xb = torch.from_numpy(rs.randn(B, Cin + (8 if slices else 0), T, H, W).astype(np.float32)).cuda()
+    dyb = torch.from_numpy(rs.randn(B, cout + (16 if slices else 0), T, H, W).astype(np.float32)).cuda()
+    x = xb[:, 4:4 + Cin] if slices else xb
+    dy = dyb[:, 8:8 + cout] if slices else dyb
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        L.set_option("OTAL_CONV_NOWDIRECT", 0)
+        dw = ops.conv_wgrad(x, dy, (cout, Cin, 3, 3, 3), (3, 3, 3), (1, 1, 1))
+        L.set_option("OTAL_WDIRECT_BLOCKS", 3)                 # few workgroups: long split-K ranges crossing samples
+        dw_few = ops.conv_wgrad(x, dy, (cout, Cin, 3, 3, 3), (3, 3, 3), (1, 1, 1))
+        L.set_option("OTAL_WDIRECT_BLOCKS", 0)
+        L.set_option("OTAL_CONV_NOWDIRECT", 1)
+        dw_vec = ops.conv_wgrad(x, dy, (cout, Cin, 3, 3, 3), (3, 3, 3), (1, 1, 1))
+    finally:
+        L.set_option("OTAL_CONV_NOWDIRECT", 0)
+        L.set_option("OTAL_WDIRECT_BLOCKS", 0)
+        ops.CONV_PRECISION = old
+    xr = _bf16_round(x.cpu()).contiguous()
+    dr = _bf16_round(dy.cpu()).contiguous()
+    w = torch.zeros(cout, Cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(xr, w, padding=1).backward(dr)
+    close(dw, w.grad)
+    close(dw_few, w.grad)
+    close(dw_vec, w.grad)
+    scale = float(w.grad.abs().max())
+    assert float((dw - dw_vec).abs().max()) <= 2e-5 * scale
