@@ -268,14 +268,18 @@ int otal_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, 
  * losses: 7 floats {loc, conf, prop_loc, prop_conf (+IoU calibration), center, act, prop_act}, normalised as the
  * reference's forward.  grads (otal_detection_loss_grad_floats): d loss_i / d input of the term that owns it, in the
  * order dloc[loc term], dloc[center term], dprop_loc[prop_loc term], dprop_loc[center term] (each (B,K,2)),
- * dconf, dprop_conf ((B,K,C)), dcenter, dact, dprop_act ((B,K)).  scratch: otal_detection_loss_scratch_floats. */
+ * dconf, dprop_conf ((B,K,C)), dcenter, dact, dprop_act ((B,K)).  scratch: otal_detection_loss_scratch_floats.
+ * cls_mode 1 = the as-shipped THUMOS14 dispatch (AFSD/thumos14/train.py:27-31 overwrites cls_loss_type 'edl' with
+ * 'focal'): the two classification terms are FocalLoss_Ori(balance_index 0, alpha = focal_alpha, gamma 2,
+ * size_average False) on the softmax scores of the positive rows (cls_loss.py:6-78); no IBM, no IoU calibration. */
 size_t otal_detection_loss_scratch_floats(int B, int K);
 size_t otal_detection_loss_grad_floats(int B, int K, int C);
 int otal_detection_loss(const float* loc, const float* conf, const float* prop_loc, const float* prop_conf,
                         const float* center, const float* act, const float* prop_act, const float* priors,
                         const float* gt, const unsigned char* gvalid, float* weight_accum, int B, int K, int C, int G,
                         float clip_length, float overlap_thresh, int ibm_active, int num_bins, float momentum,
-                        int iou_aware, float* losses, float* grads, float* scratch, void* stream);
+                        int iou_aware, int cls_mode, float focal_alpha, float* losses, float* grads, float* scratch,
+                        void* stream);
 
 /* Clip preparation on the device: uint8 frames (T',Hs,Ws,3) -> normalised fp32 batch (B,3,T,Ho,Wo).
  * Replaces AFSD/common/thumos_dataset.py:136-137,:246-262 and videotransforms.py:44-124 (temporal zero padding,

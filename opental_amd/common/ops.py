@@ -526,7 +526,7 @@ class DetectionLossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, loc, conf, prop_loc, prop_conf, center, act, prop_act, priors, gt, gvalid, weight_accum,
-                clip_length, overlap, ibm_active, num_bins, momentum, iou_aware):
+                clip_length, overlap, ibm_active, num_bins, momentum, iou_aware, cls_mode=0, focal_alpha=0.25):
         B, K, C = conf.shape
         G = gt.shape[1]
         tens = [t.contiguous().float() for t in (loc, conf, prop_loc, prop_conf, center, act, prop_act, priors, gt)]
@@ -542,8 +542,9 @@ class DetectionLossFunction(torch.autograd.Function):
         scratch = torch.empty(ns, dtype=torch.float32, device=loc.device)
         L.check(lib.otal_detection_loss(*[L.ptr(t) for t in tens], L.ptr(gv), L.ptr(weight_accum), B, K, C, G,
                                         ctypes.c_float(clip_length), ctypes.c_float(overlap), int(ibm_active),
-                                        int(num_bins), ctypes.c_float(momentum), int(iou_aware), L.ptr(losses),
-                                        L.ptr(grads), L.ptr(scratch), L.stream()), "otal_detection_loss")
+                                        int(num_bins), ctypes.c_float(momentum), int(iou_aware), int(cls_mode),
+                                        ctypes.c_float(focal_alpha), L.ptr(losses), L.ptr(grads), L.ptr(scratch), L.stream()),
+                "otal_detection_loss")
         ctx.save_for_backward(grads)
         ctx.dims = (B, K, C)
         return tuple(losses[i] for i in range(7))
@@ -564,7 +565,7 @@ class DetectionLossFunction(torch.autograd.Function):
         dconf, dpconf = take(A * C, (B, K, C)), take(A * C, (B, K, C))
         dcen, dact, dpact = take(A, (B, K)), take(A, (B, K)), take(A, (B, K))
         return (dloc_l * g_l + dloc_ct * g_ct, dconf * g_c, dpl_pl * g_pl + dpl_ct * g_ct, dpconf * g_pc,
-                dcen * g_ct, dact * g_a, dpact * g_pa) + (None,) * 10
+                dcen * g_ct, dact * g_a, dpact * g_pa) + (None,) * 12
 
 
 # ----------------------------------------------------------------------------- head output tails

@@ -13,8 +13,10 @@
 // intermediates in a global scratch area, reductions in a fixed order (deterministic, unlike index_add_).
 // Latency-bound by construction (SURVEY 8d puts the losses under "launch latency"); the win is 400 launches -> 1.
 //
-// Supported configuration = the final recipe: evidence 'exp', loss_type 'log', os_head, size_average False,
-// actionness rank-term weight 0.  Everything else stays on the torch formulation (thumos14/multisegment_loss.py).
+// Supported configurations: the final recipe -- evidence 'exp', loss_type 'log', os_head, size_average False, actionness
+// rank-term weight 0 -- and, with cls_mode = 1, the as-shipped THUMOS14 dispatch (train.py:27-31 overwrites 'edl' with
+// 'focal'): FocalLoss_Ori(balance_index 0, alpha 0.25, gamma 2) on softmax scores (cls_loss.py:6-78) instead
+// of the evidential terms (no IBM, no IoU calibration).  Everything else stays on the torch formulation.
 #include "common.h"
 
 namespace {
@@ -37,6 +39,8 @@ struct LossArgs {
     float clip, overlap;
     int ibm_active, num_bins, iou_aware;
     float momentum;
+    int cls_mode;                   // 0: EvidenceLoss (the OpenTAL recipe); 1: FocalLoss_Ori on softmax scores (as-shipped THUMOS14 dispatch)
+    float focal_alpha;              // FocalLoss_Ori(balance_index=0, alpha): alpha for class 0, 1 - alpha for the others
 };
 constexpr int SCR = 12;             // loc_t0, loc_t1, conf_t, prop_conf_t, iou, prop_loc_t0, prop_loc_t1, ghat, slot, binpos, per, used
 
@@ -161,6 +165,38 @@ __global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
         const float* logits = pass == 0 ? a.conf : a.prop_conf;
         float* gout = pass == 0 ? g_conf : g_pconf;
         const float norm = pass == 0 ? Nf : PNf;
+        if (a.cls_mode == 1) {
+            // FocalLoss_Ori(gamma 2, size_average False) on F.softmax(logits) of the positive rows (cls_loss.py:6-78,
+            // multisegment_loss.py:196-216): loss = -alpha_y (1 - pt)^2 log(pt), pt = p_y + 1e-6
+            float part = 0.f;
+            for (int i = t; i < A; i += LT) {
+                const float* s = a.scratch + (size_t)i * SCR;
+                const int tgt = (int)s[2 + pass];
+                const float* z = logits + (size_t)i * C;
+                float* gz = gout + (size_t)i * C;
+                if (tgt > 0) {
+                    const int y = tgt - 1;
+                    float mx = z[0];
+                    for (int k = 1; k < C; ++k) mx = fmaxf(mx, z[k]);
+                    float S = 0.f;
+                    for (int k = 0; k < C; ++k) S += expf(z[k] - mx);
+                    const float py = expf(z[y] - mx) / S;
+                    const float pt = py + 1e-6f;
+                    const float al = y == 0 ? a.focal_alpha : 1.f - a.focal_alpha;
+                    const float om = 1.f - pt, lg = logf(pt);
+                    part += -(om * om) * (al * lg);
+                    const float dpt = -al * (-2.f * om * lg + om * om / pt);       // d loss / d pt
+                    for (int k = 0; k < C; ++k) {
+                        const float pk = expf(z[k] - mx) / S;
+                        gz[k] = dpt * py * ((k == y ? 1.f : 0.f) - pk) / norm;
+                    }
+                } else {
+                    for (int k = 0; k < C; ++k) gz[k] = 0.f;
+                }
+            }
+            loss_cls[pass] = block_sum(part, red) / norm;
+            continue;
+        }
         for (int i = t; i < A; i += LT) {
             float* s = a.scratch + (size_t)i * SCR;
             const int tgt = (int)s[2 + pass];
@@ -378,18 +414,19 @@ extern "C" int otal_detection_loss(const float* loc, const float* conf, const fl
                                    const float* center, const float* act, const float* prop_act, const float* priors,
                                    const float* gt, const unsigned char* gvalid, float* weight_accum, int B, int K,
                                    int C, int G, float clip_length, float overlap_thresh, int ibm_active, int num_bins,
-                                   float momentum, int iou_aware, float* losses, float* grads, float* scratch,
-                                   void* stream) {
+                                   float momentum, int iou_aware, int cls_mode, float focal_alpha, float* losses,
+                                   float* grads, float* scratch, void* stream) {
     if (!loc || !conf || !prop_loc || !prop_conf || !center || !act || !prop_act || !priors || !gt || !gvalid ||
         !weight_accum || !losses || !grads || !scratch) return OTAL_E_NULL;
     if (B <= 0 || K <= 0 || C <= 0 || G <= 0) return OTAL_E_SHAPE;
-    if (num_bins <= 0 || num_bins > MAX_BINS || (long)B * K > MAX_A) return OTAL_E_UNSUPPORTED;
+    if (num_bins <= 0 || num_bins > MAX_BINS || (long)B * K > MAX_A || cls_mode < 0 || cls_mode > 1) return OTAL_E_UNSUPPORTED;
     LossArgs a;
     a.loc = loc; a.conf = conf; a.prop_loc = prop_loc; a.prop_conf = prop_conf; a.center = center; a.act = act;
     a.prop_act = prop_act; a.priors = priors; a.gt = gt; a.gvalid = gvalid; a.weight_accum = weight_accum;
     a.losses = losses; a.grads = grads; a.scratch = scratch;
     a.B = B; a.K = K; a.C = C; a.G = G; a.clip = clip_length; a.overlap = overlap_thresh;
-    a.ibm_active = ibm_active; a.num_bins = num_bins; a.iou_aware = iou_aware; a.momentum = momentum;
+    a.ibm_active = cls_mode == 0 ? ibm_active : 0; a.num_bins = num_bins; a.iou_aware = cls_mode == 0 ? iou_aware : 0;
+    a.momentum = momentum; a.cls_mode = cls_mode; a.focal_alpha = focal_alpha;
     hipLaunchKernelGGL(detection_loss_kernel, dim3(1), dim3(LT), 0, (hipStream_t)stream, a);
     return otal_launch_status();
 }

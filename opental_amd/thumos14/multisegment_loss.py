@@ -68,8 +68,13 @@ class MultiSegmentLoss(nn.Module):
         self.use_gpu = use_gpu
         self.cls_loss_type = cls_loss_type
         self.clip_length = clip_length      # config['dataset']['training']['clip_length'] (:110)
+        self._focal_alpha0 = None
         if cls_loss_type == 'focal':
             self.cls_loss = FocalLoss_Ori(num_classes, balance_index=0, size_average=size_average, alpha=0.25)
+            al = self.cls_loss.alpha            # still on the host here: decide once whether the HIP kernel's form applies
+            if (self.cls_loss.gamma == 2 and al.numel() >= 2 and bool((al[1:] == al[1]).all())
+                    and abs(float(al[0]) + float(al[1]) - 1.0) < 1e-6):
+                self._focal_alpha0 = float(al[0])
         elif cls_loss_type == 'edl':
             self.cls_loss = EvidenceLoss(num_classes, edl_config, size_average=size_average)
         else:
@@ -108,10 +113,12 @@ class MultiSegmentLoss(nn.Module):
     def _fused_ok(self, loc):
         """The single-launch HIP loss (csrc/loss.hip) covers the final recipe; other settings use the torch formulation."""
         cl = self.cls_loss
-        return (FUSED and loc.is_cuda and loc.dtype == torch.float32 and loc.shape[0] * loc.shape[1] <= 2048
-                and self.cls_loss_type == 'edl' and self.os_head
-                and not self.size_average and cl.loss_type == 'log' and cl.evidence == 'exp' and cl.num_bins <= 64
-                and self.act_loss.weight == 0 and not self.act_loss.size_average and not cl.size_average)
+        common = (FUSED and loc.is_cuda and loc.dtype == torch.float32 and loc.shape[0] * loc.shape[1] <= 2048
+                  and self.os_head and not self.size_average and self.act_loss.weight == 0
+                  and not self.act_loss.size_average and not cl.size_average)
+        if self.cls_loss_type == 'focal':       # the as-shipped THUMOS14 dispatch (train.py:27-31, SURVEY H2)
+            return common and self._focal_alpha0 is not None
+        return (common and self.cls_loss_type == 'edl' and cl.loss_type == 'log' and cl.evidence == 'exp' and cl.num_bins <= 64)
 
     def forward(self, output_dict, targets, pre_locs=None):
         loc, conf = output_dict['loc'], output_dict['conf']
@@ -124,6 +131,13 @@ class MultiSegmentLoss(nn.Module):
             from ..common.ops import DetectionLossFunction
             gt, valid = pad_targets(targets, loc.device) if isinstance(targets, (list, tuple)) else targets
             cl = self.cls_loss
+            if self.cls_loss_type == 'focal':
+                if getattr(self, '_no_ibm', None) is None or self._no_ibm.device != loc.device:
+                    self._no_ibm = torch.ones(1, dtype=torch.float32, device=loc.device)    # unused EMA slot of the ABI
+                return DetectionLossFunction.apply(
+                    loc, conf, prop_loc, prop_conf, center.reshape(B, K), act.reshape(B, K), prop_act.reshape(B, K),
+                    priors[:, 0], gt, valid, self._no_ibm, float(self.clip_length), float(self.overlap_thresh),
+                    False, 1, 0.0, False, 1, self._focal_alpha0)
             return DetectionLossFunction.apply(
                 loc, conf, prop_loc, prop_conf, center.reshape(B, K), act.reshape(B, K), prop_act.reshape(B, K),
                 priors[:, 0], gt, valid, cl.weight_accum, float(self.clip_length), float(self.overlap_thresh),

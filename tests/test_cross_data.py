@@ -105,3 +105,87 @@ def test_prepare_windows_is_bit_identical_to_prepare_clip():
         T.prepare_windows(videos, [(0, 300)], 256)               # offset past the end
     with pytest.raises(RuntimeError):
         T.prepare_windows([videos[0].float()], [(0, 0)], 256)    # not uint8
+
+
+# ----------------------------------------------------------------------------- pinned against the reference's own drivers
+# tests/golden/cross_data.npz is written by oracle/pin_cross_data.py, which runs the REFERENCE's test_anet /
+# exclude_overlapping / thresholding end to end with a stand-in detector (oracle/fake_heads.FakeNet) on seeded videos.
+IDX_TO_CLASS = {i + 1: f"class_{i:02d}" for i in range(15)}
+SCORINGS = ("uncertainty", "confidence", "uncertainty_actionness", "a_by_inv_u", "u_by_inv_a", "half_au")
+
+
+def _props_from_fixture(fx, key):
+    cls, rows = fx[key + "_class"], fx[key + "_rows"]
+    return [{'label': IDX_TO_CLASS[int(c)], 'segment': [float(r[0]), float(r[1])], 'score': float(r[2]),
+             'uncertainty': float(r[3]), 'actionness': float(r[4])} for c, r in zip(cls, rows)]
+
+
+def test_host_logic_matches_the_reference_fixture(golden_dir):
+    """CPU: get_offsets (test_cross_data.py:49-56), the six OOD thresholds of threshold.py:128-150 recomputed from the
+    reference's own detections, exclude_overlapping (:333-352) and the merge of its __main__ (:433-435)."""
+    import os
+    from oracle import fake_heads as FH
+    from opental_amd.thumos14 import test as T, test_cross_data as X
+    fx = np.load(os.path.join(golden_dir, "cross_data.npz"))
+    for n in (100, 256, 300, 384, 640, 700):
+        assert T.get_offsets(n, 256, 128) == fx[f"offsets_{n}"].tolist()
+    train = {name: _props_from_fixture(fx, "train_" + name) for name, _, _, _ in FH.THUMOS_TRAIN}
+    assert sum(len(v) for v in train.values()) > 1000
+    for sc in SCORINGS:
+        assert abs(T.ood_threshold(train, sc) - float(fx[f"threshold_{sc}"])) < 1e-12, sc
+    infos = {name: {'annotations': [{'label': l} for l in labels]} for name, _, _, _, _, labels in FH.ANET_VIDEOS}
+    anet = T.results_json({name[2:]: [] for name, *_ in FH.ANET_VIDEOS})
+    kept = X.exclude_overlapping(anet, infos, [c + "\n" for c in FH.OVERLAPPING])
+    assert sorted(kept['results']) == fx["anet_kept_keys"].tolist()
+    merged = X.merge_results(T.results_json({"video_test_0000004": [], "bbb222": [{"label": "old"}]}), kept)
+    assert sorted(merged['results']) == fx["merged_keys"].tolist()
+
+
+def _check_props(got, cls, rows, what):
+    assert len(got) == len(cls), (what, len(got), len(cls))
+    names = {v: k for k, v in IDX_TO_CLASS.items()}
+    assert [names[p['label']] for p in got] == cls.tolist(), what
+    mine = np.array([[p['segment'][0], p['segment'][1], p['score'], p['uncertainty'], p['actionness']] for p in got]).reshape(-1, 5)
+    np.testing.assert_allclose(mine, rows, rtol=3e-6, atol=2e-6, err_msg=what)
+
+
+@pytest.mark.gpu
+def test_cross_dataset_driver_matches_the_reference_run(golden_dir):
+    """GPU: X.test_anet (batched windows -> otal_decode_clips -> otal_softnms_classes -> duration clipping) on the seeded
+    videos and stand-in detector of the pin script must reproduce the proposal lists the REFERENCE's test_anet wrote
+    (same detections, same order, values to fp32 exp tolerance), video by video, including the videos whose duration
+    cuts segments and the one shorter than a window."""
+    import os
+    from oracle import fake_heads as FH
+    from opental_amd.thumos14 import test_cross_data as X
+    fx = np.load(os.path.join(golden_dir, "cross_data.npz"))
+    videos, infos = {}, {}
+    for name, seed, frames, fps, duration, labels in FH.ANET_VIDEOS:
+        videos[name] = torch.from_numpy(np.transpose(FH.synthetic_video(seed, frames), [3, 0, 1, 2]).copy()).cuda()
+        infos[name] = {'fps': fps, 'duration': duration, 'frame_num': frames, 'annotations': [{'label': l} for l in labels]}
+    for batch_clips, batch_videos in ((32, 8), (1, 1), (3, 2)):
+        out = X.test_anet(FH.FakeNet(), videos, infos, IDX_TO_CLASS, clip_length=256, stride=128, conf_thresh=0.01, top_k=5000,
+                          nms_sigma=0.5, batch_clips=batch_clips, batch_videos=batch_videos)
+        assert sorted(out['results']) == fx["anet_result_keys"].tolist()
+        for name in out['results']:
+            _check_props(out['results'][name], fx[f"anet_{name}_class"], fx[f"anet_{name}_rows"], name)
+            assert all(p['segment'][1] <= infos['v_' + name]['duration'] for p in out['results'][name])
+
+
+@pytest.mark.gpu
+def test_threshold_step_matches_the_reference_run(golden_dir):
+    """GPU: the threshold step (threshold.py:71-150) = the inference path over the TRAINING videos + ood_threshold: the
+    detections equal the reference run's, and so do the six operating points."""
+    import os
+    from oracle import fake_heads as FH
+    from opental_amd.thumos14 import test as T
+    fx = np.load(os.path.join(golden_dir, "cross_data.npz"))
+    vids = [torch.from_numpy(np.transpose(FH.synthetic_video(seed, frames), [3, 0, 1, 2]).copy()).cuda()
+            for _, seed, frames, _ in FH.THUMOS_TRAIN]
+    rows, counts, _, _ = T.detect_batch(FH.FakeNet(), vids, [fps for *_, fps in FH.THUMOS_TRAIN], 256, 128, 0.01, 5000, 0.5)
+    result = {}
+    for v, (name, *_rest) in enumerate(FH.THUMOS_TRAIN):
+        result[name] = T.get_video_detections(rows[v], counts[v], IDX_TO_CLASS, 5000)
+        _check_props(result[name], fx[f"train_{name}_class"], fx[f"train_{name}_rows"], name)
+    for sc in SCORINGS:
+        assert abs(T.ood_threshold(result, sc) - float(fx[f"threshold_{sc}"])) < 5e-6, sc

@@ -102,3 +102,41 @@ def test_hip_loss_matches_cpu_oracle(B, n_gt, epoch):
         g_ref = cpu[k].grad if cpu[k].grad is not None else torch.zeros_like(cpu[k])
         scale = float(g_ref.abs().max())
         assert float((v.grad.cpu() - g_ref).abs().max()) <= 3e-5 * max(scale, 1e-6) + 1e-9, (k, scale)
+
+
+
+@pytest.mark.parametrize("B,n_gt", [(1, 2), (8, [1, 3, 2, 1, 4, 2, 3, 1]), (2, "between")])
+def test_hip_focal_dispatch_matches_cpu_oracle(B, n_gt):
+    """The as-shipped THUMOS14 dispatch (AFSD/thumos14/train.py:27-31 overwrites cls_loss_type 'edl' with 'focal', SURVEY
+    H2): FocalLoss_Ori on softmax scores runs inside the same single-launch HIP kernel (cls_mode 1) and must equal
+    oracle.multisegment_loss(cls_loss_type='focal') -- pinned to the imported reference (tests/golden loss_focal0) --
+    in the seven losses and in every gradient."""
+    from oracle import afsd_oracle as O
+    from opental_amd.thumos14 import multisegment_loss as M
+    dev = torch.device("cuda", 0)
+    w = [1.0, 10.0, 1.0, 10.0, 1.0, 1.0, 1.0]
+    crit = M.MultiSegmentLoss(15, 0.5, 1.0, cls_loss_type='focal', edl_config=EDL, os_head=True, act_config=ACT).to(dev)
+    out, targets = _inputs(B, 17 + B, n_gt, dev)
+    losses = crit(out, targets)
+    assert 'DetectionLossFunction' in type(losses[0].grad_fn).__name__
+    sum(l * wi for l, wi in zip(losses, w)).backward()
+    cpu = {k: (v.detach().cpu().clone().requires_grad_(v.requires_grad)) for k, v in out.items()}
+    ref = O.multisegment_loss(cpu, [t.cpu() for t in targets], cls_loss_type="focal")
+    sum(l * wi for l, wi in zip(ref, w)).backward()
+    got = [float(l.detach()) for l in losses]
+    want = [float(l.detach()) for l in ref]
+    assert np.allclose(got, want, rtol=3e-5, atol=2e-6), (got, want)
+    for k, v in out.items():
+        if not v.requires_grad:
+            continue
+        g_ref = cpu[k].grad if cpu[k].grad is not None else torch.zeros_like(cpu[k])
+        scale = float(g_ref.abs().max())
+        assert float((v.grad.cpu() - g_ref).abs().max()) <= 3e-5 * max(scale, 1e-6) + 1e-9, (k, scale)
+    # and the package's own torch formulation (the path used for settings the kernel does not cover) agrees as well
+    M.FUSED = False
+    try:
+        out2, targets2 = _inputs(B, 17 + B, n_gt, dev)
+        l2 = crit(out2, targets2)
+        assert np.allclose([float(v.detach()) for v in l2], got, rtol=3e-5, atol=2e-6)
+    finally:
+        M.FUSED = True
