@@ -288,6 +288,12 @@ int otal_detection_loss(const float* loc, const float* conf, const float* prop_l
  * = 24 bytes each (8-byte aligned); the random decisions are taken on the host exactly as the reference takes them. */
 int otal_prepare_clips(const unsigned char* frames, const void* params, float* out, int B, int T, int Hs, int Ws,
                        int Ho, int Wo, void* stream);
+/* The same, plus the self-supervised branch's SPLICED clips from the same upload: out_ssl[b,:,t] = clip b's frame
+ * frame_map[b*T + t] (frames >= valid_t, or a negative entry, are the zero padding).  Replaces THUMOS_Dataset.augment_
+ * (AFSD/common/thumos_dataset.py:187-228: two time segments of the normalised clip change places), whose decisions stay
+ * on the host.  `out` or `out_ssl` may be null (not both); frame_map is required with out_ssl. */
+int otal_prepare_clips_map(const unsigned char* frames, const void* params, const int* frame_map, float* out,
+                           float* out_ssl, int B, int T, int Hs, int Ws, int Ho, int Wo, void* stream);
 
 /* Sliding windows of the inference path: B windows cut out of planar uint8 videos (C,Tv,H,W) resident on the device
  * -> normalised fp32 batch (B,C,T,H,W) in one pass.  Replaces AFSD/thumos14/test.py:67-76 prepare_clip per window

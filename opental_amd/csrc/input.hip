@@ -47,6 +47,44 @@ __global__ __launch_bounds__(256) void prepare_clips_kernel(const unsigned char*
     }
 }
 
+// The same preparation with an optional FRAME MAP per clip: output frame t is source frame map[t] of the (padded) clip.
+// The self-supervised branch's spliced clip (thumos_dataset.py:187-228 `augment_`: two time segments of the normalised clip
+// swap places) is exactly that, so one launch writes the plain batch and -- from the same uint8 upload and the same crop /
+// flip decisions -- the ssl batch; the reference clones and slices a 28 MB fp32 clip per sample on the host.
+__global__ __launch_bounds__(256) void prepare_clips_map_kernel(const unsigned char* __restrict__ frames,
+                                                                const ClipParams* __restrict__ params,
+                                                                const int* __restrict__ fmap, float* __restrict__ out,
+                                                                float* __restrict__ out_ssl, int T, int Hs, int Ws, int Ho, int Wo) {
+    const int b = blockIdx.y;
+    const ClipParams p = params[b];
+    const int plane = Ho * Wo;
+    const long long vol = (long long)T * plane;
+    for (int pass = 0; pass < 2; ++pass) {
+        float* dst = pass == 0 ? out : out_ssl;
+        if (!dst) continue;
+        float* ob = dst + (long long)b * 3 * vol;
+        for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < vol; idx += (long long)gridDim.x * 256) {
+            const int t = (int)(idx / plane);
+            const int r = (int)(idx - (long long)t * plane);
+            const int y = r / Wo, x = r - y * Wo;
+            const int ts = (pass == 1 && fmap) ? fmap[b * T + t] : t;
+            float v0, v1, v2;
+            if (ts >= 0 && ts < p.valid_t) {
+                const int xs = p.crop_j + (p.flip ? Wo - 1 - x : x);
+                const unsigned char* px = frames + p.frame0 + (((long long)ts * Hs + (p.crop_i + y)) * Ws + xs) * 3;
+                v0 = ((float)px[0] / 255.0f) * 2.0f - 1.0f;
+                v1 = ((float)px[1] / 255.0f) * 2.0f - 1.0f;
+                v2 = ((float)px[2] / 255.0f) * 2.0f - 1.0f;
+            } else {
+                v0 = v1 = v2 = (0.0f / 255.0f) * 2.0f - 1.0f;
+            }
+            ob[idx] = v0;
+            ob[vol + idx] = v1;
+            ob[2 * vol + idx] = v2;
+        }
+    }
+}
+
 struct WindowParams {    // one per inference window, device array (16 bytes)
     unsigned long long src;  // device address of frame `offset` of channel 0 of the window's video (planar uint8 (C,Tv,H,W))
     int chan_stride4;        // Tv * H * W / 4: distance between the channels of that video, in 4-byte words
@@ -104,5 +142,18 @@ extern "C" int otal_prepare_clips(const unsigned char* frames, const void* param
     const int bx = (int)((vol + 255) / 256 < 4096 ? (vol + 255) / 256 : 4096);
     hipLaunchKernelGGL(prepare_clips_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, frames,
                        static_cast<const ClipParams*>(params), out, T, Hs, Ws, Ho, Wo);
+    return otal_launch_status();
+}
+
+extern "C" int otal_prepare_clips_map(const unsigned char* frames, const void* params, const int* frame_map, float* out,
+                                      float* out_ssl, int B, int T, int Hs, int Ws, int Ho, int Wo, void* stream) {
+    if (!frames || !params || (!out && !out_ssl)) return OTAL_E_NULL;
+    if (out_ssl && !frame_map) return OTAL_E_NULL;
+    if (B <= 0 || T <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0 || Ho > Hs || Wo > Ws) return OTAL_E_SHAPE;
+    if (B > 65535) return OTAL_E_UNSUPPORTED;
+    const long long vol = (long long)T * Ho * Wo;
+    const int bx = (int)((vol + 255) / 256 < 4096 ? (vol + 255) / 256 : 4096);
+    hipLaunchKernelGGL(prepare_clips_map_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, frames,
+                       static_cast<const ClipParams*>(params), frame_map, out, out_ssl, T, Hs, Ws, Ho, Wo);
     return otal_launch_status();
 }

@@ -204,3 +204,94 @@ def ood_threshold(result_dict, scoring='uncertainty'):
     if n == 0:
         raise ValueError("no detections to threshold")
     return float(np.sort(all_scores)[n - int(n * 0.95) - 1])
+
+
+# ----------------------------------------------------------------------------- the inference driver (test.py:203-288)
+def prepare_data(data_path, video_name, crop_size, device='cuda'):
+    """test.py:59-64: <video>.npy uint8 (T,H,W,3) -> centre-cropped planar (3,T,crop,crop) uint8 on the device."""
+    import os
+    import numpy as np
+    data = np.load(os.path.join(data_path, video_name + '.npy'))
+    data = np.transpose(data, [3, 0, 1, 2])
+    h, w = data.shape[2:]
+    i, j = int(np.round((h - crop_size) / 2.)), int(np.round((w - crop_size) / 2.))
+    return torch.from_numpy(np.ascontiguousarray(data[:, :, i:i + crop_size, j:j + crop_size])).to(device)
+
+
+def fuse_outputs(rgb_out, flow_out):
+    """Two-stream fusion by averaging the two networks' RAW outputs before decoding (test.py:90-108)."""
+    keys = ('loc', 'conf', 'prop_loc', 'prop_conf', 'center', 'act', 'prop_act')
+    fused = {k: (rgb_out[k] + flow_out[k]) / 2.0 for k in keys if rgb_out.get(k) is not None}
+    fused['priors'] = rgb_out['priors']
+    return fused
+
+
+def test(net, video_infos, npy_data_path, idx_to_class=None, clip_length=256, stride=128, crop_size=96, conf_thresh=0.01,
+         top_k=5000, nms_sigma=0.5, batch_clips=32, batch_videos=8, rank=0, world=1, device='cuda'):
+    """The loop of test.py:203-252 over a video list, batched: `batch_videos` videos' windows go through the network
+    together and ONE decode + ONE Soft-NMS launch serve all of them.  Ranks take every world-th video (no collective)."""
+    names = list(video_infos.keys())[rank::world]
+    result_dict = {}
+    for i in range(0, len(names), batch_videos):
+        part = names[i:i + batch_videos]
+        vids = [prepare_data(npy_data_path, n, crop_size, device) for n in part]
+        rows, counts, _, _ = detect_batch(net, vids, [float(video_infos[n]['sample_fps']) for n in part], clip_length, stride,
+                                          conf_thresh, top_k, nms_sigma, batch_clips)
+        for v, n in enumerate(part):
+            result_dict[n] = get_video_detections(rows[v], counts[v], idx_to_class, top_k)
+    return result_dict
+
+
+def main(argv=None):
+    """python -m opental_amd.thumos14.test <yaml> --open_set --split 0 [--random_init] [--evaluate GT.json KNOWN.txt]
+
+    The reference's test driver (AFSD/thumos14/test.py:203-288): config -> model + checkpoint -> sliding windows over
+    every test video -> result JSON at <output_path>/<output_json>; `--evaluate` then runs the open-set evaluation of
+    opental_amd.thumos14.eval_open on it."""
+    import json
+    import os
+    import sys
+    from ..common import config as C
+    from ..common import ops
+    from ..common.thumos_dataset import get_class_index_map, get_video_info
+    from .BDNet import BDNet, model_cfg_from
+    argv = list(sys.argv[1:] if argv is None else argv)
+    random_init, evaluate, rest, i = False, None, [], 0
+    while i < len(argv):
+        if argv[i] == '--random_init':
+            random_init = True
+        elif argv[i] == '--evaluate':
+            evaluate = (argv[i + 1], argv[i + 2]); i += 2
+        else:
+            rest.append(argv[i])
+        i += 1
+    config = C.set_config(C.get_config(rest))
+    te, md, ds = config['testing'], config['model'], config['dataset']['testing']
+    if te.get('fusion', False):
+        raise NotImplementedError("two-stream runs: build both nets and pass fuse_outputs(rgb(x), flow(y)) to decode_clips")
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    torch.cuda.set_device(dev)
+    ops.CONV_PRECISION = 1 if os.environ.get('OTAL_DTYPE', 'bf16') == 'bf16' else 0
+    net = BDNet(in_channels=md['in_channels'], training=False, use_edl=md.get('use_edl', False), cfg=model_cfg_from(config))
+    if not random_init:
+        net.load_state_dict(torch.load(te['checkpoint_path'], map_location='cpu'))
+    net = net.to(dev).eval()
+    video_infos = get_video_info(config['dataset']['testing']['video_info_path'])
+    _, idx_to_class = get_class_index_map(config['dataset']['class_info_path'])
+    results = test(net, video_infos, ds['video_data_path'], idx_to_class, ds['clip_length'], ds['clip_stride'], ds['crop_size'],
+                   te['conf_thresh'], te['top_k'], te['nms_sigma'], rank=rank, world=world, device=dev)
+    os.makedirs(te['output_path'], exist_ok=True)
+    out_file = os.path.join(te['output_path'], te['output_json'] if world == 1 else f"rank{rank}_" + te['output_json'])
+    with open(out_file, 'w') as f:
+        json.dump(results_json(results), f)
+    print(f"{len(results)} videos, {sum(len(v) for v in results.values())} detections -> {out_file}")
+    if evaluate is not None and world == 1:
+        from .eval_open import evaluate_split
+        return out_file, evaluate_split(out_file, evaluate[0], evaluate[1], [0.3, 0.4, 0.5, 0.6, 0.7], ['test'], True,
+                                        te.get('ood_scoring', 'confidence'))
+    return out_file, None
+
+
+if __name__ == '__main__':
+    main()

@@ -17,6 +17,7 @@ Loss-state policy under data parallelism: EvidenceLoss.weight_accum (50 floats) 
 across ranks after each step that updates it; the per-rank normalisers N / PN / AN stay
 per-rank, i.e. the optimised objective is the mean over ranks of per-rank losses.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -597,3 +598,155 @@ class DetectorTrainer:
     def grad_norm(self):
         """get_grad_norm (train.py:133-140), as a device tensor."""
         return self.arena.grad.norm(2)
+
+
+# ----------------------------------------------------------------------------- the training driver (train.py:204-363)
+def set_seed(seed):
+    """train.py:59-66 (the cudnn switches have no counterpart: every kernel here is deterministic by construction)."""
+    import random
+    import numpy as np
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def loss_dispatch(config, as_shipped=False):
+    """cls_loss_type of the run.  The reference derives it TWICE (train.py:27 then :31): 'edl' if edl_loss, and then
+    overwrites it with 'rpl' if rpl_loss else 'focal' -- so its shipped THUMOS14 recipe trains FocalLoss_Ori (SURVEY
+    H2).  Default here: what the config says (edl_loss -> 'edl', the OpenTAL method); `as_shipped=True` reproduces
+    the overwrite."""
+    tr = config['training']
+    if tr.get('rpl_loss', False):
+        raise NotImplementedError("RPL baseline is outside the OpenTAL hot path")
+    if as_shipped:
+        return 'focal'
+    return 'edl' if tr.get('edl_loss', False) else 'focal'
+
+
+def build_training(config, device, as_shipped=False, random_init=False, dist_group=None):
+    """Model, criterion and trainer from a parsed config (train.py:306-331)."""
+    from .BDNet import BDNet, model_cfg_from
+    from .multisegment_loss import MultiSegmentLoss
+    tr, md = config['training'], config['model']
+    use_edl = md.get('use_edl', False)
+    net = BDNet(in_channels=md['in_channels'], backbone_model=md.get('backbone_model'), training=not random_init,
+                use_edl=use_edl, use_rpl=md.get('use_rpl', False), cfg=model_cfg_from(config))
+    if random_init:                 # no pretrained I3D file (synthetic runs): the architecture's glorot initialisation
+        net.backbone._model.apply(BDNet.weight_init)
+    net = net.to(device).train()
+    os_head = md.get('os_head', False)
+    num_cls = config['dataset']['num_classes'] - 1 if os_head else config['dataset']['num_classes']
+    crit = MultiSegmentLoss(num_cls, tr['piou'], 1.0, cls_loss_type=loss_dispatch(config, as_shipped),
+                            edl_config=tr.get('edl_config'), os_head=os_head, act_config=tr.get('act_config'),
+                            clip_length=config['dataset']['training']['clip_length']).to(device)
+    weights = dict(lw=tr['lw'], cw=tr['cw'], ctw=tr['ctw'], actw=tr.get('actw', 1.0), ssl=tr['ssl'])
+    trainer = DetectorTrainer(net, crit, weights, lr=tr['learning_rate'], weight_decay=tr['weight_decay'],
+                              process_group=dist_group)
+    return net, crit, trainer
+
+
+def run_one_epoch(epoch, trainer, dataset, stager, batch_size, rank=0, world=1, max_steps=None, log=print):
+    """One pass over the shuffled sliding-window list (train.py:204-303).  Every rank draws the same permutation and
+    the same per-sample decisions (shared seeds) and takes every world-th batch.  Nothing in the loop synchronises with
+    the host: the loss sums stay on the device until the epoch's log line."""
+    from ..common import thumos_dataset as D
+    dev = trainer.arena.flat.device
+    sums, n_iter = None, 0
+    it = D.batches(dataset, batch_size)
+    mine = [b for k, b in enumerate(it) if k % world == rank]
+    if max_steps is not None:
+        mine = mine[:max_steps]
+    if not mine:
+        return None
+    stager.submit(mine[0])
+    for k, samples in enumerate(mine):
+        use_ssl = bool(samples[0]['flag'])                 # `if flags[0]` (train.py:237)
+        clips, ssl_clips = stager.collect(want_ssl=use_ssl)
+        if k + 1 < len(mine):
+            stager.submit(mine[k + 1])                     # next batch crosses PCIe while this step runs
+        targets = [torch.from_numpy(s['target']).to(dev, non_blocking=True) for s in samples]
+        scores = torch.from_numpy(np.stack([s['scores'] for s in samples], 0)).to(dev, non_blocking=True)
+        ssl_targets = [torch.from_numpy(s['ssl_target'][:, :2].copy()).to(dev) for s in samples] if use_ssl else None
+        cost, losses = trainer.step(clips, targets, scores, ssl_clips if use_ssl else None, ssl_targets)
+        vec = torch.stack([cost.reshape(())] + [l.detach().reshape(()) for l in losses[:7]])
+        sums = vec if sums is None else sums + vec
+        n_iter += 1
+    v = (sums / n_iter).tolist()                           # the epoch's only host synchronisation
+    log('Epoch-{} Train Loss: Total - {:.5f}, loc - {:.5f}, conf - {:.5f}, prop_loc - {:.5f}, prop_conf - {:.5f}, '
+        'IoU - {:.5f}, start - {:.5f}, end - {:.5f}'.format(epoch, *v))
+    return v
+
+
+def main(argv=None):
+    """python -m opental_amd.thumos14.train <yaml> --lw 1 --cw 10 --piou 0.5 --ssl 0.001 --open_set --split 0 [--resume N]
+
+    The reference's command line (experiments/opental/train_opental_final.sh; AFSD/common/config.py:10-37) plus:
+      --as_shipped_dispatch   train FocalLoss_Ori as the reference's train.py:27-31 really does
+      --random_init           no pretrained I3D file (synthetic data)
+      --save_after N          save checkpoints for epochs > N (reference: 10, train.py:289)
+      --max_steps N           cap the steps per epoch (smoke runs)
+    One process per GPU; under torchrun the ranks all-reduce gradients over RCCL (DetectorTrainer)."""
+    import os
+    import sys
+    from ..common import config as C
+    from ..common import thumos_dataset as D
+    argv = list(sys.argv[1:] if argv is None else argv)
+    extra = {'as_shipped_dispatch': False, 'random_init': False, 'save_after': 10, 'max_steps': None}
+    rest, i = [], 0
+    while i < len(argv):
+        a = argv[i]
+        if a in ('--as_shipped_dispatch', '--random_init'):
+            extra[a[2:]] = True
+        elif a in ('--save_after', '--max_steps'):
+            extra[a[2:]] = int(argv[i + 1]); i += 1
+        else:
+            rest.append(a)
+        i += 1
+    config = C.set_config(C.get_config(rest))
+    tr = config['training']
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("opental_amd.thumos14.train needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=dev)
+    ops.CONV_PRECISION = 1 if os.environ.get('OTAL_DTYPE', 'bf16') == 'bf16' else 0
+    set_seed(tr['random_seed'])
+    net, crit, trainer = build_training(config, dev, extra['as_shipped_dispatch'], extra['random_init'])
+    ds_cfg = config['dataset']['training']
+    infos = D.get_video_info(ds_cfg['video_info_path'])
+    annos = D.get_video_anno(infos, ds_cfg['video_anno_path'], config['dataset']['class_info_path'])
+    data = D.load_video_data(infos, ds_cfg['video_data_path'])
+    dataset = D.THUMOS_Dataset(data, infos, annos, clip_length=ds_cfg['clip_length'], crop_size=ds_cfg['crop_size'],
+                               stride=ds_cfg['clip_stride'])
+    any_video = next(iter(data.values()))
+    stager = D.ClipStager(tr['batch_size'], ds_cfg['clip_length'], int(any_video.shape[1]), int(any_video.shape[2]),
+                          ds_cfg['crop_size'], device=dev)
+    checkpoint_path = tr['checkpoint_path']
+    train_state_path = os.path.join(checkpoint_path, 'training')
+    start_epoch = trainer.resume_training(tr['resume'], checkpoint_path, train_state_path)
+    if rank == 0:
+        print(f"batch size: {tr['batch_size']}  learning rate: {tr['learning_rate']}  weight decay: {tr['weight_decay']}  "
+              f"max epoch: {tr['max_epoch']}  cls loss: {crit.cls_loss_type}  clips: {len(dataset)}  ranks: {world}  resume: {tr['resume']}")
+    history = []
+    for epoch in range(start_epoch, tr['max_epoch'] + 1):
+        if crit.cls_loss_type == 'edl':
+            crit.cls_loss.epoch = epoch
+            crit.cls_loss.total_epoch = tr['max_epoch']
+        v = run_one_epoch(epoch, trainer, dataset, stager, tr['batch_size'], rank, world, extra['max_steps'],
+                          log=print if rank == 0 else (lambda *a: None))
+        history.append(v)
+        if epoch > extra['save_after'] and rank == 0:
+            trainer.save_model(epoch, checkpoint_path, train_state_path)
+    if world > 1:
+        dist.barrier()
+    return trainer, history
+
+
+if __name__ == '__main__':
+    main()
