@@ -243,8 +243,7 @@ class ClipStager:
                 pos += self.T * self.frame_bytes
             self.params_host[s].numpy()[:] = recs.view(np.uint8)
             self.params_dev[s].copy_(self.params_host[s], non_blocking=True)
-            if any_ssl:
-                self.maps_dev[s].copy_(self.maps_host[s], non_blocking=True)
+            self.maps_dev[s].copy_(self.maps_host[s], non_blocking=True)     # 1 KB per clip: always (collect may ask for ssl)
             self.ready[s].record(self.copy_stream)
         self.pending = (s, any_ssl)
         self.slot ^= 1

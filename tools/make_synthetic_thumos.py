@@ -29,10 +29,11 @@ def make(out, videos=2, frames=400, size=100, seed=0, test_videos=2):
         name = f"video_validation_{v:07d}"
         np.save(os.path.join(out, "train_npy", name + ".npy"), rs.randint(0, 256, (frames, size, size, 3)).astype(np.uint8))
         info.append(f"{name},30.0,10.0,{frames * 3},{frames}")
-        t = 20
-        while t + 80 < frames:                              # ~60-frame actions separated by long background
-            cid, cname = CLASSES[rs.randint(len(CLASSES))]
-            ln = int(rs.randint(50, 70))
+        t, k = 20, 0
+        while t + 80 < frames:                              # short (~14) and long (~64 frame) actions between long backgrounds:
+            cid, cname = CLASSES[rs.randint(len(CLASSES))]  # the ssl splice needs an action longer than twice the shortest one
+            ln = int(rs.randint(12, 16)) if k % 2 == 0 else int(rs.randint(58, 70))
+            k += 1
             anno.append(f"{name},{cname},{cid},{t / 10:.1f},{(t + ln) / 10:.1f},{t * 3},{(t + ln) * 3}")
             t += ln + int(rs.randint(60, 90))
     tinfo = ["video,fps,sample_fps,count,sample_count"]
