@@ -88,7 +88,18 @@ def build_trainer(device, seed=2020, force_collectives=False):
     return DetectorTrainer(net, crit, W, lr=1e-5, weight_decay=1e-3, force_collectives=force_collectives)
 
 
-def cpu_baseline(seconds_budget=20.0, threads=32):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seconds_budget=20.0, threads=32, batch=1):
     """The CPU oracle (oracle/afsd_oracle.py: the restatement pinned against the imported reference)
     doing the same training step -- forward, loss, backward, Adam -- at batch 1 on this box's host
     cores.  Bounded: the first step doubles as warm-up and is the sample if it alone exceeds the
@@ -101,9 +112,9 @@ def cpu_baseline(seconds_budget=20.0, threads=32):
     train = [k for k, v in P.items() if v.requires_grad]
     m = {k: torch.zeros_like(P[k]) for k in train}
     v = {k: torch.zeros_like(P[k]) for k in train}
-    x = torch.from_numpy(arch.make_clip(3, 1))
-    tg = [torch.from_numpy(t) for t in arch.make_targets(5, 1)]
-    sc = torch.from_numpy(arch.make_scores(arch.make_targets(5, 1)))
+    x = torch.from_numpy(arch.make_clip(3, batch))
+    tg = [torch.from_numpy(t) for t in arch.make_targets(5, batch)]
+    sc = torch.from_numpy(arch.make_scores(arch.make_targets(5, batch)))
     st = O.EvidenceState()
     st.epoch = 12
 
@@ -125,9 +136,170 @@ def cpu_baseline(seconds_budget=20.0, threads=32):
         spent += times[-1]
     dt = float(np.median(times)) if times else first
     what = f"median of {len(times)} steps after 1 warm-up" if times else "1 cold step (it alone exceeded the budget)"
-    return {"value": round(1.0 / dt, 5), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"full training step (fwd+loss+bwd+Adam) at batch 1, 256x3x96x96, fp32, {what}; "
+    return {"value": round(batch / dt, 5), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "batch": batch,
+            "sample": f"full training step (fwd+loss+bwd+Adam) at batch {batch}, 256x3x96x96, fp32, {what}; "
                       f"CPU oracle = torch-CPU restatement pinned to the reference; {dt:.2f} s/step"}
+
+
+def _timed_steps(trainer, batch, steps, warm, extra=()):
+    for _ in range(warm):
+        trainer.step(*batch, *extra)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.step(*batch, *extra)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def extras(device, batch):
+    """The other BASELINE.json configs, measured in the same run (short legs; N = 1 only): the exact-fp32 parity path,
+    the step with the ssl branch on every iteration, the ActivityNet recipe (configs[3]) at the yaml's batch, the
+    inference path over 213 synthetic videos (configs[4]) with Soft-NMS timed against the CPU C oracle, and the
+    pinned / double-buffered input pipeline."""
+    from opental_amd.common import ops
+    out = {}
+    saved = ops.CONV_PRECISION
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:                      # noqa: BLE001 -- an extra must never take the headline down
+            out[name] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    def fp32():
+        ops.CONV_PRECISION = 0
+        tr = build_trainer(device)
+        dt = _timed_steps(tr, synth_batch(batch, 1000, device), 5, 2)
+        return {"clips_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 2), "batch": batch,
+                "what": "the exact-fp32 path every 1e-4 parity test runs (v_mfma_f32_32x32x2_f32)"}
+
+    def ssl():
+        ops.CONV_PRECISION = 1
+        tr = build_trainer(device)
+        b = synth_batch(batch, 1000, device)
+        ssl_clips, _, _ = synth_batch(batch, 2000, device)
+        tg = [torch.tensor([[0.30, 0.55], [0.32, 0.52], [0.70, 0.90]], device=device) * 256 for _ in range(batch)]
+        dt = _timed_steps(tr, b, 8, 3, (ssl_clips, tg))
+        return {"clips_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 2), "batch": batch,
+                "what": "ssl / triplet branch on EVERY step (a second backbone pass; the reference runs it when flags[0])"}
+
+    def anet():
+        ops.CONV_PRECISION = 1
+        tr = build_anet_trainer(device)
+        b = synth_batch(2, 1000, device, frames=768, classes=150, score_rows=3)
+        dt = _timed_steps(tr, b, 6, 3)
+        return {"clips_per_s": round(2 / dt, 1), "ms_per_step": round(dt * 1e3, 2), "batch": 2,
+                "what": "BASELINE configs[3]: configs/anet_opental.yaml, 768-frame clips, 150 classes, per-GPU batch 2 (the yaml's)"}
+
+    def inference():
+        from opental_amd.thumos14 import test as T
+        from opental_amd.thumos14.BDNet import BDNet
+        ops.CONV_PRECISION = 1
+        torch.manual_seed(0)
+        net = BDNet(training=False, use_edl=True)
+        net.backbone._model.apply(BDNet.weight_init)
+        net = net.to(device).eval()
+        rs = np.random.RandomState(0)
+        nvid = 213                                  # THUMOS14 test videos with temporal annotations (SURVEY 8d)
+        frames = rs.randint(600, 4001, size=nvid)
+        g = torch.Generator(device=device).manual_seed(0)
+        nclips = sum(len(T.get_offsets(int(f), 256, 128)) for f in frames)
+        warm = [torch.randint(0, 256, (3, 700, 96, 96), device=device, generator=g, dtype=torch.uint8)]
+        T.detect_batch(net, warm, 10.0, batch_clips=32)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kept = 0
+        for i in range(0, nvid, 16):                # 16 videos' frames resident at a time (uint8, <= 1.8 GB)
+            vids = [torch.randint(0, 256, (3, int(f), 96, 96), device=device, generator=g, dtype=torch.uint8) for f in frames[i:i + 16]]
+            rows, counts, _, _ = T.detect_batch(net, vids, 10.0, batch_clips=32)
+            kept += int(counts.sum())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res = {"videos": nvid, "windows": nclips, "seconds": round(dt, 3), "proposals_per_s": round(126 * nclips / dt, 1),
+               "what": "BASELINE configs[4]: forward (bf16 operands) + decode + filter + Soft-NMS over 213 synthetic videos of "
+                       "600-4000 frames, 126 proposals per 256-frame window; includes generating the frames on the device"}
+        # Soft-NMS alone on head outputs with realistic overlap, against the CPU C oracle on a bounded sample
+        V, C, A, K = 213, 24, 126, 15
+        n = V * C
+        ctr = torch.rand(n, 12, device=device, generator=g) * 300
+        pick = torch.randint(0, 12, (n, A), device=device, generator=g)
+        c = torch.gather(ctr, 1, pick) + torch.randn(n, A, device=device, generator=g) * 3
+        w = torch.randn(n, A, device=device, generator=g).abs() * 4 + 6
+        sd = dict(seg=torch.stack([c - w / 2, c + w / 2], -1).contiguous(),
+                  score=torch.distributions.Beta(0.5, 2.0).sample((n, K, A)).to(device).contiguous(),
+                  unct=torch.rand(n, A, device=device, generator=g), actn=torch.rand(n, A, device=device, generator=g) * 0.6 + 0.4)
+        sd["flag"] = ((sd["score"] > 0.01) & (sd["actn"][:, None, :] > 0.5)).to(torch.uint8)
+        cs = list(range(0, n + 1, C))
+        T.softnms_classes(sd, cs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); T.softnms_classes(sd, cs); e1.record(); torch.cuda.synchronize()
+        cand = int(sd["flag"].sum())
+        res.update({"softnms_candidates": cand, "softnms_ms": round(e0.elapsed_time(e1), 3),
+                    "softnms_candidates_per_s": round(cand / e0.elapsed_time(e1) * 1e3, 1)})
+        from oracle import afsd_oracle as O
+        flag = sd["flag"][:8 * C].cpu().numpy().astype(bool); seg = sd["seg"][:8 * C].cpu().numpy(); sc = sd["score"][:8 * C].cpu().numpy()
+        t0 = time.perf_counter(); ncpu = 0
+        for v in range(8):
+            for k in range(K):
+                rows_ = [np.concatenate([seg[ci][flag[ci, k]], sc[ci, k][flag[ci, k], None]], -1) for ci in range(cs[v], cs[v + 1])]
+                cnd = torch.from_numpy(np.concatenate(rows_, 0))
+                ncpu += len(cnd); O.softnms_v2_c(cnd)
+        res["cpu_softnms_candidates_per_s"] = round(ncpu / (time.perf_counter() - t0), 1)
+        res["cpu_sample"] = f"{8 * K} (video, class) problems, C oracle (oracle/bmp_ref.c), 1 core"
+        return res
+
+    def input_pipeline():
+        from opental_amd.common import thumos_dataset as D
+        ops.CONV_PRECISION = 1
+        rs = np.random.RandomState(1)
+        vids = [torch.from_numpy(rs.randint(0, 256, (1200, 112, 112, 3)).astype(np.uint8)).pin_memory() for _ in range(4)]
+        st = D.ClipStager(batch, 256, 112, 112, 96, device=device)
+
+        def samples(k):
+            r = np.random.RandomState(k)
+            return [{"video": vids[int(r.randint(4))], "offset": int(r.randint(0, 900)), "frame_map": None,
+                     "crop": (int(r.randint(17)), int(r.randint(17)), bool(r.randint(2)))} for _ in range(batch)]
+        for k in range(3):
+            st.submit(samples(k)); st.collect()
+        torch.cuda.synchronize()
+        n = 30
+        t0 = time.perf_counter()
+        st.submit(samples(100))
+        for k in range(n):
+            clips, _ = st.collect()
+            st.submit(samples(101 + k))
+        st.collect()
+        torch.cuda.synchronize()
+        alone = batch * (n + 1) / (time.perf_counter() - t0)
+        tr = build_trainer(device)
+        b = synth_batch(batch, 1000, device)
+        for _ in range(3):
+            tr.step(*b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st.submit(samples(200))
+        for k in range(12):
+            clips, _ = st.collect()
+            st.submit(samples(201 + k))
+            tr.step(clips, b[1], b[2])              # the step consumes the staged batch while the next one crosses PCIe
+        st.collect()
+        torch.cuda.synchronize()
+        fed = batch * 12 / (time.perf_counter() - t0)
+        return {"prepared_clips_per_s_alone": round(alone, 1), "clips_per_s_training_fed_by_the_pipeline": round(fed, 1),
+                "what": "uint8 256x112x112x3 clip slices from PINNED host videos -> async H2D on a copy stream (double buffered) -> "
+                        "otal_prepare_clips_map (crop 96, flip, normalise, THWC->CTHW); 9.6 MB of PCIe traffic per clip"}
+
+    leg("fp32_parity", fp32)
+    leg("ssl_on", ssl)
+    leg("anet", anet)
+    leg("inference", inference)
+    leg("input_pipeline", input_pipeline)
+    ops.CONV_PRECISION = saved
+    return out
 
 
 def main():
@@ -146,6 +318,8 @@ def main():
                     help="also run the self-supervised triplet branch every step (train.py:237-242 runs it when flags[0]): a second "
                          "backbone pass on the spliced clip + 3 BoundaryMaxPooling calls + triplet losses; eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the short legs for the other BASELINE configs (fp32 parity path, ssl on, ActivityNet, inference, input pipeline)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hbm-kernels", action="store_true",
                     help="skip the achieved-GB/s table of the HBM-bound kernel classes (tools/bench_hbm_kernels.py)")
@@ -275,6 +449,7 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
 
+    nbuckets = len(trainer.arena.buckets)
     roofline = None
     if rank == 0 and not args.no_roofline:
         from opental_amd.common import ops
@@ -323,9 +498,16 @@ def main():
                for k, v in measure_hbm_kernels(args.batch).items()}
         _o.CONV_PRECISION = saved_prec
         torch.cuda.empty_cache()
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extras and not anet and not args.ssl and args.dtype == "bf16":
+        del trainer
+        torch.cuda.empty_cache()
+        extra = extras(device, args.batch)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not anet:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(seconds_budget=12.0)
+        if not args.no_extras:
+            cpu["batch8"] = cpu_baseline(seconds_budget=10.0, batch=8)
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -341,13 +523,14 @@ def main():
                                    "EDL+IBM loss, ssl branch " + ("ON" if args.ssl else "off") + "), 256x3x96x96 clips, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "rccl_ranks": dist.get_world_size() if (world > 1 or force_dist) else 1,
+                       "arena_buckets": nbuckets,
                        "grad_allreduce": "RCCL sum over xGMI of the flat fp32 gradient arena in %d contiguous buckets, issued from inside "
                                          "the backward pass (the backbone hands its finished layers over while it runs); "
-                                         "exposed = compute-stream wait for the collectives after backward" % len(trainer.arena.buckets),
+                                         "exposed = compute-stream wait for the collectives after backward" % nbuckets,
                        "allreduce_exposed_ms": None if exposed_ms is None else round(exposed_ms, 3),
                        "ssl_branch": bool(args.ssl), "launch_probe": launch_probe,
                        "launch": "one captured HIP graph per step" if graphed else "eager launches"},
-            "roofline": roofline, "hbm_kernels": hbm, "cpu_baseline": cpu}))
+            "roofline": roofline, "hbm_kernels": hbm, "other_configs": extra, "cpu_baseline": cpu}))
     if world > 1 or force_dist:
         dist.barrier()              # every rank leaves together (rank 0 was busy with the roofline steps)
         dist.destroy_process_group()
