@@ -2323,6 +2323,7 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 }
 
 #include "conv_wgrad_direct.inc"
+#include "conv1d_tile.inc"
 
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -2342,6 +2343,10 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         if (conv1a_direct_eligible(a.g, MODE, a.prec, a.x)) return launch_conv1a_direct(a, ws, ws_bytes, st);
     }
     if constexpr (MODE != MODE_WGRAD) {
+        if (conv1d_tile_eligible(a.g, MODE, a.prec, MODE == MODE_FWD ? (const void*)a.x : (const void*)a.dy, a)) {
+            const int e = launch_conv1d_tile<MODE>(a, ws, ws_bytes, st);
+            if (e != OTAL_E_UNSUPPORTED) return e;
+        }
         if (direct_eligible(a.g, MODE, a.prec, a.M)) return launch_direct<MODE>(a, ws, ws_bytes, st);
         if (chunk_eligible(a.g, MODE, a.prec)) return launch_chunked<MODE>(a, ws, ws_bytes, st);
     }

@@ -586,3 +586,50 @@ def test_direct_wgrad_3x3x3_matches_reference_and_vector_kernel(shape, cout, sli
     close(dw_vec, w.grad)
     scale = float(w.grad.abs().max())
     assert float((dw - dw_vec).abs().max()) <= 2e-5 * scale
+
+
+LEV126 = (0, 64, 96, 112, 120, 124, 126)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,cin,cout,T,k,lev", [(8, 512, 512, 126, 3, LEV126), (3, 512, 1024, 126, 1, None), (2, 2048, 512, 126, 1, None),
+                                                (2, 512, 512, 256, 3, None), (2, 512, 512, 256, 1, None), (4, 512, 15, 126, 3, LEV126),
+                                                (2, 128, 40, 64, 3, (0, 32, 48, 64)), (1, 256, 512, 131, 3, None)])
+def test_conv1d_tile_kernel_matches_reference_and_tiled_kernels(B, cin, cout, T, k, lev):
+    """conv1d_tile_kernel (csrc/conv1d_tile.inc: one launch, whole K streamed through LDS, no split-K) -- forward with
+    bias + ReLU epilogue and data gradient -- on the temporal-pyramid shapes: equal to fp32 conv1d on the bf16-ROUNDED
+    operands per level (1e-4 of scale) and to the tiled kernel + split-K reduce it replaces; x and dy may be channel
+    slices of larger buffers; an odd row length exercises the 4-byte aligned vector loads."""
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    rs = np.random.RandomState(cin + cout + T + k)
+    xb = torch.from_numpy(rs.randn(B, cin + 6, T).astype(np.float32)).cuda()
+    x = xb[:, 2:2 + cin]
+    w = torch.from_numpy((rs.randn(cout, cin, k) / np.sqrt(cin * k)).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    dyb = torch.from_numpy(rs.randn(B, cout + 4, T).astype(np.float32)).cuda()
+    dy = dyb[:, 1:1 + cout]
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        res = []
+        for off in (0, 1):
+            L.set_option("OTAL_CONV_NO1DTILE", off)
+            y = ops.conv_forward(x, w.view(cout, cin, k, 1, 1), (k, 1, 1), (1, 1, 1), shift=bias, relu=True, levels=lev)
+            dx = ops.conv_dgrad(dy, w.view(cout, cin, k, 1, 1), x.shape, (k, 1, 1), (1, 1, 1), levels=lev)
+            res.append((y, dx))
+    finally:
+        L.set_option("OTAL_CONV_NO1DTILE", 0)
+        ops.CONV_PRECISION = old
+    xr = _bf16_round(x.cpu()).contiguous().requires_grad_(True)
+    wr = _bf16_round(w.cpu())
+    bounds = lev if lev is not None else (0, T)
+    ys = [F.conv1d(xr[:, :, bounds[i]:bounds[i + 1]], wr, bias.cpu(), padding=k // 2) for i in range(len(bounds) - 1)]
+    yref = torch.cat(ys, 2)
+    yref.backward(_bf16_round(dy.cpu()))                    # d/dx of the convolution itself (the ReLU is applied below)
+    close(res[0][0], yref.detach().clamp(min=0))
+    close(res[0][1], xr.grad)
+    close(res[1][0], yref.detach().clamp(min=0))
+    close(res[1][1], xr.grad)
+    for a, b_ in zip(res[0], res[1]):
+        assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max())
