@@ -2324,10 +2324,15 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 
 #include "conv_wgrad_direct.inc"
 #include "conv1d_tile.inc"
+#include "conv1a_wgrad.inc"
 
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if constexpr (MODE == MODE_WGRAD) {
+        if (conv1a_wgrad_eligible(a.g, a.prec, a.x, a.dy)) {
+            const int e = launch_conv1a_wgrad(a, ws, ws_bytes, st);
+            if (e != OTAL_E_UNSUPPORTED) return e;
+        }
         if (wgrad_direct_eligible(a.g, a.prec, a.x, a.dy)) {
             const int e = launch_wgrad_direct(a, ws, ws_bytes, st);
             if (e != OTAL_E_UNSUPPORTED) return e;          // slabs do not fit: the vector kernel below

@@ -15,6 +15,15 @@ sys.path.insert(0, os.path.join(REPO, "tools"))
 FLAGS = ['--open_set', '--split', '0', '--lw', '1', '--cw', '10', '--piou', '0.5', '--ssl', '0.001', '--batch_size', '2']
 
 
+@pytest.fixture(autouse=True)
+def _restore_precision():
+    """The drivers select the GEMM operand type for the process (OTAL_DTYPE, default bf16): put it back for the other tests."""
+    from opental_amd.common import ops
+    old = ops.CONV_PRECISION
+    yield
+    ops.CONV_PRECISION = old
+
+
 def test_train_resume_and_test_drivers(tmp_path):
     from make_synthetic_thumos import make
     from opental_amd.thumos14 import train as R, test as T

@@ -633,3 +633,33 @@ def test_conv1d_tile_kernel_matches_reference_and_tiled_kernels(B, cin, cout, T,
     close(res[1][1], xr.grad)
     for a, b_ in zip(res[0], res[1]):
         assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout,splits", [((1, 3, 8, 96, 96), 64, 0), ((2, 3, 4, 96, 96), 48, 5), ((1, 3, 12, 96, 96), 64, 1)])
+def test_conv1a_direct_wgrad_matches_reference_and_pair_kernel(shape, cout, splits):
+    """conv1a_wgrad_direct_kernel (csrc/conv1a_wgrad.inc) -- the 7x7x7 stride-2 weight gradient from an LDS-staged
+    channel-last patch with transposed LDS reads -- equals the fp32 weight gradient on bf16-rounded operands (1e-4 of
+    scale) and the pair-mode vector kernel it replaces; zero padding in t / h / w, Cout < 64, few / one split."""
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape) + cout)
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    B, _, T, H, W = shape
+    dy = torch.from_numpy(rs.randn(B, cout, T // 2, H // 2, W // 2).astype(np.float32)).cuda()
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        L.set_option("OTAL_W1A_SPLITS", splits)
+        dw = ops.conv_wgrad(x, dy, (cout, 3, 7, 7, 7), (7, 7, 7), (2, 2, 2))
+        L.set_option("OTAL_CONV_NO1AW", 1)
+        dw_pair = ops.conv_wgrad(x, dy, (cout, 3, 7, 7, 7), (7, 7, 7), (2, 2, 2))
+    finally:
+        L.set_option("OTAL_CONV_NO1AW", 0)
+        L.set_option("OTAL_W1A_SPLITS", 0)
+        ops.CONV_PRECISION = old
+    w = torch.zeros(cout, 3, 7, 7, 7, requires_grad=True)
+    F.conv3d(F.pad(_bf16_round(x.cpu()), [2, 3, 2, 3, 2, 3]), w, stride=2).backward(_bf16_round(dy.cpu()))
+    close(dw, w.grad)
+    close(dw_pair, w.grad)
+    assert float((dw - dw_pair).abs().max()) <= 2e-5 * float(w.grad.abs().max())
