@@ -469,7 +469,8 @@ def main():
         tot_f = sum(e[0] for e in by.values()); tot_t = sum(e[1] for e in by.values()); tot_n = sum(e[2] for e in by.values())
         ach = tot_f / tot_t / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        roofline = {"bound": "mfma", "kernel": ("conv_gemm_bf16c_kernel (fwd/dgrad) + conv_wgrad_bf16v_kernel (wgrad) + conv_gemm_kernel (irregular geometries)"
+        roofline = {"bound": "mfma", "kernel": ("implicit-GEMM convolution family: conv3_direct / conv_gemm_bf16c / conv1a_direct / conv1d_tile (fwd, dgrad), "
+                                          "conv3_wgrad_direct / conv1a_wgrad_direct / conv_wgrad_bf16v / conv_wgrad1d (wgrad), conv_gemm_kernel (irregular geometries)"
                                if args.dtype == "bf16" else "conv_gemm_kernel") +
                               f": implicit-GEMM convolution, {args.dtype} MFMA operands, fp32 accumulate; per-op time incl. prologue and split-K reduce",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
@@ -478,13 +479,13 @@ def main():
                     "conv_time_ms_per_step": round(tot_t / 2 * 1e3, 2),
                     "by_mode_TFLOPs": {k: round(e[0] / e[1] / 1e12, 2) for k, e in by.items()}}
         # ... the committed rocprofv3 --pmc passes over this very command (tools/pmc_step.sh) supply it for the default workload
-        pmc = os.path.join(REPO, "profiles", "r01_pmc_step_traffic.json")
+        pmc = os.path.join(REPO, "profiles", "r02_pmc_step_traffic.json")
         if os.path.exists(pmc) and args.dtype == "bf16" and not anet and args.batch == 8 and not args.ssl:
             with open(pmc) as f:
                 t = json.load(f)
             roofline["traffic"] = int(t["conv_traffic_MB_per_launch"] * 1e6)
             roofline["traffic_note"] = ("bytes of HBM traffic per convolution launch, FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 "
-                                        "--pmc passes over this command (profiles/r01_pmc_step_traffic.txt); whole step "
+                                        "--pmc passes over this command (profiles/r02_pmc_step_traffic.txt); whole step "
                                         f"{t['step_traffic_MB'] / 1e3:.1f} GB")
     hbm = None
     if rank == 0 and world == 1 and not args.no_hbm_kernels and not anet:

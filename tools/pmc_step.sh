@@ -8,12 +8,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   d=gpurun_out/pmc_step_$c
   rm -rf $d
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- \
-      python bench.py --no-cpu-baseline --no-hbm-kernels --no-roofline --graph off --steps 4 --warmup 2 > $d.log 2>&1
+      python bench.py --no-cpu-baseline --no-hbm-kernels --no-roofline --no-extras --graph off --steps 4 --warmup 2 > $d.log 2>&1
 done
 python - "$out" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
-GROUPS = [("conv gemm", ("conv_gemm", "conv_wgrad", "conv3_direct", "conv1a_direct")), ("split-K reduce", ("splitk_reduce",)),
+GROUPS = [("conv gemm", ("conv_gemm", "conv_wgrad", "conv3_direct", "conv1a_direct", "conv3_wgrad_direct", "conv1d_tile", "conv1a_wgrad")), ("split-K reduce", ("splitk_reduce",)),
           ("conv prologue", ("prep_chunks", "pack_wt", "pack_direct", "pack_conv1a", "build_")), ("max-pool", ("maxpool",)),
           ("groupnorm", ("gn_relu",)), ("adam", ("adam_flat",)), ("bmp", ("bmp_",)), ("other", ())]
 tot = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
@@ -36,7 +36,7 @@ for c in tot:
                 break
     steps = nstep
 res = {"steps_in_run": steps, "unit": "MB per step", "classes": {}}
-lines = [f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --graph off --steps 4 --warmup 2` (+ its launch probe): {steps} training steps, b=8 bf16.",
+lines = [f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --no-extras --graph off --steps 4 --warmup 2`: {steps} training steps, b=8 bf16.",
          "FETCH x2 = the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies 128-byte requests at 64 B); WRITE_SIZE 1:1.", "",
          f"{'kernel class':16s} {'launches/step':>13s} {'FETCH x2 MB/step':>17s} {'WRITE MB/step':>14s} {'total MB/step':>14s}"]
 gt = 0.0
