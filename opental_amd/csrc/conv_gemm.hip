@@ -1432,10 +1432,73 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
     }
 }
 
+// The same reduction for MANY splits of a SMALL result (weight gradients: 4 k .. 600 k outputs, up to 2048 slabs): one
+// thread walking 500 slabs is a 10 us latency chain.  Here a workgroup owns 64 float4 outputs; its four waves sum a quarter
+// of the slabs each (8 loads in flight, in slab order) and the quarters meet in LDS in a fixed order ((q0 + q1) + (q2 + q3)),
+// so the result is deterministic -- a different, equally valid summation tree than the sequential kernel's.
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_reduce_tall_kernel(const ConvArgs a) {
+    __shared__ float4 part[3][64];
+    const ConvGeom& g = a.g;
+    const int64_t total = (int64_t)a.M * a.N;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t base = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    const bool live = base < total;
+    const int per = (a.splits + 3) / 4;
+    const int s_lo = q * per, s_hi = min(a.splits, s_lo + per);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        for (int s0 = s_lo; s0 < s_hi; s0 += 8) {
+            float4 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int sidx = min(s0 + u, s_hi - 1);
+                tmp[u] = *reinterpret_cast<const float4*>(a.slab + (int64_t)sidx * total + base);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < s_hi) { acc.x += tmp[u].x; acc.y += tmp[u].y; acc.z += tmp[u].z; acc.w += tmp[u].w; }
+        }
+    }
+    if (q > 0) part[q - 1][lane] = acc;
+    __syncthreads();
+    if (q > 0 || !live) return;
+    const float4 p1 = part[0][lane], p2 = part[1][lane], p3 = part[2][lane];
+    float r[4] = {(acc.x + p1.x) + (p2.x + p3.x), (acc.y + p1.y) + (p2.y + p3.y), (acc.z + p1.z) + (p2.z + p3.z), (acc.w + p1.w) + (p2.w + p3.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t idx = base + e;
+        const int m = (int)(idx / a.N), n = (int)(idx - (int64_t)m * a.N);
+        float v = r[e];
+        int64_t off;
+        if (MODE == MODE_FWD) {
+            if (a.scale) v *= a.scale[m];
+            if (a.shift) v += a.shift[m];
+            if (a.flags & EPI_RELU) v = fmaxf(v, 0.f);
+            off = conv_out_offset(g, dec_pos_fd(n, a.fd.To, a.fd.Ho, a.fd.Wo), m);
+        } else if (MODE == MODE_DGRAD) {
+            off = conv_in_offset(g, dec_pos_fd(n, a.fd.Ti, a.fd.Hi, a.fd.Wi), m);
+            if (a.emask) v = a.emask[off] > 0.f ? v * a.escale[m] : 0.f;
+        } else if (a.flags & EPI_NPAD8) {
+            if ((n & 7) >= g.kw) continue;
+            off = (int64_t)m * ((a.N >> 3) * g.kw) + (n >> 3) * g.kw + (n & 7);
+        } else {
+            off = idx;
+        }
+        if (a.flags & EPI_ACCUM) v += a.out[off];
+        a.out[off] = v;
+    }
+}
+
 template <int MODE>
 static int launch_splitk_reduce(const ConvArgs& a, hipStream_t st) {
     const int64_t total = (int64_t)a.M * a.N;
     const bool v4 = (total % 4 == 0) && (((uintptr_t)a.slab & 15) == 0);
+    if (v4 && a.splits >= 16 && total <= (1 << 21) && !OTAL_OPT("OTAL_CONV_NOTALLREDUCE", 0)) {
+        const int blocks = (int)((total / 4 + 63) / 64);
+        hipLaunchKernelGGL((splitk_reduce_tall_kernel<MODE>), dim3(blocks), dim3(256), 0, st, a);
+        return otal_launch_status();
+    }
     const int64_t work = v4 ? total / 4 : total;
     const int blocks = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
     if (v4) hipLaunchKernelGGL((splitk_reduce_kernel<MODE, 4>), dim3(blocks), dim3(256), 0, st, a);
