@@ -2388,6 +2388,7 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 #include "conv_wgrad_direct.inc"
 #include "conv1d_tile.inc"
 #include "conv1a_wgrad.inc"
+#include "proj_gemm.inc"
 
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -2408,6 +2409,10 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         }
     }
     if constexpr (MODE == MODE_FWD) {
+        if (proj_fwd_eligible(a.g, MODE, a.prec, a.x, a.w)) {
+            const int e = launch_proj_fwd(a, ws, ws_bytes, st);
+            if (e != OTAL_E_UNSUPPORTED) return e;
+        }
         if (conv1a_direct_eligible(a.g, MODE, a.prec, a.x)) return launch_conv1a_direct(a, ws, ws_bytes, st);
     }
     if constexpr (MODE != MODE_WGRAD) {
@@ -2603,6 +2608,8 @@ int prologue_kind(const ConvGeom& g, int mode, int precision) {
         return wgrad_vector_width(g, prec) ? 2 : 0;
     }
     const int M = mode == MODE_FWD ? g.Cout : g.Cin;
+    if (mode == MODE_FWD && g.kt == 1 && g.kh == g.Hi && g.kw == g.Wi && g.Hi * g.Wi == 36 && g.Ho == 1 && g.Wo == 1 &&
+        g.Cin % 4 == 0 && !OTAL_OPT("OTAL_CONV_NOPROJ", 0)) return 0;       // the projection GEMM reads the fp32 weights in place
     if (conv1a_direct_eligible(g, mode, prec, nullptr)) return 0;
     if (direct_eligible(g, mode, prec, M)) return 0;     // the direct paths pack per launch (for now)
     return chunk_eligible(g, mode, prec) ? 1 : 0;

@@ -663,3 +663,33 @@ def test_conv1a_direct_wgrad_matches_reference_and_pair_kernel(shape, cout, spli
     close(dw, w.grad)
     close(dw_pair, w.grad)
     assert float((dw - dw_pair).abs().max()) <= 2e-5 * float(w.grad.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout", [((2, 832, 64, 6, 6), 512), ((1, 64, 8, 6, 6), 40), ((3, 96, 70, 6, 6), 64)])
+def test_projection_gemm_forward(shape, cout):
+    """proj_fwd_kernel (csrc/proj_gemm.inc): the [1,6,6] spatial_valid projection as a K-contiguous GEMM on the fp32 weights
+    in place -- equal to conv3d on bf16-rounded operands (1e-4 of scale) and to the tiled gather kernel it replaces; bias
+    + ReLU epilogue through the split-K reduce; M < 64, T not a multiple of 64, channel-sliced x."""
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape) + cout)
+    B, cin, T, H, W = shape
+    xb = torch.from_numpy(rs.randn(B, cin + 8, T, H, W).astype(np.float32)).cuda()
+    x = xb[:, 4:4 + cin]
+    w = torch.from_numpy((rs.randn(cout, cin, 1, 6, 6) / np.sqrt(cin * 36)).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        y = ops.conv_forward(x, w, (1, 6, 6), (1, 1, 1), shift=bias, relu=True, spatial_valid=True)
+        L.set_option("OTAL_CONV_NOPROJ", 1)
+        y_old = ops.conv_forward(x, w, (1, 6, 6), (1, 1, 1), shift=bias, relu=True, spatial_valid=True)
+    finally:
+        L.set_option("OTAL_CONV_NOPROJ", 0)
+        ops.CONV_PRECISION = old
+    ref = F.conv3d(_bf16_round(x.cpu()), _bf16_round(w.cpu()), bias.cpu()).clamp(min=0)
+    assert tuple(y.shape) == tuple(ref.shape) == (B, cout, T, 1, 1)
+    close(y, ref)
+    close(y_old, ref)
+    assert float((y - y_old).abs().max()) <= 2e-5 * float(ref.abs().max())
