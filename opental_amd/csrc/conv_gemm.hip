@@ -2336,7 +2336,18 @@ static inline int direct_bm(int M) {
     if (M % 96 == 0) return 96;
     if (M % 64 == 0) return 64;
     const int pad64 = (M + 63) / 64 * 64;
-    return (pad64 - M) * 5 <= M ? 64 : 0;          // accept <= 20 % padded rows
+    return (pad64 - M) * 100 <= M * OTAL_OPT("OTAL_CONV_DIRECT_PAD", 34) ? 64 : 0;     // accept <= 34 % padded rows (Mixed_4e: 144 -> 192)
+}
+// positions per workgroup: 256 (8 waves), or 128 (4 waves) when 256 would leave the chip half empty (the 6x6 planes of
+// Mixed_4x: 72 position tiles); 0 = too few tiles either way (no split-K on this path)
+static inline int direct_bnp(const ConvGeom& g, int M) {
+    const int BM = direct_bm(M);
+    if (!BM) return 0;
+    const int64_t tm = (M + BM - 1) / BM, NP = (int64_t)g.B * conv_out_positions(g);
+    const int min_tiles = OTAL_OPT("OTAL_CONV_DIRECT_MINTILES", 192);
+    if (tm * (NP / 256) >= min_tiles) return 256;
+    if (!OTAL_OPT("OTAL_CONV_DIRECT_NO128", 0) && tm * (NP / 128) >= min_tiles) return 128;
+    return 0;
 }
 static inline bool direct_eligible(const ConvGeom& g, int mode, int prec, int M) {
     const bool off = OTAL_OPT("OTAL_CONV_NODIRECT", 0) != 0;
@@ -2345,10 +2356,7 @@ static inline bool direct_eligible(const ConvGeom& g, int mode, int prec, int M)
     if (g.To != g.Ti || g.Ho != g.Hi || g.Wo != g.Wi || g.Wi > 24) return false;
     const int P = conv_out_positions(g);
     const int C = mode == MODE_FWD ? g.Cin : g.Cout;
-    if (P % 256 || C % 16 || !direct_bm(M)) return false;
-    const int BM = direct_bm(M);
-    const int min_tiles = OTAL_OPT("OTAL_CONV_DIRECT_MINTILES", 192);
-    if ((int64_t)((M + BM - 1) / BM) * ((int64_t)g.B * P / 256) < min_tiles) return false;  // no split-K on this path
+    if (P % 256 || C % 16 || !direct_bnp(g, M)) return false;
     const int64_t ext = gather_extent_bytes(g, mode);
     return ext > 0 && ext < (1LL << 31);
 }
@@ -2379,6 +2387,12 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     d.c = a;
     d.wp = reinterpret_cast<const unsigned short*>(ws);
     d.C = C; d.Ktot = C * 27; d.wp_bytes = (unsigned)wb;
+    if (direct_bnp(a.g, a.M) == 128) {
+        const dim3 grid(a.N / 128, tm, 1);
+        if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 128>), grid, dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 128>), grid, dim3(256), 0, st, d);
+        return otal_launch_status();
+    }
     const dim3 grid(a.N / 256, tm, 1);
     if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256>), grid, dim3(512), 0, st, d);
     else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 256>), grid, dim3(512), 0, st, d);
@@ -2389,6 +2403,7 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 #include "conv1d_tile.inc"
 #include "conv1a_wgrad.inc"
 #include "proj_gemm.inc"
+#include "wgrad1x1.inc"
 
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -2400,6 +2415,10 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         if (wgrad_direct_eligible(a.g, a.prec, a.x, a.dy)) {
             const int e = launch_wgrad_direct(a, ws, ws_bytes, st);
             if (e != OTAL_E_UNSUPPORTED) return e;          // slabs do not fit: the vector kernel below
+        }
+        if (wgrad1x1_wide_eligible(a.g, a.prec, a.x, a.dy)) {
+            const int e = launch_wgrad1x1_wide(a, ws, ws_bytes, st);
+            if (e != OTAL_E_UNSUPPORTED) return e;
         }
         if (wgrad_pair_mode(a.g, a.prec)) return launch_wgrad_vector(a, 8, ws, ws_bytes, st);
         if (const int cw = wgrad_vector_width(a.g, a.prec)) return launch_wgrad_vector(a, cw, ws, ws_bytes, st);

@@ -548,10 +548,12 @@ def test_wgrad_1d_kernel_matches_torch(B, Cin, Cout, T, k, lev, monkeypatch):
 @pytest.mark.parametrize("shape,cout,slices", [((1, 64, 4, 24, 24), 192, False), ((2, 96, 3, 12, 12), 128, False),
                                                ((1, 64, 2, 24, 24), 208, True),      # Cout not a multiple of the 64-row tile
                                                ((2, 80, 5, 12, 12), 64, True),       # Cin not a multiple of the 32-channel block
-                                               ((3, 128, 8, 12, 12), 192, False)])
+                                               ((3, 128, 8, 12, 12), 192, False),
+                                               ((2, 96, 16, 6, 6), 208, False),      # 6x6 planes: four planes per K step, ring of 16 slabs
+                                               ((3, 144, 8, 6, 6), 96, True), ((1, 64, 4, 6, 6), 64, False), ((2, 70, 40, 6, 6), 130, True)])
 def test_direct_wgrad_3x3x3_matches_reference_and_vector_kernel(shape, cout, slices):
     """conv3_wgrad_direct_kernel (LDS-staged receptive field, transposed LDS reads; csrc/conv_wgrad_direct.inc) on the
-    backbone's 24x24 / 12x12 layer shapes: equal to an fp32 convolution's weight gradient on the bf16-ROUNDED operands
+    backbone's 24x24 / 12x12 / 6x6 layer shapes: equal to an fp32 convolution's weight gradient on the bf16-ROUNDED operands
     (1e-4 of scale), equal to the vector kernel it replaces (same products, other summation order), with x / dy taken as
     channel slices of larger buffers (Inception concat layout), several samples / planes (zero borders in t and h), and
     split-K over the positions."""
@@ -693,3 +695,38 @@ def test_projection_gemm_forward(shape, cout):
     close(y, ref)
     close(y_old, ref)
     assert float((y - y_old).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout,accumulate", [((2, 256, 4, 12, 12), 288, False), ((1, 192, 2, 24, 24), 176, True), ((3, 832, 8, 6, 6), 624, False),
+                                                   ((2, 40, 32, 3, 3), 24, False), ((1, 480, 8, 6, 6), 304, False), ((1, 64, 1, 8, 4), 448, False)])
+def test_wide_1x1_wgrad_matches_reference_and_vector_kernel(shape, cout, accumulate):
+    """wgrad1x1_wide_kernel (csrc/wgrad1x1.inc): one workgroup holds up to 288 x 256 of dW and streams positions -- equal to
+    the fp32 weight gradient on bf16-rounded operands (1e-4 of scale) and to the tiled vector kernel it replaces; channel
+    slices of larger buffers, Cout / Cin that are not multiples of 32, several row / column blocks, one split, accumulate."""
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape) + cout)
+    B, cin, T, H, W = shape
+    xb = torch.from_numpy(rs.randn(B, cin + 8, T, H, W).astype(np.float32)).cuda()
+    x = xb[:, 4:4 + cin]
+    dyb = torch.from_numpy(rs.randn(B, cout + 4, T, H, W).astype(np.float32)).cuda()
+    dy = dyb[:, 1:1 + cout]
+    base = torch.from_numpy(rs.randn(cout, cin, 1, 1, 1).astype(np.float32)).cuda()
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        res = []
+        for off in (0, 1):
+            L.set_option("OTAL_CONV_NOW1X1", off)
+            out = base.clone() if accumulate else None
+            res.append(ops.conv_wgrad(x, dy, (cout, cin, 1, 1, 1), (1, 1, 1), (1, 1, 1), out=out, accumulate=accumulate))
+    finally:
+        L.set_option("OTAL_CONV_NOW1X1", 0)
+        ops.CONV_PRECISION = old
+    ref = torch.einsum("bmthw,bnthw->mn", _bf16_round(dy.cpu()).double(), _bf16_round(x.cpu()).double()).float().view(cout, cin, 1, 1, 1)
+    if accumulate:
+        ref = ref + base.cpu()
+    close(res[0], ref)
+    close(res[1], ref)
+    assert float((res[0] - res[1]).abs().max()) <= 2e-5 * float(ref.abs().max())
