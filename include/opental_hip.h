@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 14
+#define OTAL_ABI_VERSION 15
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -101,7 +101,14 @@ int otal_bmp_bwd_levels(const void* grad_out, const void* in, const float* seg, 
  *            1 = operands rounded to bf16 when staged into LDS, v_mfma_f32_32x32x16_bf16, fp32
  *                accumulation and fp32 tensors in HBM (the throughput path).
  *            bit 1 (value 2), otal_conv_dgrad only: `wt_packed` points at the FORWARD-layout weight
- *                (Cout, Cin, kvol); the launch re-orders it itself (no otal_conv_pack_wt call needed). */
+ *                (Cout, Cin, kvol); the launch re-orders it itself (no otal_conv_pack_wt call needed).
+ *            bit 2 (value 4), with bit 0: the LARGE activation operand of the call is STORED as bf16 in HBM
+ *                (otal_conv_fwd: y; otal_conv_wgrad / otal_conv_dgrad: dy) -- the pointer is passed through the float*
+ *                parameter, strides stay in ELEMENTS.  Only geometries for which otal_conv_half_storage() returns 1
+ *                (16-byte aligned pointer, y strides multiples of 8); anything else is OTAL_E_UNSUPPORTED.  The values
+ *                are the ones the consumer's bf16 operand rounding produces from the fp32 tensor, so the forward
+ *                results do not change; the backbone uses it for Conv3d_1a's output and its gradient (604 MB each). */
+int otal_conv_half_storage(const int* geom, const int64_t* strides, int mode, int precision);
 size_t otal_conv_workspace_bytes(const int* geom, int mode);
 
 /* y = act(scale[co] * conv(x, w) + shift[co]); scale/shift nullable (frozen BN folded, or bias). */
@@ -179,6 +186,13 @@ int otal_maxpool3d_fwd_signbits(const int* geom, const int64_t* strides, const f
 int otal_maxpool3d_bwd_signbits(const int* geom, const int64_t* strides, const float* dy, const unsigned char* argtap,
                                 float* dx, int accumulate, const unsigned char* signbits, const float* out_scale,
                                 void* stream);
+/* The same pair with the LARGE tensor stored as bf16: _fwd_signbits_h reads a bf16 pool input (written by otal_conv_fwd
+ * with precision bit 2), _bwd_signbits_h writes dx as bf16 (round to nearest even; no accumulate) for otal_conv_wgrad
+ * with precision bit 2.  (1,3,3)/(1,2,2) pools only. */
+int otal_maxpool3d_fwd_signbits_h(const int* geom, const int64_t* strides, const void* x_bf16, float* y,
+                                  unsigned char* argtap, unsigned char* signbits, void* stream);
+int otal_maxpool3d_bwd_signbits_h(const int* geom, const int64_t* strides, const float* dy, const unsigned char* argtap,
+                                  void* dx_bf16, const unsigned char* signbits, const float* out_scale, void* stream);
 
 /* ------------------------------------------------------------------ head output tails ----
  * Everything between the head convolutions and CoarsePyramid's outputs (AFSD/thumos14/BDNet.py:337-353,:399-412,:538-556;

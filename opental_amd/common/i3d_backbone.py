@@ -242,11 +242,17 @@ class I3DFeaturesFunction(Function):
         tape, found = [], {}
         cur = x
         cur_scale = None            # bn scale vector of the tensor `cur` when it is a conv/mixed output
-        for step in plan:
+        for si, step in enumerate(plan):
             kind, name = step[0], step[-1]
             if kind == "conv":
                 _, wi, k, s, _ = step
-                y = ops.conv_forward(cur, weights[wi], k, s, scale=sc(wi), shift=sh(wi), relu=True)
+                # a convolution whose output only feeds a strided pool (Conv3d_1a -> MaxPool3d_2a) may store it as bf16:
+                # the pool commutes with the rounding the next convolution applies to its operand anyway
+                half = (si == 0 and not x.requires_grad and name not in endpoints and si + 1 < len(plan) and plan[si + 1][0] == "pool"
+                        and tuple(plan[si + 1][1]) == (1, 3, 3) and tuple(plan[si + 1][2]) == (1, 2, 2)
+                        and ops.half_storage_ok(0, tuple(cur.shape), weights[wi].shape[0], k, s)
+                        and ops.half_storage_ok(2, tuple(cur.shape), weights[wi].shape[0], k, s))
+                y = ops.conv_forward(cur, weights[wi], k, s, scale=sc(wi), shift=sh(wi), relu=True, half_out=half)
                 tape.append(("conv", wi, k, s, cur, y, cur_scale, sc(wi)))
                 cur, cur_scale = y, sc(wi)
             elif kind == "pool":
@@ -349,9 +355,12 @@ class I3DFeaturesFunction(Function):
                                           out_mask=xin if in_scale is not None else None, out_scale=in_scale)
             elif step[0] == "pool":
                 _, k, s, xin, (arg, bits), in_scale, _ = step
-                dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, dcur),
-                                              out_mask=xin if (in_scale is not None and bits is None) else None,
-                                              out_scale=in_scale, out_signbits=bits)
+                if xin.dtype == torch.bfloat16:             # bf16-stored activation: its gradient is stored the same way
+                    dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out_scale=in_scale, out_signbits=bits, half_out=True)
+                else:
+                    dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, dcur),
+                                                  out_mask=xin if (in_scale is not None and bits is None) else None,
+                                                  out_scale=in_scale, out_signbits=bits)
             else:
                 _, w0, (c1, c2, c3), xin, h1, h2, pm, argm, Y, in_scale, (wf, o1, o13), _ = step
                 Zg = zg.pop(pos)            # [dh1 | dh2 | dY]; dcur is its tail

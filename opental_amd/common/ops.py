@@ -25,6 +25,9 @@ CONV_PROFILE = None
 # 0: fp32 MFMA (bit-for-bit an fp32 fma chain; the parity path).  1: bf16 MFMA operands with fp32
 # accumulation (BASELINE.json's benchmark dtype; tensors stay fp32 in HBM).  Set by bench.py --dtype.
 CONV_PRECISION = 0
+# bf16 STORAGE of the largest activations in the bf16-operand mode (Conv3d_1a's output and its gradient: the tensors are
+# only ever consumed through bf16 roundings, so the forward values do not change).  False: fp32 tensors everywhere.
+HALF_STORAGE = os.environ.get("OTAL_HALF_STORAGE", "1") != "0"
 
 
 def _prof_begin():
@@ -63,11 +66,11 @@ def _as5(t):
     return t
 
 
-def _check(t5, name):
+def _check(t5, name, dtype=torch.float32):
     if not t5.is_cuda:
         raise RuntimeError(f"{name}: opental_amd ops run on the GPU only (no CPU fallback)")
-    if t5.dtype != torch.float32:
-        raise RuntimeError(f"{name}: float32 expected, got {t5.dtype}")
+    if t5.dtype != dtype:
+        raise RuntimeError(f"{name}: {dtype} expected, got {t5.dtype}")
     _, _, T, H, W = t5.shape
     exp = {4: 1, 3: W, 2: H * W}
     for d, e in exp.items():
@@ -213,21 +216,35 @@ def _prologue(mode, ga, sa, g, x5, y5, w, prec):
     return None if reg is None else L.ptr(reg)
 
 
-def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=False, levels=None, out=None):
-    """y = act(scale * conv_SAME(x, w) + shift).  x (B,Cin,T[,H,W]); w (Cout,Cin,*k)."""
+def half_storage_ok(mode, x_shape, cout, k, s):
+    """True when the library has a kernel for this geometry with the large operand (fwd: y, wgrad: dy) stored as bf16."""
+    if not (HALF_STORAGE and int(CONV_PRECISION) & 1) or len(x_shape) != 5:
+        return False
+    k, s = _k3(k), _k3(s)
+    B, Cin, Ti, Hi, Wi = x_shape
+    g, outn = _make_geom(B, Cin, cout, (Ti, Hi, Wi), k, s, None, False)
+    ga = (ctypes.c_int * len(g))(*g)
+    P = outn[0] * outn[1] * outn[2]
+    sa = (ctypes.c_int64 * 4)(Cin * Ti * Hi * Wi, Ti * Hi * Wi, cout * P, P)
+    return bool(L.lib().otal_conv_half_storage(ga, sa, int(mode), int(CONV_PRECISION)))
+
+
+def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=False, levels=None, out=None, half_out=False):
+    """y = act(scale * conv_SAME(x, w) + shift).  x (B,Cin,T[,H,W]); w (Cout,Cin,*k).
+    half_out: y is STORED as bf16 (half_storage_ok(0, ...) geometries only)."""
     k, s = _k3(k), _k3(s)
     x5 = _as5(x)
     B, Cin, Ti, Hi, Wi = x5.shape
     Cout = w.shape[0]
     g, outn = _make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
     if out is None:
-        out = torch.empty((B, Cout) + outn, dtype=x.dtype, device=x.device)
+        out = torch.empty((B, Cout) + outn, dtype=torch.bfloat16 if half_out else x.dtype, device=x.device)
         if x.dim() == 3:
             out = out.view(B, Cout, outn[0])
     y5 = _as5(out)
     if tuple(y5.shape) != (B, Cout) + outn:
         raise RuntimeError(f"conv_forward: out has shape {tuple(y5.shape)}, expected {(B, Cout) + outn}")
-    _check(x5, "x"); _check(y5, "y")
+    _check(x5, "x"); _check(y5, "y", torch.bfloat16 if half_out else torch.float32)
     if not w.is_contiguous():
         raise RuntimeError("weights must be contiguous")
     ga, sa = _geom_arrays(g, x5, y5)
@@ -235,7 +252,8 @@ def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=F
     ev = _prof_begin()
     pre = _prologue(0, ga, sa, g, x5, y5, w, int(CONV_PRECISION))
     L.check(L.lib().otal_conv_fwd(ga, sa, L.ptr(x5), L.ptr(w), _opt(scale), _opt(shift), L.ptr(y5), int(relu),
-                                  int(CONV_PRECISION), pre, L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()), "otal_conv_fwd")
+                                  int(CONV_PRECISION) | (4 if half_out else 0), pre, L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
+            "otal_conv_fwd")
     _prof_end(ev, "fwd", g)
     return out
 
@@ -378,13 +396,15 @@ def conv_wgrad(x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None,
         out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device)
     if not out.is_contiguous():
         raise RuntimeError("dw must be contiguous")
-    _check(x5, "x"); _check(dy5, "dy")
+    half_dy = dy5.dtype == torch.bfloat16                   # bf16-stored gradient (maxpool3d_backward(half_out=True))
+    _check(x5, "x"); _check(dy5, "dy", dy5.dtype if half_dy else torch.float32)
     ga, sa = _geom_arrays(g, x5, dy5)
     ws = workspace(x.device)
     ev = _prof_begin()
-    pre = _prologue(2, ga, sa, g, x5, dy5, x, int(CONV_PRECISION))
+    pre = None if half_dy else _prologue(2, ga, sa, g, x5, dy5, x, int(CONV_PRECISION))
     L.check(L.lib().otal_conv_wgrad(ga, sa, L.ptr(x5), L.ptr(dy5), L.ptr(out),
-                                    int(accumulate), int(CONV_PRECISION), pre, L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
+                                    int(accumulate), int(CONV_PRECISION) | (4 if half_dy else 0), pre, L.ptr(ws),
+                                    ctypes.c_size_t(ws.numel()), L.stream()),
             "otal_conv_wgrad")
     _prof_end(ev, "wgrad", g)
     return out
@@ -442,6 +462,20 @@ def maxpool3d_forward(x, k, s, out=None, signbits=False):
     if out is None:
         out = torch.empty((B, C) + outn, dtype=x.dtype, device=x.device)
     arg = torch.empty((B, C) + outn, dtype=torch.uint8, device=x.device)
+    if x5.dtype == torch.bfloat16:                          # bf16-stored input (conv_forward(half_out=True)): fp32 output
+        if out is None or out.dtype != torch.float32:
+            out = torch.empty((B, C) + outn, dtype=torch.float32, device=x.device)
+        _check(x5, "x", torch.bfloat16); _check(out, "y")
+        ga, sa = _geom_arrays(g, x5, out)
+        lib = L.lib()
+        lib.otal_maxpool3d_signbits_bytes.restype = ctypes.c_size_t
+        nbytes = int(lib.otal_maxpool3d_signbits_bytes(ga, sa))
+        if not (signbits and nbytes):
+            raise RuntimeError("maxpool3d_forward: a bf16 input needs the sign-bit path of the (1,3,3)/(1,2,2) pools")
+        bits = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        L.check(lib.otal_maxpool3d_fwd_signbits_h(ga, sa, L.ptr(x5), L.ptr(out), L.ptr(arg), L.ptr(bits), L.stream()),
+                "otal_maxpool3d_fwd_signbits_h")
+        return out, arg, bits
     _check(x5, "x"); _check(out, "y")
     ga, sa = _geom_arrays(g, x5, out)
     if signbits:
@@ -457,7 +491,21 @@ def maxpool3d_forward(x, k, s, out=None, signbits=False):
     return (out, arg, None) if signbits else (out, arg)
 
 
-def maxpool3d_backward(dy, arg, x_shape, k, s, out=None, accumulate=False, out_mask=None, out_scale=None, out_signbits=None):
+def maxpool3d_backward(dy, arg, x_shape, k, s, out=None, accumulate=False, out_mask=None, out_scale=None, out_signbits=None,
+                       half_out=False):
+    """half_out: dx is STORED as bf16 (sign-bit mask, no accumulate) for conv_wgrad's bf16-dy kernels."""
+    if half_out:
+        if accumulate or out_mask is not None or out_signbits is None or out is not None:
+            raise RuntimeError("maxpool3d_backward(half_out): plain store with the sign-bit mask only")
+        out = torch.empty(tuple(x_shape), dtype=torch.bfloat16, device=dy.device)
+        g, outn = _pool_geom(out, k, s)
+        _check(out, "dx", torch.bfloat16); _check(dy, "dy")
+        if tuple(dy.shape[2:]) != outn or not arg.is_contiguous():
+            raise RuntimeError("maxpool3d_backward: shape mismatch")
+        ga, sa = _geom_arrays(g, out, dy)
+        L.check(L.lib().otal_maxpool3d_bwd_signbits_h(ga, sa, L.ptr(dy), L.ptr(arg), L.ptr(out), L.ptr(out_signbits),
+                                                      L.ptr(out_scale), L.stream()), "otal_maxpool3d_bwd_signbits_h")
+        return out
     if out is None:
         if accumulate:
             raise RuntimeError("accumulate needs an existing buffer")

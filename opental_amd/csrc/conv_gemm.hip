@@ -66,6 +66,7 @@ struct ConvArgs {
     // batched epilogue (store_acc): byte extents of the output (and of the split-K slabs) when they fit 32-bit offsets, else 0
     unsigned out_bytes, slab_bytes;
     const void* pre;       // persistent prologue region filled earlier (otal_conv_prologue[_batch]); null: build it in the workspace
+    int half;              // the large activation operand is STORED as bf16 (fwd: y, dgrad / wgrad: dy); selected kernels only
 };
 
 // ---- operand element fetch -------------------------------------------------------------------
@@ -1897,13 +1898,20 @@ __global__ __launch_bounds__(C1_NT) void conv1a_direct_fwd_kernel(const Conv1aAr
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(d.wp), 0,
                                                       (int)((int64_t)gridDim.y * BM * C1_STEPS * 64), 0x00020000);
     const unsigned avo = (unsigned)(((m0 + (tid >> 2)) * C1_STEPS) * 64 + (tid & 3) * 16);
-    Words4 ra;
-    auto load_a = [&](int s) { if (tid < 256) ra = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rw, avo, s * 64, 0)); };
-    auto store_a = [&](int buf) { if (tid < 256) *reinterpret_cast<Words4*>(smA[buf] + (tid >> 2) * C1_PA + (tid & 3) * 16) = ra; };
+    // The slices travel global -> registers -> LDS.  A slice is consumed one barrier after it is stored, and a K step is
+    // only ~130 MFMA cycles long, so a load issued two steps ahead (first version) stalled EVERY step on the L2 latency:
+    // the registers form a FIFO of seven slices (slice s lives in rq[s % 7]) -- loads run nine steps ahead of their use.
+    Words4 rq[7];
+    auto load_a = [&](int s) { if (tid < 256) rq[s % 7] = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rw, avo, s * 64, 0)); };
+    auto store_a = [&](int s) { if (tid < 256) *reinterpret_cast<Words4*>(smA[s & 1] + (tid >> 2) * C1_PA + (tid & 3) * 16) = rq[s % 7]; };
     load_a(0);
-    store_a(0);
     load_a(1);
+#pragma unroll
+    for (int s = 2; s < 7; ++s) load_a(s);
+    store_a(0);
     store_a(1);
+    load_a(7);                                              // into the registers slices 0 and 1 just left
+    load_a(8);
     __syncthreads();
 
     // this lane's output position inside the tile and its pixel 2 wo of patch row (dt = 0, dh = 0)
@@ -1932,24 +1940,59 @@ __global__ __launch_bounds__(C1_NT) void conv1a_direct_fwd_kernel(const Conv1aAr
         }
     };
     read_ops(0, 0);
-#pragma unroll 2
-    for (int s = 0; s < C1_STEPS; ++s) {    // (the trip count must stay a constant: `set` indexes register arrays)
+#pragma unroll
+    for (int s = 0; s < C1_STEPS; ++s) {    // fully unrolled: `set` and the FIFO slot index register arrays
         const int set = s & 1;
-        if (s + 2 < C1_STEPS) load_a(s + 2);
         if (s + 1 < C1_STEPS) read_ops(set ^ 1, s + 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
                 acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[set][kk][i], bv[set][kk], acc[i][0], 0, 0, 0);
-        if (s + 2 < C1_STEPS) store_a(s & 1);
+        if (s + 2 < C1_STEPS) store_a(s + 2);              // into the slot of slice s (its operands were read during step s-1)
+        if (s + 9 < C1_STEPS) load_a(s + 9);                // refills the register just stored
         __syncthreads();
+    }
+    if (a.half) {
+        // bf16 output (the layer's 604 MB of fp32 activations are only ever read back through bf16 roundings: MaxPool3d_2a
+        // commutes with the monotonic rounding and Conv3d_2b rounds its operand anyway -- the forward values are unchanged):
+        // scale / shift / ReLU, transpose through LDS (the patch is dead), 16-byte runs along w.
+        constexpr int PT = 192 * 2 + 16;                    // bytes per output-channel row of the staging tile
+        float* rows = reinterpret_cast<float*>(smA[0]);
+        if (tid < BM) {
+            const int m = m0 + tid;
+            rows[2 * tid] = (m < a.M && a.scale) ? a.scale[m] : 1.f;
+            rows[2 * tid + 1] = (m < a.M && a.shift) ? a.shift[m] : 0.f;
+        }
+        __syncthreads();
+        const bool relu = (a.flags & EPI_RELU) != 0;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[i][0][r] * rows[2 * lr] + rows[2 * lr + 1];
+                if (relu) v = fmaxf(v, 0.f);
+                *reinterpret_cast<unsigned short*>(patch + lr * PT + nl * 2) = (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);
+            }
+        __syncthreads();
+        unsigned short* yh = reinterpret_cast<unsigned short*>(a.out);
+        for (int p = tid; p < BM * 24; p += C1_NT) {
+            const int co = p / 24, rem = p - co * 24, lt2 = rem / 12, q = rem - lt2 * 12;
+            if (m0 + co >= a.M) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(patch + co * PT + (lt2 * 96 + q * 8) * 2);
+            *reinterpret_cast<uint4*>(yh + (int64_t)b * g.y_bs + (int64_t)(m0 + co) * g.y_cs + ((int64_t)(to0 + lt2) * g.Ho + ho0) * g.Wo + q * 8) = v;
+        }
+        return;
     }
     // this wave's 32 positions are consecutive in the output: rows ho0, ho0+1 of plane to0 + lt
     const int n_wave = ((b * g.To + to0 + (wave * 32) / (C1_TR * C1_WO)) * g.Ho + ho0) * g.Wo + (wave * 32) % (C1_TR * C1_WO);
     store_acc<MODE_FWD, WM, 1, BM>(a, acc, m0, n_wave, 0, 0, lane, 0, reinterpret_cast<float*>(smA[0]));
 }
 
+static inline bool conv1a_half_out_ok(const ConvGeom& g, const void* y) {
+    return g.y_bs % 8 == 0 && g.y_cs % 8 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+}
 static inline bool conv1a_direct_eligible(const ConvGeom& g, int mode, int prec, const void* x) {
     if (!prec || mode != MODE_FWD || g.nlev > 1 || OTAL_OPT("OTAL_CONV_NO1A", 0)) return false;
     if (g.Cin != 3 || g.kt != 7 || g.kh != 7 || g.kw != 7 || g.st != 2 || g.sh != 2 || g.sw != 2) return false;
@@ -2408,10 +2451,11 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if constexpr (MODE == MODE_WGRAD) {
-        if (conv1a_wgrad_eligible(a.g, a.prec, a.x, a.dy)) {
+        if (conv1a_wgrad_eligible(a.g, a.prec, a.x, a.dy) && (!a.half || a.g.y_bs % 8 + a.g.y_cs % 8 == 0)) {
             const int e = launch_conv1a_wgrad(a, ws, ws_bytes, st);
-            if (e != OTAL_E_UNSUPPORTED) return e;
+            if (e != OTAL_E_UNSUPPORTED || a.half) return e;
         }
+        if (a.half) return OTAL_E_UNSUPPORTED;              // bf16-stored dy: the kernels above only
         if (wgrad_direct_eligible(a.g, a.prec, a.x, a.dy)) {
             const int e = launch_wgrad_direct(a, ws, ws_bytes, st);
             if (e != OTAL_E_UNSUPPORTED) return e;          // slabs do not fit: the vector kernel below
@@ -2432,8 +2476,13 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
             const int e = launch_proj_fwd(a, ws, ws_bytes, st);
             if (e != OTAL_E_UNSUPPORTED) return e;
         }
+        if (a.half && !OTAL_OPT("OTAL_CONV_NO1A", 0)) {     // bf16-stored y: Conv3d_1a only
+            if (conv1a_direct_eligible(a.g, MODE, a.prec, a.x) && conv1a_half_out_ok(a.g, a.out)) return launch_conv1a_direct(a, ws, ws_bytes, st);
+            return OTAL_E_UNSUPPORTED;
+        }
         if (conv1a_direct_eligible(a.g, MODE, a.prec, a.x)) return launch_conv1a_direct(a, ws, ws_bytes, st);
     }
+    if (a.half) return OTAL_E_UNSUPPORTED;
     if constexpr (MODE != MODE_WGRAD) {
         if (conv1d_tile_eligible(a.g, MODE, a.prec, MODE == MODE_FWD ? (const void*)a.x : (const void*)a.dy, a)) {
             const int e = launch_conv1d_tile<MODE>(a, ws, ws_bytes, st);
@@ -2570,6 +2619,8 @@ extern "C" int otal_conv_fwd(const int* geom, const int64_t* strides, const floa
     a.M = a.g.Cout; a.N = a.g.B * conv_out_positions(a.g); a.K = a.g.Cin * conv_kvol(a.g);
     a.flags = relu ? EPI_RELU : 0;
     a.prec = (precision & 1) ? 1 : 0;
+    a.half = (precision & 4) ? 1 : 0;
+    if (a.half && !a.prec) return OTAL_E_UNSUPPORTED;
     a.pre = prologue;
     return launch_mode<MODE_FWD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -2589,6 +2640,8 @@ extern "C" int otal_conv_dgrad(const int* geom, const int64_t* strides, const fl
     a.flags = accumulate ? EPI_ACCUM : 0;
     a.prec = (precision & 1) ? 1 : 0;
     a.w_natural = (precision & 2) ? 1 : 0;
+    a.half = (precision & 4) ? 1 : 0;
+    if (a.half && !a.prec) return OTAL_E_UNSUPPORTED;
     a.pre = prologue;
     return launch_mode<MODE_DGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -2604,8 +2657,22 @@ extern "C" int otal_conv_wgrad(const int* geom, const int64_t* strides, const fl
     a.M = a.g.Cout; a.N = a.g.Cin * conv_kvol(a.g); a.K = a.g.B * conv_out_positions(a.g);
     a.flags = accumulate ? EPI_ACCUM : 0;
     a.prec = (precision & 1) ? 1 : 0;
+    a.half = (precision & 4) ? 1 : 0;
+    if (a.half && !a.prec) return OTAL_E_UNSUPPORTED;
     a.pre = prologue;
     return launch_mode<MODE_WGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// 1 when this geometry has a kernel for the bf16-STORED large operand (precision bit 2): fwd -> y, wgrad / dgrad -> dy.
+// Pointer alignment (16 bytes) and strides that are multiples of 8 elements are the caller's side of the contract.
+extern "C" int otal_conv_half_storage(const int* geom, const int64_t* strides, int mode, int precision) {
+    ConvArgs a = {};
+    if (!geom || !strides || fill_geom(a.g, geom) || !(precision & 1)) return 0;
+    a.g.x_bs = strides[0]; a.g.x_cs = strides[1]; a.g.y_bs = strides[2]; a.g.y_cs = strides[3];
+    if (a.g.y_bs % 8 || a.g.y_cs % 8) return 0;
+    if (mode == MODE_FWD) return conv1a_direct_eligible(a.g, MODE_FWD, 1, nullptr) && !OTAL_OPT("OTAL_CONV_NO1A", 0) ? 1 : 0;
+    if (mode == MODE_WGRAD) return conv1a_wgrad_eligible(a.g, 1, nullptr, nullptr) ? 1 : 0;
+    return 0;
 }
 
 extern "C" int otal_conv_pack_wt(const float* w, float* wt, int Cout, int Cin, int kvol, void* stream) {

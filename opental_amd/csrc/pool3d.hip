@@ -514,7 +514,9 @@ __device__ __forceinline__ void scan_tap(float v, bool in, int tap, bool first, 
 // signbits (optional): one byte per 2 x 4 block of INPUT elements -- bit i*4+j = (x[row 2a+i][col 4m+j] > 0) -- at
 // ((bc*Ti + t)*(Hi/2) + a)*(Wi/4) + m: the ReLU mask of the producing layer, which the backward kernel then reads as one
 // byte per thread instead of two float4 of the 4-byte activations (604 MB -> 19 MB for MaxPool3d_2a).
-template <int KT>
+// XH: the pool INPUT is stored as bf16 (the producing convolution wrote it so): rows are read as 8 + 2 bytes.
+__device__ __forceinline__ float bf16_bits_to_float(unsigned h) { return __uint_as_float(h << 16); }
+template <int KT, bool XH>
 __global__ __launch_bounds__(256) void maxpoolk33_s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 unsigned char* __restrict__ arg, PoolGeom g, FastDiv fW2,
                                                                 unsigned char* __restrict__ signbits) {
@@ -528,7 +530,9 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_fwd_kernel(const float* __r
     const int m = p2 - q * W2;
     const uint32_t t = fd_div(g.fHo, q);
     const int ho = q - t * g.Ho;
-    const float* xr = x + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)t * ST * g.Hi + 2 * ho) * g.Wi + 4 * m;
+    const int64_t xo = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)t * ST * g.Hi + 2 * ho) * g.Wi + 4 * m;
+    const float* xr = x + xo;
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(x) + xo;
     const bool cin = 4 * m + 4 < g.Wi;                 // the fifth column exists (else it is the zero pad)
     float4 v[KT][3];
     float e[KT][3];
@@ -538,9 +542,17 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_fwd_kernel(const float* __r
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh) {
             rin[dt][dh] = (int)t * ST + dt < g.Ti && 2 * ho + dh < g.Hi;
-            const float* r = xr + ((int64_t)dt * g.Hi + dh) * g.Wi;
-            v[dt][dh] = rin[dt][dh] ? *reinterpret_cast<const float4*>(r) : make_float4(0.f, 0.f, 0.f, 0.f);
-            e[dt][dh] = (rin[dt][dh] && cin) ? r[4] : 0.f;
+            if constexpr (XH) {
+                const unsigned short* r = xh + ((int64_t)dt * g.Hi + dh) * g.Wi;
+                const uint2 w = rin[dt][dh] ? *reinterpret_cast<const uint2*>(r) : make_uint2(0u, 0u);
+                v[dt][dh] = make_float4(bf16_bits_to_float(w.x & 0xffffu), bf16_bits_to_float(w.x >> 16),
+                                        bf16_bits_to_float(w.y & 0xffffu), bf16_bits_to_float(w.y >> 16));
+                e[dt][dh] = (rin[dt][dh] && cin) ? bf16_bits_to_float(r[4]) : 0.f;
+            } else {
+                const float* r = xr + ((int64_t)dt * g.Hi + dh) * g.Wi;
+                v[dt][dh] = rin[dt][dh] ? *reinterpret_cast<const float4*>(r) : make_float4(0.f, 0.f, 0.f, 0.f);
+                e[dt][dh] = (rin[dt][dh] && cin) ? r[4] : 0.f;
+            }
         }
     float b0 = 0.f, b1 = 0.f;
     int w0 = 255, w1 = 255;
@@ -575,7 +587,9 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_fwd_kernel(const float* __r
     }
 }
 
-template <int KT>
+// XH: dx is STORED as bf16 (round to nearest even -- the rounding the consuming weight-gradient GEMM applies anyway);
+// no accumulate, mask from the sign bits only.
+template <int KT, bool XH>
 __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
                                                                 float* __restrict__ dx, PoolGeom g, int accumulate,
                                                                 const float* __restrict__ emask, const float* __restrict__ escale,
@@ -600,8 +614,8 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __r
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        if (!signbits) mk[i] = emask ? *reinterpret_cast<const float4*>(emask + xo + i * g.Wi) : make_float4(1.f, 1.f, 1.f, 1.f);
-        old[i] = accumulate ? *reinterpret_cast<const float4*>(dx + xo + i * g.Wi) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!signbits) mk[i] = (!XH && emask) ? *reinterpret_cast<const float4*>(emask + xo + i * g.Wi) : make_float4(1.f, 1.f, 1.f, 1.f);
+        old[i] = (!XH && accumulate) ? *reinterpret_cast<const float4*>(dx + xo + i * g.Wi) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // candidate output planes, ascending tap (dt) order: KT = 1: plane t (dt 0);  KT = 3, stride 2: plane t/2 with
     // dt = t & 1, then -- for even t -- plane t/2 - 1 with dt = 2
@@ -654,8 +668,17 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __r
         s1.x = mk[1].x > 0.f ? s1.x * esc : 0.f; s1.y = mk[1].y > 0.f ? s1.y * esc : 0.f;
         s1.z = mk[1].z > 0.f ? s1.z * esc : 0.f; s1.w = mk[1].w > 0.f ? s1.w * esc : 0.f;
     }
-    *reinterpret_cast<float4*>(dx + xo) = make_float4(old[0].x + s0.x, old[0].y + s0.y, old[0].z + s0.z, old[0].w + s0.w);
-    *reinterpret_cast<float4*>(dx + xo + g.Wi) = make_float4(old[1].x + s1.x, old[1].y + s1.y, old[1].z + s1.z, old[1].w + s1.w);
+    if constexpr (XH) {
+        unsigned short* dh = reinterpret_cast<unsigned short*>(dx) + xo;
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        auto pk = [](float lo, float hi) { const f2 f = {lo, hi}; return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf2)); };
+        *reinterpret_cast<uint2*>(dh) = make_uint2(pk(s0.x, s0.y), pk(s0.z, s0.w));
+        *reinterpret_cast<uint2*>(dh + g.Wi) = make_uint2(pk(s1.x, s1.y), pk(s1.z, s1.w));
+    } else {
+        *reinterpret_cast<float4*>(dx + xo) = make_float4(old[0].x + s0.x, old[0].y + s0.y, old[0].z + s0.z, old[0].w + s0.w);
+        *reinterpret_cast<float4*>(dx + xo + g.Wi) = make_float4(old[1].x + s1.x, old[1].y + s1.y, old[1].z + s1.z, old[1].w + s1.w);
+    }
 }
 
 // 1: the (1,3,3)/(1,2,2) pools, 3: the (3,3,3)/(2,2,2) pool, 0: not one of them (or misaligned operands)
@@ -716,18 +739,21 @@ int bwd_planes(const PoolGeom& g, int& tlo_max, size_t& lds) {
 }  // namespace
 
 static int pool_fwd(const int* geom, const int64_t* strides, const float* x, float* y, unsigned char* argtap,
-                    unsigned char* signbits, void* stream) {
+                    unsigned char* signbits, void* stream, int half = 0) {
     if (!geom || !strides || !x || !y || !argtap) return OTAL_E_NULL;
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
-    if (signbits && !strided_k33_kind(g, x, y)) return OTAL_E_UNSUPPORTED;
+    if ((signbits || half) && !strided_k33_kind(g, x, y)) return OTAL_E_UNSUPPORTED;
     if (const int kind = strided_k33_kind(g, x, y)) {
         const int n2 = g.To * g.Ho * (g.Wo / 2);
         const dim3 grid((n2 + 255) / 256, g.B * g.C);
         const FastDiv fW2 = make_fastdiv((uint32_t)(g.Wo / 2));
-        if (kind == 1) hipLaunchKernelGGL(maxpoolk33_s2_fwd_kernel<1>, grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
-        else hipLaunchKernelGGL(maxpoolk33_s2_fwd_kernel<3>, grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
+        if (half) {             // bf16-stored input (8-byte rows): the (1,3,3)/(1,2,2) pools
+            if (kind != 1) return OTAL_E_UNSUPPORTED;
+            hipLaunchKernelGGL((maxpoolk33_s2_fwd_kernel<1, true>), grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
+        } else if (kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_fwd_kernel<1, false>), grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
+        else hipLaunchKernelGGL((maxpoolk33_s2_fwd_kernel<3, false>), grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
         return otal_launch_status();
     }
     if (is_333_s1(g) && !OTAL_OPT("OTAL_POOL_NOLDS", 0)) {
@@ -760,7 +786,8 @@ static int pool_fwd(const int* geom, const int64_t* strides, const float* x, flo
 }
 
 static int pool_bwd(const int* geom, const int64_t* strides, const float* dy, const unsigned char* argtap, float* dx,
-                    int accumulate, const float* out_mask, const float* out_scale, const unsigned char* signbits, void* stream) {
+                    int accumulate, const float* out_mask, const float* out_scale, const unsigned char* signbits, void* stream,
+                    int half = 0) {
     if (!geom || !strides || !dy || !dx || !argtap) return OTAL_E_NULL;
     if (((out_mask == nullptr) && (signbits == nullptr)) != (out_scale == nullptr)) return OTAL_E_NULL;
     if (out_mask && signbits) return OTAL_E_NULL;
@@ -768,13 +795,15 @@ static int pool_bwd(const int* geom, const int64_t* strides, const float* dy, co
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
     const int kind = (!out_mask || (reinterpret_cast<uintptr_t>(out_mask) & 15) == 0) ? strided_k33_kind(g, dx, dy) : 0;
-    if (signbits && !kind) return OTAL_E_UNSUPPORTED;
+    if ((signbits || half) && !kind) return OTAL_E_UNSUPPORTED;
+    if (half && (kind != 1 || accumulate || out_mask)) return OTAL_E_UNSUPPORTED;      // bf16-stored dx: plain store, sign-bit mask
     if (kind) {
         const int n4 = g.Ti * (g.Hi / 2) * (g.Wi / 4);
         const dim3 grid((n4 + 255) / 256, g.B * g.C);
         const FastDiv fW4 = make_fastdiv((uint32_t)(g.Wi / 4)), fH2 = make_fastdiv((uint32_t)(g.Hi / 2));
-        if (kind == 1) hipLaunchKernelGGL(maxpoolk33_s2_bwd_kernel<1>, grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
-        else hipLaunchKernelGGL(maxpoolk33_s2_bwd_kernel<3>, grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
+        if (half) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, true>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
+        else if (kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, false>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
+        else hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<3, false>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
         return otal_launch_status();
     }
     if (is_333_s1(g) && !OTAL_OPT("OTAL_POOL_NOLDS", 0)) {
@@ -831,4 +860,16 @@ extern "C" int otal_maxpool3d_bwd_signbits(const int* geom, const int64_t* strid
                                            void* stream) {
     if (!signbits || !out_scale) return OTAL_E_NULL;
     return pool_bwd(geom, strides, dy, argtap, dx, accumulate, nullptr, out_scale, signbits, stream);
+}
+// The same pair with the LARGE tensor (the pool input x, its gradient dx) stored as bf16 -- (1,3,3)/(1,2,2) pools behind a
+// convolution that writes bf16 (otal_conv_fwd precision bit 2): MaxPool3d_2a reads 302 MB instead of 604 MB.
+extern "C" int otal_maxpool3d_fwd_signbits_h(const int* geom, const int64_t* strides, const void* x_bf16, float* y,
+                                             unsigned char* argtap, unsigned char* signbits, void* stream) {
+    if (!signbits) return OTAL_E_NULL;
+    return pool_fwd(geom, strides, static_cast<const float*>(x_bf16), y, argtap, signbits, stream, 1);
+}
+extern "C" int otal_maxpool3d_bwd_signbits_h(const int* geom, const int64_t* strides, const float* dy, const unsigned char* argtap,
+                                             void* dx_bf16, const unsigned char* signbits, const float* out_scale, void* stream) {
+    if (!signbits || !out_scale) return OTAL_E_NULL;
+    return pool_bwd(geom, strides, dy, argtap, static_cast<float*>(dx_bf16), 0, nullptr, out_scale, signbits, stream, 1);
 }

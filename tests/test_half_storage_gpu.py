@@ -1,0 +1,111 @@
+"""bf16 STORAGE of Conv3d_1a's output and of its gradient (precision bit 2 of the C ABI; ops.HALF_STORAGE):
+the tensors are consumed through bf16 roundings only, so every kernel of the chain is checked bit for bit against the fp32
+tensors rounded to nearest even, and the model's forward values do not move."""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _bf16_mode():
+    from opental_amd.common import ops
+    old = (ops.CONV_PRECISION, ops.HALF_STORAGE)
+    ops.CONV_PRECISION, ops.HALF_STORAGE = 1, True
+    yield
+    ops.CONV_PRECISION, ops.HALF_STORAGE = old
+
+
+def _rne(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("shape,cout", [((2, 3, 8, 96, 96), 64), ((1, 3, 4, 8, 96), 40)])
+def test_conv1a_bf16_output_is_the_rounded_fp32_output(shape, cout):
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape) + cout)
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    w = torch.from_numpy((rs.randn(cout, 3, 7, 7, 7) * 0.05).astype(np.float32)).cuda()
+    sc = torch.from_numpy((rs.rand(cout) + 0.5).astype(np.float32)).cuda()
+    sh = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    assert ops.half_storage_ok(0, shape, cout, (7, 7, 7), (2, 2, 2))
+    y32 = ops.conv_forward(x, w, (7, 7, 7), (2, 2, 2), scale=sc, shift=sh, relu=True)
+    y16 = ops.conv_forward(x, w, (7, 7, 7), (2, 2, 2), scale=sc, shift=sh, relu=True, half_out=True)
+    assert y16.dtype == torch.bfloat16 and y16.shape == y32.shape
+    assert torch.equal(y16, _rne(y32))
+    assert not ops.half_storage_ok(0, (1, 64, 8, 24, 24), 192, (3, 3, 3), (1, 1, 1))      # other layers: fp32 tensors
+    with pytest.raises(RuntimeError):
+        ops.conv_forward(torch.randn(1, 64, 4, 24, 24, device="cuda"), torch.randn(64, 64, 3, 3, 3, device="cuda"), (3, 3, 3), (1, 1, 1),
+                         half_out=True)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 6, 48, 48), (1, 3, 2, 6, 8)])
+def test_strided_pool_on_bf16_input_and_bf16_gradient(shape):
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape))
+    x32 = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    xh = _rne(x32)
+    k, s = (1, 3, 3), (1, 2, 2)
+    y_ref, arg_ref, bits_ref = ops.maxpool3d_forward(xh.float(), k, s, signbits=True)
+    y, arg, bits = ops.maxpool3d_forward(xh, k, s, signbits=True)
+    assert y.dtype == torch.float32 and torch.equal(y, y_ref) and torch.equal(arg, arg_ref) and torch.equal(bits, bits_ref)
+    # max-pool commutes with the (monotonic) rounding: pooling the rounded tensor = rounding the pooled fp32 tensor
+    y32, _, _ = ops.maxpool3d_forward(x32, k, s, signbits=True)
+    assert torch.equal(y, _rne(y32).float())
+    dy = torch.from_numpy(rs.randn(*y.shape).astype(np.float32)).cuda()
+    scale = torch.from_numpy((rs.rand(shape[1]) + 0.5).astype(np.float32)).cuda()
+    dx_ref = ops.maxpool3d_backward(dy, arg, shape, k, s, out_scale=scale, out_signbits=bits)
+    dx = ops.maxpool3d_backward(dy, arg, shape, k, s, out_scale=scale, out_signbits=bits, half_out=True)
+    assert dx.dtype == torch.bfloat16 and torch.equal(dx, _rne(dx_ref))
+
+
+@pytest.mark.parametrize("shape,cout", [((2, 3, 8, 96, 96), 64), ((1, 3, 4, 96, 96), 48)])
+def test_conv1a_weight_gradient_from_a_bf16_gradient(shape, cout):
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape) + cout)
+    B, _, T, H, W = shape
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    dyh = _rne(torch.from_numpy(rs.randn(B, cout, T // 2, H // 2, W // 2).astype(np.float32)).cuda())
+    assert ops.half_storage_ok(2, shape, cout, (7, 7, 7), (2, 2, 2))
+    dw_ref = ops.conv_wgrad(x, dyh.float(), (cout, 3, 7, 7, 7), (7, 7, 7), (2, 2, 2))
+    dw = ops.conv_wgrad(x, dyh, (cout, 3, 7, 7, 7), (7, 7, 7), (2, 2, 2))
+    assert torch.equal(dw, dw_ref)          # same bf16 operands, same summation order
+
+
+def test_model_forward_is_unchanged_and_only_the_first_layer_gradient_moves(golden_dir):
+    """HALF_STORAGE on / off: identical features and losses (bit for bit); every weight gradient but Conv3d_1a's identical;
+    Conv3d_1a's differs only where two window elements became equal after rounding (the pool's first-maximum rule then
+    routes the gradient to the other one): cosine 0.997 with the fp32-stored run, against 0.77 between the bf16-operand
+    and the fp32 modes for this layer (test_bf16_compute_mode_stays_close_to_fp32)."""
+    from oracle import arch
+    from test_model_gpu import build, _criterion, W
+    from opental_amd.common import ops
+    from opental_amd.thumos14.train import forward_one_epoch, total_cost
+    fx = np.load(os.path.join(golden_dir, "thumos_b1.npz"))
+    net = build(fx)
+    x = torch.from_numpy(arch.make_clip(int(fx["clip_seed"]), 1)).cuda()
+    targets = [torch.from_numpy(fx["target_0"]).cuda()]
+    scores = torch.from_numpy(fx["scores"]).cuda()
+
+    def run(half):
+        ops.HALF_STORAGE = half
+        net.zero_grad(set_to_none=True)
+        crit = _criterion("edl", 0)
+        out = net(x)
+        losses = forward_one_epoch(net, crit, x, targets, scores, training=True, ssl=False)
+        cost = total_cost(losses, W)
+        cost.backward()
+        return ({k: v.detach().clone() for k, v in out.items() if v is not None}, float(cost.detach()),
+                {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+    o0, c0, g0 = run(False)
+    o1, c1, g1 = run(True)
+    for k in o0:
+        assert torch.equal(o0[k], o1[k]), k
+    assert c0 == c1
+    moved = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert all("Conv3d_1a" in k for k in moved), moved
+    for k in moved:
+        cos = float(torch.nn.functional.cosine_similarity(g0[k].flatten(), g1[k].flatten(), dim=0))
+        assert cos > 0.99, (k, cos)
