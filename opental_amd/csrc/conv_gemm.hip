@@ -1624,15 +1624,22 @@ struct DirectArgs {
     unsigned wp_bytes;
 };
 
-template <int BM, int MODE, int BNP>
-__global__ __launch_bounds__(BNP * 2) void conv3_direct_kernel(const DirectArgs d) {
-    constexpr int DNT = BNP * 2;                            // one wave per 32 positions: 4 waves (BNP 128) or 8 (BNP 256)
+// WN = position tiles per wave.  With one (WN = 1) every wave re-reads the whole 96 x 144 weight slice for its 32 positions:
+// 36 sixteen-byte LDS reads per 27 MFMAs, and the eight waves' reads (2300 LDS cycles per K step) outlast their MFMAs (1730).
+// WN = 2 (512 positions per workgroup, still 8 waves) shares each weight fragment between two position tiles: 45 reads
+// per 54 MFMAs -- the kernel becomes MFMA-bound.
+template <int BM, int MODE, int BNP, int WN>
+__global__ __launch_bounds__(BNP * 2 / WN) void conv3_direct_kernel(const DirectArgs d) {
+    constexpr int DNT = BNP * 2 / WN;                       // one wave per 32 * WN positions
     constexpr int WM = BM / 32, PX = 48, PA = 304, SPAN_MAX = BNP + 52;
     constexpr int A_PIECES = (BM * 18 + DNT - 1) / DNT;       // 16-byte weight pieces per thread per K step
     constexpr int X_ITEMS = (SPAN_MAX / 4 + 1) * 8;         // (quad of positions, channel pair) items per K step, upper bound
     constexpr int X_ITERS = (X_ITEMS + DNT - 1) / DNT;
-    __shared__ __attribute__((aligned(16))) unsigned char smA[2][BM * PA];
-    __shared__ __attribute__((aligned(16))) unsigned char smX[2][SPAN_MAX * PX];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];     // [2][BM * PA] weights, then [2][SPAN_MAX * PX] positions
+    unsigned char* const smA0 = dsm;
+    unsigned char* const smX0 = dsm + 2 * BM * PA;
+    auto smA = [&](int buf) { return smA0 + buf * (BM * PA); };
+    auto smX = [&](int buf) { return smX0 + buf * (SPAN_MAX * PX); };
     const ConvArgs& a = d.c;
     const ConvGeom& g = a.g;
     const ConvFastDiv& fd = a.fd;
@@ -1651,20 +1658,21 @@ __global__ __launch_bounds__(BNP * 2) void conv3_direct_kernel(const DirectArgs 
     const int p0 = n0 - (int)(bsm * fd.P.d);
     const unsigned tile_off = (unsigned)(((int64_t)bsm * sbs + p0 - (W + 1)) * 4);      // byte offset of span element 0 at dt = 1, channel 0
 
-    // this lane's output position: validity of the 3 + 3 + 3 taps (FWD form; DGRAD uses flipped taps in the pack)
-    const int nl = n0 + wave * 32 + (lane & 31);
-    unsigned tmask, hwmask = 0;
-    {
+    // this lane's output positions: validity of the 3 + 3 + 3 taps (FWD form; DGRAD uses flipped taps in the pack)
+    unsigned tmask[WN], hwmask[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int nl = n0 + (wave * WN + j) * 32 + (lane & 31);
         const PosDec o = dec_pos_fd(nl < a.N ? nl : 0, fd.To, fd.Ho, fd.Wo);
         const bool live = nl < a.N;
-        tmask = 0;
+        tmask[j] = 0; hwmask[j] = 0;
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt) tmask |= (unsigned)(live && (unsigned)(o.t + dt - 1) < (unsigned)g.Ti) << dt;
+        for (int dt = 0; dt < 3; ++dt) tmask[j] |= (unsigned)(live && (unsigned)(o.t + dt - 1) < (unsigned)g.Ti) << dt;
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh)
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw)
-                hwmask |= (unsigned)((unsigned)(o.h + dh - 1) < (unsigned)g.Hi && (unsigned)(o.w + dw - 1) < (unsigned)g.Wi) << (dh * 3 + dw);
+                hwmask[j] |= (unsigned)((unsigned)(o.h + dh - 1) < (unsigned)g.Hi && (unsigned)(o.w + dw - 1) < (unsigned)g.Wi) << (dh * 3 + dw);
     }
     // ---- per-thread load items
     unsigned xvo[X_ITERS];          // byte offset of (quad, channel pair) relative to (dt = 1, chunk 0), or 0xffffffff if unused
@@ -1727,54 +1735,60 @@ __global__ __launch_bounds__(BNP * 2) void conv3_direct_kernel(const DirectArgs 
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                *reinterpret_cast<unsigned*>(smX[buf] + xlds[i] + e * PX) =
+                *reinterpret_cast<unsigned*>(smX(buf) + xlds[i] + e * PX) =
                     cvt_pk_bf16(__uint_as_float(rx[i][0][e]), __uint_as_float(rx[i][1][e]));
         }
 #pragma unroll
         for (int j = 0; j < A_PIECES; ++j) {
             const int p = tid + DNT * j;
-            if ((BM * 18) % DNT == 0 || p < BM * 18) *reinterpret_cast<Words4*>(smA[buf] + (p / 18) * PA + (p % 18) * 16) = ra[j];
+            if ((BM * 18) % DNT == 0 || p < BM * 18) *reinterpret_cast<Words4*>(smA(buf) + (p / 18) * PA + (p % 18) * 16) = ra[j];
         }
     };
 
-    f32x16 acc[WM][1];
+    f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     load_x(0);
     load_a(0);
     store(0, 0);
     __syncthreads();
-    const int xrow = (wave * 32 + (lane & 31) + W + 1) * PX + (lane >> 5) * 16;     // this lane's own position in the span
+    const int xrow = (wave * WN * 32 + (lane & 31) + W + 1) * PX + (lane >> 5) * 16;    // this lane's first position in the span
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         const int dt = s % 3;
-        const bool tok = (tmask >> dt) & 1u;
         const int sn = s + 1 < nsteps ? s + 1 : s;          // the prefetch past the end re-reads the last step
 #pragma unroll
         for (int g9 = 0; g9 < 9; ++g9) {
             if (g9 == 0) load_x(sn);
             if (g9 == 1) load_a(sn);
             const int dh = g9 / 3, dw = g9 - dh * 3;
-            bf16x8 av[WM], bv;
+            bf16x8 av[WM], bv[WN];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                av[i] = *reinterpret_cast<const bf16x8*>(smA[buf] + (i * 32 + (lane & 31)) * PA + g9 * 32 + (lane >> 5) * 16);
-            bv = *reinterpret_cast<const bf16x8*>(smX[buf] + xrow + ((dh - 1) * W + (dw - 1)) * PX);
-            const bool ok = tok && ((hwmask >> g9) & 1u);
+                av[i] = *reinterpret_cast<const bf16x8*>(smA(buf) + (i * 32 + (lane & 31)) * PA + g9 * 32 + (lane >> 5) * 16);
             const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-            bv = ok ? bv : zero;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                bv[j] = *reinterpret_cast<const bf16x8*>(smX(buf) + xrow + (j * 32 + (dh - 1) * W + (dw - 1)) * PX);
+                const bool ok = ((tmask[j] >> dt) & 1u) && ((hwmask[j] >> g9) & 1u);
+                bv[j] = ok ? bv[j] : zero;
+            }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv, acc[i][0], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         store(buf ^ 1, sn);
         __syncthreads();
     }
-    store_acc<MODE, WM, 1, BM>(a, acc, m0, n0, 0, wave * 32, lane, 0, reinterpret_cast<float*>(smA[0]));
+    store_acc<MODE, WM, WN, BM>(a, acc, m0, n0, 0, wave * WN * 32, lane, 0, reinterpret_cast<float*>(smA(0)));
 }
 
 // weights -> [Mpad][cb][dt][dh*3+dw][16] bf16.  FWD: A[m][..] = w[m][cb*16+c][dt][dh][dw];
@@ -1940,6 +1954,8 @@ __global__ __launch_bounds__(C1_NT) void conv1a_direct_fwd_kernel(const Conv1aAr
         }
     };
     read_ops(0, 0);
+    __syncthreads();    // step 0 stores slice 2 into the slot of slice 0: every wave must have read slice 0 first (with the
+                        // register FIFO the store no longer waits for a global load, so a late wave used to read slice 2)
 #pragma unroll
     for (int s = 0; s < C1_STEPS; ++s) {    // fully unrolled: `set` and the FIFO slot index register arrays
         const int set = s & 1;
@@ -2388,6 +2404,11 @@ static inline int direct_bnp(const ConvGeom& g, int M) {
     if (!BM) return 0;
     const int64_t tm = (M + BM - 1) / BM, NP = (int64_t)g.B * conv_out_positions(g);
     const int min_tiles = OTAL_OPT("OTAL_CONV_DIRECT_MINTILES", 192);
+    // 512 positions (two tiles per wave: the weight fragments are shared, the kernel turns MFMA-bound) when that still gives
+    // every CU two rounds of workgroups and the tile stays inside one sample
+    // (96-row tiles only: a 64-row tile of 256 positions fits TWICE per CU -- 16 waves -- and measured faster than one 512 tile)
+    if (BM == 96 && !OTAL_OPT("OTAL_CONV_DIRECT_NO512", 0) && conv_out_positions(g) % 512 == 0 &&
+        tm * (NP / 512) >= OTAL_OPT("OTAL_CONV_DIRECT_MINTILES512", 512)) return 512;
     if (tm * (NP / 256) >= min_tiles) return 256;
     if (!OTAL_OPT("OTAL_CONV_DIRECT_NO128", 0) && tm * (NP / 128) >= min_tiles) return 128;
     return 0;
@@ -2406,6 +2427,22 @@ static inline bool direct_eligible(const ConvGeom& g, int mode, int prec, int M)
 static inline size_t direct_wp_bytes(int M, int C) {
     const int BM = direct_bm(M);
     return align256((size_t)((M + BM - 1) / BM * BM) * C * 27 * 2 + 1024);
+}
+
+template <int BM, int BNP>
+constexpr int direct_lds_bytes() { return 2 * BM * 304 + 2 * (BNP + 52) * 48; }
+template <int BM, int MODE>
+static int launch_direct512(const DirectArgs& d, dim3 grid, hipStream_t st) {
+    constexpr int lds = direct_lds_bytes<BM, 512>();
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_direct_kernel<BM, MODE, 512, 2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((conv3_direct_kernel<BM, MODE, 512, 2>), grid, dim3(512), lds, st, d);
+    return otal_launch_status();
 }
 
 template <int MODE>
@@ -2430,15 +2467,21 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     d.c = a;
     d.wp = reinterpret_cast<const unsigned short*>(ws);
     d.C = C; d.Ktot = C * 27; d.wp_bytes = (unsigned)wb;
-    if (direct_bnp(a.g, a.M) == 128) {
+    const int bnp = direct_bnp(a.g, a.M);
+    if (bnp == 128) {
         const dim3 grid(a.N / 128, tm, 1);
-        if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 128>), grid, dim3(256), 0, st, d);
-        else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 128>), grid, dim3(256), 0, st, d);
+        if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 128, 1>), grid, dim3(256), (direct_lds_bytes<96, 128>()), st, d);
+        else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 128, 1>), grid, dim3(256), (direct_lds_bytes<64, 128>()), st, d);
         return otal_launch_status();
     }
+    if (bnp == 512) {           // two position tiles per wave (dynamic LDS: 112 KB)
+        const dim3 grid(a.N / 512, tm, 1);
+        if (BM == 96) return launch_direct512<96, MODE>(d, grid, st);
+        return launch_direct512<64, MODE>(d, grid, st);
+    }
     const dim3 grid(a.N / 256, tm, 1);
-    if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256>), grid, dim3(512), 0, st, d);
-    else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 256>), grid, dim3(512), 0, st, d);
+    if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<96, 256>()), st, d);
+    else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<64, 256>()), st, d);
     return otal_launch_status();
 }
 

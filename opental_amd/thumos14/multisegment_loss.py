@@ -44,16 +44,35 @@ def iou_loss(pred, target, weight=None, loss_type='giou', reduction='none'):
     return loss
 
 
+_PAD_INDEX = {}     # (target counts, device) -> (row index of every target in the padded (B*G) table, validity mask); device tensors
+
+
 def pad_targets(targets, device):
-    """list of (n_i,3) [start,end,label] -> (B,G,3) padded + (B,G) validity, built from host shapes."""
-    G = max(int(t.shape[0]) for t in targets)
-    B = len(targets)
-    out = torch.zeros(B, G, 3, device=device)
-    valid = torch.zeros(B, G, dtype=torch.bool, device=device)
-    for i, t in enumerate(targets):
-        n = int(t.shape[0])
-        out[i, :n] = t.to(device)
-        valid[i, :n] = True
+    """list of (n_i,3) [start,end,label] -> (B,G,3) padded + (B,G) validity, built from host shapes.
+    Three launches whatever the batch (concatenate, zero, scatter the rows): the scatter index and the mask depend only on
+    the per-sample target counts and are cached on the device.  A first-time count pattern met while a HIP graph is being
+    captured takes the per-sample form (no host -> device copy may be recorded into the graph)."""
+    lens = tuple(int(t.shape[0]) for t in targets)
+    G, B = max(lens), len(targets)
+    device = torch.device(device)
+    key = (lens, device)
+    hit = _PAD_INDEX.get(key)
+    if hit is None and not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+        if len(_PAD_INDEX) > 256:
+            _PAD_INDEX.clear()
+        idx = torch.tensor([i * G + j for i, n in enumerate(lens) for j in range(n)], dtype=torch.long).to(device)
+        valid = (torch.arange(G).view(1, G) < torch.tensor(lens).view(B, 1)).to(device)
+        hit = _PAD_INDEX[key] = (idx, valid)
+    if hit is None:
+        out = torch.zeros(B, G, 3, device=device)
+        valid = torch.zeros(B, G, dtype=torch.bool, device=device)
+        for i, t in enumerate(targets):
+            out[i, :lens[i]] = t.to(device)
+            valid[i, :lens[i]] = True
+        return out, valid
+    idx, valid = hit
+    rows = torch.cat([t.to(device=device, dtype=torch.float32).reshape(-1, 3) for t in targets], 0)     # (sum n_i, 3)
+    out = torch.zeros(B * G, 3, device=device).index_copy_(0, idx, rows).view(B, G, 3)
     return out, valid
 
 

@@ -730,3 +730,44 @@ def test_wide_1x1_wgrad_matches_reference_and_vector_kernel(shape, cout, accumul
     close(res[0], ref)
     close(res[1], ref)
     assert float((res[0] - res[1]).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout", [((2, 32, 8, 8, 8), 96), ((1, 96, 8, 24, 24), 192), ((2, 96, 32, 12, 12), 96), ((3, 192, 128, 2, 2), 96)])
+def test_direct_conv_two_position_tiles_per_wave(shape, cout):
+    """conv3_direct_kernel<BM, MODE, 512, 2> (512 positions per workgroup, each weight fragment shared by two position tiles
+    of a wave): forward with scale / shift / ReLU and the masked data gradient equal the fp32 convolution of the bf16-rounded
+    operands (1e-4 of scale) and the 256-position variant bit for bit (same products, same summation order per output);
+    96-row tiles (the variant's domain) in forward (Cout) and data gradient (Cin), planes of 8 / 24 / 12 / 2, tiles crossing
+    t planes and rows."""
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape) + cout)
+    B, cin, T, H, W = shape
+    assert (T * H * W) % 512 == 0
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    w = torch.from_numpy((rs.randn(cout, cin, 3, 3, 3) / np.sqrt(cin * 27)).astype(np.float32)).cuda()
+    sc = torch.from_numpy((rs.rand(cout) + 0.5).astype(np.float32)).cuda()
+    sh = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    sci = torch.from_numpy((rs.rand(cin) + 0.5).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rs.randn(B, cout, T, H, W).astype(np.float32)).cuda()
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        res = []
+        for min512 in (1, 1 << 30):
+            L.set_option("OTAL_CONV_DIRECT_MINTILES512", min512)
+            y = ops.conv_forward(x, w, (3, 3, 3), (1, 1, 1), scale=sc, shift=sh, relu=True)
+            dx = ops.conv_dgrad(dy, w, x.shape, (3, 3, 3), (1, 1, 1), out_mask=x, out_scale=sci)
+            res.append((y, dx))
+    finally:
+        L.set_option("OTAL_CONV_DIRECT_MINTILES512", 512)
+        ops.CONV_PRECISION = old
+    xr = _bf16_round(x.cpu()).requires_grad_(True)
+    yr = F.conv3d(xr, _bf16_round(w.cpu()), padding=1)
+    yr.backward(_bf16_round(dy.cpu()))
+    yref = (yr.detach() * sc.cpu().view(1, -1, 1, 1, 1) + sh.cpu().view(1, -1, 1, 1, 1)).clamp(min=0)
+    dxref = xr.grad * (x.cpu() > 0) * sci.cpu().view(1, -1, 1, 1, 1)
+    close(res[0][0], yref)
+    close(res[0][1], dxref)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
