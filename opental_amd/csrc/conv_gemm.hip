@@ -1273,6 +1273,7 @@ struct PrepDesc {
     const float* wsrc;
     ConvGeom g;
     int M, Mpad, C, kvol, K, Kp, nchunk, kwv, natural, mode;
+    int direct;            // 1: the weight pack of conv3_direct_kernel ([Mpad][C/16][3][9][16] bf16) instead of a chunk-path prologue
 };
 
 template <int MODE>
@@ -1346,6 +1347,33 @@ __device__ __forceinline__ void prep_chunks_body(const PrepDesc& d, unsigned bid
 template <int MODE>
 __global__ __launch_bounds__(256) void prep_chunks_kernel(const PrepDesc d) { prep_chunks_body<MODE>(d, blockIdx.x, gridDim.x); }
 
+// weights -> [Mpad][cb][dt][dh*3+dw][16] bf16 for conv3_direct_kernel.  FWD: A[m][..] = w[m][cb*16+c][dt][dh][dw];
+// DGRAD (natural layout W (Cout, Cin, 27)): A[m = ci][..] = w[co = cb*16+c][ci][2-dt][2-dh][2-dw]
+template <int MODE>
+__device__ __forceinline__ void pack_direct_body(unsigned* __restrict__ wp, const float* __restrict__ w, int M, int Mpad, int C, int natural,
+                                                 unsigned bid, unsigned nblk) {
+    const int Ktot = C * 27;
+    const int64_t pairs = (int64_t)Mpad * Ktot / 2;
+    for (int64_t p = (int64_t)bid * 256 + threadIdx.x; p < pairs; p += (int64_t)nblk * 256) {
+        const int m = (int)(p / (Ktot / 2)), k = (int)(p - (int64_t)m * (Ktot / 2)) * 2;
+        float v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kk = k + i;
+            const int c16 = kk & 15, g9 = (kk >> 4) % 9, sdt = (kk >> 4) / 9, dt = sdt % 3, cb = sdt / 3;
+            const int c = cb * 16 + c16;
+            float x = 0.f;
+            if (m < M) {
+                if (MODE == MODE_FWD) x = w[((int64_t)m * C + c) * 27 + dt * 9 + g9];
+                else if (natural) x = w[((int64_t)c * M + m) * 27 + (2 - dt) * 9 + (8 - g9)];
+                else x = w[((int64_t)m * C + c) * 27 + (2 - dt) * 9 + (8 - g9)];      // packed W^T (Cin, Cout, 27)
+            }
+            v[i] = x;
+        }
+        wp[p] = cvt_pk_bf16(v[0], v[1]);
+    }
+}
+
 // 1-D grid; starts[l] .. starts[l+1] are the workgroups of layer l (each layer gets exactly what its own launch would use)
 __global__ __launch_bounds__(256) void prep_chunks_batch_kernel(const PrepDesc* __restrict__ descs, const int* __restrict__ starts, int n) {
     const int b = blockIdx.x;
@@ -1356,6 +1384,11 @@ __global__ __launch_bounds__(256) void prep_chunks_batch_kernel(const PrepDesc* 
     }
     const PrepDesc& d = descs[lo];
     const unsigned bid = (unsigned)(b - starts[lo]), nblk = (unsigned)(starts[lo + 1] - starts[lo]);
+    if (d.direct) {
+        if (d.mode == MODE_FWD) pack_direct_body<MODE_FWD>(d.wp, d.wsrc, d.M, d.Mpad, d.C, d.natural, bid, nblk);
+        else pack_direct_body<MODE_DGRAD>(d.wp, d.wsrc, d.M, d.Mpad, d.C, d.natural, bid, nblk);
+        return;
+    }
     if (d.mode == MODE_FWD) prep_chunks_body<MODE_FWD>(d, bid, nblk);
     else prep_chunks_body<MODE_DGRAD>(d, bid, nblk);
 }
@@ -1791,31 +1824,10 @@ __global__ __launch_bounds__(BNP * 2 / WN) void conv3_direct_kernel(const Direct
     store_acc<MODE, WM, WN, BM>(a, acc, m0, n0, 0, wave * WN * 32, lane, 0, reinterpret_cast<float*>(smA(0)));
 }
 
-// weights -> [Mpad][cb][dt][dh*3+dw][16] bf16.  FWD: A[m][..] = w[m][cb*16+c][dt][dh][dw];
-// DGRAD (natural layout W (Cout, Cin, 27)): A[m = ci][..] = w[co = cb*16+c][ci][2-dt][2-dh][2-dw]
 template <int MODE>
 __global__ __launch_bounds__(256) void pack_direct_kernel(unsigned* __restrict__ wp, const float* __restrict__ w, int M, int Mpad,
                                                           int C, int natural) {
-    const int Ktot = C * 27;
-    const int64_t pairs = (int64_t)Mpad * Ktot / 2;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (int64_t)gridDim.x * 256) {
-        const int m = (int)(p / (Ktot / 2)), k = (int)(p - (int64_t)m * (Ktot / 2)) * 2;
-        float v[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int kk = k + i;
-            const int c16 = kk & 15, g9 = (kk >> 4) % 9, sdt = (kk >> 4) / 9, dt = sdt % 3, cb = sdt / 3;
-            const int c = cb * 16 + c16;
-            float x = 0.f;
-            if (m < M) {
-                if (MODE == MODE_FWD) x = w[((int64_t)m * C + c) * 27 + dt * 9 + g9];
-                else if (natural) x = w[((int64_t)c * M + m) * 27 + (2 - dt) * 9 + (8 - g9)];
-                else x = w[((int64_t)m * C + c) * 27 + (2 - dt) * 9 + (8 - g9)];      // packed W^T (Cin, Cout, 27)
-            }
-            v[i] = x;
-        }
-        wp[p] = cvt_pk_bf16(v[0], v[1]);
-    }
+    pack_direct_body<MODE>(wp, w, M, Mpad, C, natural, blockIdx.x, gridDim.x);
 }
 
 // ---- Conv3d_1a_7x7 forward, direct: 7x7x7 taps, stride 2, THREE input channels on a 96-wide plane.
@@ -2208,14 +2220,24 @@ static void fill_prep_desc(PrepDesc& d, const ConvArgs& a, int2* ctab, unsigned 
     d.ctab = ctab; d.wp = reinterpret_cast<unsigned*>(wp); d.wsrc = a.w; d.g = a.g;
     d.M = a.M; d.Mpad = (a.M + BMsel - 1) / BMsel * BMsel; d.C = C; d.kvol = conv_kvol(a.g);
     d.K = a.K; d.Kp = chunk_kp(a.K); d.nchunk = d.Kp / 8 + CHUNK_PAD; d.kwv = kwv ? 1 : 0; d.natural = a.w_natural; d.mode = MODE;
+    d.direct = 0;
 }
 static inline unsigned prep_blocks(const PrepDesc& d) {
+    if (d.direct) {
+        const int64_t pairs = (int64_t)d.Mpad * d.C * 27 / 2;
+        return (unsigned)((pairs + 255) / 256 < 2048 ? (pairs + 255) / 256 : 2048);
+    }
     const int64_t pairs = (int64_t)d.Mpad * (d.Kp / 2);
     int64_t blocks = (pairs + 255) / 256;
     if (blocks < (d.nchunk + 255) / 256) blocks = (d.nchunk + 255) / 256;
     return (unsigned)(blocks > 2048 ? 2048 : blocks);
 }
 static void launch_prep(const PrepDesc& d, hipStream_t st) {
+    if (d.direct) {
+        if (d.mode == MODE_FWD) hipLaunchKernelGGL((pack_direct_kernel<MODE_FWD>), dim3(prep_blocks(d)), dim3(256), 0, st, d.wp, d.wsrc, d.M, d.Mpad, d.C, d.natural);
+        else hipLaunchKernelGGL((pack_direct_kernel<MODE_DGRAD>), dim3(prep_blocks(d)), dim3(256), 0, st, d.wp, d.wsrc, d.M, d.Mpad, d.C, d.natural);
+        return;
+    }
     if (d.mode == MODE_FWD) hipLaunchKernelGGL((prep_chunks_kernel<MODE_FWD>), dim3(prep_blocks(d)), dim3(256), 0, st, d);
     else hipLaunchKernelGGL((prep_chunks_kernel<MODE_DGRAD>), dim3(prep_blocks(d)), dim3(256), 0, st, d);
 }
@@ -2451,8 +2473,10 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int BM = direct_bm(a.M);
     const int tm = (a.M + BM - 1) / BM, Mpad = tm * BM;
     const size_t wb = direct_wp_bytes(a.M, C);
-    if (!ws || ws_bytes < wb) return OTAL_E_UNSUPPORTED;
-    {
+    if (a.pre) {            // packed earlier into a caller-owned region (otal_conv_prologue[_batch]): nothing to do per launch
+        ws = const_cast<void*>(a.pre);
+    } else {
+        if (!ws || ws_bytes < wb) return OTAL_E_UNSUPPORTED;
         const int64_t pairs = (int64_t)Mpad * C * 27 / 2;
         const int blocks = (int)((pairs + 255) / 256 < 2048 ? (pairs + 255) / 256 : 2048);
         hipLaunchKernelGGL((pack_direct_kernel<MODE>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<unsigned*>(ws), a.w,
@@ -2740,7 +2764,7 @@ int prologue_kind(const ConvGeom& g, int mode, int precision) {
     if (mode == MODE_FWD && g.kt == 1 && g.kh == g.Hi && g.kw == g.Wi && g.Hi * g.Wi == 36 && g.Ho == 1 && g.Wo == 1 &&
         g.Cin % 4 == 0 && !OTAL_OPT("OTAL_CONV_NOPROJ", 0)) return 0;       // the projection GEMM reads the fp32 weights in place
     if (conv1a_direct_eligible(g, mode, prec, nullptr)) return 0;
-    if (direct_eligible(g, mode, prec, M)) return 0;     // the direct paths pack per launch (for now)
+    if (direct_eligible(g, mode, prec, M)) return OTAL_OPT("OTAL_CONV_NODIRECTPRE", 0) ? 0 : 3;      // the direct kernel's weight pack
     return chunk_eligible(g, mode, prec) ? 1 : 0;
 }
 int fill_args_for_prologue(ConvArgs& a, const int* geom, const int64_t* strides, int mode, const float* w, int precision) {
@@ -2766,6 +2790,7 @@ extern "C" size_t otal_conv_prologue_bytes(const int* geom, const int64_t* strid
         return chunk_tab_bytes(a.K) + chunk_wp_bytes(a.M, choose_bm(a.M, kwv ? 0 : 1), a.K);
     }
     if (kind == 2) return ptab_bytes(a.g, a.g.sw == 2 ? 8 : wgrad_vector_width(a.g, a.prec));
+    if (kind == 3) return direct_wp_bytes(a.M, mode == MODE_FWD ? a.g.Cin : a.g.Cout);
     return 0;
 }
 
@@ -2792,6 +2817,16 @@ extern "C" int otal_conv_prologue(const int* geom, const int64_t* strides, int m
     }
     if (!w) return OTAL_E_NULL;
     PrepDesc d;
+    if (kind == 3) {
+        d = PrepDesc{};
+        const int BM = direct_bm(a.M);
+        d.wp = reinterpret_cast<unsigned*>(region); d.wsrc = w; d.g = a.g; d.M = a.M; d.Mpad = (a.M + BM - 1) / BM * BM;
+        d.C = mode == MODE_FWD ? a.g.Cin : a.g.Cout; d.natural = a.w_natural; d.mode = mode; d.direct = 1;
+        launch_prep(d, st);
+        if (int e = otal_launch_status()) return e > 0 ? -100 - e : e;
+        if (host_desc) memcpy(host_desc, &d, sizeof(d));
+        return (int)prep_blocks(d);
+    }
     int2* ctab = reinterpret_cast<int2*>(region);
     unsigned short* wp = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(region) + chunk_tab_bytes(a.K));
     if (mode == MODE_FWD) fill_prep_desc<MODE_FWD>(d, a, ctab, wp); else fill_prep_desc<MODE_DGRAD>(d, a, ctab, wp);
