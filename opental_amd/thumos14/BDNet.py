@@ -97,7 +97,20 @@ class ProposalBranch(nn.Module):
         self.roi_conv = _block(proposal_channels, proposal_channels, 1)
         self.proposal_conv = _block(proposal_channels * 4, in_channels, 1)
 
-    def forward(self, feature, frame_level_feature, segments, frame_segments, levels=None):
+    def pool_frame_level(self, frame_level_feature, frame_segments, levels=None):
+        """BoundaryMaxPooling of the frame-level map (BDNet.py:109).  Its inputs are the same for the loc and the conf
+        branch, so CoarsePyramid pools ONCE and hands the result to both (`roi_pooled=`): same values, one forward and
+        one backward launch instead of two (autograd adds the two branches' gradients before the pooling backward)."""
+        from ..prop_pooling import boundary_pooling_op as _bp
+        if levels is not None and _bp.COMPAT_REFERENCE_BWD:
+            # gradient-parity mode: the reference's backward addresses rows with stride N = t_l of each
+            # per-level call (boundary_max_pooling_kernel.cu:121), so pool level by level here
+            return torch.cat([
+                self.boundary_max_pooling(frame_level_feature, frame_segments[:, levels[i]:levels[i + 1]].contiguous())
+                for i in range(len(levels) - 1)], dim=2)
+        return self.boundary_max_pooling(frame_level_feature, frame_segments)
+
+    def forward(self, feature, frame_level_feature, segments, frame_segments, levels=None, roi_pooled=None):
         """`levels` None: one pyramid level, as the reference calls it (BDNet.py:105-113);
         a level table: all levels packed along the last axis."""
         fm_short = self.cur_point_conv(feature, levels)
@@ -106,15 +119,7 @@ class ProposalBranch(nn.Module):
             prop_feature = self.boundary_max_pooling(feature, segments)
         else:
             prop_feature = BoundaryMaxPoolingLevelsFunction.apply(feature, segments, levels, levels)
-        from ..prop_pooling import boundary_pooling_op as _bp
-        if levels is not None and _bp.COMPAT_REFERENCE_BWD:
-            # gradient-parity mode: the reference's backward addresses rows with stride N = t_l of each
-            # per-level call (boundary_max_pooling_kernel.cu:121), so pool level by level here
-            prop_roi_feature = torch.cat([
-                self.boundary_max_pooling(frame_level_feature, frame_segments[:, levels[i]:levels[i + 1]].contiguous())
-                for i in range(len(levels) - 1)], dim=2)
-        else:
-            prop_roi_feature = self.boundary_max_pooling(frame_level_feature, frame_segments)
+        prop_roi_feature = roi_pooled if roi_pooled is not None else self.pool_frame_level(frame_level_feature, frame_segments, levels)
         prop_roi_feature = self.roi_conv(prop_roi_feature, levels)
         prop_feature = torch.cat([prop_roi_feature, prop_feature, fm_short], dim=1)
         prop_feature = self.proposal_conv(prop_feature, levels)
@@ -247,8 +252,12 @@ class CoarsePyramid(nn.Module):
         unct = res[len(raws)] if self.dirichlet_exp else None
         with torch.no_grad():
             segments, frame_segments = ops.proposal_windows(loc.detach(), lev, float(self.frame_num))
-        loc_prop_feat, loc_lr = self.loc_proposal_branch(loc_feat, frame_level_feat, segments, frame_segments, lev)
-        conf_prop_feat, conf_lr = self.conf_proposal_branch(conf_feat, frame_level_feat, segments, frame_segments, lev)
+        from ..prop_pooling import boundary_pooling_op as _bp
+        # compat-gradient mode keeps one pooling per branch: the reference's (buggy) backward runs once per branch, and
+        # bwd(g1) + bwd(g2) is only bit-identical to bwd(g1 + g2) for the correct gradient up to fp32 rounding anyway
+        roi = None if _bp.COMPAT_REFERENCE_BWD else self.loc_proposal_branch.pool_frame_level(frame_level_feat, frame_segments, lev)
+        loc_prop_feat, loc_lr = self.loc_proposal_branch(loc_feat, frame_level_feat, segments, frame_segments, lev, roi)
+        conf_prop_feat, conf_lr = self.conf_proposal_branch(conf_feat, frame_level_feat, segments, frame_segments, lev, roi)
         # The six boundary maps of the output dict are (B,T,C) VIEWS of the channel-major maps (the reference returns
         # permuted copies, BDNet.py:328-331,:392-396; same values): their only consumer, the start / end losses of the
         # training step, reads the channel-major maps in place (ops.BoundaryBCEFunction via OutputDict.boundary_maps).
