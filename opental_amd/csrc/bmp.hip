@@ -8,10 +8,8 @@
 //   * the proposal windows of sample n are decoded (trunc + clamp) once per workgroup into LDS;
 //   * lanes run along k (proposals), so neighbouring lanes scan neighbouring LDS addresses and
 //     the output store is a coalesced row;
-//   * backward is deterministic and free of floating-point atomics: arg-max per (row, proposal) in parallel, then a
-//     segmented gather on ALL lanes -- per chunk of 32 proposals every (row, proposal) lane sets bit k of a per-position
-//     LDS bitmask (integer OR: order-free), and every (row, position) lane adds the gradients of its set bits in
-//     ascending k -- then a coalesced write-out.
+//   * backward is deterministic and atomic-free: arg-max per (row, proposal) in parallel, then one
+//     lane per row adds grad_out into an LDS grad_in tile in ascending k, then a coalesced write-out.
 //   * a level table lets ONE launch pool all pyramid levels (packed along T / N).
 // HBM-bound: bytes = 4*(C*T + C*N) + 16*N per sample forward (kernels/bmp).
 #include "common.h"
@@ -33,7 +31,7 @@ __device__ __forceinline__ void level_of_t(const LevelTab& lt, int i, int& kb, i
 }
 
 // LDS carve (bytes, all 16-aligned)
-struct Carve { int rows, win, g, arg, acc, total; };
+struct Carve { int rows, win, g, arg, total; };
 static Carve carve(int ROWS, int T, int N, bool bwd) {
     auto up = [](int v) { return (v + 15) & ~15; };
     Carve c;
@@ -42,19 +40,46 @@ static Carve carve(int ROWS, int T, int N, bool bwd) {
     c.win = up(ROWS * Tp * 4);
     c.g = c.win + up(N * 16);
     c.arg = c.g + (bwd ? up(ROWS * Np * 4) : 0);
-    c.acc = c.arg + (bwd ? up(ROWS * Np * 4) : 0);
-    c.total = c.acc + (bwd ? up(ROWS * Tp * 4) : 0);
+    c.total = c.arg + (bwd ? up(ROWS * Np * 4) : 0);
     return c;
 }
 
 template <typename T>
 __device__ __forceinline__ void stage_rows(float* rows, const T* src, int nrows, int len, int lenp,
                                            int lx, int tid) {
-    // 2-D thread map without integer division: (1 << lx) lanes along the row, the rest across rows
+    // 2-D thread map without integer division: (1 << lx) lanes along the row, the rest across rows.  Eight rows are
+    // loaded before the first LDS store: with one load in flight per lane (a plain loop: load, wait, store) a 16-row
+    // tile paid 16 HBM latencies back to back, which WAS the kernel's run time.
     const int tx = tid & ((1 << lx) - 1), ty = tid >> lx, ny = 256 >> lx;
-    for (int r = ty; r < nrows; r += ny)
-        for (int i = tx; i < len; i += (1 << lx))
-            rows[r * lenp + i] = ld_f32(src, (size_t)r * len + i);
+    for (int i = tx; i < len; i += (1 << lx)) {
+        int r = ty;
+        for (; r + 7 * ny < nrows; r += 8 * ny) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld_f32(src, (size_t)(r + u * ny) * len + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rows[(r + u * ny) * lenp + i] = v[u];
+        }
+        for (; r < nrows; r += ny) rows[r * lenp + i] = ld_f32(src, (size_t)r * len + i);
+    }
+}
+
+// First maximum of row[l..rr] (strict >, as boundary_max_pooling_kernel.cu:33-40), four elements per trip: indices past
+// rr are clamped to rr -- a repeated element can never beat the running maximum, so value and arg-max are unchanged --
+// which lets the four LDS reads of a trip issue together instead of one dependent read per element.
+__device__ __forceinline__ float window_max(const float* row, int l, int rr, int& arg) {
+    float best = row[l];
+    int a = l;
+    for (int i = l + 1; i <= rr; i += 4) {
+        const int i1 = i + 1 < rr ? i + 1 : rr, i2 = i + 2 < rr ? i + 2 : rr, i3 = i + 3 < rr ? i + 3 : rr;
+        const float v0 = row[i], v1 = row[i1], v2 = row[i2], v3 = row[i3];
+        if (v0 > best) { best = v0; a = i; }
+        if (v1 > best) { best = v1; a = i1; }
+        if (v2 > best) { best = v2; a = i2; }
+        if (v3 > best) { best = v3; a = i3; }
+    }
+    arg = a;
+    return best;
 }
 
 __device__ __forceinline__ void stage_windows(int* win, const float* seg, int N, const LevelTab& lt, int tid) {
@@ -93,12 +118,8 @@ __global__ __launch_bounds__(256) void bmp_fwd_kernel(const T* __restrict__ in, 
         const float* row = rows + r * Tp;
         for (int k = kx; k < Nt; k += (1 << lxN)) {
             const int l = win[k * 4 + which], rr = win[k * 4 + which + 1];
-            float best = row[l];
-            for (int i = l + 1; i <= rr; ++i) {
-                const float v = row[i];
-                if (v > best) best = v;
-            }
-            st_f32(out, (size_t)(row0 + r) * Nt + k, best);
+            int a;
+            st_f32(out, (size_t)(row0 + r) * Nt + k, window_max(row, l, rr, a));
         }
     }
 }
@@ -107,13 +128,12 @@ template <typename T, int ROWS>
 __global__ __launch_bounds__(256) void bmp_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ in,
                                                       const float* __restrict__ seg, T* __restrict__ gin,
                                                       int C, int Tt, int Nt, LevelTab lt, int lxT, int lxN,
-                                                      int off_win, int off_g, int off_arg, int off_acc) {
+                                                      int off_win, int off_g, int off_arg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* rows = reinterpret_cast<float*>(smem);
     int* win = reinterpret_cast<int*>(smem + off_win);
     float* g = reinterpret_cast<float*>(smem + off_g);
     int* arg = reinterpret_cast<int*>(smem + off_arg);
-    float* acc = reinterpret_cast<float*>(smem + off_acc);
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * ROWS;
     const int n = row0 / C, c0 = row0 - n * C;
@@ -130,54 +150,37 @@ __global__ __launch_bounds__(256) void bmp_bwd_kernel(const T* __restrict__ gout
             const float* row = rows + r * Tp;
             for (int k = kx; k < Nt; k += (1 << lxN)) {
                 const int l = win[k * 4 + which], rr = win[k * 4 + which + 1];
-                float best = row[l];
-                int a = l;
-                for (int i = l + 1; i <= rr; ++i) {
-                    const float v = row[i];
-                    if (v > best) { best = v; a = i; }
-                }
+                int a;
+                window_max(row, l, rr, a);
                 arg[r * Np + k] = a;
             }
         }
     }
     __syncthreads();
-    // phase 2: segmented gather in LDS on all 256 lanes.  The input tile is no longer needed: its LDS space becomes a
-    // per-(row, position) bitmask of the proposals whose arg-max is that position, built 32 proposals at a time with
-    // integer ORs (order-free, hence deterministic); the lane that owns a position then adds grad_out of its set bits
-    // in ascending k into the accumulator tile.  Chunks are visited in ascending k too, so every position receives its
-    // contributions in exactly the order of the serial loop `gin[arg[k]] += gout[k]` (bit-identical), at
-    // O(T + N) LDS operations per row spread over the workgroup instead of an N-long dependent chain on one lane.
-    unsigned* mask = reinterpret_cast<unsigned*>(rows);
-    const int tx = tid & ((1 << lxT) - 1), ty = tid >> lxT, nty = 256 >> lxT;
-    for (int i = tid; i < ROWS * Tp; i += 256) acc[i] = 0.f;
-    for (int k0 = 0; k0 < Nt; k0 += 32) {
-        for (int i = tid; i < ROWS * Tp; i += 256) mask[i] = 0u;
-        __syncthreads();
-        const int kn = Nt - k0 < 32 ? Nt - k0 : 32;
-        for (int p = tid; p < ROWS * 32; p += 256) {
-            const int r = p >> 5, kk = p & 31;
-            if (kk < kn) atomicOr(&mask[r * Tp + arg[r * Np + k0 + kk]], 1u << kk);
-        }
-        __syncthreads();
-        for (int r = ty; r < ROWS; r += nty) {
-            const float* gr = g + r * Np + k0;
-            for (int i = tx; i < Tt; i += (1 << lxT)) {
-                unsigned m = mask[r * Tp + i];
-                if (m) {
-                    float a = acc[r * Tp + i];
-                    do {
-                        a += gr[__ffs(m) - 1];
-                        m &= m - 1;
-                    } while (m);
-                    acc[r * Tp + i] = a;
-                }
-            }
-        }
-        __syncthreads();
+    // phase 2: scatter in LDS.  The input tile is no longer needed, its LDS space becomes the grad_in tile.
+    for (int i = tid; i < ROWS * Tp; i += 256) rows[i] = 0.f;
+    __syncthreads();
+    // One lane per row walks the proposals in ascending k and adds grad_out into grad_in[arg-max] -- a
+    // dependent chain per row (rows are independent), entirely in LDS, so every position receives its
+    // contributions in ascending k (deterministic) at O(N) per row instead of O(T*N).
+    // Measured alternatives, all slower on MI355X (level call / frame call, us): this chain 13.7 / 21.3; sixteen lanes
+    // per row, lane j owning the positions = j mod 16 and walking all proposals, 19.6 / 26.3 (LDS issue-bound: every lane
+    // reads every index); fire-and-forget ds_add_f32 from the one lane 20.8 / 32.1; per-position bitmasks of 32 proposals
+    // gathered by (row, position) lanes 29.8 / 30.1.  What did pay was in front of this phase: row staging with eight
+    // loads in flight and the four-wide window scan (17.6 / 31.0 before).
+    if (tid < ROWS) {
+        float* gi = rows + tid * Tp;
+        const int* ar = arg + tid * Np;
+        const float* gr = g + tid * Np;
+        for (int k = 0; k < Nt; ++k) gi[ar[k]] += gr[k];
     }
-    for (int r = ty; r < ROWS; r += nty)
-        for (int i = tx; i < Tt; i += (1 << lxT))
-            st_f32(gin, (size_t)(row0 + r) * Tt + i, acc[r * Tp + i]);
+    __syncthreads();
+    {
+        const int tx = tid & ((1 << lxT) - 1), ty = tid >> lxT, nty = 256 >> lxT;
+        for (int r = ty; r < ROWS; r += nty)
+            for (int i = tx; i < Tt; i += (1 << lxT))
+                st_f32(gin, (size_t)(row0 + r) * Tt + i, rows[r * Tp + i]);
+    }
 }
 
 template <typename T>
@@ -211,7 +214,7 @@ int launch_bwd(const T* gout, const T* in, const float* seg, T* gin, int B, int 
         if (cv.total > 48 * 1024 && R > 2) continue;
         if (cv.total > 64 * 1024) return OTAL_E_UNSUPPORTED;
         const dim3 grid((unsigned)((size_t)B * C / R));
-#define OTAL_BWD(RR) hipLaunchKernelGGL((bmp_bwd_kernel<T, RR>), grid, dim3(256), cv.total, s, gout, in, seg, gin, C, Tt, Nt, lt, lxT, lxN, cv.win, cv.g, cv.arg, cv.acc)
+#define OTAL_BWD(RR) hipLaunchKernelGGL((bmp_bwd_kernel<T, RR>), grid, dim3(256), cv.total, s, gout, in, seg, gin, C, Tt, Nt, lt, lxT, lxN, cv.win, cv.g, cv.arg)
         if (R == 16) OTAL_BWD(16); else if (R == 8) OTAL_BWD(8); else if (R == 4) OTAL_BWD(4); else OTAL_BWD(2);
 #undef OTAL_BWD
         return otal_launch_status();

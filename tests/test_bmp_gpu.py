@@ -50,6 +50,22 @@ def test_ties_keep_lowest_index_and_relu_zeros():
     assert torch.equal(bp.bmp_backward(g.cuda(), x.cuda(), seg.cuda()).cpu(), O.bmp_backward(g, x, seg))
 
 
+def test_backward_denormal_gradients_are_not_flushed():
+    """Subnormal gradients, and sums that land in the subnormal range, must come out as in the serial fp32 loop of the
+    oracle (which does not flush them): guards the LDS accumulation of the backward against flush-to-zero variants
+    (an LDS atomic-add version was tried; it passed this test too but was slower)."""
+    from opental_amd.prop_pooling import boundary_pooling_op as bp
+    rs = np.random.RandomState(11)
+    x, seg, g = _mk(rs, 2, 64, 48, 40)
+    g = (g * 1e-41).float()                     # subnormal inputs, subnormal sums
+    g[:, ::2] = torch.from_numpy((rs.randn(2, 32, 40) * 3e-38).astype(np.float32))      # near the normal / subnormal boundary: sums cancel into it
+    assert float(g.abs().min()) < 1e-38 and bool((g != 0).all())
+    want = O.bmp_backward(g, x, seg)
+    assert bool(((want != 0) & (want.abs() < 1.1754944e-38)).any())
+    got = bp.bmp_backward(g.cuda(), x.cuda(), seg.cuda()).cpu()
+    assert torch.equal(got, want)
+
+
 def test_autograd_function_and_module():
     from opental_amd.prop_pooling.boundary_pooling_op import BoundaryMaxPooling
     rs = np.random.RandomState(5)
