@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 15
+#define OTAL_ABI_VERSION 16
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -259,6 +259,17 @@ int otal_softnms_classes_ws(const float* seg, const float* score, const float* u
                             int A, int K, float sigma, int top_k, float score_threshold, float* out,
                             int* counts, int* out_index, int out_cols, void* scratch, size_t scratch_bytes,
                             int total_clips, void* stream);
+
+/* ------------------------------------------------------------------ gradient hand-over to the backbone ----
+ * dst[b][c][t][s] (+)= (z[b][c][t][s] > 0 ? scale[c] : 0) * src[b][c][t][s]   (scale NULL: 1; accumulate != 0: +=).
+ * Every tensor has its own element strides {batch, channel, frame} and unit stride along s (the H*W plane), so src may be
+ * the swapped-role projection gradient laid out [(b, t)][c][s] and dst / z channel slices of larger buffers.
+ * Replaces what autograd runs between the pyramid projections (AFSD/thumos14/BDNet.py:129-155, :310-319) and the last
+ * Inception modules (AFSD/common/i3d_backbone.py:33-43 F.relu + frozen BatchNorm3d backward): relu backward, the
+ * BatchNorm scale and the contiguous copy of the permuted gradient -- three passes over the map in ATen. */
+int otal_masked_scale_copy(const float* src, const int64_t* src_strides, const float* z, const int64_t* z_strides,
+                           const float* scale, float* dst, const int64_t* dst_strides, int accumulate, int B, int C,
+                           int T, int S, void* stream);
 
 /* ------------------------------------------------------------------ optimizer ----
  * torch.optim.Adam with L2 weight decay (AFSD/thumos14/train.py:321-323) over one flat fp32

@@ -303,18 +303,13 @@ class I3DFeaturesFunction(Function):
         scale, offs, out_pos, nw, need_dx = ctx.meta
         sc = lambda i: scale[offs[i]:offs[i + 1]]
         dws = [None] * nw
-        # external gradients arrive raw at the output of tape step (pos-1): apply that output's
-        # ReLU mask and BN scale once, here (these are the small Mixed_4f / Mixed_5c maps)
+        # external gradients arrive raw at the output of tape step (pos-1); that output's ReLU mask and BN scale are
+        # applied when the walk below reaches the step, in the same launch that moves the gradient into its buffer
+        # (ops.masked_scale_copy: the gradient may be a permuted view, see ops.conv_dgrad_collapse)
         pending = {}
         for pos, g, z in zip(out_pos, douts, ctx.outs):
-            if g is None:
-                continue
-            zs = tape[pos - 1][-1]
-            if zs is not None:
-                g = torch.ops.aten.threshold_backward(g, z, 0.0) * zs.view(1, -1, 1, 1, 1)     # g * (z > 0) * scale
-            else:
-                g = g.contiguous().clone()
-            pending[pos] = pending[pos] + g if pos in pending else g
+            if g is not None:
+                pending.setdefault(pos, []).append((g, z, tape[pos - 1][-1]))
         zg = {}                     # gradient buffers [dh1 | dh2 | dY] of the mixed steps, keyed by tape position
 
         def out_grad_buffer(p, shape, like):
@@ -330,16 +325,23 @@ class I3DFeaturesFunction(Function):
 
         dcur = None
         for pos in range(len(tape), 0, -1):
-            if pos in pending:
-                ext = pending.pop(pos)
+            for g, z, zs in pending.pop(pos, ()):
+                dense = g.dim() == 5 and (g.shape[4] == 1 or g.stride(4) == 1) and (g.shape[3] == 1 or g.stride(3) == g.shape[4])
+                if zs is not None and not dense:
+                    g = g.contiguous()
                 if dcur is None:
-                    if tape[pos - 1][0] == "mixed":
-                        dcur = out_grad_buffer(pos, ext.shape, ext)
-                        dcur.copy_(ext)
+                    if zs is not None:
+                        dcur = out_grad_buffer(pos, g.shape, g)
+                        ops.masked_scale_copy(g, z, zs, dcur)
+                    elif tape[pos - 1][0] == "mixed":
+                        dcur = out_grad_buffer(pos, g.shape, g)
+                        dcur.copy_(g)
                     else:
-                        dcur = ext
+                        dcur = g.contiguous().clone()
+                elif zs is not None:
+                    ops.masked_scale_copy(g, z, zs, dcur, accumulate=True)
                 else:
-                    dcur.add_(ext)
+                    dcur.add_(g)
             if dcur is None:
                 continue
             step = tape[pos - 1]

@@ -313,20 +313,41 @@ def is_full_collapse(x_shape, k, s, spatial_valid):
 
 
 def conv_dgrad_collapse(dy, w, x_shape):
-    """Data gradient of a full-collapse projection as ONE plain GEMM.
+    """Data gradient of a full-collapse projection as ONE plain GEMM with the operands' roles swapped.
 
     Every input element (ci, t, h, w) is reached by exactly one tap, so the generic data-gradient
     gather would visit kh*kw taps to find it (36x redundant work for the [1,6,6] projection).
-    Instead: dx[b, (ci,hw), t] = sum_co W[co, (ci,hw)] * dy[b, co, t] -- a forward-mode 1x1 GEMM
-    with M = Cin*kh*kw, K = Cout on the transposed weights, then (ci,hw,t) -> (ci,t,hw).
-    (Handing the launch a view of w as the natural weight of a 1x1 data gradient instead of the transposed copy was
-    measured: the prologue's strided bf16 pack of the 15.3 M weights costs 0.19 ms against 0.12 ms for this copy.)"""
+    Instead: dx[(b,t)][(ci,hw)] = sum_co dy[b, co, t] * W[co, (ci,hw)] -- a forward-mode 1x1 GEMM whose
+    "activation map" is the WEIGHT, read in place as a (1, Cout, Cin*kh*kw) channel-major tensor (61 MB for the
+    [1,6,6] projection: no transposed copy, no per-step bf16 re-pack of it), and whose "weights" are dy transposed to
+    [(b,t)][co] (1 MB).  The result is returned as a (B,Cin,T,H,W) VIEW of the [(b,t)][ci][hw] product;
+    the backbone's backward un-permutes it inside the launch that applies its ReLU / BatchNorm factor
+    (masked_scale_copy), so the map is never copied on its own.
+    (Round 1 ran the GEMM on a transposed copy of W: 96 us for the copy, 22 us to re-pack it and 37 us to permute the
+    result, around a 49 us GEMM.)"""
     B, Cin, T, H, W = x_shape
     Cout = w.shape[0]
-    wt = w.reshape(Cout, Cin * H * W).t().contiguous().view(Cin * H * W, Cout, 1)
-    dy3 = dy.reshape(B, Cout, T)
-    dxp = conv_forward(dy3, wt, 1, 1)                                   # (B, Cin*H*W, T)
-    return dxp.view(B, Cin, H * W, T).permute(0, 1, 3, 2).contiguous().view(B, Cin, T, H, W)
+    wa = w.detach().reshape(1, Cout, Cin * H * W)
+    dyt = dy.reshape(B, Cout, T).permute(0, 2, 1).reshape(B * T, Cout, 1).contiguous()
+    dxp = conv_forward(wa, dyt, 1, 1)                                   # (1, B*T, Cin*H*W)
+    return dxp.view(B, T, Cin, H, W).permute(0, 2, 1, 3, 4)
+
+
+def masked_scale_copy(src, z, scale, dst, accumulate=False):
+    """dst (+)= (z > 0) * scale[c] * src for (B,C,T,H,W) tensors with dense H x W planes and otherwise arbitrary strides
+    (otal_masked_scale_copy): ReLU + frozen-BN backward, the un-permute of a conv_dgrad_collapse view and the copy into
+    a channel slice, in one pass."""
+    B, C, T, H, W = dst.shape
+    S = H * W
+    for name, t in (("src", src), ("z", z), ("dst", dst)):
+        if not t.is_cuda or t.dtype != torch.float32 or tuple(t.shape) != (B, C, T, H, W):
+            raise RuntimeError(f"masked_scale_copy: {name} must be a float32 GPU tensor of shape {(B, C, T, H, W)}")
+        if (W > 1 and t.stride(4) != 1) or (H > 1 and t.stride(3) != W):
+            raise RuntimeError(f"masked_scale_copy: {name} needs dense H x W planes (strides {t.stride()})")
+    st = lambda t: (ctypes.c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+    L.check(L.lib().otal_masked_scale_copy(L.ptr(src), st(src), L.ptr(z), st(z), _opt(scale), L.ptr(dst), st(dst),
+                                           int(accumulate), B, C, T, S, L.stream()), "otal_masked_scale_copy")
+    return dst
 
 
 class GradSlots:

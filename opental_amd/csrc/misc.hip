@@ -1,5 +1,5 @@
 // opental_amd/csrc/misc.hip -- small fused kernels of the detection path: proposal-window index
-// math (bit-exact), flat Adam.
+// math (bit-exact), flat Adam, the masked / scaled strided copy that hands the pyramid's gradients to the backbone.
 #include "common.h"
 
 namespace {
@@ -82,6 +82,45 @@ __global__ __launch_bounds__(256) void adam_flat_dev_kernel(float* __restrict__ 
     }
 }
 
+
+// dst[b][c][t][s] (+)= (z[b][c][t][s] > 0 ? scale[c] : 0) * src[b][c][t][s], every tensor with its own (batch, channel, frame)
+// strides and unit stride along s (the H*W plane): the ReLU + frozen-BN backward that I3DFeaturesFunction.backward applies
+// to the gradients arriving at Mixed_4f / Mixed_5c (aten threshold_backward + mul + copy_ = 3 launches over the map) fused
+// with the un-permute of the projection's data gradient, which the swapped-role GEMM leaves as [(b, t)][c][s]
+// (ops.conv_dgrad_collapse) -- one pass, 12 bytes per element.  V = 4: S % 4 == 0 and 16-byte aligned rows.
+struct Strides3 { int64_t b, c, t; };
+template <int V>
+__global__ __launch_bounds__(256) void masked_scale_copy_kernel(const float* __restrict__ src, Strides3 ss, const float* __restrict__ z,
+                                                                Strides3 zs, const float* __restrict__ scale, float* __restrict__ dst,
+                                                                Strides3 ds, int C, int T, int S, int64_t total, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int SV = S / V;
+    const int sv = (int)(i % SV);
+    int64_t r = i / SV;
+    const int t = (int)(r % T); r /= T;
+    const int c = (int)(r % C);
+    const int64_t b = r / C;
+    const int64_t so = b * ss.b + c * ss.c + t * ss.t + sv * V, zo = b * zs.b + c * zs.c + t * zs.t + sv * V,
+                  dz = b * ds.b + c * ds.c + t * ds.t + sv * V;
+    const float k = scale ? scale[c] : 1.f;
+    if (V == 4) {
+        const float4 g = *reinterpret_cast<const float4*>(src + so);
+        const float4 m = *reinterpret_cast<const float4*>(z + zo);
+        float4 o;
+        o.x = m.x > 0.f ? g.x * k : 0.f; o.y = m.y > 0.f ? g.y * k : 0.f;
+        o.z = m.z > 0.f ? g.z * k : 0.f; o.w = m.w > 0.f ? g.w * k : 0.f;
+        if (accumulate) {
+            const float4 d = *reinterpret_cast<const float4*>(dst + dz);
+            o.x = d.x + o.x; o.y = d.y + o.y; o.z = d.z + o.z; o.w = d.w + o.w;
+        }
+        *reinterpret_cast<float4*>(dst + dz) = o;
+    } else {
+        const float o = z[zo] > 0.f ? src[so] * k : 0.f;
+        dst[dz] = accumulate ? dst[dz] + o : o;
+    }
+}
+
 }  // namespace
 
 extern "C" int otal_proposal_windows(const float* loc, float* seg, float* frame_seg, int B, int nlev,
@@ -121,5 +160,23 @@ extern "C" int otal_adam_flat_dev(float* p, const float* g, float* m, float* v, 
     const int blocks = (int)(blocks64 < 4096 ? blocks64 : 4096);
     hipLaunchKernelGGL(adam_flat_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
                        beta2, eps, weight_decay, bias_corr, grad_scale);
+    return otal_launch_status();
+}
+
+extern "C" int otal_masked_scale_copy(const float* src, const int64_t* src_strides, const float* z, const int64_t* z_strides,
+                                      const float* scale, float* dst, const int64_t* dst_strides, int accumulate, int B, int C,
+                                      int T, int S, void* stream) {
+    if (!src || !z || !dst || !src_strides || !z_strides || !dst_strides) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || S <= 0) return OTAL_E_SHAPE;
+    const Strides3 ss{src_strides[0], src_strides[1], src_strides[2]}, zs{z_strides[0], z_strides[1], z_strides[2]},
+                   ds{dst_strides[0], dst_strides[1], dst_strides[2]};
+    auto vec_ok = [&](const void* p, const Strides3& q) {
+        return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && q.b % 4 == 0 && q.c % 4 == 0 && q.t % 4 == 0;
+    };
+    const bool v4 = S % 4 == 0 && vec_ok(src, ss) && vec_ok(z, zs) && vec_ok(dst, ds);
+    const int64_t total = (int64_t)B * C * T * (v4 ? S / 4 : S);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (v4) hipLaunchKernelGGL(masked_scale_copy_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, src, ss, z, zs, scale, dst, ds, C, T, S, total, accumulate);
+    else hipLaunchKernelGGL(masked_scale_copy_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, src, ss, z, zs, scale, dst, ds, C, T, S, total, accumulate);
     return otal_launch_status();
 }

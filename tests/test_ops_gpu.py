@@ -771,3 +771,50 @@ def test_direct_conv_two_position_tiles_per_wave(shape, cout):
     close(res[0][0], yref)
     close(res[0][1], dxref)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,T,H,W", [(2, 48, 8, 6, 6), (3, 40, 5, 3, 3), (1, 7, 3, 1, 1)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_masked_scale_copy_matches_aten(B, C, T, H, W, accumulate):
+    """otal_masked_scale_copy = aten threshold_backward * scale (+ add) on a PERMUTED source view ([(b,t)][c][hw], what
+    ops.conv_dgrad_collapse returns) with channel-sliced mask and destination: bit-identical (one multiply, one add)."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(B * 100 + C + T)
+    src = torch.from_numpy(rs.randn(B, T, C, H, W).astype(np.float32)).cuda().permute(0, 2, 1, 3, 4)
+    zb = torch.from_numpy(rs.randn(B, C + 12, T, H, W).astype(np.float32)).cuda().clamp(min=0)
+    z = zb[:, 8:8 + C]
+    scale = torch.from_numpy(rs.uniform(0.5, 2.0, C).astype(np.float32)).cuda()
+    db = torch.from_numpy(rs.randn(B, C + 4, T, H, W).astype(np.float32)).cuda()
+    dst = db[:, 4:]
+    before = db.clone()
+    want = torch.ops.aten.threshold_backward(src.contiguous(), z.contiguous(), 0.0) * scale.view(1, -1, 1, 1, 1)
+    if accumulate:
+        want = before[:, 4:] + want
+    ops.masked_scale_copy(src, z, scale, dst, accumulate=accumulate)
+    assert torch.equal(dst, want)
+    assert torch.equal(db[:, :4], before[:, :4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("shape,cout,k", [((2, 832, 64, 6, 6), 512, (1, 6, 6)), ((2, 1024, 32, 3, 3), 512, (1, 3, 3)), ((3, 40, 7, 6, 6), 24, (1, 6, 6))])
+def test_projection_data_gradient_swapped_roles(shape, cout, k, prec):
+    """ops.conv_dgrad_collapse (the weight as the GEMM's activation map, dy as its weights, result returned as a permuted
+    view) against conv3d's input gradient -- 1e-4 on the fp32 path, and on bf16-rounded operands on the bf16 path."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape) + cout)
+    B, cin, T, H, W = shape
+    w = torch.from_numpy((rs.randn(cout, cin, *k) / np.sqrt(cin * H * W)).astype(np.float32))
+    dy = torch.from_numpy(rs.randn(B, cout, T, 1, 1).astype(np.float32))
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = prec
+    try:
+        dx = ops.conv_dgrad_collapse(dy.cuda(), w.cuda(), shape)
+    finally:
+        ops.CONV_PRECISION = old
+    assert tuple(dx.shape) == tuple(shape)
+    wr, dyr = (_bf16_round(w), _bf16_round(dy)) if prec else (w, dy)
+    x = torch.zeros(shape, requires_grad=True)
+    F.conv3d(x, wr).backward(dyr)
+    close(dx, x.grad)
