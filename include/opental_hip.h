@@ -260,6 +260,25 @@ int otal_softnms_classes_ws(const float* seg, const float* score, const float* u
                             int* counts, int* out_index, int out_cols, void* scratch, size_t scratch_bytes,
                             int total_clips, void* stream);
 
+/* ------------------------------------------------------------------ detection-head convolutions ----
+ * The skinny Unit1D heads of one CoarsePyramid stage (AFSD/thumos14/BDNet.py:205-272, :337-353, :399-412;
+ * AFSD/common/layers.py:178-214: SAME pad + nn.Conv1d(512, cout, k) + bias, cout = 1 / 2 / num_classes, k = 1 / 3) as
+ * fp32 FMA kernels over LDS-staged (B, C, N) windows: ONE launch for the forward of all heads of a stage, TWO for their
+ * backward (data gradients summed per input map; weight + bias gradients without split-K).
+ *   head h reads input map x[in_idx[h]] (B, C, N), has weights w[h] (cout[h], C, ksize[h]) and bias[h] (cout[h]) or NULL,
+ *   writes y[h] (B, cout[h], N).  lev (nlev + 1 column starts, or nlev <= 1): taps never cross a level boundary.
+ *   backward: dy[h] (B, cout[h], N) or NULL (= zeros); dx[j] (B, C, N) or NULL (not needed) receives the SUM over the
+ *   heads on input j; dw[h] like w[h]; db[h] (cout[h]) or NULL.  Plain stores, nothing is accumulated into.
+ * Limits: C % 16 == 0, at most 8 heads on 4 inputs, at most 21 output channels per input, ksize 1 or 3;
+ * otal_head_convs_supported() != 0 says the launches fit (callers fall back to otal_conv_* otherwise). */
+int otal_head_convs_supported(int n_heads, int n_inputs, const int* in_idx, const int* cout, const int* ksize, int B, int C, int N);
+int otal_head_convs_fwd(int n_heads, int n_inputs, const int* in_idx, const int* cout, const int* ksize,
+                        const float* const* x, const float* const* w, const float* const* bias, float* const* y, int B, int C,
+                        int N, int nlev, const int* lev, void* stream);
+int otal_head_convs_bwd(int n_heads, int n_inputs, const int* in_idx, const int* cout, const int* ksize,
+                        const float* const* x, const float* const* w, const float* const* dy, float* const* dx,
+                        float* const* dw, float* const* db, int B, int C, int N, int nlev, const int* lev, void* stream);
+
 /* ------------------------------------------------------------------ gradient hand-over to the backbone ----
  * dst[b][c][t][s] (+)= (z[b][c][t][s] > 0 ? scale[c] : 0) * src[b][c][t][s]   (scale NULL: 1; accumulate != 0: +=).
  * Every tensor has its own element strides {batch, channel, frame} and unit stride along s (the H*W plane), so src may be

@@ -691,6 +691,90 @@ class HeadOutputsFunction(torch.autograd.Function):
         return (None, None, None) + tuple(aligned[l, :1] for l in range(nlev)) + tuple(draws)
 
 
+# ----------------------------------------------------------------------------- detection-head convolutions
+def _hc_meta(heads, n_inputs):
+    n = len(heads)
+    return (n, n_inputs, L.int_array([h[0] for h in heads]), L.int_array([h[1] for h in heads]), L.int_array([h[2] for h in heads]))
+
+
+def head_convs_supported(heads, n_inputs, B, C, N):
+    """heads: [(input index, cout, k)].  True when the heads of a stage fit the fused launches (csrc/headconv.hip)."""
+    if not 1 <= len(heads) <= 8 or not 1 <= n_inputs <= 4:
+        return False
+    n, ni, idx, co, ks = _hc_meta(heads, n_inputs)
+    return bool(L.lib().otal_head_convs_supported(n, ni, idx, co, ks, int(B), int(C), int(N)))
+
+
+class HeadConvsFunction(torch.autograd.Function):
+    """The Unit1D heads of one CoarsePyramid stage (BDNet.py:337-353 / :399-412) -- conv1d(512, cout, k) + bias with
+    cout = 1 / 2 / num_classes -- in one launch forward and two backward (otal_head_convs_fwd / _bwd).
+
+    apply(levels, heads, n_inputs, *tensors): heads = ((input index, k), ...); tensors = the n_inputs feature maps
+    (B, C, N), then every head's weight (cout, C, k), then every head's bias.  Returns the raw maps (B, cout, N)."""
+
+    @staticmethod
+    def forward(ctx, levels, heads, n_inputs, *tensors):
+        nh = len(heads)
+        xs = [t.contiguous() for t in tensors[:n_inputs]]
+        ws = list(tensors[n_inputs:n_inputs + nh])
+        bs = list(tensors[n_inputs + nh:n_inputs + 2 * nh])
+        L.require_device(*xs, *ws, *[b for b in bs if b is not None])
+        B, C, N = xs[0].shape
+        spec = [(heads[i][0], int(ws[i].shape[0]), int(heads[i][1])) for i in range(nh)]
+        for (j, co, k), w in zip(spec, ws):
+            if tuple(w.shape) != (co, C, k) or tuple(xs[j].shape) != (B, C, N) or w.dtype != torch.float32:
+                raise RuntimeError("head_convs: weight / input shapes do not match")
+        meta = _hc_meta(spec, n_inputs)
+        nlev, lev = _lev_arg(levels)
+        ys = [torch.empty((B, co, N), dtype=torch.float32, device=xs[0].device) for _, co, _ in spec]
+        VP = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+        L.check(L.lib().otal_head_convs_fwd(*meta, VP(xs), VP(ws), VP(bs), VP(ys), B, C, N, nlev, lev, L.stream()),
+                "otal_head_convs_fwd")
+        ctx.cfg = (meta, nlev, lev, n_inputs, nh, (B, C, N), [b is not None for b in bs])
+        ctx.save_for_backward(*xs, *ws)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        meta, nlev, lev, n_inputs, nh, (B, C, N), has_bias = ctx.cfg
+        saved = ctx.saved_tensors
+        xs, ws = list(saved[:n_inputs]), list(saved[n_inputs:])
+        dys = [None if g is None else g.contiguous() for g in dys]
+        dxs = [torch.empty_like(x) if ctx.needs_input_grad[3 + j] else None for j, x in enumerate(xs)]
+        dws = []
+        for w in ws:
+            slot = grad_slot(w)
+            dws.append(slot if slot is not None else torch.empty_like(w))
+        dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if hb else None for w, hb in zip(ws, has_bias)]
+        VP = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+        L.check(L.lib().otal_head_convs_bwd(*meta, VP(xs), VP(ws), VP(dys), VP(dxs), VP(dws), VP(dbs), B, C, N, nlev, lev, L.stream()),
+                "otal_head_convs_bwd")
+        return (None, None, None) + tuple(dxs) + tuple(dws) + tuple(dbs)
+
+
+def head_convs(levels, items):
+    """items: [(feature map (B,C,N), Unit1D head)] -> raw maps, or None when the fused launches do not cover the stage
+    (e.g. the 150-class ActivityNet heads): the caller then runs the heads one by one."""
+    maps, heads = [], []
+    for x, unit in items:
+        j = next((i for i, m in enumerate(maps) if m is x), None)
+        if j is None:
+            j = len(maps)
+            maps.append(x)
+        conv = unit.conv1d
+        k = conv.kernel_size[0]
+        if conv.stride[0] != 1 or k not in (1, 3) or x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda:
+            return None
+        heads.append((j, k, conv))
+    B, C, N = maps[0].shape
+    if any(tuple(m.shape) != (B, C, N) for m in maps) or C % 16:
+        return None
+    if not head_convs_supported([(j, conv.out_channels, k) for j, k, conv in heads], len(maps), B, C, N):
+        return None
+    return HeadConvsFunction.apply(None if levels is None else tuple(levels), tuple((j, k) for j, k, _ in heads), len(maps),
+                                   *maps, *[c.weight for _, _, c in heads], *[c.bias for _, _, c in heads])
+
+
 # ----------------------------------------------------------------------------- boundary (start / end) losses
 class BoundaryBCEFunction(torch.autograd.Function):
     """(loss_start, loss_end) = calc_bce_loss on the two channel halves of x (B,C,T), read in place (x may be a slice along

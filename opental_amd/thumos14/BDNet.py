@@ -243,9 +243,12 @@ class CoarsePyramid(nn.Module):
         # (csrc/heads.hip): the coarse stage here, the refined stage after the proposal branches.
         scales = [h.scale for h in self.loc_heads]
         um = 2 if self.dirichlet_exp else 0
-        raws = [self.loc_head(loc_feat, lev), self.conf_head(self._drop(conf_feat), lev)]
+        # the skinny heads of a stage: one fused launch (csrc/headconv.hip) where it applies, else head by head
+        stage = [(loc_feat, self.loc_head), (self._drop(conf_feat), self.conf_head)]
         if self.os_head:
-            raws.append(self.actionness_head(conf_feat, lev))
+            stage.append((conf_feat, self.actionness_head))
+        raws = ops.head_convs(lev, stage)
+        raws = list(raws) if raws is not None else [head(x, lev) for x, head in stage]
         res = ops.HeadOutputsFunction.apply(tuple(lev), self.fpn_strides, (1, um, 0)[:len(raws)], *scales, *raws)
         loc, conf = res[0], res[1]
         act = res[2] if self.os_head else None
@@ -269,9 +272,11 @@ class CoarsePyramid(nn.Module):
         start_loc_prop, end_loc_prop = pv(loc_lr[:, :ndim, :t0]), pv(loc_lr[:, ndim:, :t0])
         start_conf_prop, end_conf_prop = pv(conf_lr[:, :ndim, :t0]), pv(conf_lr[:, ndim:, :t0])
         boundary_maps = (frame_level_feat, loc_lr[:, :, :t0], conf_lr[:, :, :t0])
-        raws = [self.prop_loc_head(loc_prop_feat), self.prop_conf_head(self._drop(conf_prop_feat)), self.center_head(loc_prop_feat, lev)]
+        stage = [(loc_prop_feat, self.prop_loc_head), (self._drop(conf_prop_feat), self.prop_conf_head), (loc_prop_feat, self.center_head)]
         if self.os_head:
-            raws.append(self.prop_actionness_head(conf_prop_feat))
+            stage.append((conf_prop_feat, self.prop_actionness_head))
+        raws = ops.head_convs(lev, stage)
+        raws = list(raws) if raws is not None else [head(x, lev) if head._kernel_shape != 1 else head(x) for x, head in stage]
         res = ops.HeadOutputsFunction.apply(tuple(lev), None, (0, um, 0, 0)[:len(raws)], *[h.detach() for h in scales], *raws)
         prop_loc, prop_conf, center = res[0], res[1], res[2]
         prop_act = res[3] if self.os_head else None

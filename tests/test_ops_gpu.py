@@ -818,3 +818,58 @@ def test_projection_data_gradient_swapped_roles(shape, cout, k, prec):
     x = torch.zeros(shape, requires_grad=True)
     F.conv3d(x, wr).backward(dyr)
     close(dx, x.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,N,lev", [(8, 512, 126, (0, 64, 96, 112, 120, 124, 126)), (2, 64, 37, None), (3, 48, 16, (0, 8, 12, 14, 15, 16))])
+@pytest.mark.parametrize("stage", ["coarse", "refined"])
+def test_fused_head_convs_match_conv1d(B, C, N, lev, stage):
+    """csrc/headconv.hip: the heads of a CoarsePyramid stage in one launch forward / two backward against F.conv1d with
+    SAME zero padding per pyramid level (fp32, 1e-5 of scale): outputs, the summed input gradients, weight and bias
+    gradients; one head without an incoming gradient (dy = None -> zeros)."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(B * 1000 + C + N)
+    heads = [(0, 2, 3), (1, 15, 3), (1, 1, 3)] if stage == "coarse" else [(0, 2, 1), (1, 15, 1), (0, 1, 3), (1, 1, 1)]
+    xs = [torch.from_numpy(rs.randn(B, C, N).astype(np.float32)) for _ in range(2)]
+    ws = [torch.from_numpy((rs.randn(co, C, k) / np.sqrt(C * k)).astype(np.float32)) for _, co, k in heads]
+    bs = [torch.from_numpy(rs.randn(co).astype(np.float32)) for _, co, _ in heads]
+    dys = [torch.from_numpy(rs.randn(B, co, N).astype(np.float32)) for _, co, _ in heads]
+    skip = len(heads) - 1                       # the last head receives no gradient
+    bounds = list(lev) if lev is not None else [0, N]
+
+    def reference():
+        xr = [x.clone().requires_grad_(True) for x in xs]
+        wr = [w.clone().requires_grad_(True) for w in ws]
+        br = [b.clone().requires_grad_(True) for b in bs]
+        ys = []
+        for (j, co, k), w, b in zip(heads, wr, br):
+            ys.append(torch.cat([F.conv1d(F.pad(xr[j][:, :, lo:hi], (k // 2, k // 2)), w, b) for lo, hi in zip(bounds[:-1], bounds[1:])], 2))
+        torch.autograd.backward([y for i, y in enumerate(ys) if i != skip], [g for i, g in enumerate(dys) if i != skip])
+        return ys, xr, wr, br
+
+    ys_r, xr, wr, br = reference()
+    assert ops.head_convs_supported(heads, 2, B, C, N)
+    xd = [x.cuda().requires_grad_(True) for x in xs]
+    wd = [w.cuda().requires_grad_(True) for w in ws]
+    bd = [b.cuda().requires_grad_(True) for b in bs]
+    ys = ops.HeadConvsFunction.apply(lev, tuple((j, k) for j, _, k in heads), 2, *xd, *wd, *bd)
+    torch.autograd.backward([y for i, y in enumerate(ys) if i != skip], [g.cuda() for i, g in enumerate(dys) if i != skip])
+    for y, yr in zip(ys, ys_r):
+        close(y, yr, tol=1e-5)
+    for a, b_ in zip(xd, xr):
+        close(a.grad, b_.grad, tol=1e-5)
+    for i, (a, b_) in enumerate(zip(wd, wr)):
+        if i == skip:
+            assert float(a.grad.abs().max()) == 0.0
+        else:
+            close(a.grad, b_.grad, tol=2e-5)
+    for i, (a, b_) in enumerate(zip(bd, br)):
+        if i != skip:
+            close(a.grad, b_.grad, tol=2e-5)
+
+
+@pytest.mark.gpu
+def test_fused_head_convs_decline_wide_heads():
+    """150-class ActivityNet heads do not fit (more than 21 rows on one input): the caller runs them one by one."""
+    from opental_amd.common import ops
+    assert not ops.head_convs_supported([(0, 2, 3), (1, 150, 3), (1, 1, 3)], 2, 2, 512, 189)
