@@ -10,8 +10,9 @@
 // a forward launch plus SIX backward launches (weight transpose, tap table, data gradient, weight gradient, split-K
 // reduce, bias sum) of 4-12 us each -- 49 launches and 0.38 ms per step for 56 MFLOP.  Here the heads of a stage are plain
 // fp32 FMA loops over LDS-staged (B, C, T) windows, as the north star asks for the temporal heads:
-//   * forward : a workgroup owns 16 positions of one sample and one head; the 512 x 18 input window is staged once in LDS
-//               (odd pitch), thread (co, ci mod 16) walks its channels, 16-lane shuffles finish the sums;
+//   * forward : a workgroup owns 8 positions of one sample and one head; the 512 x 10 input window is staged once in LDS,
+//               thread (co, ci mod 16) walks its channels with its weights prefetched through registers, 16-lane shuffles
+//               finish the sums;
 //   * dgrad   : a workgroup owns 16 input channels of one sample and one input map; the output gradients of ALL heads on
 //               that map (<= 21 rows, zero halo) and their weight slices sit in LDS; one coalesced store per element, the
 //               heads' contributions summed in a fixed order;
@@ -25,7 +26,7 @@
 namespace {
 
 constexpr int HC_MAX_HEADS = 8, HC_MAX_INPUTS = 4, HC_MAX_ROWS = 21;    // rows = output channels of all heads on one input
-constexpr int HC_P = 16;                                                 // positions per forward workgroup
+constexpr int HC_P = 8;                                                  // positions per forward workgroup
 
 struct HcLevels { int nlev; int lev[OTAL_MAX_LEVELS + 1]; };
 struct HcArgs {
@@ -51,30 +52,41 @@ __device__ __forceinline__ void level_bounds(const HcLevels& L, int n, int& lo, 
         if (j < L.nlev && n >= L.lev[j]) { lo = L.lev[j]; hi = L.lev[j + 1]; }
 }
 
+// Global -> LDS staging with U loads of a lane in flight before its first LDS store.  These kernels are pure latency: a plain
+// `lds[f(e)] = global[g(e)]` loop keeps one load in flight per lane and pays one memory round trip per element it owns
+// (the first version of the weight-gradient kernel spent 30 of its 40 us that way).
+template <int U, typename Ld, typename St>
+__device__ __forceinline__ void stage_batched(int tid, int total, Ld ld, St st) {
+    for (int e0 = tid; e0 < total; e0 += U * 256) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * 256;
+            v[u] = e < total ? ld(e) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * 256;
+            if (e < total) st(e, v[u]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
-// grid (ceil(N / 16), B, n_heads); LDS: C x 19 floats
+// grid (ceil(N / 8), B, n_heads); LDS: C x 12 floats
 __global__ __launch_bounds__(256) void head_convs_fwd_kernel(const HcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float hsm[];
-    constexpr int PITCH = HC_P + 3;                     // 18 columns used (one halo column each side), odd pitch
+    constexpr int PITCH = HC_P + 4;                     // 10 columns used (one halo column each side); 48-byte rows:
+                                                        // 16-byte aligned and conflict-free for ds_read_b128
     const int tid = threadIdx.x, h = blockIdx.z, b = blockIdx.y, n0 = blockIdx.x * HC_P;
     const int C = a.C, N = a.N, k = a.k[h], cout = a.cout[h];
     const float* __restrict__ x = a.x[a.in_idx[h]] + (size_t)b * C * N;
-    // stage x[b][:, n0 - 1 .. n0 + 16]; columns outside [0, N) read as zero
-    for (int e0 = tid; e0 < C * (HC_P + 2); e0 += 8 * 256) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * 256;
-            const int ci = e / (HC_P + 2), j = e - ci * (HC_P + 2), n = n0 - 1 + j;
-            v[u] = (e < C * (HC_P + 2) && n >= 0 && n < N) ? x[(size_t)ci * N + n] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * 256;
-            const int ci = e / (HC_P + 2), j = e - ci * (HC_P + 2);
-            if (e < C * (HC_P + 2)) hsm[ci * PITCH + j] = v[u];
-        }
-    }
+    // stage x[b][:, n0 - 1 .. n0 + 8] in one memory round trip (20 loads in flight per lane at C = 512); columns outside
+    // [0, N) read as zero; columns 10, 11 of a row are never read
+    stage_batched<24>(tid, C * (HC_P + 2),
+                     [&](int e) { const int ci = e / (HC_P + 2), n = n0 - 1 + e - ci * (HC_P + 2);
+                                  return (n >= 0 && n < N) ? x[(size_t)ci * N + n] : 0.f; },
+                     [&](int e, float v) { const int ci = e / (HC_P + 2); hsm[ci * PITCH + e - ci * (HC_P + 2)] = v; });
     // validity of the left / right tap of each position (a tap stays inside its level)
     unsigned lmask = 0, rmask = 0;
 #pragma unroll
@@ -94,24 +106,49 @@ __global__ __launch_bounds__(256) void head_convs_fwd_kernel(const HcArgs a) {
         float acc[HC_P];
 #pragma unroll
         for (int p = 0; p < HC_P; ++p) acc[p] = 0.f;
-        for (int ci = cl; ci < C; ci += 16) {
-            const float* row = hsm + ci * PITCH;
-            float f[HC_P + 2];
+        // the lane's weights travel through registers one chunk (8 channel steps = 128 channels) ahead of their use:
+        // loaded inside the loop they cost one L2 round trip per channel step
+        constexpr int CH = 8;
+        float wc[CH][3], wn[CH][3];
+        auto load_w = [&](float (&dst)[CH][3], int ci0) {
 #pragma unroll
-            for (int j = 0; j < HC_P + 2; ++j) f[j] = row[j];
-            if (k == 3) {
-                const float w0 = live ? w[ci * 3 + 0] : 0.f, w1 = live ? w[ci * 3 + 1] : 0.f, w2 = live ? w[ci * 3 + 2] : 0.f;
+            for (int i = 0; i < CH; ++i) {
+                const int ci = ci0 + 16 * i;
+                const bool ok = live && ci < C;
 #pragma unroll
-                for (int p = 0; p < HC_P; ++p) {
-                    acc[p] = fmaf(w0, (lmask >> p) & 1u ? f[p] : 0.f, acc[p]);
-                    acc[p] = fmaf(w1, f[p + 1], acc[p]);
-                    acc[p] = fmaf(w2, (rmask >> p) & 1u ? f[p + 2] : 0.f, acc[p]);
-                }
-            } else {
-                const float w0 = live ? w[ci] : 0.f;
-#pragma unroll
-                for (int p = 0; p < HC_P; ++p) acc[p] = fmaf(w0, f[p + 1], acc[p]);
+                for (int t = 0; t < 3; ++t) dst[i][t] = (ok && t < k) ? w[ci * k + t] : 0.f;
             }
+        };
+        load_w(wc, cl);
+        for (int ci0 = cl; ci0 < C; ci0 += 16 * CH) {
+            if (ci0 + 16 * CH < C) load_w(wn, ci0 + 16 * CH);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int ci = ci0 + 16 * i;
+                if (ci >= C) break;
+                const float4* row = reinterpret_cast<const float4*>(hsm + ci * PITCH);
+                float f[HC_P + 4];
+#pragma unroll
+                for (int q = 0; q < (HC_P + 4) / 4; ++q) {
+                    const float4 v = row[q];
+                    f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+                }
+                if (k == 3) {
+#pragma unroll
+                    for (int p = 0; p < HC_P; ++p) {
+                        acc[p] = fmaf(wc[i][0], (lmask >> p) & 1u ? f[p] : 0.f, acc[p]);
+                        acc[p] = fmaf(wc[i][1], f[p + 1], acc[p]);
+                        acc[p] = fmaf(wc[i][2], (rmask >> p) & 1u ? f[p + 2] : 0.f, acc[p]);
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < HC_P; ++p) acc[p] = fmaf(wc[i][0], f[p + 1], acc[p]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) wc[i][t] = wn[i][t];
         }
         float mine = 0.f;
 #pragma unroll
@@ -121,7 +158,7 @@ __global__ __launch_bounds__(256) void head_convs_fwd_kernel(const HcArgs a) {
             if (cl == p) mine = v;
         }
         const int n = n0 + cl;
-        if (live && n < N) a.y[h][((size_t)b * cout + co) * N + n] = mine + (a.bias[h] ? a.bias[h][co] : 0.f);
+        if (live && cl < HC_P && n < N) a.y[h][((size_t)b * cout + co) * N + n] = mine + (a.bias[h] ? a.bias[h][co] : 0.f);
     }
 }
 
@@ -138,18 +175,27 @@ __global__ __launch_bounds__(256) void head_convs_dgrad_kernel(const HcArgs a) {
         if (a.in_idx[h] != j) continue;
         const int cout = a.cout[h], k = a.k[h], r0 = a.row0[h];
         const float* dy = a.dy[h] ? a.dy[h] + (size_t)b * cout * N : nullptr;
-        for (int e = tid; e < cout * NP; e += 256) {
-            const int co = e / NP, q = e - co * NP, n = q - 1;
-            g[(r0 + co) * NP + q] = (dy && n >= 0 && n < N) ? dy[(size_t)co * N + n] : 0.f;
-        }
-        for (int e = tid; e < cout * 48; e += 256) {
-            const int co = e / 48, r = e - co * 48, tap = r >> 4, ci = r & 15;
-            // k = 1: the single tap sits in the centre slot
-            float v = 0.f;
-            if (k == 3) v = a.w[h][((size_t)co * C + c0 + ci) * 3 + tap];
-            else if (tap == 1) v = a.w[h][(size_t)co * C + c0 + ci];
-            wt[(r0 + co) * 48 + r] = v;
-        }
+        const float* wh = a.w[h];
+        for (int co = tid >> 5; co < cout; co += 8)              // thread (row mod 8, column mod 32): no runtime division
+            for (int q0 = 0; q0 < NP; q0 += 256) {
+                float v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int q = q0 + (tid & 31) + 32 * t, n = q - 1;
+                    v[t] = (dy && q < NP && n >= 0 && n < N) ? dy[(size_t)co * N + n] : 0.f;
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int q = q0 + (tid & 31) + 32 * t;
+                    if (q < NP) g[(r0 + co) * NP + q] = v[t];
+                }
+            }
+        // k = 1: the single tap sits in the centre slot
+        stage_batched<4>(tid, cout * 48,
+                         [&](int e) { const int co = e / 48, r = e - co * 48, tap = r >> 4, ci = r & 15;
+                                      if (k == 3) return wh[((size_t)co * C + c0 + ci) * 3 + tap];
+                                      return tap == 1 ? wh[(size_t)co * C + c0 + ci] : 0.f; },
+                         [&](int e, float v) { const int co = e / 48; wt[(r0 + co) * 48 + e - co * 48] = v; });
     }
     __syncthreads();
     const int ci = tid >> 4, nl = tid & 15;
@@ -181,30 +227,69 @@ __global__ __launch_bounds__(256) void head_convs_wgrad_kernel(const HcArgs a) {
     float* xs = hsm;                        // [3 taps][4 ci][B * N]
     float* gt = hsm + 12 * BN;              // [B * N][RP]
     const float* __restrict__ x = a.x[j];
-    for (int e = tid; e < 4 * BN; e += 256) {
-        const int ci = e / BN, q = e - ci * BN, b = q / N, n = q - b * N;
-        int lo, hi;
-        level_bounds(a.L, n, lo, hi);
-        const float* row = x + ((size_t)b * C + c0 + ci) * N;
-        const float c = row[n], l = n > lo ? row[n - 1] : 0.f, r = n + 1 < hi ? row[n + 1] : 0.f;
-        xs[(0 * 4 + ci) * BN + q] = l;
-        xs[(1 * 4 + ci) * BN + q] = c;
-        xs[(2 * 4 + ci) * BN + q] = r;
-    }
+    // Centre windows and transposed gradients from HBM / L2.  Thread (b mod 8, n mod 32): no integer division per element
+    // (a flat index cost three runtime divisions ~ 120 VALU instructions per element: 10 us of a 40 us kernel), sixteen
+    // loads in flight per lane.
+    const int bl = tid >> 5, nl = tid & 31;
+    for (int b = bl; b < B; b += 8)
+        for (int n0 = 0; n0 < N; n0 += 128) {
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int n = n0 + nl + 32 * t;
+                    v[u][t] = n < N ? x[((size_t)b * C + c0 + u) * N + n] : 0.f;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int n = n0 + nl + 32 * t;
+                    if (n < N) xs[(4 + u) * BN + b * N + n] = v[u][t];
+                }
+        }
     for (int h = 0; h < a.n_heads; ++h) {
         if (a.in_idx[h] != j) continue;
         const int cout = a.cout[h], r0 = a.row0[h];
         const float* dy = a.dy[h];
-        for (int e = tid; e < cout * BN; e += 256) {        // lanes along n: coalesced reads, odd-pitch (conflict-free) writes
-            const int co = e / BN, q = e - co * BN, b = q / N, n = q - b * N;
-            gt[q * RP + r0 + co] = dy ? dy[((size_t)b * cout + co) * N + n] : 0.f;
-        }
+        for (int b = bl; b < B; b += 8)
+            for (int cb = 0; cb < cout; cb += 4)
+                for (int n0 = 0; n0 < N; n0 += 128) {
+                    float v[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int n = n0 + nl + 32 * t;
+                            v[u][t] = (dy && cb + u < cout && n < N) ? dy[((size_t)b * cout + cb + u) * N + n] : 0.f;
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int n = n0 + nl + 32 * t;     // lanes along n: coalesced reads, odd-pitch (conflict-free) writes
+                            if (cb + u < cout && n < N) gt[(b * N + n) * RP + r0 + cb + u] = v[u][t];
+                        }
+                }
     }
+    __syncthreads();
+    // ... then the left / right windows from the centre one, with the level mask applied (LDS -> LDS)
+    for (int b = bl; b < B; b += 8)
+        for (int n = nl; n < N; n += 32) {
+            int lo, hi;
+            level_bounds(a.L, n, lo, hi);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = u * BN + b * N + n;
+                xs[e] = n > lo ? xs[4 * BN + e - 1] : 0.f;
+                xs[8 * BN + e] = n + 1 < hi ? xs[4 * BN + e + 1] : 0.f;
+            }
+        }
     __syncthreads();
     const int ci = tid >> 6, slot = tid & 63, r = slot / 3, tap = slot - r * 3;
     if (r >= rows) return;
-    // which head owns row r
-    int h = -1;
+    int h = 0;                              // the head that owns row r
     for (int q = 0; q < a.n_heads; ++q)
         if (a.in_idx[q] == j && r >= a.row0[q] && r < a.row0[q] + a.cout[q]) h = q;
     const int k = a.k[h], co = r - a.row0[h];
@@ -212,21 +297,32 @@ __global__ __launch_bounds__(256) void head_convs_wgrad_kernel(const HcArgs a) {
     const bool wlane = k == 3 || tap == 1;
     const float* xw = xs + (tap * 4 + ci) * BN;
     const float* gr = gt + r;
-    float acc = 0.f, sb = 0.f;
+    // sixteen positions per trip, four interleaved partial sums (combined in a fixed order at the end): the loop is LDS
+    // latency, and one dependent fma chain with 5 reads per 4 positions left the four waves of the workgroup waiting
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int q = 0;
     if ((BN & 3) == 0) {                    // window rows are 16-byte aligned: four positions per LDS read of x
-        for (; q < BN; q += 4) {
-            const float4 xv = *reinterpret_cast<const float4*>(xw + q);
-            const float g0 = gr[q * RP], g1 = gr[(q + 1) * RP], g2 = gr[(q + 2) * RP], g3 = gr[(q + 3) * RP];
-            acc = fmaf(g0, xv.x, acc); acc = fmaf(g1, xv.y, acc); acc = fmaf(g2, xv.z, acc); acc = fmaf(g3, xv.w, acc);
-            sb += g0; sb += g1; sb += g2; sb += g3;
+        for (; q + 16 <= BN; q += 16) {
+            float4 xv[4];
+            float gv[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const float4*>(xw + q + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) gv[u] = gr[(q + u) * RP];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                p0 = fmaf(gv[4 * u], xv[u].x, p0); p1 = fmaf(gv[4 * u + 1], xv[u].y, p1);
+                p2 = fmaf(gv[4 * u + 2], xv[u].z, p2); p3 = fmaf(gv[4 * u + 3], xv[u].w, p3);
+                s0 += gv[4 * u]; s1 += gv[4 * u + 1]; s2 += gv[4 * u + 2]; s3 += gv[4 * u + 3];
+            }
         }
     }
     for (; q < BN; ++q) {
         const float gq = gr[q * RP];
-        acc = fmaf(gq, xw[q], acc);
-        sb += gq;
+        p0 = fmaf(gq, xw[q], p0);
+        s0 += gq;
     }
+    const float acc = (p0 + p1) + (p2 + p3), sb = (s0 + s1) + (s2 + s3);
     if (wlane) a.dw[h][((size_t)co * C + c0 + ci) * k + (k == 3 ? tap : 0)] = acc;
     if (blockIdx.x == 0 && ci == 0 && tap == 1 && a.db[h]) a.db[h][co] = sb;
 }
@@ -286,7 +382,7 @@ extern "C" int otal_head_convs_supported(int n_heads, int n_inputs, const int* i
     if (fill(a, n_heads, n_inputs, in_idx, cout, ksize, B, C, N, 1, nullptr)) return 0;
     int maxrows = 0;
     for (int j = 0; j < n_inputs; ++j) maxrows = a.rows[j] > maxrows ? a.rows[j] : maxrows;
-    const size_t fwd = (size_t)C * (HC_P + 3) * 4, dg = ((size_t)maxrows * (N + 2) + (size_t)maxrows * 48) * 4;
+    const size_t fwd = (size_t)C * (HC_P + 4) * 4, dg = ((size_t)maxrows * (N + 2) + (size_t)maxrows * 48) * 4;
     return fwd <= HC_LDS_MAX && dg <= HC_LDS_MAX && wgrad_lds(a) <= HC_LDS_MAX;
 }
 
@@ -301,7 +397,7 @@ extern "C" int otal_head_convs_fwd(int n_heads, int n_inputs, const int* in_idx,
         if (!w[h] || !y[h]) return OTAL_E_NULL;
         a.w[h] = w[h]; a.bias[h] = bias[h]; a.y[h] = y[h];
     }
-    const size_t lds = (size_t)C * (HC_P + 3) * 4;
+    const size_t lds = (size_t)C * (HC_P + 4) * 4;
     if (lds > HC_LDS_MAX) return OTAL_E_UNSUPPORTED;
     if (int e = allow_lds(head_convs_fwd_kernel, lds)) return e;
     hipLaunchKernelGGL(head_convs_fwd_kernel, dim3((N + HC_P - 1) / HC_P, B, n_heads), dim3(256), lds, (hipStream_t)stream, a);
