@@ -31,6 +31,22 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// Visit every (channel c, frame t) of a level of `len` frames with `nlanes` lanes, WITHOUT an integer division per element
+// (the flat form `c = i / len` costs ~40 VALU instructions per element on this hardware -- a third of these kernels):
+// long levels: channel by channel, lanes along t; short levels: a lane keeps its t and walks the channels, nlanes / len
+// channels per trip (one division per level).
+template <typename F>
+__device__ __forceinline__ void for_level(int lane, int nlanes, int cpg, int len, F f) {
+    if (len >= nlanes) {
+        for (int c = 0; c < cpg; ++c)
+            for (int t = lane; t < len; t += nlanes) f(c, t);
+    } else {
+        const int cpl = nlanes / len, cl = lane / len, t = lane - cl * len;
+        if (cl < cpl)
+            for (int c = cl; c < cpg; c += cpl) f(c, t);
+    }
+}
+
 // x,y: (B,C,T); stats out: (B,G,nlev,2) = {mean, rstd}
 __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y,
@@ -38,12 +54,15 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
                                                           float eps, int relu, GnLevels L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* buf = reinterpret_cast<float*>(smem);
-    float* red = buf + (size_t)(C / G) * T;
+    float* red = buf + (size_t)(C / G) * T;                      // 8 floats
+    float* gam = red + 8;                                        // the group's affine parameters
     const int tid = threadIdx.x;
     const int b = blockIdx.x / G, g = blockIdx.x % G;
     const int cpg = C / G;
+    float* bet = gam + cpg;
     const int64_t base = ((int64_t)b * C + (int64_t)g * cpg) * T;
     const int n = cpg * T;
+    if (tid < cpg) { gam[tid] = gamma[g * cpg + tid]; bet[tid] = beta[g * cpg + tid]; }
     for (int i = tid; i < n; i += 256) buf[i] = x[base + i];
     __syncthreads();
     if (L.nlev == 1) {          // one level: the whole workgroup reduces it
@@ -59,12 +78,11 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
             stats[((int64_t)b * G + g) * 2 + 0] = mean;
             stats[((int64_t)b * G + g) * 2 + 1] = rstd;
         }
-        for (int i = tid; i < cnt; i += 256) {
-            const int ch = g * cpg + i / T;
-            float v = (buf[i] - mean) * rstd * gamma[ch] + beta[ch];
+        for_level(tid, 256, cpg, T, [&](int c, int t) {
+            float v = (buf[c * T + t] - mean) * rstd * gam[c] + bet[c];
             if (relu) v = fmaxf(v, 0.f);
-            y[base + i] = v;
-        }
+            y[base + (int64_t)c * T + t] = v;
+        });
         return;
     }
     // level-packed maps: one WAVE per level (levels l = wave, wave + 4, ...), wave-local reductions only -- the 12
@@ -76,23 +94,21 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
         const int lo = L.lev[l], len = L.lev[l + 1] - lo;
         const int cnt = cpg * len;
         float s = 0.f;
-        for (int i = lane; i < cnt; i += 64) { const int c = i / len, t = i - c * len; s += buf[c * T + lo + t]; }
+        for_level(lane, 64, cpg, len, [&](int c, int t) { s += buf[c * T + lo + t]; });
         const float mean = __shfl(wave_sum(s), 0, 64) / (float)cnt;
         float q = 0.f;
-        for (int i = lane; i < cnt; i += 64) { const int c = i / len, t = i - c * len; const float d = buf[c * T + lo + t] - mean; q += d * d; }
+        for_level(lane, 64, cpg, len, [&](int c, int t) { const float d = buf[c * T + lo + t] - mean; q += d * d; });
         const float var = __shfl(wave_sum(q), 0, 64) / (float)cnt;
         const float rstd = 1.0f / sqrtf(var + eps);
         if (lane == 0) {
             stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 0] = mean;
             stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 1] = rstd;
         }
-        for (int i = lane; i < cnt; i += 64) {
-            const int c = i / len, t = i - c * len;
-            const int ch = g * cpg + c;
-            float v = (buf[c * T + lo + t] - mean) * rstd * gamma[ch] + beta[ch];
+        for_level(lane, 64, cpg, len, [&](int c, int t) {
+            float v = (buf[c * T + lo + t] - mean) * rstd * gam[c] + bet[c];
             if (relu) v = fmaxf(v, 0.f);
             y[base + (int64_t)c * T + lo + t] = v;
-        }
+        });
     }
 }
 
@@ -107,11 +123,14 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
     const int cpg = C / G;
     float* xb = reinterpret_cast<float*>(smem);          // x, later xhat
     float* gb = xb + (size_t)cpg * T;                    // dy masked (dyh), later dx
-    float* red = gb + (size_t)cpg * T;
+    float* red = gb + (size_t)cpg * T;                   // 8 floats
+    float* gam = red + 8;                                // the group's affine parameters
+    float* bet = gam + cpg;
     const int tid = threadIdx.x;
     const int b = blockIdx.x / G, g = blockIdx.x % G;
     const int64_t base = ((int64_t)b * C + (int64_t)g * cpg) * T;
     const int n = cpg * T;
+    if (tid < cpg) { gam[tid] = gamma[g * cpg + tid]; bet[tid] = beta[g * cpg + tid]; }
     for (int i = tid; i < n; i += 256) { xb[i] = x[base + i]; gb[i] = dy[base + i]; }
     __syncthreads();
     // level l is handled by the whole workgroup when it is the only one, else by wave l % 4 on its own (see the forward)
@@ -125,17 +144,18 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
         const float mean = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 0];
         const float rstd = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 1];
         float s1 = 0.f, s2 = 0.f;
-        for (int i = first; i < cnt; i += stride) {
-            const int c = i / len, t = i - c * len, ch = g * cpg + c, p = c * T + lo + t;
+        for_level(first, stride, cpg, len, [&](int c, int t) {
+            const int p = c * T + lo + t;
+            const float ga = gam[c];
             const float xh = (xb[p] - mean) * rstd;
             float d = gb[p];
-            if (relu && !(xh * gamma[ch] + beta[ch] > 0.f)) d = 0.f;
+            if (relu && !(xh * ga + bet[c] > 0.f)) d = 0.f;
             xb[p] = xh;
             gb[p] = d;
-            const float dg = d * gamma[ch];
+            const float dg = d * ga;
             s1 += dg;
             s2 += dg * xh;
-        }
+        });
         float m1, m2;
         if (solo) {
             m1 = block_sum(s1, red, tid) / (float)cnt;
@@ -144,11 +164,11 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
             m1 = __shfl(wave_sum(s1), 0, 64) / (float)cnt;   // a wave re-reads only what it wrote itself
             m2 = __shfl(wave_sum(s2), 0, 64) / (float)cnt;
         }
-        for (int i = first; i < cnt; i += stride) {
-            const int c = i / len, t = i - c * len, ch = g * cpg + c, p = c * T + lo + t;
-            const float v = rstd * (gb[p] * gamma[ch] - m1 - xb[p] * m2);
+        for_level(first, stride, cpg, len, [&](int c, int t) {
+            const int p = c * T + lo + t;
+            const float v = rstd * (gb[p] * gam[c] - m1 - xb[p] * m2);
             dx[base + (int64_t)c * T + lo + t] = v;
-        }
+        });
     }
     __syncthreads();            // xb / gb of every level (and the dx stores the sums below re-read) are complete
     // per-channel sums over all t (all levels), fixed order: one wave per channel, lanes stride t
@@ -199,7 +219,7 @@ extern "C" int otal_gn_relu_fwd(const float* x, const float* gamma, const float*
     if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G) return OTAL_E_SHAPE;
     GnLevels L;
     if (int e = fill_levels(L, T, nlev, lev)) return e;
-    const size_t lds = (size_t)(C / G) * T * 4 + 64;
+    const size_t lds = (size_t)(C / G) * T * 4 + 64 + (size_t)(C / G) * 8;
     if (lds > LDS_MAX) return OTAL_E_UNSUPPORTED;
     static bool large_ok = false;
     if (int e = allow_large_lds(gn_relu_fwd_kernel, lds, large_ok)) return e;
@@ -215,7 +235,7 @@ extern "C" int otal_gn_relu_bwd(const float* dy, const float* x, const float* ga
     if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G) return OTAL_E_SHAPE;
     GnLevels L;
     if (int e = fill_levels(L, T, nlev, lev)) return e;
-    const size_t lds = (size_t)(C / G) * T * 8 + 64;
+    const size_t lds = (size_t)(C / G) * T * 8 + 64 + (size_t)(C / G) * 8;
     if (lds > LDS_MAX) return OTAL_E_UNSUPPORTED;
     static bool large_ok = false;
     if (int e = allow_large_lds(gn_relu_bwd_kernel, lds, large_ok)) return e;
