@@ -394,6 +394,10 @@ def main():
     # decision and the outcome of the capture are agreed between the ranks (MAX / MIN all-reduce), so all ranks replay or
     # none does.
     want_graph = args.graph == "on"
+    # A step that issues RCCL collectives is never captured as ONE graph: ProcessGroupNCCL's watchdog thread queries the
+    # events of the all-reduces it was handed, and a query of an event recorded in a capturing stream is an error
+    # (hipErrorCapturedEvent) that takes the process down (measured with one forced rank).  Data-parallel runs capture the
+    # step as TWO graphs with the collectives issued between them (DetectorTrainer.capture_step(split=True)).
     if args.graph == "auto" and not args.ssl:
         for _ in range(3):
             trainer.step(clips, targets, scores)
@@ -413,7 +417,7 @@ def main():
     if want_graph:
         ok = 1
         try:
-            trainer.capture_step(clips, targets, scores)
+            trainer.capture_step(clips, targets, scores, split=multi)
         except Exception as e:                      # noqa: BLE001 -- any capture failure means eager launches
             if args.graph == "on":
                 raise
@@ -429,7 +433,7 @@ def main():
             trainer._graph = None
     for _ in range(args.warmup):
         trainer.step(clips, targets, scores, *ssl_args)
-    trainer.measure_exposed = multi and not graphed      # HIP events around the wait for the gradient all-reduces
+    trainer.measure_exposed = multi      # HIP events around the wait for the gradient all-reduces (eager or between the two graphs)
     trainer.exposed_events = []
     barrier()
     t0 = time.perf_counter()
@@ -530,7 +534,8 @@ def main():
                                          "exposed = compute-stream wait for the collectives after backward" % nbuckets,
                        "allreduce_exposed_ms": None if exposed_ms is None else round(exposed_ms, 3),
                        "ssl_branch": bool(args.ssl), "launch_probe": launch_probe,
-                       "launch": "one captured HIP graph per step" if graphed else "eager launches"},
+                       "launch": ("two captured HIP graphs per step, the gradient all-reduces issued between them" if multi else
+                                  "one captured HIP graph per step") if graphed else "eager launches"},
             "roofline": roofline, "hbm_kernels": hbm, "other_configs": extra, "cpu_baseline": cpu}))
     if world > 1 or force_dist:
         dist.barrier()              # every rank leaves together (rank 0 was busy with the roofline steps)

@@ -170,9 +170,56 @@ class InceptionI3d(nn.Module):
             self._fold = (torch.cat([sc for sc, _ in folded]), torch.cat([sh for _, sh in folded]), offs)
             self._fold_key = key
         scale, shift, offs = self._fold
-        outs = I3DFeaturesFunction.apply(x, plan, tuple(endpoints), scale, shift, offs,
-                                         *[u.conv3d.weight for u in units])
+        weights = [u.conv3d.weight for u in units]
+        cut = self._stem_cut(plan, endpoints) if self.split_backward else 0
+        if cut:
+            # Two autograd nodes instead of one, cut behind MaxPool3d_4a: a data-parallel trainer runs the backward pass
+            # in two phases -- everything down to the cut, then the stem (Conv3d_1a .. Mixed_3c: a third of the backward's
+            # GPU time, 3 % of the parameters) -- and all-reduces the first phase's gradients while the second runs
+            # (thumos14/train.py, capture_step(split=True)).  The cut tensor is a pool output: its gradient is raw.
+            (stem_out,) = I3DFeaturesFunction.apply(x, plan[:cut], (plan[cut - 1][-1],), scale, shift, offs, *weights)
+            self.stem_out = cut_in = stem_out
+            if self.detach_cut and torch.is_grad_enabled() and stem_out.requires_grad:
+                # the trunk reads a LEAF copy of the cut tensor (same storage): backward(cost) then stops at the cut and
+                # leaves its gradient in cut_leaf.grad; the caller runs the stem with backward(stem_out, cut_leaf.grad).
+                # (Naming the non-leaf stem_out in backward(inputs=...) would not do: autograd executes the node that
+                # owns a requested non-leaf tensor.)
+                self.cut_leaf = cut_in = stem_out.detach().requires_grad_(True)
+            outs = I3DFeaturesFunction.apply(cut_in, plan[cut:], tuple(endpoints), scale, shift, offs, *weights)
+        else:
+            self.stem_out = None
+            outs = I3DFeaturesFunction.apply(x, plan, tuple(endpoints), scale, shift, offs, *weights)
         return dict(zip(endpoints, outs))
+
+    split_backward = False      # set by a trainer that wants the two-phase backward (see extract_features)
+    detach_cut = False          # ... and, while it captures the two phases, the autograd graph broken at the cut
+    stem_out = None             # the cut tensor of the last forward pass when split_backward is on
+    cut_leaf = None             # its leaf twin when detach_cut is on
+    STEM_CUT_AFTER = 'MaxPool3d_4a_3x3'
+
+    def _stem_cut(self, plan, endpoints):
+        """Index of the first trunk step, or 0 when the plan cannot be cut (an endpoint inside the stem, no such pool)."""
+        names = [st[-1] for st in plan]
+        if self.STEM_CUT_AFTER not in names:
+            return 0
+        cut = names.index(self.STEM_CUT_AFTER) + 1
+        if cut >= len(plan) or any(e in names[:cut] for e in endpoints):
+            return 0
+        return cut
+
+    def stem_parameters(self):
+        """The convolution weights in front of the cut (Conv3d_1a .. Mixed_3c)."""
+        if self._plan is None:
+            self._plan = self._make_plan()
+        plan, units = self._plan
+        cut = self._stem_cut(plan, ())
+        idx = set()
+        for st in plan[:cut]:
+            if st[0] == "conv":
+                idx.add(st[1])
+            elif st[0] == "mixed":
+                idx.update(range(st[1], st[1] + 6))
+        return [units[i].conv3d.weight for i in sorted(idx)]
 
     def forward(self, x):
         raise NotImplementedError("classification logits are not part of the detection path; use extract_features")
@@ -324,6 +371,7 @@ class I3DFeaturesFunction(Function):
             return torch.empty(tuple(shape), dtype=like.dtype, device=like.device)
 
         dcur = None
+        cloned = True               # False while dcur still aliases an incoming gradient tensor
         for pos in range(len(tape), 0, -1):
             for g, z, zs in pending.pop(pos, ()):
                 dense = g.dim() == 5 and (g.shape[4] == 1 or g.stride(4) == 1) and (g.shape[3] == 1 or g.stride(3) == g.shape[4])
@@ -337,10 +385,13 @@ class I3DFeaturesFunction(Function):
                         dcur = out_grad_buffer(pos, g.shape, g)
                         dcur.copy_(g)
                     else:
-                        dcur = g.contiguous().clone()
+                        dcur = g.contiguous()       # only read from here on unless another gradient is added below
+                        cloned = False
                 elif zs is not None:
                     ops.masked_scale_copy(g, z, zs, dcur, accumulate=True)
                 else:
+                    if not cloned:                  # never modify a caller's tensor in place
+                        dcur, cloned = dcur.clone(), True
                     dcur.add_(g)
             if dcur is None:
                 continue

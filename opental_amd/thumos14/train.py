@@ -162,9 +162,17 @@ class DetectorTrainer:
         # ... and the weight whose gradient is computed LAST (the first trainable backbone parameter: Conv3d_1a) gets a
         # bucket of its own: the only all-reduce that cannot hide under later backward work is then a 260 KB one
         last = next((id(p) for p in (backbone.parameters() if late else ()) if p.requires_grad), None)
+        # ... and the stem (the layers in front of MaxPool3d_4a: a third of the backward's GPU time, 3 % of the parameters)
+        # is kept apart from the trunk: the two-phase captured step all-reduces everything else while the stem's backward
+        # graph replays (capture_step(split=True))
+        model = getattr(backbone, '_model', None)
+        stem = {id(p) for p in model.stem_parameters()} if hasattr(model, 'stem_parameters') else set()
+        self._stem_ids = stem
         self.arena = FlatArena(list(net.parameters()), bucket_mb << 20, adjacent,
-                               split_key=lambda p: 2 if id(p) == last else int(id(p) in late))
+                               split_key=lambda p: 3 if id(p) == last else (2 if id(p) in stem else int(id(p) in late)))
         a = self.arena
+        self.stem_buckets = [b for b in range(len(a.buckets)) if id(a.params[a.bucket_members[b][0]]) in stem]
+        self._capturing = False     # inside a stream capture: gradient copies are recorded, collectives are not issued
         # Collectives are ISSUED in one fixed order on every rank -- the pyramid / head buckets (complete first), then the
         # backbone's -- whatever order the gradients happen to arrive in: a rank whose batch leaves a parameter unused
         # would otherwise issue its all-reduces in a different order than its peers (mismatched collectives hang).
@@ -273,9 +281,12 @@ class DetectorTrainer:
                 dst.append(a.grad_views[i]); src.append(g)
         if dst:
             torch._foreach_copy_(dst, src)
-        if self.collectives:
-            lo, hi = a.buckets[b]
-            self._works.append(dist.all_reduce(a.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.collectives and not self._capturing:
+            self._issue_allreduce(b)
+
+    def _issue_allreduce(self, b):
+        lo, hi = self.arena.buckets[b]
+        self._works.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def begin_backward(self, early=True):
         """Call before cost.backward(): gradients start undefined, buckets open.  `early=False` (a step that runs the
@@ -294,7 +305,7 @@ class DetectorTrainer:
         self._slots.reset()
         ops.GRAD_SLOTS = self._slots                # weight gradients are written straight into the arena
         ops.GRAD_READY = self._grads_ready
-        if self.collectives and self._ibm_state() is not None:
+        if self.collectives and not self._capturing and self._ibm_state() is not None:
             # the loss kernel updated the IBM EMA in the forward pass: its 50-float average travels under the backward
             self._ibm_work = dist.all_reduce(self._ibm_state(), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -315,7 +326,7 @@ class DetectorTrainer:
         self._finish_allreduce()
 
     def _finish_allreduce(self):
-        if not self.collectives:
+        if not self.collectives or self._capturing:
             return
         ev = None
         if self.measure_exposed:
@@ -348,6 +359,7 @@ class DetectorTrainer:
             if self._graph_key == self._capture_key():
                 return self._replay(clips, targets, scores)
             stale = True            # a baked-in host scalar changed (learning rate, IBM switch): eager now, capture again
+            was_split = self._graph[0] == "split"
             self._graph = None
         # an eager step next to a captured graph (ssl branch) must not touch the descriptor buffers the graph replays
         # from: it works on its own prologue cache
@@ -365,7 +377,7 @@ class DetectorTrainer:
         self.step_count += 1
         self.optimizer_update()
         if stale:
-            self.capture_step(clips, targets, scores, warmup=0)
+            self.capture_step(clips, targets, scores, warmup=0, split=was_split)
         return cost.detach(), losses
 
     def _eager_prologues(self):
@@ -432,7 +444,7 @@ class DetectorTrainer:
         self._restore_skipped(keep)
         return cost.detach(), losses
 
-    def capture_step(self, clips, targets, scores, warmup=2):
+    def capture_step(self, clips, targets, scores, warmup=2, split=False):
         """Capture forward + losses + backward (+ gradient all-reduce) + Adam for inputs of these shapes.
 
         The captured launches bake in every host-side scalar of the step; the only one that changes per step --
@@ -441,6 +453,14 @@ class DetectorTrainer:
         `warmup` eager steps run first on a side stream (they are real optimisation steps)."""
         dev = clips.device
         self._graph = None
+        if split:
+            return self._capture_split(clips, targets, scores, warmup)
+        if self.collectives:
+            # ProcessGroupNCCL's watchdog thread queries the events of the collectives it is handed; for an event recorded
+            # in a capturing stream that query fails (hipErrorCapturedEvent) and the watchdog terminates the process
+            raise RuntimeError("capture_step: a step with RCCL collectives cannot be captured as ONE graph (watchdog event "
+                               "query inside stream capture); use split=True (two graphs, collectives between them) or "
+                               "eager launches")
         self._bias_corr = torch.zeros(2, dtype=torch.float32, device=dev)
         clone = lambda t: None if t is None else ([u.clone() for u in t] if isinstance(t, (list, tuple)) else t.clone())
         static = tuple(clone(t) for t in (clips, targets, scores))
@@ -469,14 +489,103 @@ class DetectorTrainer:
         self._graph_keepalive = (self._prologues.dev_descs, self._prologues.dev_starts)
         return self
 
-    def _set_bias(self, step):
-        bc = ops.adam_bias_corrections(step, self.betas[0], self.betas[1])
-        self._bias_corr.copy_(torch.tensor(bc, dtype=torch.float32), non_blocking=False)
+    # ---- the data-parallel step as TWO HIP graphs with the collectives between them
+    # graph 1: forward, losses, backward down to the cut behind MaxPool3d_4a (97 % of the parameters' gradients final);
+    # eager : their bucket all-reduces go to RCCL's stream (fixed order);
+    # graph 2: the stem's backward (Conv3d_1a .. Mixed_3c, ~4 ms of GPU time at b = 8) replays WHILE those all-reduces run;
+    # eager : the stem's two small buckets, the wait, Adam (one launch).
+    # Nothing of RCCL is captured (its watchdog cannot cope with events recorded during capture), the host issues two graph
+    # launches and ~10 collectives per step instead of ~480 kernel launches, and the only exposed communication is the
+    # stem's 5.6 MB.  Needs the backbone's two-node form (InceptionI3d.split_backward).
+    def _capture_split(self, clips, targets, scores, warmup):
+        model = getattr(getattr(self.net, 'backbone', None), '_model', None)
+        if model is None or not self._stem_ids or not self.stem_buckets:
+            raise RuntimeError("capture_step(split=True): the model has no stem / trunk cut")
+        dev = clips.device
+        a = self.arena
+        model.split_backward = True
+        self._bias_corr = torch.zeros(2, dtype=torch.float32, device=dev)
+        clone = lambda t: None if t is None else ([u.clone() for u in t] if isinstance(t, (list, tuple)) else t.clone())
+        static = tuple(clone(t) for t in (clips, targets, scores))
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):         # eager data-parallel steps in the two-node form (real steps)
+                self.step(*static)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        ops.activate_prologues(self._prologues)     # upload the descriptors of regions created by the warm-up
+        ops.deactivate_prologues()
+        torch.cuda.synchronize(dev)
+        stem_ids = self._stem_ids
+        phase1 = [p for p in a.params if id(p) not in stem_ids]
+        phase2 = [p for p in a.params if id(p) in stem_ids]
+        n1 = len(self._flush_order) - len(self.stem_buckets)        # the stem's buckets are issued last
+        if sorted(self._flush_order[n1:]) != sorted(self.stem_buckets):
+            raise RuntimeError("capture_step(split=True): the stem's buckets are not the last in the issue order")
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self._set_bias(self.step_count + 1)
+        self._capturing = True
+        model.detach_cut = True                     # the autograd graph of the captured pass is cut into its two phases
+        try:
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                ops.activate_prologues(self._prologues)
+                cost, losses = self.compute_cost(*static)
+                self.begin_backward()
+                stem_out, cut_leaf = model.stem_out, model.cut_leaf
+                cut_leaf.grad = None
+                torch.autograd.backward(cost, inputs=[cut_leaf] + phase1)
+                while self._cursor < n1:
+                    self._flush_bucket(self._flush_order[self._cursor])      # stragglers of phase 1 -> arena (copies only)
+                    self._cursor += 1
+                gcut = cut_leaf.grad
+            with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+                torch.autograd.backward(stem_out, grad_tensors=gcut, inputs=phase2)
+                self.end_backward()
+        finally:
+            self._capturing = False
+            model.detach_cut = False
+            model.cut_leaf = None
+            ops.deactivate_prologues()
+            ops.GRAD_SLOTS = None
+            ops.GRAD_READY = None
+            self._pending = None
+        if self._skipped:
+            raise RuntimeError("capture_step(split=True): a parameter received no gradient; use eager launches")
+        out = (cost.detach(), losses)
+        self._graph = ("split", g1, g2, static, out)
+        self._graph_key = self._capture_key()
+        self._graph_keepalive = (self._prologues.dev_descs, self._prologues.dev_starts, stem_out, gcut)
+        return self
 
-    def _replay(self, clips, targets, scores):
-        graph, static, out = self._graph
+    def _replay_split(self, clips, targets, scores):
+        _, g1, g2, static, out = self._graph
+        self._copy_inputs(static, (clips, targets, scores))
+        self.step_count += 1
+        self._set_bias(self.step_count)
+        a = self.arena
+        g1.replay()
+        if self.collectives:
+            if self._ibm_state() is not None:
+                self._ibm_work = dist.all_reduce(self._ibm_state(), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            for b in self._flush_order:
+                if b not in self.stem_buckets:
+                    self._issue_allreduce(b)
+        g2.replay()
+        if self.collectives:
+            for b in self._flush_order:
+                if b in self.stem_buckets:
+                    self._issue_allreduce(b)
+        self._finish_allreduce()
+        for lo, hi, g_lr in self._group_ranges:
+            g_lr = g_lr * (self.lr / self._base_lr) if self._base_lr else g_lr
+            ops.adam_flat_dev(a.flat[lo:hi], a.grad[lo:hi], a.m[lo:hi], a.v[lo:hi], self._bias_corr, g_lr,
+                              self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
+        return out
+
+    def _copy_inputs(self, static, given):
         pairs = []
-        for dst, src in zip(static, (clips, targets, scores)):
+        for dst, src in zip(static, given):
             if isinstance(dst, list):
                 if len(dst) != len(src):
                     raise RuntimeError("captured step replayed with a different batch; call capture_step again")
@@ -488,6 +597,16 @@ class DetectorTrainer:
                 if dst.shape != src.shape:      # ragged targets: the per-sample row counts are baked into the capture
                     raise RuntimeError("captured step replayed with different input shapes; call capture_step again")
                 dst.copy_(src, non_blocking=True)
+
+    def _set_bias(self, step):
+        bc = ops.adam_bias_corrections(step, self.betas[0], self.betas[1])
+        self._bias_corr.copy_(torch.tensor(bc, dtype=torch.float32), non_blocking=False)
+
+    def _replay(self, clips, targets, scores):
+        if self._graph[0] == "split":
+            return self._replay_split(clips, targets, scores)
+        graph, static, out = self._graph
+        self._copy_inputs(static, (clips, targets, scores))
         self.step_count += 1
         self._set_bias(self.step_count)
         graph.replay()

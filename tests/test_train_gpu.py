@@ -105,3 +105,58 @@ def test_resumed_trainer_continues_the_same_trajectory(tmp_path, captured):
         assert list(sd_a) == list(sd_b) and all(torch.equal(sd_a[n], sd_b[n]) for n in sd_a)
     finally:
         ops.CONV_PRECISION = old
+
+
+def test_two_graph_data_parallel_step_equals_eager_steps_on_one_rccl_rank():
+    """DetectorTrainer.capture_step(split=True): the data-parallel step as two HIP graphs (forward + backward down to the
+    cut behind MaxPool3d_4a | the stem's backward) with the bucket all-reduces issued on RCCL between them, exercised
+    on ONE forced RCCL rank (run in a child process: the process group is global state).  From the same weights and the
+    same batch, the parameters after k replayed steps are BIT-IDENTICAL to k eager data-parallel steps (same kernels,
+    same order), and identical to a trainer without collectives (all-reduce over one rank is the identity); the
+    one-graph capture refuses a step with collectives."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import os, sys, torch
+        import torch.distributed as dist
+        sys.path.insert(0, os.getcwd())
+        import bench
+        from opental_amd.common import ops
+        ops.CONV_PRECISION = 1
+        dev = torch.device("cuda", 0)
+        dist.init_process_group(backend="nccl", device_id=dev)
+        clips, targets, scores = bench.synth_batch(4, 1000, dev)
+        def run(mode):
+            tr = bench.build_trainer(dev, seed=5, force_collectives=(mode != "plain"))
+            tr.lr = 1e-4
+            tr.net.backbone._model.split_backward = True
+            if mode == "split":
+                try:
+                    tr.capture_step(clips, targets, scores)
+                    raise SystemExit("one-graph capture accepted a step with collectives")
+                except RuntimeError:
+                    pass
+                start_steps = 1                     # the capture's warm-up step is a real step
+                tr.capture_step(clips, targets, scores, warmup=1, split=True)
+                assert tr._graph[0] == "split"
+            else:
+                start_steps = 0
+            costs = []
+            for _ in range(4 - start_steps):
+                costs.append(float(tr.step(clips, targets, scores)[0]))
+            torch.cuda.synchronize()
+            return tr.arena.flat.detach().clone(), tr.arena.m.detach().clone(), costs, tr.step_count
+        pe, me, ce, ne = run("eager")
+        ps, ms, cs, ns = run("split")
+        pp, mp, cp, np_ = run("plain")
+        assert ne == ns == np_ == 4, (ne, ns, np_)
+        assert torch.equal(pe, ps) and torch.equal(me, ms), float((pe - ps).abs().max())
+        assert torch.equal(pe, pp), float((pe - pp).abs().max())
+        assert ce[-len(cs):] == cs, (ce, cs)
+        print("OK", cs)
+        dist.destroy_process_group()
+    ''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
