@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 16
+#define OTAL_ABI_VERSION 17
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -157,10 +157,17 @@ int otal_conv_pack_wt(const float* w, float* wt, int Cout, int Cin, int kvol, vo
 int otal_gn_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
                      int B, int C, int T, int G, float eps, int relu, int nlev, const int* lev, void* stream);
 /* dx and per-(sample,channel) partial sums partial[(b*3 + {0,1,2})*C + c] = {d_gamma, d_beta, sum_t dx}
- * (sum over b by the caller; sum_t dx is the gradient of the preceding convolution's bias). */
-int otal_gn_relu_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
+ * (sum over b by the caller, e.g. otal_sum_partials; sum_t dx is the gradient of the preceding convolution's bias).
+ * dy_batch_stride (elements; 0 = C*T): dy may be a channel slice of a wider (B, Ctot, T) map -- the gradient of a
+ * torch.cat along the channels (BDNet.py:111) is read in place instead of through a contiguous copy. */
+int otal_gn_relu_bwd(const float* dy, int64_t dy_batch_stride, const float* x, const float* gamma, const float* beta,
                      const float* stats, float* dx, float* partial, int B, int C, int T, int G,
                      int relu, int nlev, const int* lev, void* stream);
+/* Batch sums of MANY layers' partials in one launch: for item i, dst{0,1,2}[i][c] = sum_b partial[i][(b*3 + r)*C + c]
+ * (r = 0,1,2; ascending b; a NULL dst row is skipped).  Replaces the per-layer torch sum over the batch that follows
+ * every GroupNorm backward (21 per step); the destinations may be slices of a flat gradient arena. */
+int otal_sum_partials(int n_items, const float* const* partial, float* const* dst0, float* const* dst1,
+                      float* const* dst2, const int* channels, const int* batches, void* stream);
 
 /* ------------------------------------------------------------------ MaxPool3dSamePadding ----
  * geom: 17 ints B,C, Ti,Hi,Wi, To,Ho,Wo, kt,kh,kw, st,sh,sw, pt,ph,pw (front pads; ZERO padding);

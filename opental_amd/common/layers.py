@@ -58,14 +58,17 @@ class ConvGNReLUFunction(Function):
         c3 = c.view(c.shape[0], c.shape[1], c.shape[2]) if c.dim() == 5 else c
         y, stats = ops.gn_relu_forward(c3, gamma, beta, groups, eps, True, levels)
         ctx.cfg = (k, s, spatial_valid, levels, groups)
-        ctx.save_for_backward(x, w, c3, gamma, beta, stats)
+        ctx.save_for_backward(x, w, c3, gamma, beta, stats, *([b] if b is not None else []))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, c3, gamma, beta, stats = ctx.saved_tensors
+        x, w, c3, gamma, beta, stats = ctx.saved_tensors[:6]
+        bias = ctx.saved_tensors[6] if len(ctx.saved_tensors) > 6 else None
         k, s, sv, lev, groups = ctx.cfg
-        dc, dgamma, dbeta, dbias = ops.gn_relu_backward(dy.contiguous(), c3, gamma, beta, stats, groups, True, lev)
+        # dy is read in place when it is a channel slice of a wider map (the gradient of torch.cat); the three batch sums
+        # are deferred to the trainer's next bucket flush when it is running (ops.gn_relu_backward)
+        dc, dgamma, dbeta, dbias = ops.gn_relu_backward(dy, c3, gamma, beta, stats, groups, True, lev, bias=bias)
         dc5 = dc.view(dc.shape[0], dc.shape[1], dc.shape[2], 1, 1) if x.dim() == 5 else dc
         dx = None
         if ctx.needs_input_grad[0]:

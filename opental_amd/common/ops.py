@@ -384,6 +384,16 @@ class GradSlots:
             self.written[q] = True
         return self.grad[off:end].view(w.shape)
 
+    def release(self, w):
+        """Give a slot back that take(w) handed out and nothing was written to."""
+        off = (w.data_ptr() - self.base) // 4
+        i = bisect.bisect_left(self.offsets, off)
+        j, cur, end = i, off, off + w.numel()
+        while j < len(self.offsets) and cur < end:
+            self.written[j] = False
+            cur += self.numels[j]
+            j += 1
+
 
 GRAD_SLOTS = None       # the running trainer's GradSlots (DetectorTrainer.begin_backward / end_backward)
 GRAD_READY = None       # the running trainer's callback for weight gradients that are final before their node returns
@@ -449,17 +459,49 @@ def gn_relu_forward(x, gamma, beta, groups=32, eps=1e-5, relu=True, levels=None)
     return y, stats
 
 
-def gn_relu_backward(dy, x, gamma, beta, stats, groups=32, relu=True, levels=None):
-    L.require_device(dy, x, gamma, beta, stats)
+PENDING_SUMS = None     # the running trainer's list of deferred batch sums (DetectorTrainer.begin_backward), or None
+
+
+def gn_relu_backward(dy, x, gamma, beta, stats, groups=32, relu=True, levels=None, bias=None):
+    """(dx, d_gamma, d_beta, d_conv_bias).  dy may be a channel slice of a wider (B, Ctot, T) map (read in place).
+    With a running trainer (PENDING_SUMS) whose gradient arena has free slots for gamma, beta and `bias` (the preceding
+    convolution's bias parameter), the three batch sums are DEFERRED: the returned gradients are the arena slices and
+    flush_pending_sums() fills them -- one launch for all layers pending at the next bucket flush."""
     B, C, T = x.shape
+    if dy.dim() != 3 or tuple(dy.shape) != (B, C, T) or dy.stride(2) != 1 or dy.stride(1) != T or dy.stride(0) < C * T:
+        dy = dy.contiguous()
+    L.require_device(x, gamma, beta, stats)
+    if not dy.is_cuda:
+        raise RuntimeError("opental_amd ops run on the GPU only")
     nlev, lev = _lev_arg(levels)
     dx = torch.empty_like(x)
     partial = torch.empty((B, 3, C), dtype=torch.float32, device=x.device)
-    L.check(L.lib().otal_gn_relu_bwd(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.ptr(dx),
-                                     L.ptr(partial), B, C, T, groups, int(relu), nlev, lev, L.stream()),
+    L.check(L.lib().otal_gn_relu_bwd(L.ptr(dy), ctypes.c_int64(dy.stride(0)), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(stats),
+                                     L.ptr(dx), L.ptr(partial), B, C, T, groups, int(relu), nlev, lev, L.stream()),
             "otal_gn_relu_bwd")
+    if PENDING_SUMS is not None and bias is not None and GRAD_SLOTS is not None:
+        slots = [GRAD_SLOTS.take(t) for t in (gamma, beta, bias)]
+        if all(sl is not None for sl in slots):
+            PENDING_SUMS.append((partial, slots, C, B))
+            return dx, slots[0], slots[1], slots[2]
+        for t, sl in zip((gamma, beta, bias), slots):       # hand back what was taken: the plain path returns fresh tensors
+            if sl is not None:
+                GRAD_SLOTS.release(t)
     red = partial.sum(0)            # (3,C): d_gamma, d_beta, d_conv_bias -- three contiguous rows, no copies
     return dx, red[0], red[1], red[2]
+
+
+def flush_pending_sums():
+    """Run the deferred batch sums of gn_relu_backward: one launch for every layer pending (otal_sum_partials)."""
+    items = PENDING_SUMS
+    if not items:
+        return
+    n = len(items)
+    VP = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    L.check(L.lib().otal_sum_partials(n, VP([it[0] for it in items]), VP([it[1][0] for it in items]), VP([it[1][1] for it in items]),
+                                      VP([it[1][2] for it in items]), L.int_array([it[2] for it in items]),
+                                      L.int_array([it[3] for it in items]), L.stream()), "otal_sum_partials")
+    del items[:]
 
 
 # ----------------------------------------------------------------------------- MaxPool3d (SAME, zero pad)

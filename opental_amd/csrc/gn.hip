@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ stats, float* __restrict__ dx,
                                                           float* __restrict__ partial, int C, int T, int G, int relu,
-                                                          GnLevels L) {
+                                                          GnLevels L, int64_t dy_bs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int cpg = C / G;
     float* xb = reinterpret_cast<float*>(smem);          // x, later xhat
@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
     const int64_t base = ((int64_t)b * C + (int64_t)g * cpg) * T;
     const int n = cpg * T;
     if (tid < cpg) { gam[tid] = gamma[g * cpg + tid]; bet[tid] = beta[g * cpg + tid]; }
-    for (int i = tid; i < n; i += 256) { xb[i] = x[base + i]; gb[i] = dy[base + i]; }
+    const int64_t dbase = (int64_t)b * dy_bs + (int64_t)g * cpg * T;         // dy may be a channel slice of a wider map
+    for (int i = tid; i < n; i += 256) { xb[i] = x[base + i]; gb[i] = dy[dbase + i]; }
     __syncthreads();
     // level l is handled by the whole workgroup when it is the only one, else by wave l % 4 on its own (see the forward)
     const bool solo = L.nlev == 1;
@@ -228,11 +229,13 @@ extern "C" int otal_gn_relu_fwd(const float* x, const float* gamma, const float*
     return otal_launch_status();
 }
 
-extern "C" int otal_gn_relu_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
+extern "C" int otal_gn_relu_bwd(const float* dy, int64_t dy_batch_stride, const float* x, const float* gamma, const float* beta,
                                 const float* stats, float* dx, float* partial, int B, int C, int T, int G,
                                 int relu, int nlev, const int* lev, void* stream) {
     if (!dy || !x || !gamma || !beta || !stats || !dx || !partial) return OTAL_E_NULL;
     if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G) return OTAL_E_SHAPE;
+    if (dy_batch_stride == 0) dy_batch_stride = (int64_t)C * T;
+    if (dy_batch_stride < (int64_t)C * T) return OTAL_E_SHAPE;
     GnLevels L;
     if (int e = fill_levels(L, T, nlev, lev)) return e;
     const size_t lds = (size_t)(C / G) * T * 8 + 64 + (size_t)(C / G) * 8;
@@ -240,6 +243,50 @@ extern "C" int otal_gn_relu_bwd(const float* dy, const float* x, const float* ga
     static bool large_ok = false;
     if (int e = allow_large_lds(gn_relu_bwd_kernel, lds, large_ok)) return e;
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(256), lds, (hipStream_t)stream,
-                       dy, x, gamma, beta, stats, dx, partial, C, T, G, relu, L);
+                       dy, x, gamma, beta, stats, dx, partial, C, T, G, relu, L, dy_batch_stride);
     return otal_launch_status();
+}
+
+// ---- batch sums of the backward's partials, MANY layers per launch.  Item i: dst{0,1,2}[i][c] = sum_b partial[i][(b*3 + r)*C + c]
+// in ascending b (deterministic).  The trainer defers these sums and runs them when a gradient bucket is flushed: 21
+// reduce launches per step become 2-4, and the results land directly in the gradient arena.
+namespace {
+constexpr int SP_MAX = 32;
+struct SumItems { const float* src[SP_MAX]; float* dst[SP_MAX][3]; int C[SP_MAX]; int B[SP_MAX]; };
+__global__ __launch_bounds__(256) void sum_partials_kernel(const SumItems it) {
+    const int i = blockIdx.y, r = blockIdx.z, c = blockIdx.x * 256 + threadIdx.x;
+    const int C = it.C[i], B = it.B[i];
+    if (c >= C || !it.dst[i][r]) return;
+    const float* p = it.src[i] + (size_t)r * C + c;
+    float v[8];
+    float s = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 8) {            // eight loads in flight, added in ascending b
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = b0 + u < B ? p[(size_t)(b0 + u) * 3 * C] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (b0 + u < B) s += v[u];
+    }
+    it.dst[i][r][c] = s;
+}
+}  // namespace
+
+extern "C" int otal_sum_partials(int n_items, const float* const* partial, float* const* dst0, float* const* dst1,
+                                 float* const* dst2, const int* channels, const int* batches, void* stream) {
+    if (!partial || !dst0 || !dst1 || !dst2 || !channels || !batches) return OTAL_E_NULL;
+    if (n_items < 0) return OTAL_E_SHAPE;
+    for (int i0 = 0; i0 < n_items; i0 += SP_MAX) {
+        SumItems it = {};
+        const int n = n_items - i0 < SP_MAX ? n_items - i0 : SP_MAX;
+        int cmax = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!partial[i0 + i] || channels[i0 + i] <= 0 || batches[i0 + i] <= 0) return OTAL_E_SHAPE;
+            it.src[i] = partial[i0 + i];
+            it.dst[i][0] = dst0[i0 + i]; it.dst[i][1] = dst1[i0 + i]; it.dst[i][2] = dst2[i0 + i];
+            it.C[i] = channels[i0 + i]; it.B[i] = batches[i0 + i];
+            cmax = channels[i0 + i] > cmax ? channels[i0 + i] : cmax;
+        }
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((cmax + 255) / 256, n, 3), dim3(256), 0, (hipStream_t)stream, it);
+        if (int e = otal_launch_status()) return e;
+    }
+    return 0;
 }

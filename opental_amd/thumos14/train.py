@@ -269,6 +269,7 @@ class DetectorTrainer:
             return
         self._flushed[b] = True
         a = self.arena
+        ops.flush_pending_sums()                        # deferred GroupNorm batch sums land in their arena slices: one launch
         dst, src = [], []
         for i in a.bucket_members[b]:
             if self._in_arena[i]:
@@ -305,6 +306,9 @@ class DetectorTrainer:
         self._slots.reset()
         ops.GRAD_SLOTS = self._slots                # weight gradients are written straight into the arena
         ops.GRAD_READY = self._grads_ready
+        # GroupNorm's batch sums are deferred to the bucket flushes -- unless a parameter may be used twice in this backward
+        # (ssl step): a second gradient would be accumulated into the arena slice before the deferred sum is written there
+        ops.PENDING_SUMS = [] if early else None
         if self.collectives and not self._capturing and self._ibm_state() is not None:
             # the loss kernel updated the IBM EMA in the forward pass: its 50-float average travels under the backward
             self._ibm_work = dist.all_reduce(self._ibm_state(), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -317,9 +321,11 @@ class DetectorTrainer:
     def end_backward(self):
         """Call after cost.backward(): flush the buckets that did not complete (unused parameters), wait for the
         all-reduces, and leave every .grad aliasing its arena slice."""
+        self._drain(force=True)
+        ops.flush_pending_sums()
+        ops.PENDING_SUMS = None
         ops.GRAD_SLOTS = None
         ops.GRAD_READY = None
-        self._drain(force=True)
         self._pending = None
         for p, v in zip(self.arena.params, self.arena.grad_views):
             p.grad = v
@@ -374,6 +380,7 @@ class DetectorTrainer:
             ops.deactivate_prologues()
             ops.GRAD_SLOTS = None
             ops.GRAD_READY = None
+            ops.PENDING_SUMS = None
         self.step_count += 1
         self.optimizer_update()
         if stale:
@@ -435,6 +442,7 @@ class DetectorTrainer:
             ops.deactivate_prologues()
             ops.GRAD_SLOTS = None
             ops.GRAD_READY = None
+            ops.PENDING_SUMS = None
         a = self.arena
         keep = self._stash_skipped()
         for lo, hi, g_lr in self._group_ranges:
@@ -549,6 +557,7 @@ class DetectorTrainer:
             ops.deactivate_prologues()
             ops.GRAD_SLOTS = None
             ops.GRAD_READY = None
+            ops.PENDING_SUMS = None
             self._pending = None
         if self._skipped:
             raise RuntimeError("capture_step(split=True): a parameter received no gradient; use eager launches")

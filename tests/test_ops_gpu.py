@@ -873,3 +873,38 @@ def test_fused_head_convs_decline_wide_heads():
     """150-class ActivityNet heads do not fit (more than 21 rows on one input): the caller runs them one by one."""
     from opental_amd.common import ops
     assert not ops.head_convs_supported([(0, 2, 3), (1, 150, 3), (1, 1, 3)], 2, 2, 512, 189)
+
+
+@pytest.mark.gpu
+def test_groupnorm_backward_reads_sliced_gradients_and_defers_batch_sums():
+    """otal_gn_relu_bwd with dy as a channel slice of a wider map (the gradient of torch.cat) is bit-identical to the
+    contiguous copy; otal_sum_partials (many layers per launch, ascending b) equals the per-layer batch sums."""
+    import ctypes
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    rs = np.random.RandomState(7)
+    B, C, T, lev = 8, 512, 126, (0, 64, 96, 112, 120, 124, 126)
+    x = torch.from_numpy(rs.randn(B, C, T).astype(np.float32)).cuda()
+    ga = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)).cuda()
+    be = torch.from_numpy(rs.randn(C).astype(np.float32)).cuda()
+    wide = torch.from_numpy(rs.randn(B, C + 1024 + 512, T).astype(np.float32)).cuda()
+    dy = wide[:, 1024:1024 + C]
+    assert not dy.is_contiguous()
+    _, stats = ops.gn_relu_forward(x, ga, be, levels=lev)
+    a = ops.gn_relu_backward(dy, x, ga, be, stats, levels=lev)
+    b = ops.gn_relu_backward(dy.contiguous(), x, ga, be, stats, levels=lev)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    parts = [torch.from_numpy(rs.randn(bb, 3, cc).astype(np.float32)).cuda() for bb, cc in ((8, 512), (8, 1024), (3, 40), (1, 7))] * 10
+    outs = [[torch.full((p.shape[2],), 7.0, device="cuda") for _ in range(3)] for p in parts]
+    outs[2][1] = None                                   # a skipped row
+    n = len(parts)
+    VP = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    L.check(L.lib().otal_sum_partials(n, VP(parts), VP([o[0] for o in outs]), VP([o[1] for o in outs]), VP([o[2] for o in outs]),
+                                      L.int_array([p.shape[2] for p in parts]), L.int_array([p.shape[0] for p in parts]), L.stream()),
+            "otal_sum_partials")
+    for p, o in zip(parts, outs):
+        want = p.double().sum(0)
+        for r in range(3):
+            if o[r] is not None:
+                assert float((o[r].double() - want[r]).abs().max()) < 1e-5
