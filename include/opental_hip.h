@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 17
+#define OTAL_ABI_VERSION 18
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -227,6 +227,14 @@ int otal_boundary_bce(const float* x, int64_t x_batch_stride, int64_t x_channel_
                       int64_t mask_batch_stride, int64_t mask_row_stride, int mask_row0, int mask_step, float* terms,
                       float* dx, int B, int C, int T, void* stream);
 
+/* The tails of the n (<= 4) boundary losses of a step (train.py:193-201: the frame-level map with weight 1 and the two
+ * level-0 proposal maps with weight 0.1): out2[h] = sum_i weights[i] * mean_{b,t} terms_i[b][h][t] in one launch, and
+ * the matching backward out_i[b][c][t] = dx_i[b][c][t] * weights[i] * (c < C_i / 2 ? *g_start : *g_end) for all maps in
+ * one launch (dx_i: as written by otal_boundary_bce; g_start / g_end: device scalars, NULL = 0). */
+int otal_boundary_finish(int n, const float* const* terms, const float* weights, const int* T, int B, float* out2, void* stream);
+int otal_boundary_scale(int n, const float* const* dx, float* const* out, const float* weights, const int* C, const int* T,
+                        int B, const float* g_start, const float* g_end, void* stream);
+
 /* ------------------------------------------------------------------ proposal window indices ----
  * loc (B,Ntot,2) -> level-space windows seg (B,Ntot,4) and frame-space windows frame_seg (B,Ntot,4)
  * for all levels at once; bit-exact restatement of the no_grad block of CoarsePyramid.forward
@@ -331,6 +339,13 @@ int otal_detection_loss(const float* loc, const float* conf, const float* prop_l
                         float clip_length, float overlap_thresh, int ibm_active, int num_bins, float momentum,
                         int iou_aware, int cls_mode, float focal_alpha, float* losses, float* grads, float* scratch,
                         void* stream);
+
+/* Backward of otal_detection_loss in one launch: the gradients w.r.t. the seven head outputs from the stored per-loss
+ * gradients (`grads` as written by otal_detection_loss) and the incoming gradients of the seven losses g7[i] (device
+ * scalars in the order loss_l, loss_c, loss_prop_l, loss_prop_c, loss_ct, loss_act, loss_prop_act; NULL = 0).
+ * out: d_loc (2A) | d_prop_loc (2A) | d_conf (A C) | d_prop_conf (A C) | d_center (A) | d_act (A) | d_prop_act (A), A = B K.
+ * Replaces the autograd of the weighted loss sum over multisegment_loss.py:92-259 (nine multiplies, two adds). */
+int otal_detection_loss_bwd(const float* grads, const float* const* g7, float* out, int B, int K, int C, void* stream);
 
 /* Clip preparation on the device: uint8 frames (T',Hs,Ws,3) -> normalised fp32 batch (B,3,T,Ho,Wo).
  * Replaces AFSD/common/thumos_dataset.py:136-137,:246-262 and videotransforms.py:44-124 (temporal zero padding,

@@ -665,18 +665,20 @@ class DetectionLossFunction(torch.autograd.Function):
         (grads,) = ctx.saved_tensors
         B, K, C = ctx.dims
         A = B * K
+        gs = [None if g is None else g.contiguous() for g in (g_l, g_c, g_pl, g_pc, g_ct, g_a, g_pa)]
+        out = torch.empty(4 * A + 2 * A * C + 3 * A, dtype=torch.float32, device=grads.device)
+        g7 = (ctypes.c_void_p * 7)(*[None if g is None else g.data_ptr() for g in gs])
+        L.check(L.lib().otal_detection_loss_bwd(L.ptr(grads), g7, L.ptr(out), B, K, C, L.stream()), "otal_detection_loss_bwd")
         o = 0
         def take(n, shape):
             nonlocal o
-            v = grads[o:o + n].view(shape)
+            v = out[o:o + n].view(shape)
             o += n
             return v
-        dloc_l, dloc_ct = take(2 * A, (B, K, 2)), take(2 * A, (B, K, 2))
-        dpl_pl, dpl_ct = take(2 * A, (B, K, 2)), take(2 * A, (B, K, 2))
-        dconf, dpconf = take(A * C, (B, K, C)), take(A * C, (B, K, C))
-        dcen, dact, dpact = take(A, (B, K)), take(A, (B, K)), take(A, (B, K))
-        return (dloc_l * g_l + dloc_ct * g_ct, dconf * g_c, dpl_pl * g_pl + dpl_ct * g_ct, dpconf * g_pc,
-                dcen * g_ct, dact * g_a, dpact * g_pa) + (None,) * 12
+        d_loc, d_pl = take(2 * A, (B, K, 2)), take(2 * A, (B, K, 2))
+        d_conf, d_pconf = take(A * C, (B, K, C)), take(A * C, (B, K, C))
+        d_cen, d_act, d_pact = take(A, (B, K)), take(A, (B, K)), take(A, (B, K))
+        return (d_loc, d_conf, d_pl, d_pconf, d_cen, d_act, d_pact) + (None,) * 12
 
 
 # ----------------------------------------------------------------------------- head output tails
@@ -848,3 +850,49 @@ class BoundaryBCEFunction(torch.autograd.Function):
         z = dx.new_zeros(())
         g = torch.stack([z if g_start is None else g_start.reshape(()), z if g_end is None else g_end.reshape(())])
         return (dx.view(B, 2, C // 2, T) * g.view(1, 2, 1, 1)).view(B, C, T), None, None, None
+
+
+class BoundaryLossesFunction(torch.autograd.Function):
+    """(loss_start, loss_end) of a training step: sum_i weights[i] * calc_bce_loss(map_i) over the frame-level map and
+    the two level-0 proposal maps (train.py:193-201, weights 1, 0.1, 0.1) -- one otal_boundary_bce launch per map, ONE
+    launch for all the means and the weighted sums, ONE for the backward of all maps.
+    apply(mask, steps, weights, *maps): maps[i] (B, C_i, T_i) read in place, mask sampled every steps[i] frames."""
+
+    @staticmethod
+    def forward(ctx, mask, steps, weights, *xs):
+        n = len(xs)
+        B = xs[0].shape[0]
+        terms, dxs = [], []
+        for x, step in zip(xs, steps):
+            if not (x.is_cuda and mask.is_cuda) or x.stride(2) != 1 or mask.stride(2) != 1 or x.dtype != torch.float32:
+                raise RuntimeError("boundary losses: float32 GPU maps with unit time stride")
+            _, C, T = x.shape
+            if 2 > mask.shape[1] or (T - 1) * step >= mask.shape[2]:
+                raise RuntimeError("boundary losses: mask rows / length do not cover the map")
+            t = torch.empty((B, 2, T), dtype=torch.float32, device=x.device)
+            dx = torch.empty((B, C, T), dtype=torch.float32, device=x.device)
+            L.check(L.lib().otal_boundary_bce(L.ptr(x), ctypes.c_int64(x.stride(0)), ctypes.c_int64(x.stride(1)), L.ptr(mask),
+                                              ctypes.c_int64(mask.stride(0)), ctypes.c_int64(mask.stride(1)), 0, int(step),
+                                              L.ptr(t), L.ptr(dx), B, C, T, L.stream()), "otal_boundary_bce")
+            terms.append(t); dxs.append(dx)
+        out = torch.empty(2, dtype=torch.float32, device=xs[0].device)
+        wa = (ctypes.c_float * n)(*[float(w) for w in weights])
+        VP = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        L.check(L.lib().otal_boundary_finish(n, VP(terms), wa, L.int_array([t.shape[2] for t in terms]), B, L.ptr(out), L.stream()),
+                "otal_boundary_finish")
+        ctx.save_for_backward(*dxs)
+        ctx.meta = (n, B, [float(w) for w in weights])
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_start, g_end):
+        dxs = ctx.saved_tensors
+        n, B, weights = ctx.meta
+        outs = [torch.empty_like(d) for d in dxs]
+        wa = (ctypes.c_float * n)(*weights)
+        VP = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        gs = [None if g is None else g.contiguous() for g in (g_start, g_end)]
+        L.check(L.lib().otal_boundary_scale(n, VP(dxs), VP(outs), wa, L.int_array([d.shape[1] for d in dxs]),
+                                            L.int_array([d.shape[2] for d in dxs]), B, _opt(gs[0]), _opt(gs[1]), L.stream()),
+                "otal_boundary_scale")
+        return (None, None, None) + tuple(outs)

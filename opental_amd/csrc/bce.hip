@@ -49,6 +49,51 @@ __global__ __launch_bounds__(256) void boundary_bce_kernel(const float* __restri
     }
 }
 
+
+// ---- the tails of the three boundary losses of a training step in one launch each way.
+// forward: out[h] = sum_i weight[i] * mean_{b,t} terms_i[b][h][t]   (h = start / end; i = the frame-level map and the two
+// level-0 proposal maps, weights 1, 0.1, 0.1: AFSD/thumos14/train.py:193-201) -- ONE workgroup, fixed summation order.
+// backward: out_i[b][c][t] = dx_i[b][c][t] * (weight[i] * g[half of c])  for all three maps (the stored d loss_h / d x,
+// scaled by the incoming gradients of the two combined losses).
+constexpr int BL_MAX = 4;
+struct BlItems { int n; const float* terms[BL_MAX]; const float* dx[BL_MAX]; float* out[BL_MAX]; float weight[BL_MAX]; int T[BL_MAX]; int C[BL_MAX]; };
+
+__global__ __launch_bounds__(256) void boundary_finish_kernel(BlItems it, int B, float* __restrict__ out) {
+    __shared__ float red[256];
+    for (int h = 0; h < 2; ++h) {
+        float total = 0.f;
+        for (int i = 0; i < it.n; ++i) {
+            const int T = it.T[i], cnt = B * T;
+            float acc = 0.f;
+            for (int e = threadIdx.x; e < cnt; e += 256) {
+                const int b = e / T, t = e - b * T;
+                acc += it.terms[i][((size_t)b * 2 + h) * T + t];
+            }
+            red[threadIdx.x] = acc;
+            __syncthreads();
+            for (int s = 128; s > 0; s >>= 1) {
+                if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+                __syncthreads();
+            }
+            total += it.weight[i] * (red[0] / (float)cnt);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[h] = total;
+    }
+}
+
+// grid (ceil(max elements / 256), n)
+__global__ __launch_bounds__(256) void boundary_scale_kernel(BlItems it, int B, const float* __restrict__ g_start,
+                                                             const float* __restrict__ g_end) {
+    const int i = blockIdx.y;
+    const int T = it.T[i], C = it.C[i];
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)B * C * T) return;
+    const int c = (int)((e / T) % C);
+    const float g = c < C / 2 ? (g_start ? *g_start : 0.f) : (g_end ? *g_end : 0.f);
+    it.out[i][e] = it.dx[i][e] * (it.weight[i] * g);
+}
+
 }  // namespace
 
 extern "C" int otal_boundary_bce(const float* x, int64_t x_batch_stride, int64_t x_channel_stride, const float* mask,
@@ -58,5 +103,37 @@ extern "C" int otal_boundary_bce(const float* x, int64_t x_batch_stride, int64_t
     if (B <= 0 || C <= 0 || T <= 0 || (C & 1) || mask_step <= 0 || mask_row0 < 0) return OTAL_E_SHAPE;
     hipLaunchKernelGGL(boundary_bce_kernel, dim3((T + 15) / 16, B, 2), dim3(256), 0, (hipStream_t)stream, x, x_batch_stride,
                        x_channel_stride, mask, mask_batch_stride, mask_row_stride, mask_row0, mask_step, terms, dx, B, C, T);
+    return otal_launch_status();
+}
+
+extern "C" int otal_boundary_finish(int n, const float* const* terms, const float* weights, const int* T, int B, float* out2,
+                                    void* stream) {
+    if (!terms || !weights || !T || !out2) return OTAL_E_NULL;
+    if (n < 1 || n > BL_MAX || B <= 0) return OTAL_E_SHAPE;
+    BlItems it = {};
+    it.n = n;
+    for (int i = 0; i < n; ++i) {
+        if (!terms[i] || T[i] <= 0) return OTAL_E_SHAPE;
+        it.terms[i] = terms[i]; it.weight[i] = weights[i]; it.T[i] = T[i];
+    }
+    hipLaunchKernelGGL(boundary_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, it, B, out2);
+    return otal_launch_status();
+}
+
+extern "C" int otal_boundary_scale(int n, const float* const* dx, float* const* out, const float* weights, const int* C,
+                                   const int* T, int B, const float* g_start, const float* g_end, void* stream) {
+    if (!dx || !out || !weights || !C || !T) return OTAL_E_NULL;
+    if (n < 1 || n > BL_MAX || B <= 0) return OTAL_E_SHAPE;
+    BlItems it = {};
+    it.n = n;
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!dx[i] || !out[i] || T[i] <= 0 || C[i] <= 0 || (C[i] & 1)) return OTAL_E_SHAPE;
+        it.dx[i] = dx[i]; it.out[i] = out[i]; it.weight[i] = weights[i]; it.T[i] = T[i]; it.C[i] = C[i];
+        const int64_t cnt = (int64_t)B * C[i] * T[i];
+        most = cnt > most ? cnt : most;
+    }
+    hipLaunchKernelGGL(boundary_scale_kernel, dim3((unsigned)((most + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, it, B,
+                       g_start, g_end);
     return otal_launch_status();
 }

@@ -430,3 +430,45 @@ extern "C" int otal_detection_loss(const float* loc, const float* conf, const fl
     hipLaunchKernelGGL(detection_loss_kernel, dim3(1), dim3(LT), 0, (hipStream_t)stream, a);
     return otal_launch_status();
 }
+
+
+// ---- backward of the fused detection loss: the seven head gradients from the stored per-loss gradients and the incoming
+// scalar gradients of the seven losses, in ONE launch (the autograd formulation is 9 multiplies and 2 adds = 11 launches).
+//   grads layout (otal_detection_loss): dloc_l (2A) | dloc_ct (2A) | dpl_pl (2A) | dpl_ct (2A) | dconf (AC) | dpconf (AC) |
+//                                        dcen (A) | dact (A) | dpact (A),  A = B K
+//   g: device scalars {loss_l, loss_c, loss_prop_l, loss_prop_c, loss_ct, loss_act, loss_prop_act} (NULL = 0)
+//   out layout: d_loc (2A) | d_prop_loc (2A) | d_conf (AC) | d_prop_conf (AC) | d_center (A) | d_act (A) | d_prop_act (A)
+namespace {
+struct LossG { const float* g[7]; };
+__global__ __launch_bounds__(256) void detection_loss_bwd_kernel(const float* __restrict__ grads, LossG lg, float* __restrict__ out,
+                                                                 int A, int C) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t A2 = 2 * (int64_t)A, AC = (int64_t)A * C;
+    const int64_t total = 2 * A2 + 2 * AC + 3 * (int64_t)A;
+    if (e >= total) return;
+    auto gv = [&](int i) { return lg.g[i] ? *lg.g[i] : 0.f; };
+    const float* dloc_l = grads, *dloc_ct = grads + A2, *dpl_pl = grads + 2 * A2, *dpl_ct = grads + 3 * A2;
+    const float* dconf = grads + 4 * A2, *dpconf = dconf + AC, *dcen = dpconf + AC, *dact = dcen + A, *dpact = dact + A;
+    float v;
+    if (e < A2) v = dloc_l[e] * gv(0) + dloc_ct[e] * gv(4);
+    else if (e < 2 * A2) v = dpl_pl[e - A2] * gv(2) + dpl_ct[e - A2] * gv(4);
+    else if (e < 2 * A2 + AC) v = dconf[e - 2 * A2] * gv(1);
+    else if (e < 2 * A2 + 2 * AC) v = dpconf[e - 2 * A2 - AC] * gv(3);
+    else if (e < 2 * A2 + 2 * AC + A) v = dcen[e - 2 * A2 - 2 * AC] * gv(4);
+    else if (e < 2 * A2 + 2 * AC + 2 * (int64_t)A) v = dact[e - 2 * A2 - 2 * AC - A] * gv(5);
+    else v = dpact[e - 2 * A2 - 2 * AC - 2 * (int64_t)A] * gv(6);
+    out[e] = v;
+}
+}  // namespace
+
+extern "C" int otal_detection_loss_bwd(const float* grads, const float* const* g7, float* out, int B, int K, int C, void* stream) {
+    if (!grads || !g7 || !out) return OTAL_E_NULL;
+    if (B <= 0 || K <= 0 || C <= 0) return OTAL_E_SHAPE;
+    LossG lg;
+    for (int i = 0; i < 7; ++i) lg.g[i] = g7[i];
+    const int A = B * K;
+    const int64_t total = 4 * (int64_t)A + 2 * (int64_t)A * C + 3 * (int64_t)A;
+    hipLaunchKernelGGL(detection_loss_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grads, lg,
+                       out, A, C);
+    return otal_launch_status();
+}

@@ -50,11 +50,11 @@ def forward_one_epoch(net, criterion, clips, targets, scores=None, training=True
     loss_l, loss_c, loss_prop_l, loss_prop_c, loss_ct, loss_act, loss_prop_act = criterion(output_dict, targets)
     src = getattr(output_dict, 'boundary_maps', None)
     if src is not None and src[0].is_cuda and src[0].dtype == torch.float32:
-        # one launch per map: tanh, channel mean, BCE and the gradient, on the channel-major maps in place (csrc/bce.hip)
-        from ..common.ops import BoundaryBCEFunction
-        loss_start, loss_end = BoundaryBCEFunction.apply(src[0], scores, 0, 1)
-        a, b = BoundaryBCEFunction.apply(src[1], scores, 0, 4)       # F.interpolate(scale_factor=1/4), nearest
-        c, d = BoundaryBCEFunction.apply(src[2], scores, 0, 4)
+        # one launch per map (tanh, channel mean, BCE and the gradient, on the channel-major maps in place: csrc/bce.hip),
+        # one for the six means and the two weighted sums below, one for the backward of all three maps
+        from ..common.ops import BoundaryLossesFunction
+        loss_start, loss_end = BoundaryLossesFunction.apply(scores, (1, 4, 4), (1.0, 0.1, 0.1), *src)    # 4: F.interpolate(1/4)
+        return loss_l, loss_c, loss_prop_l, loss_prop_c, loss_ct, loss_start, loss_end, loss_act, loss_prop_act
     else:
         loss_start, loss_end = calc_bce_loss(output_dict['start'], output_dict['end'], scores)
         scores_ = scores[:, :, ::4]     # F.interpolate(scale_factor=1/4), nearest

@@ -908,3 +908,29 @@ def test_groupnorm_backward_reads_sliced_gradients_and_defers_batch_sums():
         for r in range(3):
             if o[r] is not None:
                 assert float((o[r].double() - want[r]).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_boundary_losses_fused_tails_match_calc_bce_loss():
+    """ops.BoundaryLossesFunction (three otal_boundary_bce launches + one launch for the means / weighted sums + one for the
+    backward of all maps) against the reference formulation of train.py:193-201 built from calc_bce_loss."""
+    from opental_amd.common import ops
+    from opental_amd.thumos14.train import calc_bce_loss
+    rs = np.random.RandomState(3)
+    B = 4
+    post_relu = lambda *shape: torch.from_numpy(np.abs(rs.randn(*shape)).astype(np.float32) * 0.6)      # post-ReLU features
+    maps = [post_relu(B, 512, 256), post_relu(B, 1024, 64), post_relu(B, 1024, 64)]
+    mask = torch.from_numpy((rs.rand(B, 2, 256) < 0.2).astype(np.float32))
+    xr = [m.clone().requires_grad_(True) for m in maps]
+    half = lambda x: (x[:, :x.shape[1] // 2].permute(0, 2, 1), x[:, x.shape[1] // 2:].permute(0, 2, 1))
+    s0, e0 = calc_bce_loss(*half(xr[0]), mask)
+    a, b_ = calc_bce_loss(*half(xr[1]), mask[:, :, ::4])
+    c, d = calc_bce_loss(*half(xr[2]), mask[:, :, ::4])
+    ls, le = s0 + 0.1 * (a + c), e0 + 0.1 * (b_ + d)
+    (2.0 * ls + 3.0 * le).backward()
+    xd = [m.cuda().requires_grad_(True) for m in maps]
+    gs, ge = ops.BoundaryLossesFunction.apply(mask.cuda(), (1, 4, 4), (1.0, 0.1, 0.1), *xd)
+    (2.0 * gs + 3.0 * ge).backward()
+    assert abs(float(gs) - float(ls)) < 1e-5 * abs(float(ls)) and abs(float(ge) - float(le)) < 1e-5 * abs(float(le))
+    for u, v in zip(xd, xr):
+        close(u.grad, v.grad, tol=1e-4)
