@@ -482,7 +482,10 @@ def gn_relu_backward(dy, x, gamma, beta, stats, groups=32, relu=True, levels=Non
     if PENDING_SUMS is not None and bias is not None and GRAD_SLOTS is not None:
         slots = [GRAD_SLOTS.take(t) for t in (gamma, beta, bias)]
         if all(sl is not None for sl in slots):
-            PENDING_SUMS.append((partial, slots, C, B))
+            # only ADDRESSES are kept: a second reference to a slot tensor would make autograd clone it instead of
+            # adopting it as .grad (AccumulateGrad steals a gradient only while it holds the sole reference), and the
+            # clone -- taken before the deferred sum has run -- would later be copied over the sum
+            PENDING_SUMS.append((partial, tuple(sl.data_ptr() for sl in slots), C, B))
             return dx, slots[0], slots[1], slots[2]
         for t, sl in zip((gamma, beta, bias), slots):       # hand back what was taken: the plain path returns fresh tensors
             if sl is not None:
@@ -497,9 +500,9 @@ def flush_pending_sums():
     if not items:
         return
     n = len(items)
-    VP = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
-    L.check(L.lib().otal_sum_partials(n, VP([it[0] for it in items]), VP([it[1][0] for it in items]), VP([it[1][1] for it in items]),
-                                      VP([it[1][2] for it in items]), L.int_array([it[2] for it in items]),
+    VP = lambda ps: (ctypes.c_void_p * n)(*ps)
+    L.check(L.lib().otal_sum_partials(n, VP([it[0].data_ptr() for it in items]), VP([it[1][0] for it in items]),
+                                      VP([it[1][1] for it in items]), VP([it[1][2] for it in items]), L.int_array([it[2] for it in items]),
                                       L.int_array([it[3] for it in items]), L.stream()), "otal_sum_partials")
     del items[:]
 

@@ -160,3 +160,49 @@ def test_two_graph_data_parallel_step_equals_eager_steps_on_one_rccl_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_trainer_arena_gradients_equal_plain_autograd(prec):
+    """Everything the trainer does to gradients on their way into the flat arena -- weight gradients written in place
+    (grad slots), GroupNorm batch sums deferred to the bucket flushes, stragglers copied by the flush, the backbone's
+    early hand-over -- must leave exactly the gradients that plain autograd leaves in .grad.  The arena is poisoned with
+    NaN first: a slot that is adopted but never written, or written and then overwritten by a stale copy, shows."""
+    import bench
+    from opental_amd.common import ops
+    dev = torch.device("cuda", 0)
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = prec
+    try:
+        tr = bench.build_trainer(dev, seed=9)
+        clips, targets, scores = bench.synth_batch(2, 1000, dev)
+        a = tr.arena
+        ibm = tr.criterion.cls_loss.weight_accum        # the loss kernel advances this EMA on every forward pass: every
+        ibm0 = ibm.detach().clone()                     # pass below starts from the same state
+        for _ in range(2):                          # the second pass runs with every cache warm, as a training step does
+            ibm.copy_(ibm0)
+            a.grad.fill_(float("nan"))
+            ops.activate_prologues(tr._prologues)
+            try:
+                cost, _ = tr.compute_cost(clips, targets, scores)
+                tr.begin_backward()
+                cost.backward()
+                tr.end_backward()
+            finally:
+                ops.deactivate_prologues()
+            got = a.grad.detach().clone()
+        assert bool(torch.isfinite(got).all()), int((~torch.isfinite(got)).sum())
+        for p in a.params:
+            p.grad = None
+        ibm.copy_(ibm0)
+        cost2, _ = tr.compute_cost(clips, targets, scores)
+        cost2.backward()
+        worst = 0.0
+        for p, off in zip(a.params, a.offsets):
+            want = p.grad.reshape(-1)
+            have = got[off:off + p.numel()]
+            scale = float(want.abs().max()) + 1e-12
+            worst = max(worst, float((have - want).abs().max()) / scale)
+        assert worst < 1e-5, worst
+    finally:
+        ops.CONV_PRECISION = old
