@@ -460,10 +460,24 @@ def main():
         saved_graph, trainer._graph = trainer._graph, None      # per-launch HIP events need eager launches
         # rank 0 runs these two profiling steps ALONE: no gradient all-reduce in them (the other ranks are not there to join)
         saved_coll, trainer.collectives = trainer.collectives, False
+        # The per-op HIP events only bracket GPU time while the GPU is the slower side: with the host lagging (it issues
+        # two extra event records per op here) an idle GPU timestamps the start marker the moment it arrives and the op's
+        # "duration" then contains the host's time between the marker and the launch (10-20 us per op, 2-3 ms per step on
+        # a slow host).  A spin kernel keeps the stream busy while the host issues the whole instrumented step ahead.
+        spin = None
+        try:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); torch.cuda._sleep(2_000_000); e1.record(); torch.cuda.synchronize()
+            per_cycle_ms = e0.elapsed_time(e1) / 2_000_000
+            spin = int(min(30.0 / max(per_cycle_ms, 1e-9), 2e9))          # ~30 ms of GPU time in front of each step
+        except Exception:                           # noqa: BLE001 -- no spin kernel: measure as before
+            spin = None
         ops.CONV_PROFILE = []
         for _ in range(2):
+            if spin:
+                torch.cuda._sleep(spin)
             trainer.step(clips, targets, scores)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
         trainer._graph, trainer.collectives = saved_graph, saved_coll
         by = {}
@@ -483,13 +497,13 @@ def main():
                     "conv_time_ms_per_step": round(tot_t / 2 * 1e3, 2),
                     "by_mode_TFLOPs": {k: round(e[0] / e[1] / 1e12, 2) for k, e in by.items()}}
         # ... the committed rocprofv3 --pmc passes over this very command (tools/pmc_step.sh) supply it for the default workload
-        pmc = os.path.join(REPO, "profiles", "r02_pmc_step_traffic.json")
+        pmc = os.path.join(REPO, "profiles", "r02b_pmc_step_traffic.json")
         if os.path.exists(pmc) and args.dtype == "bf16" and not anet and args.batch == 8 and not args.ssl:
             with open(pmc) as f:
                 t = json.load(f)
             roofline["traffic"] = int(t["conv_traffic_MB_per_launch"] * 1e6)
             roofline["traffic_note"] = ("bytes of HBM traffic per convolution launch, FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 "
-                                        "--pmc passes over this command (profiles/r02_pmc_step_traffic.txt); whole step "
+                                        "--pmc passes over this command (profiles/r02b_pmc_step_traffic.txt); whole step "
                                         f"{t['step_traffic_MB'] / 1e3:.1f} GB")
     hbm = None
     if rank == 0 and world == 1 and not args.no_hbm_kernels and not anet:
