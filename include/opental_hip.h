@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 18
+#define OTAL_ABI_VERSION 19
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -145,6 +145,21 @@ size_t otal_conv_prologue_desc_bytes(void);
 int otal_conv_prologue(const int* geom, const int64_t* strides, int mode, const float* w, int precision, void* region,
                        size_t region_bytes, void* host_desc, void* stream);
 int otal_conv_prologue_batch(int n, const void* device_descs, const int* device_starts, int total_blocks, void* stream);
+
+/* Deferred weight-gradient reductions.  Nobody reads a weight gradient before the optimizer / the gradient all-reduce, so
+ * its split-K reduce need not follow its GEMM: after otal_conv_defer_reduces(1), otal_conv_wgrad launches whose reduction is
+ * the plain fixed-order slab sum leave their slabs in the workspace and record the reduction instead of launching it;
+ * otal_conv_deferred_end() != 0 then is the address one past those slabs -- the caller must hand every later launch workspace
+ * BEHIND it until otal_conv_flush_reduces(stream) has run all recorded reductions (up to 24; more flush by themselves) as
+ * ONE launch.  Launches with a transposing reduce (direct 3x3x3 kernels) or unaligned slabs reduce at once as before
+ * (deferred_end() == 0).  otal_conv_defer_reduces(0) needs an empty record.  The summation order is the one of the
+ * immediate reduce for >= 16 slabs (quarter sums in slab order, (q0+q1)+(q2+q3)); deterministic.  Process-global state: one
+ * issuing thread.  Replaces nothing in the reference (autograd of nn.Conv1d / nn.Conv3d, i3d_backbone.py:33-43,
+ * layers.py:187-192, has no split-K); it removes ~40 of this library's own launches per training step. */
+int otal_conv_defer_reduces(int on);
+size_t otal_conv_deferred_end(void);
+int otal_conv_deferred_count(void);
+int otal_conv_flush_reduces(void* stream);
 
 /* (Cout,Cin,kvol) -> (Cin,Cout,kvol): the A operand of the data-gradient GEMM. */
 int otal_conv_pack_wt(const float* w, float* wt, int Cout, int Cin, int kvol, void* stream);

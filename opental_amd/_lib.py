@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTAL_LIB_PATH") or os.path.join(_HERE, "lib", "libopental_hip.so")   # override: A/B kernel builds
-ABI_VERSION = 18
+ABI_VERSION = 19
 F32, BF16 = 0, 1
 
 _lib = None

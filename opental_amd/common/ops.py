@@ -15,7 +15,8 @@ from .. import _lib as L
 from .conv_geom import make_geom
 
 _WORKSPACE = {}
-WORKSPACE_BYTES = 192 << 20
+WORKSPACE_BYTES = 192 << 20         # what one launch is offered (its split-K choice depends on it: kept fixed)
+WORKSPACE_TOTAL = 512 << 20         # the buffer: room for the slabs of deferred weight-gradient reductions in front of that
 
 # Optional per-launch timing of the implicit-GEMM kernels (bench.py's roofline leg): when a list is
 # installed here, every conv launch is bracketed by HIP events recorded on the launch stream
@@ -53,9 +54,50 @@ def workspace(device):
     key = (device.type, device.index)
     ws = _WORKSPACE.get(key)
     if ws is None:
-        ws = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        ws = torch.empty(WORKSPACE_TOTAL, dtype=torch.uint8, device=device)
         _WORKSPACE[key] = ws
     return ws
+
+
+# ---- deferred weight-gradient reductions (include/opental_hip.h: otal_conv_defer_reduces).  While a trainer's backward
+# runs, the split-K reduce of a weight gradient is recorded instead of launched; its slabs stay in the workspace and every
+# later launch works BEHIND them (_WS_CURSOR); flush_reduces() runs all recorded reductions as one launch -- called when
+# the backbone announces a module's gradients (grads_ready), at the trainer's bucket flushes, and when the slabs fill up.
+_DEFER = False
+_WS_CURSOR = 0
+
+
+def _ws_args(device):
+    """(pointer, size) of the workspace a launch may use now."""
+    ws = workspace(device)
+    return ctypes.c_void_p(ws.data_ptr() + _WS_CURSOR), ctypes.c_size_t(min(ws.numel() - _WS_CURSOR, WORKSPACE_BYTES))
+
+
+def defer_reduces(on):
+    global _DEFER
+    if not on:
+        flush_reduces()
+    L.check(L.lib().otal_conv_defer_reduces(int(bool(on))), "otal_conv_defer_reduces")
+    _DEFER = bool(on)
+
+
+def flush_reduces():
+    global _WS_CURSOR
+    if _DEFER and _WS_CURSOR:
+        L.check(L.lib().otal_conv_flush_reduces(L.stream()), "otal_conv_flush_reduces")
+    _WS_CURSOR = 0
+
+
+def _after_wgrad(device):
+    """Advance the workspace cursor past the slabs a deferred reduction still needs; flush when they pile up."""
+    global _WS_CURSOR
+    lib = L.lib()
+    lib.otal_conv_deferred_end.restype = ctypes.c_size_t
+    end = int(lib.otal_conv_deferred_end())
+    if end:
+        _WS_CURSOR = (end - workspace(device).data_ptr() + 255) & ~255
+        if _WS_CURSOR > WORKSPACE_TOTAL - WORKSPACE_BYTES:
+            flush_reduces()
 
 
 def _as5(t):
@@ -248,11 +290,11 @@ def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=F
     if not w.is_contiguous():
         raise RuntimeError("weights must be contiguous")
     ga, sa = _geom_arrays(g, x5, y5)
-    ws = workspace(x.device)
+    wsp, wsn = _ws_args(x.device)
     ev = _prof_begin()
     pre = _prologue(0, ga, sa, g, x5, y5, w, int(CONV_PRECISION))
     L.check(L.lib().otal_conv_fwd(ga, sa, L.ptr(x5), L.ptr(w), _opt(scale), _opt(shift), L.ptr(y5), int(relu),
-                                  int(CONV_PRECISION) | (4 if half_out else 0), pre, L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
+                                  int(CONV_PRECISION) | (4 if half_out else 0), pre, wsp, wsn, L.stream()),
             "otal_conv_fwd")
     _prof_end(ev, "fwd", g)
     return out
@@ -291,7 +333,7 @@ def conv_dgrad(dy, w, x_shape, k, s, spatial_valid=False, levels=None, out=None,
         wt = w if w.is_contiguous() else w.contiguous()
         prec |= 2
     ga, sa = _geom_arrays(g, x5, dy5)
-    ws = workspace(dy.device)
+    wsp, wsn = _ws_args(dy.device)
     ev = _prof_begin()
     if out_mask is not None:
         m5 = _as5(out_mask)
@@ -300,7 +342,7 @@ def conv_dgrad(dy, w, x_shape, k, s, spatial_valid=False, levels=None, out=None,
     pre = _prologue(1, ga, sa, g, x5, dy5, wt, prec) if (prec & 2) else None     # regions are keyed on the live weight tensor
     L.check(L.lib().otal_conv_dgrad(ga, sa, L.ptr(dy5), L.ptr(wt), L.ptr(x5),
                                     int(accumulate), _opt(out_mask), _opt(out_scale), prec, pre,
-                                    L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
+                                    wsp, wsn, L.stream()),
             "otal_conv_dgrad")
     _prof_end(ev, "dgrad", g)
     return out
@@ -402,6 +444,7 @@ GRAD_READY = None       # the running trainer's callback for weight gradients th
 def grads_ready(pairs):
     """A multi-layer autograd node (the I3D backbone) announces (weight, gradient) pairs as soon as they are final, so a
     data-parallel trainer can hand the finished arena range to RCCL while the node's remaining layers still run."""
+    flush_reduces()                 # the announced gradients are final: their recorded reductions run now, as one launch
     cb = GRAD_READY
     if cb is not None:
         cb(pairs)
@@ -430,13 +473,16 @@ def conv_wgrad(x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None,
     half_dy = dy5.dtype == torch.bfloat16                   # bf16-stored gradient (maxpool3d_backward(half_out=True))
     _check(x5, "x"); _check(dy5, "dy", dy5.dtype if half_dy else torch.float32)
     ga, sa = _geom_arrays(g, x5, dy5)
-    ws = workspace(x.device)
+    if _DEFER and accumulate:
+        flush_reduces()             # a recorded reduction may still be on its way to this very buffer
+    wsp, wsn = _ws_args(x.device)
     ev = _prof_begin()
     pre = None if half_dy else _prologue(2, ga, sa, g, x5, dy5, x, int(CONV_PRECISION))
     L.check(L.lib().otal_conv_wgrad(ga, sa, L.ptr(x5), L.ptr(dy5), L.ptr(out),
-                                    int(accumulate), int(CONV_PRECISION) | (4 if half_dy else 0), pre, L.ptr(ws),
-                                    ctypes.c_size_t(ws.numel()), L.stream()),
+                                    int(accumulate), int(CONV_PRECISION) | (4 if half_dy else 0), pre, wsp, wsn, L.stream()),
             "otal_conv_wgrad")
+    if _DEFER:
+        _after_wgrad(x.device)
     _prof_end(ev, "wgrad", g)
     return out
 

@@ -1524,10 +1524,85 @@ __global__ __launch_bounds__(256) void splitk_reduce_tall_kernel(const ConvArgs 
     }
 }
 
+// ---- deferred weight-gradient reductions.  A weight gradient is consumed by nobody before the optimizer (or the gradient
+// all-reduce), so its split-K reduce need not follow its GEMM: between otal_conv_defer_reduces(1) and
+// otal_conv_flush_reduces() the weight-gradient launches leave their slabs in the caller's workspace (the caller hands every
+// later launch the workspace BEHIND otal_conv_deferred_end()) and up to DEFER_MAX reductions run as ONE launch -- the six
+// weight gradients of an Inception module, or the GroupNorm blocks between two bucket flushes of the trainer.  Same
+// summation tree as splitk_reduce_tall_kernel (four quarter sums in slab order, combined (q0+q1)+(q2+q3)): deterministic.
+// Process-global state, used from the one thread that issues the training step.
+constexpr int DEFER_MAX = 24;
+struct DeferItem { const float* slab; float* out; int64_t total; int splits, flags, N, kw; };
+struct DeferBatch { DeferItem it[DEFER_MAX]; };
+static struct { bool on = false; int n = 0; DeferBatch batch; uintptr_t last_end = 0; } g_defer;
+
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const DeferBatch b) {
+    __shared__ float4 part[3][64];
+    const DeferItem& d = b.it[blockIdx.y];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t base = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    if ((int64_t)blockIdx.x * 256 >= d.total) return;              // workgroup beyond this item (uniform)
+    const bool live = base < d.total;
+    const int per = (d.splits + 3) / 4;
+    const int s_lo = q * per, s_hi = min(d.splits, s_lo + per);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        for (int s0 = s_lo; s0 < s_hi; s0 += 8) {
+            float4 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int sidx = min(s0 + u, s_hi - 1);
+                tmp[u] = *reinterpret_cast<const float4*>(d.slab + (int64_t)sidx * d.total + base);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < s_hi) { acc.x += tmp[u].x; acc.y += tmp[u].y; acc.z += tmp[u].z; acc.w += tmp[u].w; }
+        }
+    }
+    if (q > 0) part[q - 1][lane] = acc;
+    __syncthreads();
+    if (q > 0 || !live) return;
+    const float4 p1 = part[0][lane], p2 = part[1][lane], p3 = part[2][lane];
+    float r[4] = {(acc.x + p1.x) + (p2.x + p3.x), (acc.y + p1.y) + (p2.y + p3.y), (acc.z + p1.z) + (p2.z + p3.z), (acc.w + p1.w) + (p2.w + p3.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t idx = base + e;
+        float v = r[e];
+        int64_t off = idx;
+        if (d.flags & EPI_NPAD8) {
+            const int m = (int)(idx / d.N), n = (int)(idx - (int64_t)m * d.N);
+            if ((n & 7) >= d.kw) continue;
+            off = (int64_t)m * ((d.N >> 3) * d.kw) + (n >> 3) * d.kw + (n & 7);
+        }
+        if (d.flags & EPI_ACCUM) v += d.out[off];
+        d.out[off] = v;
+    }
+}
+
+static int flush_deferred(hipStream_t st) {
+    if (g_defer.n == 0) return 0;
+    int64_t most = 0;
+    for (int i = 0; i < g_defer.n; ++i) most = g_defer.batch.it[i].total > most ? g_defer.batch.it[i].total : most;
+    hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3((unsigned)((most + 255) / 256), g_defer.n), dim3(256), 0, st, g_defer.batch);
+    g_defer.n = 0;
+    return otal_launch_status();
+}
+
 template <int MODE>
 static int launch_splitk_reduce(const ConvArgs& a, hipStream_t st) {
     const int64_t total = (int64_t)a.M * a.N;
     const bool v4 = (total % 4 == 0) && (((uintptr_t)a.slab & 15) == 0);
+    if (MODE == MODE_WGRAD) {
+        g_defer.last_end = 0;
+        if (g_defer.on && v4 && total <= (1 << 23)) {
+            if (g_defer.n == DEFER_MAX)
+                if (int e = flush_deferred(st)) return e;
+            DeferItem& d = g_defer.batch.it[g_defer.n++];
+            d.slab = a.slab; d.out = a.out; d.total = total; d.splits = a.splits; d.flags = a.flags; d.N = a.N; d.kw = a.g.kw;
+            g_defer.last_end = reinterpret_cast<uintptr_t>(a.slab + (int64_t)a.splits * total);
+            return 0;
+        }
+    }
     if (v4 && a.splits >= 16 && total <= (1 << 21) && !OTAL_OPT("OTAL_CONV_NOTALLREDUCE", 0)) {
         const int blocks = (int)((total / 4 + 63) / 64);
         hipLaunchKernelGGL((splitk_reduce_tall_kernel<MODE>), dim3(blocks), dim3(256), 0, st, a);
@@ -2847,3 +2922,14 @@ extern "C" int otal_conv_prologue_batch(int n, const void* device_descs, const i
                        static_cast<const PrepDesc*>(device_descs), device_starts, n);
     return otal_launch_status();
 }
+
+
+extern "C" int otal_conv_defer_reduces(int on) {
+    if (!on && g_defer.n) return OTAL_E_SHAPE;          // flush first
+    g_defer.on = on != 0;
+    g_defer.last_end = 0;
+    return 0;
+}
+extern "C" size_t otal_conv_deferred_end(void) { return (size_t)g_defer.last_end; }
+extern "C" int otal_conv_deferred_count(void) { return g_defer.n; }
+extern "C" int otal_conv_flush_reduces(void* stream) { return flush_deferred((hipStream_t)stream); }

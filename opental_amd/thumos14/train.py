@@ -269,6 +269,7 @@ class DetectorTrainer:
             return
         self._flushed[b] = True
         a = self.arena
+        ops.flush_reduces()                             # recorded weight-gradient reductions: one launch
         ops.flush_pending_sums()                        # deferred GroupNorm batch sums land in their arena slices: one launch
         dst, src = [], []
         for i in a.bucket_members[b]:
@@ -309,6 +310,7 @@ class DetectorTrainer:
         # GroupNorm's batch sums are deferred to the bucket flushes -- unless a parameter may be used twice in this backward
         # (ssl step): a second gradient would be accumulated into the arena slice before the deferred sum is written there
         ops.PENDING_SUMS = [] if early else None
+        ops.defer_reduces(early and ops.CONV_PROFILE is None)     # split-K reduces of weight gradients: batched (per-op timing: at once)
         if self.collectives and not self._capturing and self._ibm_state() is not None:
             # the loss kernel updated the IBM EMA in the forward pass: its 50-float average travels under the backward
             self._ibm_work = dist.all_reduce(self._ibm_state(), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -322,6 +324,7 @@ class DetectorTrainer:
         """Call after cost.backward(): flush the buckets that did not complete (unused parameters), wait for the
         all-reduces, and leave every .grad aliasing its arena slice."""
         self._drain(force=True)
+        ops.defer_reduces(False)                        # flushes what is still recorded
         ops.flush_pending_sums()
         ops.PENDING_SUMS = None
         ops.GRAD_SLOTS = None
@@ -381,6 +384,7 @@ class DetectorTrainer:
             ops.GRAD_SLOTS = None
             ops.GRAD_READY = None
             ops.PENDING_SUMS = None
+            ops.defer_reduces(False)
         self.step_count += 1
         self.optimizer_update()
         if stale:
@@ -443,6 +447,7 @@ class DetectorTrainer:
             ops.GRAD_SLOTS = None
             ops.GRAD_READY = None
             ops.PENDING_SUMS = None
+            ops.defer_reduces(False)
         a = self.arena
         keep = self._stash_skipped()
         for lo, hi, g_lr in self._group_ranges:
@@ -558,6 +563,7 @@ class DetectorTrainer:
             ops.GRAD_SLOTS = None
             ops.GRAD_READY = None
             ops.PENDING_SUMS = None
+            ops.defer_reduces(False)
             self._pending = None
         if self._skipped:
             raise RuntimeError("capture_step(split=True): a parameter received no gradient; use eager launches")
