@@ -1,0 +1,126 @@
+"""GPU: the data-parallel training step of the REAL detector on TWO ranks.
+
+The build and test boxes have one GPU, and RCCL refuses two ranks on one device -- so the two rank processes share cuda:0
+and the collectives run on gloo (device tensors).  Everything else is the product path: the flat arena and its buckets,
+the fixed issue order, the backbone's early hand-over, the deferred reductions / sums, the IBM state average, Adam with
+grad_scale 1 / world, and the two-graph step with the collectives issued BETWEEN the graphs (capture_step(split=True)).
+Checked against a single-process restatement of what data parallelism must compute: per-rank gradients of the
+per-rank losses, summed, scaled by 1 / world; the IBM EMA averaged over ranks."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RANK_CODE = textwrap.dedent('''
+    import os, sys, torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.getcwd())
+    import bench
+    from opental_amd.common import ops
+    ops.CONV_PRECISION = 1
+    rank, world, mode, out = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[1], sys.argv[2]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    tr = bench.build_trainer(dev, seed=5)
+    assert tr.collectives and tr.world == world
+    tr.lr = 1e-4
+    clips, targets, scores = bench.synth_batch(2, 1000 + rank, dev)
+    steps = 3
+    if mode == "split":
+        tr.capture_step(clips, targets, scores, warmup=1, split=True)       # one real (eager) step, then the capture
+        assert tr._graph[0] == "split"
+        done = 1
+    else:
+        done = 0
+    costs = []
+    for _ in range(steps - done):
+        costs.append(float(tr.step(clips, targets, scores)[0]))
+    torch.cuda.synchronize()
+    assert tr.step_count == steps
+    torch.save({"flat": tr.arena.flat.cpu(), "m": tr.arena.m.cpu(), "ibm": tr.criterion.cls_loss.weight_accum.cpu(),
+                "costs": costs, "order": list(tr._flush_order), "buckets": list(tr.arena.buckets)}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def _run(mode, tmp_path, port):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / f"res_{mode}")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2")
+        procs.append(subprocess.Popen([sys.executable, "-c", RANK_CODE, mode, out], cwd=root, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError(f"{mode}: the ranks did not finish")
+        logs.append((p.returncode, o[-1500:], e[-3000:]))
+    assert all(rc == 0 for rc, _, _ in logs), logs
+    import torch
+    return [torch.load(out + f".{r}") for r in range(2)]
+
+
+def _reference(steps=3):
+    """What two data-parallel ranks must compute, in ONE process without collectives."""
+    import torch
+    import bench
+    from opental_amd.common import ops
+    dev = torch.device("cuda", 0)
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        tr = bench.build_trainer(dev, seed=5)
+        tr.lr = 1e-4
+        tr.world = 2                                    # Adam's grad_scale = 1 / world
+        batches = [bench.synth_batch(2, 1000 + r, dev) for r in range(2)]
+        ibm = tr.criterion.cls_loss.weight_accum
+        for _ in range(steps):
+            state = ibm.detach().clone()
+            total, states = torch.zeros_like(tr.arena.grad), []
+            for b in batches:
+                ibm.copy_(state)
+                ops.activate_prologues(tr._prologues)
+                try:
+                    cost, _ = tr.compute_cost(*b)
+                    tr.begin_backward()
+                    cost.backward()
+                    tr.end_backward()
+                finally:
+                    ops.deactivate_prologues()
+                total += tr.arena.grad
+                states.append(ibm.detach().clone())
+            tr.arena.grad.copy_(total)
+            ibm.copy_((states[0] + states[1]) / 2)
+            tr.step_count += 1
+            tr.optimizer_update()
+        torch.cuda.synchronize()
+        return tr.arena.flat.cpu(), tr.arena.m.cpu(), ibm.cpu()
+    finally:
+        ops.CONV_PRECISION = old
+
+
+@pytest.mark.parametrize("mode", ["eager", "split"])
+def test_two_ranks_on_one_gpu_match_the_single_process_restatement(mode, tmp_path):
+    import torch
+    res = _run(mode, tmp_path, 29551 if mode == "eager" else 29552)
+    # both ranks hold the same parameters, moments and IBM state, and issued their collectives in the same order
+    assert torch.equal(res[0]["flat"], res[1]["flat"]) and torch.equal(res[0]["m"], res[1]["m"])
+    assert torch.equal(res[0]["ibm"], res[1]["ibm"]) and res[0]["order"] == res[1]["order"] and res[0]["buckets"] == res[1]["buckets"]
+    flat, m, ibm = _reference()
+    scale = float(flat.abs().max())
+    # the sum over ranks is one fp32 add per element either way; what may differ is the order of the two addends (none:
+    # a + b) and the reference's extra accumulate through a zero tensor (0 + a + b): exact
+    assert float((res[0]["flat"] - flat).abs().max()) <= 1e-6 * scale, float((res[0]["flat"] - flat).abs().max())
+    assert float((res[0]["m"] - m).abs().max()) <= 1e-6 * float(m.abs().max())
+    assert float((res[0]["ibm"] - ibm).abs().max()) <= 1e-6 * float(ibm.abs().max() + 1e-12)
