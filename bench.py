@@ -349,6 +349,8 @@ def main():
     if world != args.gpus and not os.environ.get("OTAL_FORCE_DIST"):
         raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python bench.py --gpus N does it by itself)")
+    if os.environ.get("OTAL_ONE_GPU"):      # test hook: every rank on cuda:0 (with OTAL_DIST_BACKEND=gloo: the N > 1 control
+        local = 0                           # flow of this file on a one-GPU box; RCCL refuses two ranks on one device)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     force_dist = bool(os.environ.get("OTAL_FORCE_DIST"))      # exercise the RCCL path on a single rank
@@ -356,7 +358,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        backend = os.environ.get("OTAL_DIST_BACKEND", "nccl")       # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
         if dist.get_world_size() != world:
             raise SystemExit(f"RCCL reports {dist.get_world_size()} ranks, expected {world}")
     from opental_amd.common import ops as _ops
@@ -429,6 +435,19 @@ def main():
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             ok = int(okt)
         graphed = bool(ok)
+        if graphed and multi and launch_probe is not None:
+            # insurance on hardware this file has never seen: the two-graph step must actually beat the eager one it replaces
+            # (both timed here, MAX over ranks); otherwise back to eager launches
+            barrier()
+            t = time.perf_counter()
+            for _ in range(3):
+                trainer.step(clips, targets, scores)
+            torch.cuda.synchronize()
+            tt = torch.tensor([(time.perf_counter() - t) / 3], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            launch_probe["two_graph_ms"] = round(float(tt[0]) * 1e3, 3)
+            if float(tt[0]) * 1e3 > launch_probe["eager_ms"]:
+                graphed = False
         if not graphed:
             trainer._graph = None
     for _ in range(args.warmup):
