@@ -449,7 +449,7 @@ def main():
             if float(tt[0]) * 1e3 > launch_probe["eager_ms"]:
                 graphed = False
         if not graphed:
-            trainer._graph = None
+            trainer.drop_graph()
     for _ in range(args.warmup):
         trainer.step(clips, targets, scores, *ssl_args)
     trainer.measure_exposed = multi      # HIP events around the wait for the gradient all-reduces (eager or between the two graphs)

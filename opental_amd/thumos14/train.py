@@ -613,6 +613,15 @@ class DetectorTrainer:
                     raise RuntimeError("captured step replayed with different input shapes; call capture_step again")
                 dst.copy_(src, non_blocking=True)
 
+    def drop_graph(self):
+        """Back to eager launches: forget the captured step (and the two-node form of the backbone it needed)."""
+        self._graph = None
+        self._graph_keepalive = None
+        model = getattr(getattr(self.net, 'backbone', None), '_model', None)
+        if model is not None and hasattr(model, 'split_backward'):
+            model.split_backward = False
+            model.stem_out = None
+
     def _set_bias(self, step):
         bc = ops.adam_bias_corrections(step, self.betas[0], self.betas[1])
         self._bias_corr.copy_(torch.tensor(bc, dtype=torch.float32), non_blocking=False)
