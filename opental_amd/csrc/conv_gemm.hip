@@ -1296,10 +1296,10 @@ __device__ __forceinline__ void prep_chunks_body(const PrepDesc& d, unsigned bid
             }
             ctab[gid] = e;
         }
-        const int half = Kp / 2;
-        const int64_t pairs = (int64_t)Mpad * half;
-        for (int64_t p = gid; p < pairs; p += (int64_t)nblk * 256) {
-            const int m = (int)(p / half), k = (int)(p - (int64_t)m * half) * 2;
+        const unsigned half = (unsigned)Kp / 2;
+        const unsigned pairs = (unsigned)Mpad * half;           // < 2^31 (checked by the launcher): 32-bit index math --
+        for (unsigned p = (unsigned)gid; p < pairs; p += nblk * 256u) {    // a 64-bit division is ~80 VALU instructions
+            const int m = (int)(p / half), k = (int)(p - (unsigned)m * half) * 2;
             float v[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -1327,10 +1327,10 @@ __device__ __forceinline__ void prep_chunks_body(const PrepDesc& d, unsigned bid
         }
         ctab[gid] = e;
     }
-    const int half = Kp / 2;
-    const int64_t pairs = (int64_t)Mpad * half;
-    for (int64_t p = gid; p < pairs; p += (int64_t)nblk * 256) {
-        const int m = (int)(p / half), k = (int)(p - (int64_t)m * half) * 2;
+    const unsigned half = (unsigned)Kp / 2;
+    const unsigned pairs = (unsigned)Mpad * half;
+    for (unsigned p = (unsigned)gid; p < pairs; p += nblk * 256u) {
+        const int m = (int)(p / half), k = (int)(p - (unsigned)m * half) * 2;
         float v[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1353,9 +1353,9 @@ template <int MODE>
 __device__ __forceinline__ void pack_direct_body(unsigned* __restrict__ wp, const float* __restrict__ w, int M, int Mpad, int C, int natural,
                                                  unsigned bid, unsigned nblk) {
     const int Ktot = C * 27;
-    const int64_t pairs = (int64_t)Mpad * Ktot / 2;
-    for (int64_t p = (int64_t)bid * 256 + threadIdx.x; p < pairs; p += (int64_t)nblk * 256) {
-        const int m = (int)(p / (Ktot / 2)), k = (int)(p - (int64_t)m * (Ktot / 2)) * 2;
+    const unsigned hk = (unsigned)Ktot / 2, pairs = (unsigned)Mpad * hk;       // < 2^31: 32-bit index math
+    for (unsigned p = bid * 256u + threadIdx.x; p < pairs; p += nblk * 256u) {
+        const int m = (int)(p / hk), k = (int)(p - (unsigned)m * hk) * 2;
         float v[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -2298,11 +2298,14 @@ static void fill_prep_desc(PrepDesc& d, const ConvArgs& a, int2* ctab, unsigned 
     d.direct = 0;
 }
 static inline unsigned prep_blocks(const PrepDesc& d) {
+    // the pack kernels index with 32 bits: a weight matrix of 2^31 bf16 pairs (8 GB) is refused (0 blocks = launch error)
     if (d.direct) {
         const int64_t pairs = (int64_t)d.Mpad * d.C * 27 / 2;
+        if (pairs >= (1LL << 31)) return 0;
         return (unsigned)((pairs + 255) / 256 < 2048 ? (pairs + 255) / 256 : 2048);
     }
     const int64_t pairs = (int64_t)d.Mpad * (d.Kp / 2);
+    if (pairs >= (1LL << 31)) return 0;
     int64_t blocks = (pairs + 255) / 256;
     if (blocks < (d.nchunk + 255) / 256) blocks = (d.nchunk + 255) / 256;
     return (unsigned)(blocks > 2048 ? 2048 : blocks);
