@@ -245,17 +245,52 @@ def deactivate_prologues():
     PROLOGUES = None
 
 
-def _prologue(mode, ga, sa, g, x5, y5, w, prec):
+def _prologue(mode, ga, sa, pkey, w, prec):
+    """pkey: the launch's static identity (mode, geometry, strides) from its plan."""
     c = PROLOGUES
     if c is None or not (prec & 1):
         return None
+    wp = 0
     if mode != 2:
+        wp = w.data_ptr()
         r = c.persistent_range
-        if r is None or not (r[0] <= w.data_ptr() < r[1]):
+        if r is None or not (r[0] <= wp < r[1]):
             return None
-    key = (mode, w.data_ptr() if (w is not None and mode != 2) else 0, tuple(g), _bs(x5), _bs(y5), prec)
-    reg = c.region(mode, ga, sa, key, w, prec)
+    reg = c.region(mode, ga, sa, (wp, pkey, prec), w, prec)
     return None if reg is None else L.ptr(reg)
+
+
+# ---- launch plans.  Everything about a convolution launch that depends only on shapes and strides -- the geometry record,
+# its ctypes arrays, the layout checks, the static part of the prologue key -- is derived once per (mode, shapes, strides,
+# kernel, stride, levels) and found again with one dictionary lookup: the wrappers below run ~180 times per training step
+# and their Python overhead (about half of a ~17 us call) is what makes eager data-parallel ranks host-bound.
+_PLANS = {}
+
+
+def _plan(mode, xs, ys, Cout, k, s, levels, spatial_valid, xname, yname):
+    """xs: the tensor on the convolution's input side (x or dx), ys: on its output side (y or dy); (B,C,T) or (B,C,T,H,W)."""
+    key = (mode, xs.shape, xs.stride(), ys.shape, ys.stride(), Cout, k, s, levels, spatial_valid, xs.dtype, ys.dtype)
+    plan = _PLANS.get(key)
+    if plan is None:
+        x5, y5 = _as5(xs), _as5(ys)
+        B, Cin, Ti, Hi, Wi = x5.shape
+        g, outn = _make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
+        if tuple(y5.shape) != (B, Cout) + outn:
+            raise RuntimeError(f"{yname} has shape {tuple(y5.shape)}, expected {(B, Cout) + outn}")
+        _check(x5, xname, x5.dtype)         # layout checks; the callers have checked the dtypes
+        _check(y5, yname, y5.dtype)
+        ga, sa = _geom_arrays(g, x5, y5)
+        plan = (g, ga, sa, (mode, tuple(g), _bs(x5), _bs(y5)), (tuple(x5.shape), _bs(x5)))
+        if len(_PLANS) > 4096:
+            _PLANS.clear()
+        _PLANS[key] = plan
+    return plan
+
+
+def _out_positions(x, Cout, k, s, levels, spatial_valid):
+    x5 = _as5(x)
+    B, Cin, Ti, Hi, Wi = x5.shape
+    return _make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)[1]
 
 
 def half_storage_ok(mode, x_shape, cout, k, s):
@@ -275,26 +310,24 @@ def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=F
     """y = act(scale * conv_SAME(x, w) + shift).  x (B,Cin,T[,H,W]); w (Cout,Cin,*k).
     half_out: y is STORED as bf16 (half_storage_ok(0, ...) geometries only)."""
     k, s = _k3(k), _k3(s)
-    x5 = _as5(x)
-    B, Cin, Ti, Hi, Wi = x5.shape
+    if levels is not None:
+        levels = tuple(levels)
     Cout = w.shape[0]
-    g, outn = _make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
     if out is None:
-        out = torch.empty((B, Cout) + outn, dtype=torch.bfloat16 if half_out else x.dtype, device=x.device)
-        if x.dim() == 3:
-            out = out.view(B, Cout, outn[0])
-    y5 = _as5(out)
-    if tuple(y5.shape) != (B, Cout) + outn:
-        raise RuntimeError(f"conv_forward: out has shape {tuple(y5.shape)}, expected {(B, Cout) + outn}")
-    _check(x5, "x"); _check(y5, "y", torch.bfloat16 if half_out else torch.float32)
+        outn = _out_positions(x, Cout, k, s, levels, spatial_valid)
+        out = torch.empty((x.shape[0], Cout) + (outn if x.dim() == 5 else outn[:1]),
+                          dtype=torch.bfloat16 if half_out else x.dtype, device=x.device)
+    if out.dtype != (torch.bfloat16 if half_out else torch.float32) or x.dtype != torch.float32:
+        raise RuntimeError("conv_forward: float32 tensors (bfloat16 y with half_out)")
+    g, ga, sa, pkey, _ = _plan(0, x, out, Cout, k, s, levels, spatial_valid, "x", "y")
     if not w.is_contiguous():
         raise RuntimeError("weights must be contiguous")
-    ga, sa = _geom_arrays(g, x5, y5)
     wsp, wsn = _ws_args(x.device)
     ev = _prof_begin()
-    pre = _prologue(0, ga, sa, g, x5, y5, w, int(CONV_PRECISION))
-    L.check(L.lib().otal_conv_fwd(ga, sa, L.ptr(x5), L.ptr(w), _opt(scale), _opt(shift), L.ptr(y5), int(relu),
-                                  int(CONV_PRECISION) | (4 if half_out else 0), pre, wsp, wsn, L.stream()),
+    prec = int(CONV_PRECISION)
+    pre = _prologue(0, ga, sa, pkey, w, prec)
+    L.check(L.lib().otal_conv_fwd(ga, sa, L.ptr(x), L.ptr(w), _opt(scale), _opt(shift), L.ptr(out), int(relu),
+                                  prec | (4 if half_out else 0), pre, wsp, wsn, L.stream()),
             "otal_conv_fwd")
     _prof_end(ev, "fwd", g)
     return out
@@ -315,32 +348,30 @@ def conv_dgrad(dy, w, x_shape, k, s, spatial_valid=False, levels=None, out=None,
     out_mask/out_scale: multiply this contribution by (out_mask > 0) * out_scale[ci] in the store
     (ReLU + frozen-BN backward of the layer that produced x; out_mask has dx's layout)."""
     k, s = _k3(k), _k3(s)
-    dy5 = _as5(dy)
-    xs5 = tuple(x_shape) + (1, 1) if len(x_shape) == 3 else tuple(x_shape)
-    B, Cin, Ti, Hi, Wi = xs5
+    if levels is not None:
+        levels = tuple(levels)
     Cout = w.shape[0]
-    g, outn = _make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
     if out is None:
         if accumulate:
             raise RuntimeError("accumulate needs an existing buffer")
         out = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
-    x5 = _as5(out)
-    _check(x5, "dx"); _check(dy5, "dy")
-    if tuple(dy5.shape) != (B, Cout) + outn:
-        raise RuntimeError(f"conv_dgrad: dy has shape {tuple(dy5.shape)}, expected {(B, Cout) + outn}")
+    elif tuple(out.shape) != tuple(x_shape):
+        raise RuntimeError(f"conv_dgrad: out has shape {tuple(out.shape)}, expected {tuple(x_shape)}")
+    if out.dtype != torch.float32 or dy.dtype != torch.float32:
+        raise RuntimeError("conv_dgrad: float32 tensors")
+    g, ga, sa, pkey, xlay = _plan(1, out, dy, Cout, k, s, levels, spatial_valid, "dx", "dy")
     prec = int(CONV_PRECISION)
     if wt is None:          # hand the forward-layout weight over; the launch re-orders it in its own prologue
         wt = w if w.is_contiguous() else w.contiguous()
         prec |= 2
-    ga, sa = _geom_arrays(g, x5, dy5)
     wsp, wsn = _ws_args(dy.device)
     ev = _prof_begin()
     if out_mask is not None:
         m5 = _as5(out_mask)
-        if tuple(m5.shape) != tuple(x5.shape) or tuple(_bs(m5)) != tuple(_bs(x5)):
+        if (tuple(m5.shape), _bs(m5)) != xlay or out_mask.dtype != torch.float32:
             raise RuntimeError("out_mask must share dx's shape and layout")
-    pre = _prologue(1, ga, sa, g, x5, dy5, wt, prec) if (prec & 2) else None     # regions are keyed on the live weight tensor
-    L.check(L.lib().otal_conv_dgrad(ga, sa, L.ptr(dy5), L.ptr(wt), L.ptr(x5),
+    pre = _prologue(1, ga, sa, pkey, wt, prec) if (prec & 2) else None     # regions are keyed on the live weight tensor
+    L.check(L.lib().otal_conv_dgrad(ga, sa, L.ptr(dy), L.ptr(wt), L.ptr(out),
                                     int(accumulate), _opt(out_mask), _opt(out_scale), prec, pre,
                                     wsp, wsn, L.stream()),
             "otal_conv_dgrad")
@@ -452,34 +483,33 @@ def grads_ready(pairs):
 
 def grad_slot(w):
     """Destination of `w`'s gradient in the running trainer's arena, or None (no trainer, foreign weight, slot taken)."""
-    return GRAD_SLOTS.take(w) if GRAD_SLOTS is not None and not os.environ.get("OTAL_NO_GRAD_SLOTS") else None
+    return GRAD_SLOTS.take(w) if GRAD_SLOTS is not None and "OTAL_NO_GRAD_SLOTS" not in os.environ else None
 
 
 def conv_wgrad(x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None, accumulate=False):
     """dw (+)= d conv / d w."""
     k, s = _k3(k), _k3(s)
-    x5, dy5 = _as5(x), _as5(dy)
-    B, Cin, Ti, Hi, Wi = x5.shape
+    if levels is not None:
+        levels = tuple(levels)
     Cout = w_shape[0]
-    g, outn = _make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)
-    if tuple(dy5.shape) != (B, Cout) + outn:
-        raise RuntimeError(f"conv_wgrad: dy has shape {tuple(dy5.shape)}, expected {(B, Cout) + outn}")
+    half_dy = dy.dtype == torch.bfloat16                    # bf16-stored gradient (maxpool3d_backward(half_out=True))
+    if x.dtype != torch.float32 or not (half_dy or dy.dtype == torch.float32):
+        raise RuntimeError("conv_wgrad: float32 x, float32 or bfloat16 dy")
+    g, ga, sa, pkey, _ = _plan(2, x, dy, Cout, k, s, levels, spatial_valid, "x", "dy")
     if out is None:
         if accumulate:
             raise RuntimeError("accumulate needs an existing buffer")
         out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device)
     if not out.is_contiguous():
         raise RuntimeError("dw must be contiguous")
-    half_dy = dy5.dtype == torch.bfloat16                   # bf16-stored gradient (maxpool3d_backward(half_out=True))
-    _check(x5, "x"); _check(dy5, "dy", dy5.dtype if half_dy else torch.float32)
-    ga, sa = _geom_arrays(g, x5, dy5)
     if _DEFER and accumulate:
         flush_reduces()             # a recorded reduction may still be on its way to this very buffer
     wsp, wsn = _ws_args(x.device)
     ev = _prof_begin()
-    pre = None if half_dy else _prologue(2, ga, sa, g, x5, dy5, x, int(CONV_PRECISION))
-    L.check(L.lib().otal_conv_wgrad(ga, sa, L.ptr(x5), L.ptr(dy5), L.ptr(out),
-                                    int(accumulate), int(CONV_PRECISION) | (4 if half_dy else 0), pre, wsp, wsn, L.stream()),
+    prec = int(CONV_PRECISION)
+    pre = None if half_dy else _prologue(2, ga, sa, pkey, x, prec)
+    L.check(L.lib().otal_conv_wgrad(ga, sa, L.ptr(x), L.ptr(dy), L.ptr(out),
+                                    int(accumulate), prec | (4 if half_dy else 0), pre, wsp, wsn, L.stream()),
             "otal_conv_wgrad")
     if _DEFER:
         _after_wgrad(x.device)
