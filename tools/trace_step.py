@@ -18,6 +18,6 @@ for r in step:
     g = s - prev_end
     busy += e - s
     gap += max(g, 0)
-    print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:7.1f}  gap {g / 1e3:6.1f}  grid {r.get('Grid_Size', '?'):>8}  {short(r['Kernel_Name'])}")
+    print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:7.1f}  gap {g / 1e3:6.1f}  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>9}  {short(r['Kernel_Name'])}")
     prev_end = max(prev_end, e)
 print(f"step: {len(step)} kernels, wall {(prev_end - t0) / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms, idle {gap / 1e6:.3f} ms")
