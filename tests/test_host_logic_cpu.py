@@ -1,0 +1,56 @@
+"""CPU: host-side logic added in round 2's second session -- gradient-slot hand-out / release, the backbone's stem / trunk
+cut, and the arena buckets of the two-phase data-parallel step (no kernels involved)."""
+import torch
+
+from opental_amd.common import ops
+from opental_amd.common.i3d_backbone import InceptionI3d
+
+
+def test_grad_slots_take_release_and_spanning_views():
+    flat = torch.zeros(100)
+    grad = torch.arange(100, dtype=torch.float32)
+    offsets, numels = [0, 10, 30, 60], [10, 20, 30, 40]
+    slots = ops.GradSlots(flat, grad, offsets, numels)
+    p1 = flat[10:30].view(4, 5)
+    v = slots.take(p1)
+    assert v is not None and v.shape == (4, 5) and v.data_ptr() == grad[10:30].data_ptr()
+    assert slots.take(p1) is None                       # handed out once per step
+    slots.release(p1)
+    assert slots.take(p1) is not None                   # ... unless given back unwritten
+    span = flat[30:100].view(70)                        # two adjacent parameters read as one fused weight
+    w = slots.take(span)
+    assert w is not None and w.numel() == 70
+    assert slots.take(flat[60:100]) is None             # part of the span: taken
+    assert slots.take(flat[5:15]) is None               # not a parameter boundary
+    slots.reset()
+    assert slots.take(flat[60:100]) is not None
+
+
+def test_backbone_stem_cut_and_stem_parameters():
+    m = InceptionI3d(final_endpoint='Mixed_5c')
+    m.build()
+    plan, units = m._make_plan()
+    cut = m._stem_cut(plan, ('Mixed_4f', 'Mixed_5c'))
+    names = [st[-1] for st in plan]
+    assert names[cut - 1] == 'MaxPool3d_4a_3x3' and names[cut] == 'Mixed_4b'
+    assert m._stem_cut(plan, ('Mixed_3c', 'Mixed_5c')) == 0        # an endpoint inside the stem: no cut
+    stem = m.stem_parameters()
+    # Conv3d_1a, 2b, 2c + 6 convolutions in each of Mixed_3b / 3c
+    assert len(stem) == 3 + 12
+    stem_ids = {id(p) for p in stem}
+    by_name = dict(m.named_parameters())
+    assert id(by_name['Conv3d_1a_7x7.conv3d.weight']) in stem_ids and id(by_name['Mixed_3c.b3b.conv3d.weight']) in stem_ids
+    assert id(by_name['Mixed_4b.b0.conv3d.weight']) not in stem_ids
+    n_stem = sum(p.numel() for p in stem)
+    n_all = sum(p.numel() for n, p in by_name.items() if n.endswith('conv3d.weight'))
+    assert 0.08 < n_stem / n_all < 0.15                 # a small share of the parameters, a third of the backward's time
+
+
+def test_plan_cache_distinguishes_layouts():
+    # the plan key holds shapes AND strides: a channel slice of a wider buffer is a different launch than a dense tensor
+    x = torch.zeros(2, 8, 16)
+    wide = torch.zeros(2, 12, 16)
+    k1 = (0, x.shape, x.stride(), x.shape, x.stride(), 8, (1, 1, 1), (1, 1, 1), None, False, x.dtype, x.dtype)
+    xs = wide[:, 2:10]
+    k2 = (0, xs.shape, xs.stride(), x.shape, x.stride(), 8, (1, 1, 1), (1, 1, 1), None, False, xs.dtype, x.dtype)
+    assert k1 != k2 and hash(k1) != hash(k2)
