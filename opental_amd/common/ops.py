@@ -269,7 +269,8 @@ _PLANS = {}
 
 def _plan(mode, xs, ys, Cout, k, s, levels, spatial_valid, xname, yname):
     """xs: the tensor on the convolution's input side (x or dx), ys: on its output side (y or dy); (B,C,T) or (B,C,T,H,W)."""
-    key = (mode, xs.shape, xs.stride(), ys.shape, ys.stride(), Cout, k, s, levels, spatial_valid, xs.dtype, ys.dtype)
+    key = (mode, xs.shape, xs.stride(), ys.shape, ys.stride(), Cout, k, s, levels, spatial_valid, xs.dtype, ys.dtype,
+           xs.device, ys.device)       # the device: _check's is_cuda test must not be skipped by a hit from another device
     plan = _PLANS.get(key)
     if plan is None:
         x5, y5 = _as5(xs), _as5(ys)
@@ -451,7 +452,14 @@ class GradSlots:
         while j < len(self.offsets) and cur < end:
             cur += self.numels[j]
             j += 1
-        if cur != end or any(self.written[i:j]):
+        if cur != end:
+            return None
+        if any(self.written[i:j]):
+            # second use of a parameter in this backward (a module applied twice): the caller gets a fresh tensor and
+            # autograd ADDS the first use's slot to it -- so whatever is still deferred into that slot (GroupNorm batch
+            # sums, recorded split-K reductions) has to be written now, not at the next bucket flush
+            flush_pending_sums()
+            flush_reduces()
             return None
         for q in range(i, j):
             self.written[q] = True

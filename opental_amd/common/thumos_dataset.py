@@ -200,8 +200,11 @@ class ClipStager:
         stager.submit(samples)            # decisions of batch k+1: async copies start now, on the copy stream
         clips, ssl_clips = stager.collect()   # on the compute stream: waits for the copies, one prepare launch
 
-    `submit` never blocks the host on the GPU: the copies are cudaMemcpyAsync from pinned memory; the only wait is the
-    compute stream's event wait inside `collect`."""
+    The copies are cudaMemcpyAsync from pinned memory.  `submit` waits on the HOST only for one thing: the H2D copies
+    it queued from the same slot two batches ago (`ready[s]`), because it is about to overwrite the pinned records
+    (crop / flip / frame maps) those copies read -- a host running more than two batches ahead of the device would
+    otherwise pair batch k's frames with batch k+2's decisions.  That wait is over long before it is reached unless
+    the host really is that far ahead."""
 
     def __init__(self, batch, clip_length, H, W, crop, device="cuda"):
         self.B, self.T, self.H, self.W, self.crop = batch, clip_length, H, W, crop
@@ -217,11 +220,14 @@ class ClipStager:
         self.consumed = [torch.cuda.Event() for _ in range(2)]
         self.slot = 0
         self.pending = None
+        self._copied = [False, False]       # slot s has H2D copies queued that read params_host[s] / maps_host[s]
 
     def submit(self, samples):
         if len(samples) != self.B:
             raise RuntimeError("ClipStager: batch size mismatch")
         s = self.slot
+        if self._copied[s]:
+            self.ready[s].synchronize()     # the queued DMA out of this slot's pinned records has run (see class docstring)
         recs = np.zeros(self.B, _PARAM_DTYPE)
         maps = self.maps_host[s].numpy().reshape(self.B, self.T)
         any_ssl = False
@@ -245,6 +251,7 @@ class ClipStager:
             self.params_dev[s].copy_(self.params_host[s], non_blocking=True)
             self.maps_dev[s].copy_(self.maps_host[s], non_blocking=True)     # 1 KB per clip: always (collect may ask for ssl)
             self.ready[s].record(self.copy_stream)
+        self._copied[s] = True
         self.pending = (s, any_ssl)
         self.slot ^= 1
 

@@ -193,6 +193,8 @@ class DetectorTrainer:
         self.collectives = self.distributed and (self.world > 1 or force_collectives)   # force: 1-rank RCCL smoke test
         self._flushed = None
         self._skipped = []          # arena indices of parameters that received no gradient in the current step
+        self._used_ones = None      # data-parallel: per-parameter "used on this rank" flags, summed over the ranks
+        self._used_work, self._used_global = None, None
         self._early = True          # the backbone may hand finished weight gradients over from inside its backward
         self.measure_exposed = False    # bench.py: record HIP events around the wait for the all-reduces
         self.exposed_events = []
@@ -334,9 +336,27 @@ class DetectorTrainer:
             p.grad = v
         self._finish_allreduce()
 
+    def _issue_used_mask(self):
+        """Data parallel: whether a parameter is left alone by Adam must be decided GLOBALLY.  A parameter unused on this
+        rank has its slice zeroed and then all-reduced, i.e. it holds the peers' gradient; restoring it here while the
+        peers apply the update would let the replicas diverge for good.  Every rank therefore contributes a 0/1 flag per
+        parameter (one tiny all-reduce per step, issued by every kind of step -- eager, ssl, two-graph -- at the same
+        place of the collective order), and a locally unused parameter is put back only where the sum is zero."""
+        if not self.collectives or self._capturing:
+            return
+        a = self.arena
+        if self._used_ones is None:
+            self._used_ones = torch.ones(len(a.params), dtype=torch.float32, device=a.flat.device)
+        used = self._used_ones.clone()
+        if self._skipped:
+            used[torch.tensor(self._skipped, dtype=torch.long, device=used.device)] = 0.0     # rare: the only H2D copy
+        self._used_global = used
+        self._used_work = dist.all_reduce(used, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def _finish_allreduce(self):
         if not self.collectives or self._capturing:
             return
+        self._issue_used_mask()
         ev = None
         if self.measure_exposed:
             ev = torch.cuda.Event(enable_timing=True)
@@ -344,6 +364,9 @@ class DetectorTrainer:
         for w in self._works:
             w.wait()
         self._works = []
+        if self._used_work is not None:
+            self._used_work.wait()
+            self._used_work = None
         if self._ibm_work is not None:
             self._ibm_work.wait()
             self._ibm_work = None
@@ -431,8 +454,15 @@ class DetectorTrainer:
 
     def _restore_skipped(self, keep):
         a = self.arena
-        for sl, p, m, v in keep:
-            a.flat[sl].copy_(p); a.m[sl].copy_(m); a.v[sl].copy_(v)
+        g = self._used_global if self.collectives else None
+        for (sl, p, m, v), i in zip(keep, self._skipped):
+            if g is None:
+                a.flat[sl].copy_(p); a.m[sl].copy_(m); a.v[sl].copy_(v)
+            else:       # device-side decision (no host sync): keep the update where any peer used the parameter
+                unused = g[i] == 0
+                a.flat[sl].copy_(torch.where(unused, p, a.flat[sl]))
+                a.m[sl].copy_(torch.where(unused, m, a.m[sl]))
+                a.v[sl].copy_(torch.where(unused, v, a.v[sl]))
 
     # ---- the same step as ONE HIP graph: ~1500 launches per step are replayed without host involvement
     def _graph_body(self, clips, targets, scores):
@@ -516,6 +546,9 @@ class DetectorTrainer:
             raise RuntimeError("capture_step(split=True): the model has no stem / trunk cut")
         dev = clips.device
         a = self.arena
+        # a stale re-capture (step() just ran this batch eagerly in the two-node form) needs no further warm-up step:
+        # forcing one would apply the same batch twice and advance Adam's step count past the reference schedule
+        already_split = bool(getattr(model, 'split_backward', False))
         model.split_backward = True
         self._bias_corr = torch.zeros(2, dtype=torch.float32, device=dev)
         clone = lambda t: None if t is None else ([u.clone() for u in t] if isinstance(t, (list, tuple)) else t.clone())
@@ -524,7 +557,7 @@ class DetectorTrainer:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):         # eager data-parallel steps in the two-node form (real steps)
+            for _ in range(max(warmup, 0 if already_split else 1)):     # eager data-parallel steps in the two-node form (real steps)
                 self.step(*static)
         torch.cuda.current_stream(dev).wait_stream(side)
         ops.activate_prologues(self._prologues)     # upload the descriptors of regions created by the warm-up
@@ -576,6 +609,7 @@ class DetectorTrainer:
     def _replay_split(self, clips, targets, scores):
         _, g1, g2, static, out = self._graph
         self._copy_inputs(static, (clips, targets, scores))
+        self._skipped = []                          # (a captured step has none: _capture_split refuses otherwise)
         self.step_count += 1
         self._set_bias(self.step_count)
         a = self.arena
@@ -790,6 +824,16 @@ def build_training(config, device, as_shipped=False, random_init=False, dist_gro
     return net, crit, trainer
 
 
+def rank_batches(every, rank, world):
+    """The batches of one epoch that rank `rank` of `world` runs: every world-th one of a list truncated to a multiple of
+    `world` -- drop_last across ranks.  Every rank must run the SAME number of steps (each step's bucket / IBM / used-mask
+    all-reduces need all peers; a rank with one batch more would wait for collectives nobody else issues until the RCCL
+    watchdog aborts the job at the end of the first epoch)."""
+    every = list(every)
+    every = every[:len(every) // world * world]
+    return every[rank::world]
+
+
 def run_one_epoch(epoch, trainer, dataset, stager, batch_size, rank=0, world=1, max_steps=None, log=print):
     """One pass over the shuffled sliding-window list (train.py:204-303).  Every rank draws the same permutation and
     the same per-sample decisions (shared seeds) and takes every world-th batch.  Nothing in the loop synchronises with
@@ -797,8 +841,7 @@ def run_one_epoch(epoch, trainer, dataset, stager, batch_size, rank=0, world=1, 
     from ..common import thumos_dataset as D
     dev = trainer.arena.flat.device
     sums, n_iter = None, 0
-    it = D.batches(dataset, batch_size)
-    mine = [b for k, b in enumerate(it) if k % world == rank]
+    mine = rank_batches(D.batches(dataset, batch_size), rank, world)
     if max_steps is not None:
         mine = mine[:max_steps]
     if not mine:

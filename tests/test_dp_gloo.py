@@ -358,3 +358,122 @@ def test_real_detector_arena_two_ranks_early_handover_and_issue_order(tmp_path):
             off, n = where[id(p)]
             want[off:off + n] += torch.randn(p.shape, generator=gen).reshape(-1)
     assert torch.allclose(g0, want, rtol=0, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- round 3: ADVICE (round 2) regressions
+def test_rank_batches_gives_every_rank_the_same_number_of_steps():
+    """run_one_epoch's shard of an epoch (ADVICE high): with a batch count that is not a multiple of the world size the
+    surplus batches are dropped on EVERY rank -- a rank with one step more would issue collectives without peers."""
+    from opental_amd.thumos14.train import rank_batches
+    for n, world in ((7, 2), (9, 4), (8, 8), (3, 4), (10, 1)):
+        shards = [rank_batches(range(n), r, world) for r in range(world)]
+        assert len({len(s) for s in shards}) == 1
+        assert len(shards[0]) == n // world
+        flat = sorted(b for s in shards for b in s)
+        assert flat == list(range(n // world * world))          # disjoint, and the first floor(n / world) * world batches
+
+
+class _Mixed(nn.Module):
+    """`opt` is used only where `self.use_opt` (per rank); `never` is used on no rank."""
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 16)
+        self.opt = nn.Linear(16, 16)
+        self.never = nn.Linear(4, 4)
+        self.c = nn.Linear(16, 1)
+        self.use_opt = True
+
+    def forward(self, x):
+        h = torch.relu(self.a(x))
+        if self.use_opt:
+            h = h + self.opt(h)
+        return self.c(h)
+
+
+def _mixed_trainer(world_aware):
+    from opental_amd.thumos14.train import DetectorTrainer
+    from oracle import afsd_oracle as O
+
+    class CpuTrainer(DetectorTrainer):
+        def compute_cost(self, clips, targets, scores, ssl_clips=None, ssl_targets=None):
+            cost = ((self.net(clips) - targets) ** 2).mean()
+            return cost, (cost,)
+
+        def optimizer_update(self):         # the product's stash / flat update / restore around the oracle's Adam
+            a = self.arena
+            keep = self._stash_skipped()
+            with torch.no_grad():
+                O.adam_step(a.flat, a.grad / self.world, a.m, a.v, self.step_count, self.lr, self.wd)
+            self._restore_skipped(keep)
+
+    torch.manual_seed(0)
+    net = _Mixed()
+    return CpuTrainer(net, nn.Module(), {}, lr=1e-2, weight_decay=1e-1, bucket_mb=0, distributed=world_aware), net
+
+
+def _mixed_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tr, net = _mixed_trainer(True)
+        net.use_opt = rank == 0                      # rank 1 leaves `opt` unused; nobody uses `never`
+        g = torch.Generator().manual_seed(7)
+        xs, ys = torch.randn(world, 3, 5, 8, generator=g), torch.randn(world, 3, 5, 1, generator=g)
+        never0 = net.never.weight.detach().clone()
+        for step in range(3):
+            tr.step(xs[rank, step], ys[rank, step], None)
+        names = {id(p): n for n, p in net.named_parameters()}
+        skipped = sorted(names[id(tr.arena.params[i])] for i in tr._skipped)
+        q.put((rank, tr.arena.flat.clone(), tr.arena.m.clone(), skipped, torch.equal(never0, net.never.weight.detach()),
+               net.opt.weight.detach().clone()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unused_parameter_decision_is_global_under_data_parallelism():
+    """ADVICE medium: a parameter unused on ONE rank holds the peers' all-reduced gradient and must be updated like on the
+    peers (the replicas would diverge otherwise); a parameter unused on EVERY rank is left alone as torch.optim.Adam does."""
+    import queue
+    world = 2
+    ctx = mp.get_context("spawn")
+    res = None
+    for attempt in range(2):
+        port = _free_port()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_mixed_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+        except queue.Empty:
+            res = None
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        if res is not None and all(p.exitcode == 0 for p in procs):
+            break
+    assert res is not None
+    (_, flat0, m0, sk0, never_same0, opt0), (_, flat1, m1, sk1, never_same1, opt1) = res
+    assert sk0 == ['never.bias', 'never.weight'] and sk1 == ['never.bias', 'never.weight', 'opt.bias', 'opt.weight']
+    assert torch.equal(flat0, flat1) and torch.equal(m0, m1)        # replicas stay identical
+    assert never_same0 and never_same1                              # globally unused: untouched (no weight decay either)
+    # ... and `opt` really moved on the rank that did not use it
+    torch.manual_seed(0)
+    init = _Mixed().opt.weight.detach()
+    assert not torch.equal(opt1, init) and torch.equal(opt0, opt1)
+
+
+def test_second_use_of_a_gradient_slot_flushes_deferred_work(monkeypatch):
+    """ADVICE low: when a parameter's slot is already handed out (a module applied twice in one backward), the deferred
+    GroupNorm sums / split-K reductions targeting that slot are run before the second gradient is returned."""
+    from opental_amd.common import ops
+    calls = []
+    monkeypatch.setattr(ops, "flush_pending_sums", lambda: calls.append("sums"))
+    monkeypatch.setattr(ops, "flush_reduces", lambda: calls.append("reduces"))
+    flat, grad = torch.zeros(20), torch.zeros(20)
+    slots = ops.GradSlots(flat, grad, [0, 10], [10, 10])
+    assert slots.take(flat[:10]) is not None and calls == []
+    assert slots.take(flat[:10]) is None and calls == ["sums", "reduces"]
