@@ -15,6 +15,8 @@ How the reference is made importable on CPU:
   * torch.Tensor.cuda -> identity (EvidenceLoss.__init__ calls .cuda(), cls_loss.py:114).
 
 Usage:  python -m oracle.pin_against_reference            (from the repo root)
+        python -m oracle.pin_against_reference --batch=1  (one model fixture; b = 1 includes the ssl / triplet branch, a14)
+        python -m oracle.pin_against_reference --ssl-only (a14 alone, merged into tests/golden/thumos_b1.npz)
 """
 import os
 import sys
@@ -83,6 +85,81 @@ def strided(t, n=4096):
     return f[::step].contiguous().numpy().copy()
 
 
+SSL_CLIP_SEED = 77
+# three (start, end) frame-space proposals per set, as thumos_dataset.py:110-141's splice writes them: the (moved)
+# ground-truth piece, the piece it was cut from, and the seam; set 1 is the hand-picked triple of the first GPU test
+SSL_PROPOSALS = ([[40., 90.], [100., 150.], [10., 30.]],
+                 [[61., 118.], [142., 199.], [119., 141.]])
+
+
+def pin_ssl(net, params_np, report):
+    """a14: the reference's BDNet.forward(x, proposals, ssl=True) (BDNet.py:482-503) and the three TripletMarginLoss terms
+    of forward_one_epoch(ssl=True) (train.py:177-184) at b = 1, next to O.ssl_triplets / O.triplet_cost; gradients of the
+    triplet cost through the WHOLE network (second backbone pass), reference addressing (the extension's backward) and
+    the correct one, with fp64 yardsticks.  -> fixture entries `ssl{set}_*`."""
+    import torch.nn as nn
+    fx = {"ssl_clip_seed": np.int64(SSL_CLIP_SEED), "ssl_proposals": np.array(SSL_PROPOSALS, np.float32)}
+    x = torch.from_numpy(arch.make_clip(SSL_CLIP_SEED, 1))
+    weights = [1, 0.1, 0.1]
+    for si, props in enumerate(SSL_PROPOSALS):
+        targets = [torch.tensor(props, dtype=torch.float32)]
+        net.zero_grad()
+        ra, rp, rn = net(x, proposals=targets, ssl=True)
+        terms = [nn.TripletMarginLoss()(ra[i], rp[i], rn[i]) * weights[i] for i in range(3)]   # train.py:180-183
+        trip = torch.stack(terms).sum(0)
+        trip.backward()
+        ref_grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        P = O.to_torch(params_np, requires_grad=True)
+        oa, op, on = O.ssl_triplets(P, x, targets, compat_reference_bwd=True)
+        worst = max(maxdiff(a, b) for ra_, oa_ in ((ra, oa), (rp, op), (rn, on)) for a, b in zip(ra_, oa_))
+        cost = O.triplet_cost(oa, op, on, 1.0)
+        report.append(f"ssl set {si}: anchor/positive/negative max|ref-oracle| = {worst:.3e}; triplet cost ref "
+                      f"{float(trip):.6f} oracle {float(cost):.6f}; terms {[round(float(t), 6) for t in terms]}")
+        assert worst < 1e-5 and abs(float(trip) - float(cost)) < 1e-5 * max(1.0, abs(float(trip)))
+        cost.backward()
+        rel = 0.0
+        for k, g in ref_grads.items():
+            assert P[k].grad is not None, k
+            rel = max(rel, maxdiff(g, P[k].grad) / (float(g.abs().max()) + 1e-12))
+        report.append(f"ssl set {si}: backward (reference addressing) worst relative grad diff = {rel:.3e} over "
+                      f"{len(ref_grads)} tensors")
+        assert rel < 1e-3, rel
+        g_compat = {k: P[k].grad.clone() for k in ref_grads}
+        P2 = O.to_torch(params_np, requires_grad=True)
+        O.triplet_cost(*O.ssl_triplets(P2, x, targets, compat_reference_bwd=False), 1.0).backward()
+        g_correct = {k: P2[k].grad.clone() for k in ref_grads}
+
+        def grads64(compat):
+            Pd = {k: (torch.from_numpy(v).double() if v.dtype == np.float32 else torch.from_numpy(v))
+                  for k, v in params_np.items()}
+            for k, v in Pd.items():
+                if v.is_floating_point() and ".bn." not in k:
+                    v.requires_grad_(True)
+            c = O.triplet_cost(*O.ssl_triplets(Pd, x.double(), [t.double() for t in targets], compat_reference_bwd=compat), 1.0)
+            c.backward()
+            return {k: Pd[k].grad.clone() for k in ref_grads}, float(c)
+        g64_correct, c64 = grads64(False)
+        g64_compat, _ = grads64(True)
+        names = sorted(ref_grads)
+        t = f"ssl{si}_"
+        for nm, tr3 in (("anchor", ra), ("positive", rp), ("negative", rn)):
+            for i in range(3):
+                fx[f"{t}{nm}_{i}"] = tr3[i].detach().numpy().copy()
+        fx[t + "terms"] = np.array([float(v) for v in terms], np.float64)
+        fx[t + "cost"] = np.float64(trip)
+        fx[t + "cost64"] = np.float64(c64)
+        fx[t + "grad_names"] = np.array(names)
+        fx[t + "gradnorm_reference"] = np.array([float(ref_grads[k].double().norm()) for k in names])
+        for mode, g32, g64 in (("compat", g_compat, g64_compat), ("correct", g_correct, g64_correct)):
+            fx[f"{t}grad64norm_{mode}"] = np.array([float(g64[k].norm()) for k in names])
+            fx[f"{t}grad32dist_{mode}"] = np.array([float((g32[k].double() - g64[k]).norm() / (g64[k].norm() + 1e-30))
+                                                    for k in names])
+        report.append(f"ssl set {si}: fp64 cost {c64:.8f}; CPU-fp32 vs fp64 gradient distance median "
+                      f"{np.median(fx[t + 'grad32dist_correct']):.2e}, max {fx[t + 'grad32dist_correct'].max():.2e}")
+    net.zero_grad()
+    return fx
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
@@ -121,6 +198,18 @@ def main():
         raise RuntimeError("no seed with a safe rounding margin")
 
     only = [int(a.split("=")[1]) for a in ARGV if a.startswith("--batch=")]     # e.g. --batch=4: just that fixture
+    if "--ssl-only" in ARGV:        # re-pin a14 alone: the other entries of thumos_b1.npz are kept as they are
+        path = os.path.join(GOLD, "thumos_b1.npz")
+        old = dict(np.load(path))
+        old = {k: v for k, v in old.items() if not k.startswith("ssl")}
+        old.update(pin_ssl(net, params_np, report))
+        np.savez_compressed(path, **old)
+        with open(os.path.join(GOLD, "PIN_REPORT.txt"), "a") as f:
+            f.write("\n".join(report[1:]) + "\n")
+        print("\n".join(report))
+        leftovers = [os.path.join(d, n) for d, _, fs in os.walk(REF) for n in fs if n.endswith(".pyc")]
+        assert not leftovers, leftovers
+        return
     for batch, first, need in ((1, 11, 6e-4), (2, 500, 4e-4), (4, 900, 3e-4)):
         if only and batch not in only:
             continue
@@ -286,6 +375,8 @@ def main():
         report.append(f"{tag}: CPU-fp32 vs fp64 gradient distance: median "
                       f"{np.median(fx['grad32dist_correct']):.2e}, max {fx['grad32dist_correct'].max():.2e} "
                       f"({names[int(fx['grad32dist_correct'].argmax())]})")
+        if batch == 1:
+            fx.update(pin_ssl(net, params_np, report))       # a14: the self-supervised triplet branch
         np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **fx)
         report.append(f"{tag}: wrote tests/golden/{tag}.npz")
 

@@ -163,19 +163,49 @@ def test_eval_mode_inference_matches_train_mode_forward(run):
     assert rel_err(out['loc'].cpu().numpy(), fx["out_loc"]) < 1e-4
 
 
-def test_ssl_triplet_branch(golden_dir):
-    from oracle import afsd_oracle as O
+@pytest.mark.parametrize("si", [0, 1])
+def test_ssl_triplet_branch(golden_dir, si):
+    """a14 against the REFERENCE (fixture entries ssl{si}_* written by oracle/pin_against_reference.py::pin_ssl from the
+    reference's BDNet.forward(ssl=True), BDNet.py:482-503, and the three TripletMarginLoss terms of train.py:177-184):
+    anchor / positive / negative features, the weighted terms, and the gradients of the triplet cost through the second
+    backbone pass -- reference addressing vs the reference's own fp32 gradient norms, correct backward vs fp64."""
+    from opental_amd.prop_pooling import boundary_pooling_op as bp
     from opental_amd.thumos14.train import forward_one_epoch
+    import torch.nn as nn
     fx = np.load(os.path.join(golden_dir, "thumos_b1.npz"))
     net = build(fx)
-    xh = torch.from_numpy(arch.make_clip(77, 1))
-    props = [torch.tensor([[40., 90.], [100., 150.], [10., 30.]])]
-    P = O.to_torch(arch.make_params(int(fx["param_seed"])))
+    x = torch.from_numpy(arch.make_clip(int(fx["ssl_clip_seed"]), 1)).cuda()
+    props = [torch.from_numpy(fx["ssl_proposals"][si]).cuda()]
+    t = f"ssl{si}_"
     with torch.no_grad():
-        a, p, n = O.ssl_triplets(P, xh, props)
-        ref = float(O.triplet_cost(a, p, n, 1.0))
-        got = float(forward_one_epoch(net, None, xh.cuda(), [t.cuda() for t in props], training=True, ssl=True))
-    assert abs(got - ref) < 1e-4 * max(1.0, abs(ref))
+        a, p, n = net(x, proposals=props, ssl=True)
+    for nm, got in (("anchor", a), ("positive", p), ("negative", n)):
+        for i in range(3):
+            assert rel_err(got[i].cpu().numpy(), fx[f"{t}{nm}_{i}"]) < 1e-4, (nm, i)
+    terms = [float(nn.TripletMarginLoss()(a[i], p[i], n[i]) * w) for i, w in enumerate((1, 0.1, 0.1))]
+    assert np.abs(np.array(terms) - fx[t + "terms"]).max() < 1e-4
+    names = [str(v) for v in fx[t + "grad_names"]]
+    for compat in (True, False):
+        net.zero_grad(set_to_none=True)
+        bp.COMPAT_REFERENCE_BWD = compat
+        try:
+            cost = forward_one_epoch(net, None, x, props, training=True, ssl=True)
+            cost.backward()
+        finally:
+            bp.COMPAT_REFERENCE_BWD = False
+        assert abs(float(cost.detach()) - float(fx[t + "cost"])) < 1e-4 * max(1.0, abs(float(fx[t + "cost"])))
+        grads = dict((k, q.grad) for k, q in net.named_parameters() if q.grad is not None)
+        assert sorted(grads) == names
+        mode = "compat" if compat else "correct"
+        d32, n64 = fx[f"{t}grad32dist_{mode}"], fx[f"{t}grad64norm_{mode}"]
+        got = np.array([float(grads[k].double().norm()) for k in names])
+        live = n64 > 1e-7 * n64.max()                       # structurally zero gradients carry no relative error
+        allowed = 10.0 * d32 + (1e-3 if compat else 3e-4)   # the criterion of test_training_cost_and_gradients
+        worst = (np.abs(got - n64) / (n64 + 1e-30) / allowed)[live]
+        assert worst.max() < 1.0, (mode, names[int(np.flatnonzero(live)[worst.argmax()])], float(worst.max()))
+        if compat:      # ... and against the reference's own fp32 gradients
+            ref = fx[t + "gradnorm_reference"]
+            assert (np.abs(got - ref) / (ref + 1e-30) / (2 * allowed))[live].max() < 1.0
 
 
 def test_bf16_compute_mode_stays_close_to_fp32(golden_dir):

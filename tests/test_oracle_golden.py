@@ -72,3 +72,22 @@ def test_softnms_quirks():
     three = torch.tensor([[0., 1., 0.2, 0, 0], [5., 6., 0.9, 0, 0], [10., 11., 0.5, 0, 0]])
     rows, cnt, mask = O.softnms_v2(three)
     assert cnt == 2 and mask.tolist() == [False, True, True] and rows[0, 2] == 0.9 and rows[1, 2] == 0.5
+
+
+def test_ssl_triplet_branch_matches_reference_vectors(golden_dir):
+    """a14: O.ssl_triplets / O.triplet_cost regenerate what the reference's BDNet.forward(ssl=True) and its three
+    TripletMarginLoss terms gave in the build container (fixture entries ssl{set}_*, oracle/pin_against_reference.py)."""
+    fx = np.load(os.path.join(golden_dir, "thumos_b1.npz"))
+    P = O.to_torch(arch.make_params(int(fx["param_seed"])))
+    x = torch.from_numpy(arch.make_clip(int(fx["ssl_clip_seed"]), 1))
+    torch.set_num_threads(os.cpu_count())
+    for si in range(fx["ssl_proposals"].shape[0]):
+        props = [torch.from_numpy(fx["ssl_proposals"][si])]
+        with torch.no_grad():
+            a, p, n = O.ssl_triplets(P, x, props)
+            cost = float(O.triplet_cost(a, p, n, 1.0))
+        for nm, got in (("anchor", a), ("positive", p), ("negative", n)):
+            for i in range(3):
+                np.testing.assert_allclose(got[i].numpy(), fx[f"ssl{si}_{nm}_{i}"], rtol=0, atol=1e-6)
+        assert abs(cost - float(fx[f"ssl{si}_cost"])) < 1e-5
+        assert abs(cost - float(fx[f"ssl{si}_terms"].sum())) < 1e-5
