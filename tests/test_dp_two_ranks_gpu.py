@@ -31,7 +31,18 @@ RANK_CODE = textwrap.dedent('''
     tr.lr = 1e-4
     clips, targets, scores = bench.synth_batch(2, 1000 + rank, dev)
     steps = 3
-    if mode == "split":
+    ssl_args = ()
+    if mode.startswith("mixed") and rank == 0:
+        # rank 0's sampler flag is set (train.py:237 `if flags[0]`), rank 1's is not: rank 0 runs the triplet branch (a
+        # second backbone pass, an eager step with early=False) while rank 1 runs the plain step -- or replays its graphs
+        ssl_clips, _, _ = bench.synth_batch(2, 2000, dev)
+        ssl_targets = [torch.tensor([[0.30, 0.55], [0.32, 0.52], [0.70, 0.90]], device=dev) * 256 for _ in range(2)]
+        ssl_args = (ssl_clips, ssl_targets)
+    if mode == "mixed_split":
+        tr.capture_step(clips, targets, scores, warmup=1, split=True)       # both ranks: same collectives in the warm-up
+        assert tr._graph[0] == "split"
+        done = 1
+    elif mode == "split":
         tr.capture_step(clips, targets, scores, warmup=1, split=True)       # one real (eager) step, then the capture
         assert tr._graph[0] == "split"
         done = 1
@@ -39,7 +50,7 @@ RANK_CODE = textwrap.dedent('''
         done = 0
     costs = []
     for _ in range(steps - done):
-        costs.append(float(tr.step(clips, targets, scores)[0]))
+        costs.append(float(tr.step(clips, targets, scores, *ssl_args)[0]))
     torch.cuda.synchronize()
     assert tr.step_count == steps
     torch.save({"flat": tr.arena.flat.cpu(), "m": tr.arena.m.cpu(), "ibm": tr.criterion.cls_loss.weight_accum.cpu(),
@@ -71,8 +82,9 @@ def _run(mode, tmp_path, port):
     return [torch.load(out + f".{r}") for r in range(2)]
 
 
-def _reference(steps=3):
-    """What two data-parallel ranks must compute, in ONE process without collectives."""
+def _reference(steps=3, ssl_rank0_from=None):
+    """What two data-parallel ranks must compute, in ONE process without collectives.  `ssl_rank0_from`: first step
+    (0-based) from which rank 0's cost includes the triplet branch."""
     import torch
     import bench
     from opental_amd.common import ops
@@ -84,16 +96,19 @@ def _reference(steps=3):
         tr.lr = 1e-4
         tr.world = 2                                    # Adam's grad_scale = 1 / world
         batches = [bench.synth_batch(2, 1000 + r, dev) for r in range(2)]
+        ssl_clips, _, _ = bench.synth_batch(2, 2000, dev)
+        ssl_targets = [torch.tensor([[0.30, 0.55], [0.32, 0.52], [0.70, 0.90]], device=dev) * 256 for _ in range(2)]
         ibm = tr.criterion.cls_loss.weight_accum
-        for _ in range(steps):
+        for k in range(steps):
             state = ibm.detach().clone()
             total, states = torch.zeros_like(tr.arena.grad), []
-            for b in batches:
+            for r, b in enumerate(batches):
                 ibm.copy_(state)
                 ops.activate_prologues(tr._prologues)
+                with_ssl = r == 0 and ssl_rank0_from is not None and k >= ssl_rank0_from
                 try:
-                    cost, _ = tr.compute_cost(*b)
-                    tr.begin_backward()
+                    cost, _ = tr.compute_cost(*b, *((ssl_clips, ssl_targets) if with_ssl else ()))
+                    tr.begin_backward(early=not with_ssl)
                     cost.backward()
                     tr.end_backward()
                 finally:
@@ -123,4 +138,22 @@ def test_two_ranks_on_one_gpu_match_the_single_process_restatement(mode, tmp_pat
     # a + b) and the reference's extra accumulate through a zero tensor (0 + a + b): exact
     assert float((res[0]["flat"] - flat).abs().max()) <= 1e-6 * scale, float((res[0]["flat"] - flat).abs().max())
     assert float((res[0]["m"] - m).abs().max()) <= 1e-6 * float(m.abs().max())
+    assert float((res[0]["ibm"] - ibm).abs().max()) <= 1e-6 * float(ibm.abs().max() + 1e-12)
+
+
+@pytest.mark.parametrize("mode", ["mixed", "mixed_split"])
+def test_mixed_ssl_and_plain_ranks_stay_in_step(mode, tmp_path):
+    """run_one_epoch decides `use_ssl` per rank, so one rank may run the triplet branch (eager step,
+    gradients final only when autograd returns them) while its peer runs the plain step or replays the two-graph step.
+    The fixed collective order (IBM state, buckets in _flush_order, used-parameter flags) must keep them aligned, and
+    the result must equal the single-process restatement: rank 0's gradient of (cost + ssl * triplet) plus rank 1's."""
+    import torch
+    res = _run(mode, tmp_path, 29553 if mode == "mixed" else 29554)
+    assert torch.equal(res[0]["flat"], res[1]["flat"]) and torch.equal(res[0]["m"], res[1]["m"])
+    assert torch.equal(res[0]["ibm"], res[1]["ibm"])
+    # mixed_split: the warm-up step of the capture is a plain step on both ranks, the ssl steps follow
+    flat, m, ibm = _reference(ssl_rank0_from=1 if mode == "mixed_split" else 0)
+    scale = float(flat.abs().max())
+    assert float((res[0]["flat"] - flat).abs().max()) <= 2e-6 * scale, float((res[0]["flat"] - flat).abs().max())
+    assert float((res[0]["m"] - m).abs().max()) <= 2e-6 * float(m.abs().max())
     assert float((res[0]["ibm"] - ibm).abs().max()) <= 1e-6 * float(ibm.abs().max() + 1e-12)
