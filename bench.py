@@ -59,20 +59,18 @@ def synth_batch(batch, seed, device, frames=256, classes=15, score_rows=2):
 
 
 def build_anet_trainer(device, seed=2020, force_collectives=False):
-    """BASELINE configs[3]: configs/anet_opental.yaml (768-frame clips, 150 classes, lr 1e-4 / backbone 1e-5, wd 1e-4),
-    flags of AFSD/anet/README.md:61 (--lw=1 --cw=1 --piou=0.6)."""
-    from opental_amd.anet.BDNet import BDNet
-    from opental_amd.anet.multisegment_loss import MultiSegmentLoss
-    from opental_amd.anet.train import make_trainer
+    """BASELINE configs[3], read from configs/anet_opental.yaml (768-frame clips, 150 classes + background, batch 2, lr 1e-4 /
+    backbone 1e-5, wd 1e-4) with the flags of AFSD/anet/README.md:61 (--lw=1 --cw=1 --piou=0.6), through the recipe's own
+    builder (opental_amd.anet.train.build_training: the path `python -m opental_amd.anet.train <yaml>` takes)."""
+    from opental_amd.anet.train import build_training
+    from opental_amd.common import config as C
+    cfg = C.get_config([os.path.join(REPO, "configs", "anet_opental.yaml"), "--open_set", "--split", "0",
+                        "--lw", "1", "--cw", "1", "--piou", "0.6", "--ssl", "0.1"])
     torch.manual_seed(seed)
-    net = BDNet(in_channels=3, training=False, use_edl=True)
-    net.backbone._model.apply(BDNet.weight_init)
-    net = net.to(device).train()
-    edl = dict(evidence='exp', loss_type='log', iou_aware=True, with_ibm=True, ibm_start=10, momentum=0.99, num_bins=50)
-    crit = MultiSegmentLoss(150, 0.6, 1.0, cls_loss_type='edl', edl_config=edl, os_head=True).to(device)
-    crit.cls_loss.epoch = 12
-    return make_trainer(net, crit, dict(lw=1.0, cw=1.0, ctw=1.0, actw=1.0, ssl=0.1), learning_rate=1e-4, weight_decay=1e-4,
-                        force_collectives=force_collectives)
+    net, crit, trainer = build_training(cfg, device, random_init=True, force_collectives=force_collectives)
+    crit.cls_loss.epoch = 12            # past ibm_start: the IBM re-weighting runs inside the timed step
+    trainer.yaml_batch = int(cfg['training']['batch_size'])
+    return trainer
 
 
 def build_trainer(device, seed=2020, force_collectives=False):
@@ -142,6 +140,28 @@ def cpu_baseline(seconds_budget=20.0, threads=32, batch=1):
                       f"CPU oracle = torch-CPU restatement pinned to the reference; {dt:.2f} s/step"}
 
 
+def cpu_baseline_all_threads(timeout_s=60):
+    """One training step of the CPU oracle at os.cpu_count() threads, in a child process that is killed after `timeout_s`:
+    torch-CPU's conv3d gets SLOWER past a few dozen threads on the many-core hosts of the GPU boxes (256 threads: 392 s
+    per step measured), so the all-threads figure is reported as measured-or-timed-out next to the 32-thread one."""
+    import subprocess
+    code = ("import sys, json, os; sys.path.insert(0, %r); import bench; "
+            "r = bench.cpu_baseline(seconds_budget=0.0, threads=os.cpu_count(), batch=1); print('CPUALL ' + json.dumps(r))" % REPO)
+    t0 = time.time()
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s).stdout
+        for line in out.splitlines():
+            if line.startswith("CPUALL "):
+                r = json.loads(line[7:])
+                return {"value": r["value"], "unit": "clips/s", "cores": r["cores"], "sample": r["sample"]}
+        return {"value": None, "cores": os.cpu_count(), "note": "child process produced no result"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "cores": os.cpu_count(), "timeout_s": timeout_s,
+                "note": f"one cold step at {os.cpu_count()} threads did not finish within {timeout_s} s (< {1.0 / timeout_s:.4f} clips/s)"}
+    except Exception as e:                          # noqa: BLE001
+        return {"value": None, "cores": os.cpu_count(), "note": f"{type(e).__name__}: {str(e)[:120]} after {time.time() - t0:.0f} s"}
+
+
 def _timed_steps(trainer, batch, steps, warm, extra=()):
     for _ in range(warm):
         trainer.step(*batch, *extra)
@@ -176,6 +196,17 @@ def extras(device, batch):
         dt = _timed_steps(tr, synth_batch(batch, 1000, device), 5, 2)
         return {"clips_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 2), "batch": batch,
                 "what": "the exact-fp32 path every 1e-4 parity test runs (v_mfma_f32_32x32x2_f32)"}
+
+    def b1():
+        ops.CONV_PRECISION = 1
+        tr = build_trainer(device)
+        b = synth_batch(1, 1000, device)
+        eager = _timed_steps(tr, b, 20, 5)
+        tr.capture_step(*b)                         # one clip per step is launch-bound: the step replays from ONE HIP graph
+        dt = _timed_steps(tr, b, 100, 20)           # 20 warm-up + 100 timed steps
+        return {"clips_per_s": round(1 / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": 1, "steps": 100, "warmup": 20,
+                "launch": "one captured HIP graph per step", "eager_ms_per_step": round(eager * 1e3, 3),
+                "what": "BASELINE configs[1] at the yaml's own batch_size: 1 (configs/thumos14_opental_final.yaml), bf16 operands"}
 
     def ssl():
         ops.CONV_PRECISION = 1
@@ -293,6 +324,7 @@ def extras(device, batch):
                 "what": "uint8 256x112x112x3 clip slices from PINNED host videos -> async H2D on a copy stream (double buffered) -> "
                         "otal_prepare_clips_map (crop 96, flip, normalise, THWC->CTHW); 9.6 MB of PCIe traffic per clip"}
 
+    leg("b1", b1)
     leg("fp32_parity", fp32)
     leg("ssl_on", ssl)
     leg("anet", anet)
@@ -300,6 +332,50 @@ def extras(device, batch):
     leg("input_pipeline", input_pipeline)
     ops.CONV_PRECISION = saved
     return out
+
+
+def inference_sharded(device, rank, world, nvid=213):
+    """BASELINE configs[4] at N ranks: the video list is sharded (every world-th video), no collective in the
+    data path; per-rank result dicts are gathered on rank 0 (opental_amd.thumos14.test.gather_results); proposals/s =
+    126 x all windows / slowest rank's time between two barriers."""
+    from opental_amd.common import ops
+    from opental_amd.thumos14 import test as T
+    from opental_amd.thumos14.BDNet import BDNet
+    saved = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        torch.manual_seed(0)
+        net = BDNet(training=False, use_edl=True)
+        net.backbone._model.apply(BDNet.weight_init)
+        net = net.to(device).eval()
+        frames = np.random.RandomState(0).randint(600, 4001, size=nvid)
+        names = [f"video_{i:04d}" for i in range(nvid)]
+        mine = list(range(nvid))[rank::world]
+        g = torch.Generator(device=device).manual_seed(rank)
+        T.detect_batch(net, [torch.randint(0, 256, (3, 700, 96, 96), device=device, generator=g, dtype=torch.uint8)], 10.0, batch_clips=32)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        results = {}
+        for i in range(0, len(mine), 16):
+            part = mine[i:i + 16]
+            vids = [torch.randint(0, 256, (3, int(frames[v]), 96, 96), device=device, generator=g, dtype=torch.uint8) for v in part]
+            rows, counts, _, _ = T.detect_batch(net, vids, 10.0, batch_clips=32)
+            for k, v in enumerate(part):
+                results[names[v]] = T.get_video_detections(rows[k], counts[k], None, 5000)
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        merged = T.gather_results(results, names, rank, world, device)
+        nwin = sum(len(T.get_offsets(int(f), 256, 128)) for f in frames)
+        if rank != 0:
+            return None
+        return {"videos": nvid, "videos_in_merged_result": len(merged), "windows": nwin, "ranks": world,
+                "seconds": round(float(t[0]), 3), "proposals_per_s": round(126 * nwin / float(t[0]), 1),
+                "detections": sum(len(v) for v in merged.values()),
+                "what": "BASELINE configs[4] at N ranks: video list sharded, per-rank result dicts gathered on rank 0; includes "
+                        "generating the frames on the device and the host-side result lists"}
+    finally:
+        ops.CONV_PRECISION = saved
 
 
 def main():
@@ -393,12 +469,39 @@ def main():
     graphed = False
     launch_probe = None
     multi = world > 1 or force_dist
+    backend = dist.get_backend() if multi else None
+
+    def replica_check(where):
+        """Data-parallel self-check: every rank must hold bit-identical parameters and Adam moments (identical updates of
+        identical all-reduced gradients).  MIN and MAX over ranks of three checksums; a difference aborts the run -- a
+        throughput number of diverged replicas would be worthless."""
+        if not multi:
+            return None
+        a = trainer.arena
+        cs = torch.stack([a.flat.double().sum(), a.flat.double().abs().sum(), a.m.double().sum(), a.v.double().sum()])
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit(f"[bench] rank {rank}: replicas DIVERGED {where}: checksum min {lo.tolist()} max {hi.tolist()}")
+        return True
+
+    def exposed_of(events):
+        if not events:
+            return None
+        v = sum(a.elapsed_time(b) for a, b in events) / len(events)
+        if multi:
+            t = torch.tensor([v], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            v = float(t[0])
+        return round(v, 3)
+
     # Launch mode.  The step is GPU-bound since the loss / gradient hand-over stopped issuing ~800 tiny kernels: eager
     # launches and a replayed HIP graph give the same throughput when the host has slack.  `auto` checks for that slack on
-    # every rank (the probe steps are ordinary data-parallel steps, all ranks take part): if issuing the launches of a step
-    # takes < 90 % of the step on the SLOWEST host thread, eager launches it is; only a host-bound step is captured.  The
-    # decision and the outcome of the capture are agreed between the ranks (MAX / MIN all-reduce), so all ranks replay or
-    # none does.
+    # every rank (the probe steps are ordinary data-parallel steps, all ranks take part): one GPU -- if issuing the launches
+    # of a step takes < 90 % of the step, eager launches it is, only a host-bound step is captured; several ranks -- both
+    # forms are built and TIMED (MAX over ranks) and the faster one runs.  Decisions and the outcome of the capture are
+    # agreed between the ranks (MAX / MIN all-reduce), so all ranks replay or none does.
     want_graph = args.graph == "on"
     # A step that issues RCCL collectives is never captured as ONE graph: ProcessGroupNCCL's watchdog thread queries the
     # events of the all-reduces it was handed, and a query of an event recorded in a capturing stream is an error
@@ -408,18 +511,28 @@ def main():
         for _ in range(3):
             trainer.step(clips, targets, scores)
         barrier()
+        trainer.measure_exposed, trainer.exposed_events = multi, []
         t = time.perf_counter()
         for _ in range(6):
             trainer.step(clips, targets, scores)
         t_issue = time.perf_counter() - t
         torch.cuda.synchronize()
         t_total = time.perf_counter() - t
+        trainer.measure_exposed = False
+        per_rank_issue = None
         if multi:
+            mine = torch.tensor([t_issue / 6 * 1e3], device=device, dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(allr, mine)
+            per_rank_issue = [round(float(v), 3) for v in allr]
             tt = torch.tensor([t_issue, t_total], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t_issue, t_total = float(tt[0]), float(tt[1])
         launch_probe = {"eager_ms": round(t_total / 6 * 1e3, 3), "host_issue_ms": round(t_issue / 6 * 1e3, 3)}
-        want_graph = t_issue > 0.9 * t_total
+        if multi:
+            launch_probe["host_issue_ms_per_rank"] = per_rank_issue
+            launch_probe["allreduce_exposed_ms_eager"] = exposed_of(trainer.exposed_events)
+        want_graph = multi or t_issue > 0.9 * t_total
     if want_graph:
         ok = 1
         try:
@@ -436,22 +549,28 @@ def main():
             ok = int(okt)
         graphed = bool(ok)
         if graphed and multi and launch_probe is not None:
-            # insurance on hardware this file has never seen: the two-graph step must actually beat the eager one it replaces
-            # (both timed here, MAX over ranks); otherwise back to eager launches
+            # the two-graph step must actually beat the eager one it replaces (both timed here, MAX over ranks); otherwise
+            # back to eager launches
+            for _ in range(2):
+                trainer.step(clips, targets, scores)
             barrier()
+            trainer.measure_exposed, trainer.exposed_events = True, []
             t = time.perf_counter()
-            for _ in range(3):
+            for _ in range(6):
                 trainer.step(clips, targets, scores)
             torch.cuda.synchronize()
-            tt = torch.tensor([(time.perf_counter() - t) / 3], device=device, dtype=torch.float64)
+            tt = torch.tensor([(time.perf_counter() - t) / 6], device=device, dtype=torch.float64)
+            trainer.measure_exposed = False
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             launch_probe["two_graph_ms"] = round(float(tt[0]) * 1e3, 3)
+            launch_probe["allreduce_exposed_ms_two_graph"] = exposed_of(trainer.exposed_events)
             if float(tt[0]) * 1e3 > launch_probe["eager_ms"]:
                 graphed = False
         if not graphed:
             trainer.drop_graph()
     for _ in range(args.warmup):
         trainer.step(clips, targets, scores, *ssl_args)
+    replicas_ok = replica_check("after the warm-up steps")
     trainer.measure_exposed = multi      # HIP events around the wait for the gradient all-reduces (eager or between the two graphs)
     trainer.exposed_events = []
     barrier()
@@ -471,8 +590,16 @@ def main():
         exposed_ms = float(t[1]) if float(t[1]) >= 0 else None
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
+    replicas_ok = replica_check("after the timed steps") and replicas_ok
 
     nbuckets = len(trainer.arena.buckets)
+    infer_n = None
+    if world > 1 and not args.no_extras and not anet:
+        try:
+            infer_n = inference_sharded(device, rank, world)
+        except Exception as e:                      # noqa: BLE001 -- an extra must never take the headline down
+            infer_n = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+            torch.cuda.synchronize()
     roofline = None
     if rank == 0 and not args.no_roofline:
         from opental_amd.common import ops
@@ -546,6 +673,7 @@ def main():
         cpu = cpu_baseline(seconds_budget=12.0)
         if not args.no_extras:
             cpu["batch8"] = cpu_baseline(seconds_budget=10.0, batch=8)
+            cpu["all_threads"] = cpu_baseline_all_threads()
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -560,7 +688,9 @@ def main():
                                    "OpenTAL THUMOS14 split_0 training step (configs/thumos14_opental_final.yaml, "
                                    "EDL+IBM loss, ssl branch " + ("ON" if args.ssl else "off") + "), 256x3x96x96 clips, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "rccl_ranks": dist.get_world_size() if (world > 1 or force_dist) else 1,
+                       "parallelism": f"dp{world}", "backend": backend, "ranks": dist.get_world_size() if multi else 1,
+                       "rccl_ranks": dist.get_world_size() if (multi and backend == "nccl") else (1 if not multi else 0),
+                       "replicas_bit_identical": replicas_ok,
                        "arena_buckets": nbuckets,
                        "grad_allreduce": "RCCL sum over xGMI of the flat fp32 gradient arena in %d contiguous buckets, issued from inside "
                                          "the backward pass (the backbone hands its finished layers over while it runs); "
@@ -569,7 +699,9 @@ def main():
                        "ssl_branch": bool(args.ssl), "launch_probe": launch_probe,
                        "launch": ("two captured HIP graphs per step, the gradient all-reduces issued between them" if multi else
                                   "one captured HIP graph per step") if graphed else "eager launches"},
-            "roofline": roofline, "hbm_kernels": hbm, "other_configs": extra, "cpu_baseline": cpu}))
+            "roofline": roofline, "hbm_kernels": hbm,
+            "other_configs": extra if extra is not None else ({"inference": infer_n} if infer_n is not None else None),
+            "cpu_baseline": cpu}))
     if world > 1 or force_dist:
         dist.barrier()              # every rank leaves together (rank 0 was busy with the roofline steps)
         dist.destroy_process_group()

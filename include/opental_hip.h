@@ -40,6 +40,8 @@ extern "C" {
 /* dtype codes for feature tensors; proposals/segments are always float32 */
 #define OTAL_F32  0
 #define OTAL_BF16 1
+#define OTAL_F16  2   /* otal_bmp_*: the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF (boundary_max_pooling_kernel.cu:99,:131) */
+#define OTAL_F64  3   /* otal_bmp_* only */
 
 #define OTAL_MAX_LEVELS 8
 
@@ -366,7 +368,9 @@ int otal_detection_loss_bwd(const float* grads, const float* const* g7, float* o
  * Replaces AFSD/common/thumos_dataset.py:136-137,:246-262 and videotransforms.py:44-124 (temporal zero padding,
  * random / centre crop, horizontal flip, float(), (x/255)*2-1, THWC -> CTHW).  params: device array of B records
  * {int64 frame0 (element offset of the clip's first frame in `frames`), int32 valid_t, crop_i, crop_j, flip}
- * = 24 bytes each (8-byte aligned); the random decisions are taken on the host exactly as the reference takes them. */
+ * = 24 bytes each (8-byte aligned); the random decisions are taken on the host exactly as the reference takes them.
+ * flip bit 0 = mirror along W; flip bit 1 = the frames past valid_t are 127.5 before normalisation (exactly 0.0 after it),
+ * the ActivityNet loader's padding (AFSD/common/anet_dataset.py:226-229), instead of 0 (-1.0 after it). */
 int otal_prepare_clips(const unsigned char* frames, const void* params, float* out, int B, int T, int Hs, int Ws,
                        int Ho, int Wo, void* stream);
 /* The same, plus the self-supervised branch's SPLICED clips from the same upload: out_ssl[b,:,t] = clip b's frame

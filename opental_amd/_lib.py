@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTAL_LIB_PATH") or os.path.join(_HERE, "lib", "libopental_hip.so")   # override: A/B kernel builds
 ABI_VERSION = 19
-F32, BF16 = 0, 1
+F32, BF16, F16, F64 = 0, 1, 2, 3
 
 _lib = None
 
@@ -61,7 +61,11 @@ def dtype_code(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
-    raise RuntimeError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+    if t.dtype == torch.float16:
+        return F16
+    if t.dtype == torch.float64:
+        return F64
+    raise RuntimeError(f"unsupported dtype {t.dtype} (float32 / bfloat16 / float16 / float64)")
 
 
 def require_device(*tensors):

@@ -238,11 +238,11 @@ class ClipStager:
                 v, off = smp['video'], int(smp['offset'])
                 if tuple(v.shape[1:]) != (self.H, self.W, 3) or v.dtype != torch.uint8:
                     raise RuntimeError("ClipStager: videos must be uint8 (T,H,W,3) of the configured frame size")
-                sl = v[off: off + self.T]                             # contiguous frame range of the pinned video
+                sl = v[off: off + min(self.T, int(smp.get('valid', self.T)))]     # contiguous frame range of the pinned video
                 n = sl.shape[0] * self.frame_bytes
                 self.stage[s][pos: pos + n].copy_(sl.reshape(-1), non_blocking=True)
                 i, j, flip = smp['crop']
-                recs[b] = (pos, sl.shape[0], i, j, int(flip))
+                recs[b] = (pos, sl.shape[0], i, j, int(flip) | (2 if smp.get('pad_half') else 0))    # bit 1: pad with 127.5
                 fm = smp.get('frame_map')
                 maps[b] = np.arange(self.T, dtype=np.int32) if fm is None else fm
                 any_ssl = any_ssl or fm is not None

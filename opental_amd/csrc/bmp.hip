@@ -16,6 +16,21 @@
 
 namespace {
 
+// Feature dtypes (the reference dispatches float / double / half, boundary_max_pooling_kernel.cu:99,:131; bf16 is this
+// library's own storage type).  S = the type rows are staged and gradients are summed in: float for f32 / bf16 / f16
+// (loads are exact, the selected maximum is an input value, so the stored output is exact too), double for f64.
+typedef _Float16 f16_t;
+template <typename S> __device__ __forceinline__ S ld_as(const float* p, size_t i) { return (S)p[i]; }
+template <typename S> __device__ __forceinline__ S ld_as(const bf16_t* p, size_t i) { return (S)bf16_to_f32(p[i]); }
+template <typename S> __device__ __forceinline__ S ld_as(const f16_t* p, size_t i) { return (S)(float)p[i]; }
+template <typename S> __device__ __forceinline__ S ld_as(const double* p, size_t i) { return (S)p[i]; }
+template <typename S> __device__ __forceinline__ void st_as(float* p, size_t i, S v) { p[i] = (float)v; }
+template <typename S> __device__ __forceinline__ void st_as(bf16_t* p, size_t i, S v) { p[i] = f32_to_bf16((float)v); }
+template <typename S> __device__ __forceinline__ void st_as(f16_t* p, size_t i, S v) { p[i] = (f16_t)(float)v; }
+template <typename S> __device__ __forceinline__ void st_as(double* p, size_t i, S v) { p[i] = (double)v; }
+template <typename T> struct StageOf { typedef float type; };
+template <> struct StageOf<double> { typedef double type; };
+
 // level lookup with compile-time indices so the table stays in SGPRs
 __device__ __forceinline__ void level_of_n(const LevelTab& lt, int k, int& tb, int& te) {
     tb = lt.ts[0]; te = lt.ts[1];
@@ -32,20 +47,20 @@ __device__ __forceinline__ void level_of_t(const LevelTab& lt, int i, int& kb, i
 
 // LDS carve (bytes, all 16-aligned)
 struct Carve { int rows, win, g, arg, total; };
-static Carve carve(int ROWS, int T, int N, bool bwd) {
+static Carve carve(int ROWS, int T, int N, bool bwd, int esz) {       // esz = sizeof(staging type)
     auto up = [](int v) { return (v + 15) & ~15; };
     Carve c;
     const int Tp = T | 1, Np = N | 1;
     c.rows = 0;
-    c.win = up(ROWS * Tp * 4);
+    c.win = up(ROWS * Tp * esz);
     c.g = c.win + up(N * 16);
-    c.arg = c.g + (bwd ? up(ROWS * Np * 4) : 0);
+    c.arg = c.g + (bwd ? up(ROWS * Np * esz) : 0);
     c.total = c.arg + (bwd ? up(ROWS * Np * 4) : 0);
     return c;
 }
 
-template <typename T>
-__device__ __forceinline__ void stage_rows(float* rows, const T* src, int nrows, int len, int lenp,
+template <typename T, typename S>
+__device__ __forceinline__ void stage_rows(S* rows, const T* src, int nrows, int len, int lenp,
                                            int lx, int tid) {
     // 2-D thread map without integer division: (1 << lx) lanes along the row, the rest across rows.  Eight rows are
     // loaded before the first LDS store: with one load in flight per lane (a plain loop: load, wait, store) a 16-row
@@ -54,25 +69,26 @@ __device__ __forceinline__ void stage_rows(float* rows, const T* src, int nrows,
     for (int i = tx; i < len; i += (1 << lx)) {
         int r = ty;
         for (; r + 7 * ny < nrows; r += 8 * ny) {
-            float v[8];
+            S v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ld_f32(src, (size_t)(r + u * ny) * len + i);
+            for (int u = 0; u < 8; ++u) v[u] = ld_as<S>(src, (size_t)(r + u * ny) * len + i);
 #pragma unroll
             for (int u = 0; u < 8; ++u) rows[(r + u * ny) * lenp + i] = v[u];
         }
-        for (; r < nrows; r += ny) rows[r * lenp + i] = ld_f32(src, (size_t)r * len + i);
+        for (; r < nrows; r += ny) rows[r * lenp + i] = ld_as<S>(src, (size_t)r * len + i);
     }
 }
 
 // First maximum of row[l..rr] (strict >, as boundary_max_pooling_kernel.cu:33-40), four elements per trip: indices past
 // rr are clamped to rr -- a repeated element can never beat the running maximum, so value and arg-max are unchanged --
 // which lets the four LDS reads of a trip issue together instead of one dependent read per element.
-__device__ __forceinline__ float window_max(const float* row, int l, int rr, int& arg) {
-    float best = row[l];
+template <typename S>
+__device__ __forceinline__ S window_max(const S* row, int l, int rr, int& arg) {
+    S best = row[l];
     int a = l;
     for (int i = l + 1; i <= rr; i += 4) {
         const int i1 = i + 1 < rr ? i + 1 : rr, i2 = i + 2 < rr ? i + 2 : rr, i3 = i + 3 < rr ? i + 3 : rr;
-        const float v0 = row[i], v1 = row[i1], v2 = row[i2], v3 = row[i3];
+        const S v0 = row[i], v1 = row[i1], v2 = row[i2], v3 = row[i3];
         if (v0 > best) { best = v0; a = i; }
         if (v1 > best) { best = v1; a = i1; }
         if (v2 > best) { best = v2; a = i2; }
@@ -101,8 +117,9 @@ template <typename T, int ROWS>
 __global__ __launch_bounds__(256) void bmp_fwd_kernel(const T* __restrict__ in, const float* __restrict__ seg,
                                                       T* __restrict__ out, int C, int Tt, int Nt,
                                                       LevelTab lt, int lxT, int lxN, int off_win) {
+    typedef typename StageOf<T>::type S;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* rows = reinterpret_cast<float*>(smem);
+    S* rows = reinterpret_cast<S*>(smem);
     int* win = reinterpret_cast<int*>(smem + off_win);
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * ROWS;          // global (n*C + c) row; C % ROWS == 0
@@ -115,11 +132,11 @@ __global__ __launch_bounds__(256) void bmp_fwd_kernel(const T* __restrict__ in, 
     const int half = C >> 1;
     for (int r = ky; r < ROWS; r += nky) {
         const int which = (c0 + r) >= half ? 2 : 0;
-        const float* row = rows + r * Tp;
+        const S* row = rows + r * Tp;
         for (int k = kx; k < Nt; k += (1 << lxN)) {
             const int l = win[k * 4 + which], rr = win[k * 4 + which + 1];
             int a;
-            st_f32(out, (size_t)(row0 + r) * Nt + k, window_max(row, l, rr, a));
+            st_as<S>(out, (size_t)(row0 + r) * Nt + k, window_max(row, l, rr, a));
         }
     }
 }
@@ -129,10 +146,11 @@ __global__ __launch_bounds__(256) void bmp_bwd_kernel(const T* __restrict__ gout
                                                       const float* __restrict__ seg, T* __restrict__ gin,
                                                       int C, int Tt, int Nt, LevelTab lt, int lxT, int lxN,
                                                       int off_win, int off_g, int off_arg) {
+    typedef typename StageOf<T>::type S;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* rows = reinterpret_cast<float*>(smem);
+    S* rows = reinterpret_cast<S*>(smem);
     int* win = reinterpret_cast<int*>(smem + off_win);
-    float* g = reinterpret_cast<float*>(smem + off_g);
+    S* g = reinterpret_cast<S*>(smem + off_g);
     int* arg = reinterpret_cast<int*>(smem + off_arg);
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * ROWS;
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(256) void bmp_bwd_kernel(const T* __restrict__ gout
         const int half = C >> 1;
         for (int r = ky; r < ROWS; r += nky) {
             const int which = (c0 + r) >= half ? 2 : 0;
-            const float* row = rows + r * Tp;
+            const S* row = rows + r * Tp;
             for (int k = kx; k < Nt; k += (1 << lxN)) {
                 const int l = win[k * 4 + which], rr = win[k * 4 + which + 1];
                 int a;
@@ -158,7 +176,7 @@ __global__ __launch_bounds__(256) void bmp_bwd_kernel(const T* __restrict__ gout
     }
     __syncthreads();
     // phase 2: scatter in LDS.  The input tile is no longer needed, its LDS space becomes the grad_in tile.
-    for (int i = tid; i < ROWS * Tp; i += 256) rows[i] = 0.f;
+    for (int i = tid; i < ROWS * Tp; i += 256) rows[i] = (S)0;
     __syncthreads();
     // One lane per row walks the proposals in ascending k and adds grad_out into grad_in[arg-max] -- a
     // dependent chain per row (rows are independent), entirely in LDS, so every position receives its
@@ -169,9 +187,9 @@ __global__ __launch_bounds__(256) void bmp_bwd_kernel(const T* __restrict__ gout
     // gathered by (row, position) lanes 29.8 / 30.1.  What did pay was in front of this phase: row staging with eight
     // loads in flight and the four-wide window scan (17.6 / 31.0 before).
     if (tid < ROWS) {
-        float* gi = rows + tid * Tp;
+        S* gi = rows + tid * Tp;
         const int* ar = arg + tid * Np;
-        const float* gr = g + tid * Np;
+        const S* gr = g + tid * Np;
         for (int k = 0; k < Nt; ++k) gi[ar[k]] += gr[k];
     }
     __syncthreads();
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(256) void bmp_bwd_kernel(const T* __restrict__ gout
         const int tx = tid & ((1 << lxT) - 1), ty = tid >> lxT, nty = 256 >> lxT;
         for (int r = ty; r < ROWS; r += nty)
             for (int i = tx; i < Tt; i += (1 << lxT))
-                st_f32(gin, (size_t)(row0 + r) * Tt + i, rows[r * Tp + i]);
+                st_as<S>(gin, (size_t)(row0 + r) * Tt + i, rows[r * Tp + i]);
     }
 }
 
@@ -190,7 +208,7 @@ int launch_fwd(const T* in, const float* seg, T* out, int B, int C, int Tt, int 
     for (int ci = 0; ci < 4; ++ci) {
         const int R = cand[ci];
         if (C % R) continue;
-        const Carve cv = carve(R, Tt, Nt, false);
+        const Carve cv = carve(R, Tt, Nt, false, (int)sizeof(typename StageOf<T>::type));
         if (cv.total > 48 * 1024 && R > 2) continue;
         if (cv.total > 64 * 1024) return OTAL_E_UNSUPPORTED;
         const dim3 grid((unsigned)((size_t)B * C / R));
@@ -210,7 +228,7 @@ int launch_bwd(const T* gout, const T* in, const float* seg, T* gin, int B, int 
     for (int ci = 0; ci < 4; ++ci) {
         const int R = cand[ci];
         if (C % R) continue;
-        const Carve cv = carve(R, Tt, Nt, true);
+        const Carve cv = carve(R, Tt, Nt, true, (int)sizeof(typename StageOf<T>::type));
         if (cv.total > 48 * 1024 && R > 2) continue;
         if (cv.total > 64 * 1024) return OTAL_E_UNSUPPORTED;
         const dim3 grid((unsigned)((size_t)B * C / R));
@@ -247,6 +265,8 @@ extern "C" int otal_bmp_fwd_levels(const void* in, const float* seg, void* out, 
     hipStream_t s = (hipStream_t)stream;
     if (dtype == OTAL_F32) return launch_fwd<float>((const float*)in, seg, (float*)out, B, C, Tt, Nt, lt, s);
     if (dtype == OTAL_BF16) return launch_fwd<bf16_t>((const bf16_t*)in, seg, (bf16_t*)out, B, C, Tt, Nt, lt, s);
+    if (dtype == OTAL_F16) return launch_fwd<f16_t>((const f16_t*)in, seg, (f16_t*)out, B, C, Tt, Nt, lt, s);
+    if (dtype == OTAL_F64) return launch_fwd<double>((const double*)in, seg, (double*)out, B, C, Tt, Nt, lt, s);
     return OTAL_E_DTYPE;
 }
 
@@ -261,6 +281,8 @@ extern "C" int otal_bmp_bwd_levels(const void* gout, const void* in, const float
     hipStream_t s = (hipStream_t)stream;
     if (dtype == OTAL_F32) return launch_bwd<float>((const float*)gout, (const float*)in, seg, (float*)gin, B, C, Tt, Nt, lt, s);
     if (dtype == OTAL_BF16) return launch_bwd<bf16_t>((const bf16_t*)gout, (const bf16_t*)in, seg, (bf16_t*)gin, B, C, Tt, Nt, lt, s);
+    if (dtype == OTAL_F16) return launch_bwd<f16_t>((const f16_t*)gout, (const f16_t*)in, seg, (f16_t*)gin, B, C, Tt, Nt, lt, s);
+    if (dtype == OTAL_F64) return launch_bwd<double>((const double*)gout, (const double*)in, seg, (double*)gin, B, C, Tt, Nt, lt, s);
     return OTAL_E_DTYPE;
 }
 
@@ -282,7 +304,8 @@ extern "C" int otal_bmp_bwd(const void* gout, const void* in, const float* seg, 
         // reference launcher: tscale = grad_output.size(2) = N (boundary_max_pooling_kernel.cu:121).
         // Same kernel over the same buffers viewed as (B*C) rows of N; the tail stays zero.
         if (N > T) return OTAL_E_SHAPE;   // the reference would write out of bounds here
-        const size_t esz = dtype == OTAL_F32 ? 4 : 2;
+        if (dtype < OTAL_F32 || dtype > OTAL_F64) return OTAL_E_DTYPE;
+        const size_t esz = dtype == OTAL_F32 ? 4 : (dtype == OTAL_F64 ? 8 : 2);
         hipError_t e = hipMemsetAsync(gin, 0, (size_t)B * C * T * esz, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
         Teff = N;

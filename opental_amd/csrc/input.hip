@@ -16,7 +16,8 @@ struct ClipParams {      // one per clip, device array
     long long frame0;    // element offset of this clip's first frame in the uint8 frame buffer
     int valid_t;         // frames available (the rest of the clip is zero BEFORE normalisation, i.e. -1.0 after it)
     int crop_i, crop_j;  // top-left corner of the crop in the source frame
-    int flip;            // 1: mirror along W after cropping
+    int flip;            // bit 0: mirror along W after cropping; bit 1: pad frames are 127.5 before normalisation (exactly
+                         // 0.0 after it: the ActivityNet loader, AFSD/common/anet_dataset.py:226-229) instead of 0 (-1.0)
 };
 
 __global__ __launch_bounds__(256) void prepare_clips_kernel(const unsigned char* __restrict__ frames,
@@ -33,13 +34,13 @@ __global__ __launch_bounds__(256) void prepare_clips_kernel(const unsigned char*
         const int y = r / Wo, x = r - y * Wo;
         float v0, v1, v2;
         if (t < p.valid_t) {
-            const int xs = p.crop_j + (p.flip ? Wo - 1 - x : x);
+            const int xs = p.crop_j + ((p.flip & 1) ? Wo - 1 - x : x);
             const unsigned char* px = frames + p.frame0 + (((long long)t * Hs + (p.crop_i + y)) * Ws + xs) * 3;
             v0 = ((float)px[0] / 255.0f) * 2.0f - 1.0f;     // same operation order as the reference (no fma: -ffp-contract=off)
             v1 = ((float)px[1] / 255.0f) * 2.0f - 1.0f;
             v2 = ((float)px[2] / 255.0f) * 2.0f - 1.0f;
         } else {
-            v0 = v1 = v2 = (0.0f / 255.0f) * 2.0f - 1.0f;
+            v0 = v1 = v2 = (((p.flip & 2) ? 127.5f : 0.0f) / 255.0f) * 2.0f - 1.0f;
         }
         ob[idx] = v0;
         ob[vol + idx] = v1;
@@ -70,13 +71,13 @@ __global__ __launch_bounds__(256) void prepare_clips_map_kernel(const unsigned c
             const int ts = (pass == 1 && fmap) ? fmap[b * T + t] : t;
             float v0, v1, v2;
             if (ts >= 0 && ts < p.valid_t) {
-                const int xs = p.crop_j + (p.flip ? Wo - 1 - x : x);
+                const int xs = p.crop_j + ((p.flip & 1) ? Wo - 1 - x : x);
                 const unsigned char* px = frames + p.frame0 + (((long long)ts * Hs + (p.crop_i + y)) * Ws + xs) * 3;
                 v0 = ((float)px[0] / 255.0f) * 2.0f - 1.0f;
                 v1 = ((float)px[1] / 255.0f) * 2.0f - 1.0f;
                 v2 = ((float)px[2] / 255.0f) * 2.0f - 1.0f;
             } else {
-                v0 = v1 = v2 = (0.0f / 255.0f) * 2.0f - 1.0f;
+                v0 = v1 = v2 = (((p.flip & 2) ? 127.5f : 0.0f) / 255.0f) * 2.0f - 1.0f;
             }
             ob[idx] = v0;
             ob[vol + idx] = v1;

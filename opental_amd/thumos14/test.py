@@ -242,6 +242,31 @@ def test(net, video_infos, npy_data_path, idx_to_class=None, clip_length=256, st
     return result_dict
 
 
+def gather_results(result_dict, names, rank, world, device=None):
+    """Several ranks (video list sharded): every rank's result dict travels to rank 0, which returns the merged
+    dict in the video list's order (the pattern sketched in AFSD/anet/test.py:248-273, with a collective instead of
+    multiprocessing queues); the other ranks return None.  One rank: the dict itself."""
+    if world == 1:
+        return result_dict
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        import os
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29534')
+        if device is not None and torch.device(device).type == 'cuda':
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(result_dict, parts, dst=0)
+    if rank != 0:
+        return None
+    merged = {}
+    for part in parts:
+        merged.update(part)
+    return {n: merged[n] for n in names if n in merged}
+
+
 def main(argv=None):
     """python -m opental_amd.thumos14.test <yaml> --open_set --split 0 [--random_init] [--evaluate GT.json KNOWN.txt]
 
@@ -281,12 +306,15 @@ def main(argv=None):
     _, idx_to_class = get_class_index_map(config['dataset']['class_info_path'])
     results = test(net, video_infos, ds['video_data_path'], idx_to_class, ds['clip_length'], ds['clip_stride'], ds['crop_size'],
                    te['conf_thresh'], te['top_k'], te['nms_sigma'], rank=rank, world=world, device=dev)
+    results = gather_results(results, list(video_infos.keys()), rank, world, dev)
+    if results is None:
+        return None, None           # ranks > 0: their detections went to rank 0
     os.makedirs(te['output_path'], exist_ok=True)
-    out_file = os.path.join(te['output_path'], te['output_json'] if world == 1 else f"rank{rank}_" + te['output_json'])
+    out_file = os.path.join(te['output_path'], te['output_json'])
     with open(out_file, 'w') as f:
         json.dump(results_json(results), f)
     print(f"{len(results)} videos, {sum(len(v) for v in results.values())} detections -> {out_file}")
-    if evaluate is not None and world == 1:
+    if evaluate is not None:
         from .eval_open import evaluate_split
         return out_file, evaluate_split(out_file, evaluate[0], evaluate[1], [0.3, 0.4, 0.5, 0.6, 0.7], ['test'], True,
                                         te.get('ood_scoring', 'confidence'))

@@ -834,10 +834,47 @@ def rank_batches(every, rank, world):
     return every[rank::world]
 
 
-def run_one_epoch(epoch, trainer, dataset, stager, batch_size, rank=0, world=1, max_steps=None, log=print):
+class StepLog:
+    """Per-step scalars without a host synchronisation (the reference calls .item() ~20 times per step for TensorBoard and
+    the progress bar, train.py:255-283): every `every` steps the step's [cost, 7 losses] vector is copied
+    to a pinned host slot with ONE asynchronous D2H copy + an event; a slot is read (and handed to `sink`) only once its
+    event has completed, i.e. a few steps later, while the GPU keeps running."""
+    NAMES = ('total', 'loc', 'conf', 'prop_loc', 'prop_conf', 'IoU', 'start', 'end')
+
+    def __init__(self, every=20, sink=None, slots=4):
+        self.every, self.sink = int(every), sink
+        self._free = [(torch.empty(8, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.empty(8),
+                       torch.cuda.Event() if torch.cuda.is_available() else None) for _ in range(slots)]
+        self._inflight = []
+        self.records = []
+
+    def push(self, step, vec):
+        self.poll()
+        if self.every <= 0 or step % self.every or not self._free:
+            return
+        buf, ev = self._free.pop()
+        buf.copy_(vec.detach(), non_blocking=True)
+        if ev is not None:
+            ev.record()
+        self._inflight.append((step, buf, ev))
+
+    def poll(self, wait=False):
+        while self._inflight and (wait or self._inflight[0][2] is None or self._inflight[0][2].query()):
+            step, buf, ev = self._inflight.pop(0)
+            if wait and ev is not None:
+                ev.synchronize()
+            rec = (step, buf.tolist())
+            self.records.append(rec)
+            if self.sink is not None:
+                self.sink(*rec)
+            self._free.append((buf, ev))
+
+
+def run_one_epoch(epoch, trainer, dataset, stager, batch_size, rank=0, world=1, max_steps=None, log=print, step_log=None):
     """One pass over the shuffled sliding-window list (train.py:204-303).  Every rank draws the same permutation and
     the same per-sample decisions (shared seeds) and takes every world-th batch.  Nothing in the loop synchronises with
-    the host: the loss sums stay on the device until the epoch's log line."""
+    the host: the loss sums stay on the device until the epoch's log line; `step_log` (StepLog) receives the per-step
+    scalars through asynchronous copies."""
     from ..common import thumos_dataset as D
     dev = trainer.arena.flat.device
     sums, n_iter = None, 0
@@ -859,6 +896,10 @@ def run_one_epoch(epoch, trainer, dataset, stager, batch_size, rank=0, world=1, 
         vec = torch.stack([cost.reshape(())] + [l.detach().reshape(()) for l in losses[:7]])
         sums = vec if sums is None else sums + vec
         n_iter += 1
+        if step_log is not None:
+            step_log.push(trainer.step_count, vec)
+    if step_log is not None:
+        step_log.poll(wait=True)
     v = (sums / n_iter).tolist()                           # the epoch's only host synchronisation
     log('Epoch-{} Train Loss: Total - {:.5f}, loc - {:.5f}, conf - {:.5f}, prop_loc - {:.5f}, prop_conf - {:.5f}, '
         'IoU - {:.5f}, start - {:.5f}, end - {:.5f}'.format(epoch, *v))
@@ -873,19 +914,20 @@ def main(argv=None):
       --random_init           no pretrained I3D file (synthetic data)
       --save_after N          save checkpoints for epochs > N (reference: 10, train.py:289)
       --max_steps N           cap the steps per epoch (smoke runs)
+      --log_every N           per-step loss line every N steps through asynchronous D2H copies (StepLog; 0 = epoch lines only)
     One process per GPU; under torchrun the ranks all-reduce gradients over RCCL (DetectorTrainer)."""
     import os
     import sys
     from ..common import config as C
     from ..common import thumos_dataset as D
     argv = list(sys.argv[1:] if argv is None else argv)
-    extra = {'as_shipped_dispatch': False, 'random_init': False, 'save_after': 10, 'max_steps': None}
+    extra = {'as_shipped_dispatch': False, 'random_init': False, 'save_after': 10, 'max_steps': None, 'log_every': 0}
     rest, i = [], 0
     while i < len(argv):
         a = argv[i]
         if a in ('--as_shipped_dispatch', '--random_init'):
             extra[a[2:]] = True
-        elif a in ('--save_after', '--max_steps'):
+        elif a in ('--save_after', '--max_steps', '--log_every'):
             extra[a[2:]] = int(argv[i + 1]); i += 1
         else:
             rest.append(a)
@@ -920,12 +962,17 @@ def main(argv=None):
         print(f"batch size: {tr['batch_size']}  learning rate: {tr['learning_rate']}  weight decay: {tr['weight_decay']}  "
               f"max epoch: {tr['max_epoch']}  cls loss: {crit.cls_loss_type}  clips: {len(dataset)}  ranks: {world}  resume: {tr['resume']}")
     history = []
+    step_log = None
+    if extra['log_every'] > 0 and rank == 0:
+        step_log = StepLog(extra['log_every'], sink=lambda step, v: print(
+            'step {} '.format(step) + ', '.join('{} {:.5f}'.format(n, x) for n, x in zip(StepLog.NAMES, v))))
+    trainer.step_log = step_log
     for epoch in range(start_epoch, tr['max_epoch'] + 1):
         if crit.cls_loss_type == 'edl':
             crit.cls_loss.epoch = epoch
             crit.cls_loss.total_epoch = tr['max_epoch']
         v = run_one_epoch(epoch, trainer, dataset, stager, tr['batch_size'], rank, world, extra['max_steps'],
-                          log=print if rank == 0 else (lambda *a: None))
+                          log=print if rank == 0 else (lambda *a: None), step_log=step_log)
         history.append(v)
         if epoch > extra['save_after'] and rank == 0:
             trainer.save_model(epoch, checkpoint_path, train_state_path)

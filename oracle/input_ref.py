@@ -24,13 +24,17 @@ def sample_params(h, w, crop, training, rng=random):
     return int(np.round((h - crop) / 2.)), int(np.round((w - crop) / 2.)), False
 
 
-def prepare_clip(video_thwc, offset, clip_length, crop, i, j, flip):
-    """video (T,H,W,3) uint8 -> (3, clip_length, crop, crop) float32."""
+def prepare_clip(video_thwc, offset, clip_length, crop, i, j, flip, valid=None, pad_value=0.0):
+    """video (T,H,W,3) uint8 -> (3, clip_length, crop, crop) float32.  `valid` / `pad_value=127.5`: the ActivityNet loader
+    (anet_dataset.py:219-229) keeps min(frame_num, clip_length) frames and pads with 127.5 in floating point."""
     data = np.transpose(video_thwc, [3, 0, 1, 2])                       # thumos_dataset.py:137
-    x = data[:, offset: offset + clip_length]
+    x = data[:, offset: offset + (clip_length if valid is None else valid)]
     c, t, h, w = x.shape
     if t < clip_length:                                                  # :248-252
-        x = np.concatenate([x, np.zeros([c, clip_length - t, h, w], x.dtype)], 1)
+        if pad_value:
+            x = np.concatenate([x.astype(np.float64), np.ones([c, clip_length - t, h, w], np.float64) * pad_value], 1)
+        else:
+            x = np.concatenate([x, np.zeros([c, clip_length - t, h, w], x.dtype)], 1)
     x = x[:, :, i:i + crop, j:j + crop]                                  # videotransforms.py:67-69
     if flip:
         x = np.flip(x, axis=3).copy()                                    # :119-121

@@ -477,3 +477,35 @@ def test_second_use_of_a_gradient_slot_flushes_deferred_work(monkeypatch):
     slots = ops.GradSlots(flat, grad, [0, 10], [10, 10])
     assert slots.take(flat[:10]) is not None and calls == []
     assert slots.take(flat[:10]) is None and calls == ["sums", "reduces"]
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from opental_amd.thumos14.test import gather_results
+        names = [f"v{i}" for i in range(7)]
+        mine = {n: [{"label": n, "score": float(rank)}] for n in names[rank::world]}
+        q.put((rank, gather_results(mine, names, rank, world, device="cpu")))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_inference_results_are_gathered_on_rank_0_in_list_order():
+    """SURVEY 8e inference: ranks take every world-th video; rank 0 ends up with ONE dict in the video list's order."""
+    import queue
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res[1] is None
+    assert list(res[0].keys()) == [f"v{i}" for i in range(7)]
+    assert [res[0][f"v{i}"][0]["score"] for i in range(7)] == [0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0]
