@@ -1736,16 +1736,26 @@ struct DirectArgs {
 // 36 sixteen-byte LDS reads per 27 MFMAs, and the eight waves' reads (2300 LDS cycles per K step) outlast their MFMAs (1730).
 // WN = 2 (512 positions per workgroup, still 8 waves) shares each weight fragment between two position tiles: 45 reads
 // per 54 MFMAs -- the kernel becomes MFMA-bound.
-template <int BM, int MODE, int BNP, int WN>
-__global__ __launch_bounds__(BNP * 2 / WN) void conv3_direct_kernel(const DirectArgs d) {
+// PX = byte pitch of a position's 16 channels in LDS.  48: padded, conflict-free as it is.  32: dense, with the two 16-byte
+// halves of a position swapped where bit 3 of the position index is set -- slot(p, h) = 2 (p mod 8) + (h ^ ((p >> 3) & 1)) is a
+// bijection of (p mod 16, h) onto the sixteen 16-byte slots of a bank row, so the sixteen lanes of every ds_read_b128 group
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ... : sixteen distinct positions mod 16 whatever the tap shift) never collide.
+// The dense pitch brings a 96 x 256 tile of four waves under 80 KB: TWO workgroups per CU that are not barrier-coupled, so
+// one's staging / store / epilogue phases run under the other's MFMAs (the 8-wave 512-position tile leaves the matrix
+// pipes idle in those phases: ~12 us of epilogue per 50 us tile on Conv3d_2c).
+template <int BM, int MODE, int BNP, int WN, int PX = 48, int MINW = 1>
+__global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const DirectArgs d) {
     constexpr int DNT = BNP * 2 / WN;                       // one wave per 32 * WN positions
-    constexpr int WM = BM / 32, PX = 48, PA = 304, SPAN_MAX = BNP + 52;
+    constexpr int WM = BM / 32, PA = 304, SPAN_MAX = BNP + 52;
+    static_assert(PX == 48 || PX == 32, "position pitch");
     constexpr int A_PIECES = (BM * 18 + DNT - 1) / DNT;       // 16-byte weight pieces per thread per K step
     constexpr int X_ITEMS = (SPAN_MAX / 4 + 1) * 8;         // (quad of positions, channel pair) items per K step, upper bound
     constexpr int X_ITERS = (X_ITEMS + DNT - 1) / DNT;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];     // [2][BM * PA] weights, then [2][SPAN_MAX * PX] positions
     unsigned char* const smA0 = dsm;
     unsigned char* const smX0 = dsm + 2 * BM * PA;
+    const unsigned char* const smZero = dsm + 2 * BM * PA + 2 * SPAN_MAX * PX;      // 16 zero bytes (written below)
+    if (threadIdx.x < 4) reinterpret_cast<unsigned*>(dsm + 2 * BM * PA + 2 * SPAN_MAX * PX)[threadIdx.x] = 0u;
     auto smA = [&](int buf) { return smA0 + buf * (BM * PA); };
     auto smX = [&](int buf) { return smX0 + buf * (SPAN_MAX * PX); };
     const ConvArgs& a = d.c;
@@ -1791,7 +1801,8 @@ __global__ __launch_bounds__(BNP * 2 / WN) void conv3_direct_kernel(const Direct
         const int cp = item & 7, q = item >> 3;            // channel pair fastest: consecutive lanes write consecutive LDS dwords
         const bool used = q < nq;
         xvo[i] = used ? tile_off + (unsigned)((2 * cp * scs + 4 * q) * 4) : 0xffffffffu;
-        xlds[i] = (4 * q) * PX + cp * 4;
+        xlds[i] = PX == 48 ? (4 * q) * PX + cp * 4                 // positions 4q .. 4q+3 share bit 3 = bit 1 of q
+                           : (4 * q) * PX + ((((cp >> 2) ^ (q >> 1)) & 1) << 4) + (cp & 3) * 4;
     }
     unsigned avo[A_PIECES];
 #pragma unroll
@@ -1865,32 +1876,66 @@ __global__ __launch_bounds__(BNP * 2 / WN) void conv3_direct_kernel(const Direct
     load_a(0);
     store(0, 0);
     __syncthreads();
-    const int xrow = (wave * WN * 32 + (lane & 31) + W + 1) * PX + (lane >> 5) * 16;    // this lane's first position in the span
+    const int xpos = wave * WN * 32 + (lane & 31) + W + 1;                               // this lane's first position in the span
+    const int xrow = xpos * PX + (lane >> 5) * 16;
+    // Fragment reads of tap group g + 1 are issued ONE BY ONE BETWEEN the MFMAs of group g (second register set): the reads'
+    // issue slots and their LDS latency then sit inside the matrix pipe's 32-cycle issue intervals instead of in front of a
+    // burst of MFMAs.  tools/ubench/ldsmfma.hip (this loop without global traffic, random operands): "reads, then MFMAs"
+    // 1515 -> interleaved 1858 TFLOP/s at 8 waves x (96 x 32) tiles, 1541 -> 1923 at 16 waves x (64 x 32); the MFMA-only
+    // ceiling of the same loops is 1564 - 1834 TFLOP/s on this chip with random data (clock under matrix load), not 2500.
+    // A tap outside the tensor reads sixteen zero bytes kept behind the tiles: the ADDRESS is selected before the read, so
+    // nothing touches a fragment between its read and its MFMAs.
+    auto frag_a = [&](int buf, int g9, int i) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(smA(buf) + (i * 32 + (lane & 31)) * PA + g9 * 32 + (lane >> 5) * 16);
+    };
+    auto frag_b = [&](int buf, int dt, int g9, int j) -> bf16x8 {
+        const int dh = g9 / 3, dw = g9 - dh * 3;
+        const unsigned char* src;
+        if (PX == 48) {
+            src = smX(buf) + xrow + (j * 32 + (dh - 1) * W + (dw - 1)) * PX;
+        } else {
+            const int p = xpos + j * 32 + (dh - 1) * W + (dw - 1);
+            src = smX(buf) + p * PX + ((((lane >> 5) ^ (p >> 3)) & 1) << 4);
+        }
+        const bool ok = ((tmask[j] >> dt) & 1u) && ((hwmask[j] >> g9) & 1u);
+        return *reinterpret_cast<const bf16x8*>(ok ? src : smZero);
+    };
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         const int dt = s % 3;
         const int sn = s + 1 < nsteps ? s + 1 : s;          // the prefetch past the end re-reads the last step
+        bf16x8 avA[WM], bvA[WN], avB[WM], bvB[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) avA[i] = frag_a(buf, 0, i);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bvA[j] = frag_b(buf, dt, 0, j);
 #pragma unroll
         for (int g9 = 0; g9 < 9; ++g9) {
             if (g9 == 0) load_x(sn);
             if (g9 == 1) load_a(sn);
-            const int dh = g9 / 3, dw = g9 - dh * 3;
-            bf16x8 av[WM], bv[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-                av[i] = *reinterpret_cast<const bf16x8*>(smA(buf) + (i * 32 + (lane & 31)) * PA + g9 * 32 + (lane >> 5) * 16);
-            const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                bv[j] = *reinterpret_cast<const bf16x8*>(smX(buf) + xrow + (j * 32 + (dh - 1) * W + (dw - 1)) * PX);
-                const bool ok = ((tmask[j] >> dt) & 1u) && ((hwmask[j] >> g9) & 1u);
-                bv[j] = ok ? bv[j] : zero;
-            }
+            bf16x8 (&av)[WM] = (g9 & 1) ? avB : avA;
+            bf16x8 (&bv)[WN] = (g9 & 1) ? bvB : bvA;
+            bf16x8 (&avn)[WM] = (g9 & 1) ? avA : avB;
+            bf16x8 (&bvn)[WN] = (g9 & 1) ? bvA : bvB;
+            int n = 0;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j)
+                for (int j = 0; j < WN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    if (g9 < 8) {
+                        if (n < WM) avn[n] = frag_a(buf, g9 + 1, n);
+                        else if (n < WM + WN) bvn[n - WM] = frag_b(buf, dt, g9 + 1, n - WM);
+                    }
+                    ++n;
+                }
+            if (WM * WN < WM + WN && g9 < 8) {              // one position tile per wave (WN = 1): WM MFMAs, WM + 1 fragments
+#pragma unroll
+                for (int r = WM * WN; r < WM + WN; ++r) {
+                    if (r < WM) avn[r] = frag_a(buf, g9 + 1, r);
+                    else bvn[r - WM] = frag_b(buf, dt, g9 + 1, r - WM);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         store(buf ^ 1, sn);
@@ -2529,8 +2574,36 @@ static inline size_t direct_wp_bytes(int M, int C) {
     return align256((size_t)((M + BM - 1) / BM * BM) * C * 27 * 2 + 1024);
 }
 
-template <int BM, int BNP>
-constexpr int direct_lds_bytes() { return 2 * BM * 304 + 2 * (BNP + 52) * 48; }
+template <int BM, int BNP, int PX = 48>
+constexpr int direct_lds_bytes() { return 2 * BM * 304 + 2 * (BNP + 52) * PX + 16; }
+// four waves x two position tiles, dense LDS pitch: 78 KB (BM = 96) / 59 KB (BM = 64) -> two workgroups per CU
+template <int BM, int MODE>
+static int launch_direct256x2(const DirectArgs& d, dim3 grid, hipStream_t st) {
+    constexpr int lds = direct_lds_bytes<BM, 256, 32>();
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_direct_kernel<BM, MODE, 256, 2, 32, 2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((conv3_direct_kernel<BM, MODE, 256, 2, 32, 2>), grid, dim3(256), lds, st, d);
+    return otal_launch_status();
+}
+// eight waves x one position tile, dense pitch, <= 128 registers: two 8-wave workgroups (16 waves) per CU
+template <int BM, int MODE>
+static int launch_direct256d(const DirectArgs& d, dim3 grid, hipStream_t st) {
+    constexpr int lds = direct_lds_bytes<BM, 256, 32>();
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_direct_kernel<BM, MODE, 256, 1, 32, 4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((conv3_direct_kernel<BM, MODE, 256, 1, 32, 4>), grid, dim3(512), lds, st, d);
+    return otal_launch_status();
+}
 template <int BM, int MODE>
 static int launch_direct512(const DirectArgs& d, dim3 grid, hipStream_t st) {
     constexpr int lds = direct_lds_bytes<BM, 512>();
@@ -2582,6 +2655,11 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         return launch_direct512<64, MODE>(d, grid, st);
     }
     const dim3 grid(a.N / 256, tm, 1);
+    if (OTAL_OPT("OTAL_CONV_DIRECT_256X2", 0) == 1) {
+        if (BM == 96) return launch_direct256x2<96, MODE>(d, grid, st);
+        return launch_direct256x2<64, MODE>(d, grid, st);
+    }
+    if (OTAL_OPT("OTAL_CONV_DIRECT_256X2", 0) == 2 && BM == 96) return launch_direct256d<96, MODE>(d, grid, st);
     if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<96, 256>()), st, d);
     else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<64, 256>()), st, d);
     return otal_launch_status();
