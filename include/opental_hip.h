@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 19
+#define OTAL_ABI_VERSION 20
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -131,6 +131,21 @@ int otal_conv_wgrad(const int* geom, const int64_t* strides, const float* x, con
                     float* dw, int accumulate, int precision, const void* prologue, void* ws, size_t ws_bytes,
                     void* stream);
 
+/* PAIR launches (ABI 20): TWO problems of the same geometry, strides and options in ONE launch -- arrays of two pointers
+ * each, results as of two separate calls (bit-identical: a workgroup never sees the other problem).  For the 1-D
+ * temporal layers the model applies as siblings -- the loc / conf towers and the two ProposalBranches
+ * (AFSD/thumos14/BDNet.py:64-113,:333-412 run them one after the other) -- whose launches sit at about twice the launch
+ * floor: two of them in one grid cost what one does.  Only the geometries of the one-launch 1-D kernels (stride 1,
+ * k = 1 / 3, H = W = 1, channels % 128 == 0, precision bit 0 set); anything else returns OTAL_E_UNSUPPORTED and the
+ * caller issues the two launches itself.  otal_conv_dgrad_pair takes forward-layout weights (precision bit 1 implied). */
+int otal_conv_fwd_pair(const int* geom, const int64_t* strides, const float* const* x, const float* const* w,
+                       const float* const* scale, const float* const* shift, float* const* y, int relu, int precision,
+                       const void* const* prologue, void* ws, size_t ws_bytes, void* stream);
+int otal_conv_dgrad_pair(const int* geom, const int64_t* strides, const float* const* dy, const float* const* w,
+                         float* const* dx, int precision, const void* const* prologue, void* ws, size_t ws_bytes, void* stream);
+int otal_conv_wgrad_pair(const int* geom, const int64_t* strides, const float* const* x, const float* const* dy,
+                         float* const* dw, int precision, void* ws, size_t ws_bytes, void* stream);
+
 /* Persistent prologues.  A bf16 launch first builds its tables and (fwd / dgrad) re-packs the weights to bf16; by default
  * that happens inside every launch, in the workspace.  A caller that runs the same layers repeatedly (a training loop) can
  * own one region per (layer, mode) instead and pass it as `prologue` (NULL = build in the workspace):
@@ -180,6 +195,13 @@ int otal_gn_relu_fwd(const float* x, const float* gamma, const float* beta, floa
 int otal_gn_relu_bwd(const float* dy, int64_t dy_batch_stride, const float* x, const float* gamma, const float* beta,
                      const float* stats, float* dx, float* partial, int B, int C, int T, int G,
                      int relu, int nlev, const int* lev, void* stream);
+/* The same for TWO maps of one shape in one launch (ABI 20; see the convolution pair launches). */
+int otal_gn_relu_fwd_pair(const float* const* x, const float* const* gamma, const float* const* beta, float* const* y,
+                          float* const* stats, int B, int C, int T, int G, float eps, int relu, int nlev, const int* lev,
+                          void* stream);
+int otal_gn_relu_bwd_pair(const float* const* dy, const int64_t* dy_batch_stride, const float* const* x,
+                          const float* const* gamma, const float* const* beta, const float* const* stats, float* const* dx,
+                          float* const* partial, int B, int C, int T, int G, int relu, int nlev, const int* lev, void* stream);
 /* Batch sums of MANY layers' partials in one launch: for item i, dst{0,1,2}[i][c] = sum_b partial[i][(b*3 + r)*C + c]
  * (r = 0,1,2; ascending b; a NULL dst row is skipped).  Replaces the per-layer torch sum over the batch that follows
  * every GroupNorm backward (21 per step); the destinations may be slices of a flat gradient arena. */

@@ -78,6 +78,60 @@ class ConvGNReLUFunction(Function):
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
+class ConvGNReLUPairFunction(Function):
+    """Two ConvGNReLU blocks of ONE geometry -- sibling layers the model applies side by side: the loc / conf towers, the
+    two ProposalBranches -- as one autograd node whose five kernels each carry both problems (pair launches,
+    include/opental_hip.h): (y0, y1) = (block0(x0), block1(x1)).  Every value is what ConvGNReLUFunction gives for the block
+    on its own (a workgroup never sees the other problem); where the library has no pair kernel for the geometry the two
+    problems are launched one after the other."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, w0, w1, b0, b1, g0, g1, be0, be1, k, s, levels, groups, eps):
+        k, s = _tuple3(k), _tuple3(s)
+        cs = ops.conv_forward_pair((x0, x1), (w0, w1), k, s, (b0, b1), levels)
+        if cs is None:
+            cs = [ops.conv_forward(x, w, k, s, shift=b, levels=levels) for x, w, b in ((x0, w0, b0), (x1, w1, b1))]
+        ys = ops.gn_relu_forward_pair(cs, (g0, g1), (be0, be1), groups, eps, True, levels)
+        if ys is None:
+            ys = [ops.gn_relu_forward(c, g, be, groups, eps, True, levels) for c, g, be in ((cs[0], g0, be0), (cs[1], g1, be1))]
+        ctx.cfg = (k, s, levels, groups)
+        ctx.save_for_backward(x0, x1, w0, w1, cs[0], cs[1], g0, g1, be0, be1, ys[0][1], ys[1][1], b0, b1)
+        return ys[0][0], ys[1][0]
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        x0, x1, w0, w1, c0, c1, g0, g1, be0, be1, st0, st1, b0, b1 = ctx.saved_tensors
+        k, s, lev, groups = ctx.cfg
+        r = ops.gn_relu_backward_pair((dy0, dy1), (c0, c1), (g0, g1), (be0, be1), (st0, st1), groups, True, lev, (b0, b1))
+        if r is None:
+            r = [ops.gn_relu_backward(dy, c, g, be, st, groups, True, lev, bias=b)
+                 for dy, c, g, be, st, b in ((dy0, c0, g0, be0, st0, b0), (dy1, c1, g1, be1, st1, b1))]
+        (dc0, dg0, dbe0, db0), (dc1, dg1, dbe1, db1) = r
+        dxs = (None, None)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dxs = ops.conv_dgrad_pair((dc0, dc1), (w0, w1), x0.shape, k, s, lev)
+            if dxs is None:
+                dxs = [ops.conv_dgrad(dc, w, x0.shape, k, s, levels=lev) for dc, w in ((dc0, w0), (dc1, w1))]
+        slots = (ops.grad_slot(w0), ops.grad_slot(w1))
+        dws = ops.conv_wgrad_pair((x0, x1), (dc0, dc1), w0.shape, k, s, lev, slots)
+        if dws is None:
+            dws = [ops.conv_wgrad(x, dc, w0.shape, k, s, levels=lev, out=o) for x, dc, o in ((x0, dc0, slots[0]), (x1, dc1, slots[1]))]
+        return (dxs[0], dxs[1], dws[0], dws[1], db0, db1, dg0, dg1, dbe0, dbe1, None, None, None, None, None)
+
+
+def conv_gn_relu_pair(block0, block1, x0, x1, levels=None):
+    """(block0(x0, levels), block1(x1, levels)) for two ConvGNReLU blocks around Unit1D layers of the same shape."""
+    u0, n0, u1, n1 = block0[0], block0[1], block1[0], block1[1]
+    same = (isinstance(u0, Unit1D) and isinstance(u1, Unit1D) and u0.conv1d.weight.shape == u1.conv1d.weight.shape
+            and u0._kernel_shape == u1._kernel_shape and u0._stride == u1._stride == 1 and n0.num_groups == n1.num_groups
+            and n0.eps == n1.eps and x0.shape == x1.shape and (u0.conv1d.bias is None) == (u1.conv1d.bias is None))
+    if not same or not ops.PAIR_LAUNCHES or not x0.is_cuda:
+        return block0(x0, levels), block1(x1, levels)
+    return ConvGNReLUPairFunction.apply(x0, x1, u0.conv1d.weight, u1.conv1d.weight, u0.conv1d.bias, u1.conv1d.bias,
+                                        n0.weight, n1.weight, n0.bias, n1.bias, u0._kernel_shape, u0._stride, levels,
+                                        n0.num_groups, n0.eps)
+
+
 class Unit1D(nn.Module):
     def __init__(self, in_channels, output_channels, kernel_shape=1, stride=1, padding='same',
                  activation_fn=F.relu, use_bias=True):

@@ -39,13 +39,13 @@ def _prof_begin():
     return ev
 
 
-def _prof_end(ev, mode, g):
+def _prof_end(ev, mode, g, problems=1):
     if ev is None:
         return
     end = torch.cuda.Event(enable_timing=True)
     end.record()
     B, Cin, Cout = g[0], g[1], g[2]
-    flops = 2.0 * B * Cout * g[6] * g[7] * g[8] * Cin * g[9] * g[10] * g[11]
+    flops = 2.0 * B * Cout * g[6] * g[7] * g[8] * Cin * g[9] * g[10] * g[11] * problems
     CONV_PROFILE.append((mode, flops, ev, end))
 
 
@@ -525,6 +525,117 @@ def conv_wgrad(x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None,
     return out
 
 
+# ----------------------------------------------------------------------------- pair launches (two sibling 1-D layers, one grid)
+PAIR_LAUNCHES = os.environ.get("OTAL_PAIR_LAUNCHES", "1") != "0"
+_VP2 = ctypes.c_void_p * 2
+
+
+def _pp(a, b):
+    return _VP2(a.data_ptr() if a is not None else None, b.data_ptr() if b is not None else None)
+
+
+def _same_layout(a, b):
+    return a.shape == b.shape and a.stride() == b.stride() and a.dtype == b.dtype and a.device == b.device
+
+
+def conv_forward_pair(xs, ws, k, s, shifts=None, levels=None):
+    """(y0, y1) = conv_SAME(x_i, w_i) + shift_i for two problems of one geometry in ONE launch (otal_conv_fwd_pair), or None
+    when the library has no pair kernel for it (the caller then runs them one after the other)."""
+    k, s = _k3(k), _k3(s)
+    if levels is not None:
+        levels = tuple(levels)
+    if not PAIR_LAUNCHES or not (int(CONV_PRECISION) & 1) or not _same_layout(xs[0], xs[1]) or ws[0].shape != ws[1].shape:
+        return None
+    if xs[0].dtype != torch.float32 or not (ws[0].is_contiguous() and ws[1].is_contiguous()):
+        return None
+    Cout = ws[0].shape[0]
+    outn = _out_positions(xs[0], Cout, k, s, levels, False)
+    ys = [torch.empty((x.shape[0], Cout) + outn[:1], dtype=x.dtype, device=x.device) for x in xs]
+    g, ga, sa, pkey, _ = _plan(0, xs[0], ys[0], Cout, k, s, levels, False, "x", "y")
+    prec = int(CONV_PRECISION)
+    pres = [_prologue(0, ga, sa, pkey, w, prec) for w in ws]
+    if (pres[0] is None) != (pres[1] is None):
+        return None
+    wsp, wsn = _ws_args(xs[0].device)
+    ev = _prof_begin()
+    sh = None if shifts is None or shifts[0] is None else _pp(shifts[0], shifts[1])
+    rc = L.lib().otal_conv_fwd_pair(ga, sa, _pp(*xs), _pp(*ws), None, sh, _pp(*ys), 0, prec,
+                                    None if pres[0] is None else _VP2(pres[0].value, pres[1].value), wsp, wsn, L.stream())
+    if rc == L.E_UNSUPPORTED:
+        return None
+    L.check(rc, "otal_conv_fwd_pair")
+    _prof_end(ev, "fwd", g, 2)
+    return ys
+
+
+def conv_dgrad_pair(dys, ws, x_shape, k, s, levels=None):
+    k, s = _k3(k), _k3(s)
+    if levels is not None:
+        levels = tuple(levels)
+    if not PAIR_LAUNCHES or not (int(CONV_PRECISION) & 1) or not _same_layout(dys[0], dys[1]) or ws[0].shape != ws[1].shape:
+        return None
+    if dys[0].dtype != torch.float32 or not (ws[0].is_contiguous() and ws[1].is_contiguous()):
+        return None
+    Cout = ws[0].shape[0]
+    outs = [torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device) for dy in dys]
+    g, ga, sa, pkey, _ = _plan(1, outs[0], dys[0], Cout, k, s, levels, False, "dx", "dy")
+    prec = int(CONV_PRECISION) | 2
+    pres = [_prologue(1, ga, sa, pkey, w, prec) for w in ws]
+    if (pres[0] is None) != (pres[1] is None):
+        return None
+    wsp, wsn = _ws_args(dys[0].device)
+    ev = _prof_begin()
+    rc = L.lib().otal_conv_dgrad_pair(ga, sa, _pp(*dys), _pp(*ws), _pp(*outs), prec,
+                                      None if pres[0] is None else _VP2(pres[0].value, pres[1].value), wsp, wsn, L.stream())
+    if rc == L.E_UNSUPPORTED:
+        return None
+    L.check(rc, "otal_conv_dgrad_pair")
+    _prof_end(ev, "dgrad", g, 2)
+    return outs
+
+
+def conv_wgrad_pair(xs, dys, w_shape, k, s, levels=None, outs=(None, None)):
+    k, s = _k3(k), _k3(s)
+    if levels is not None:
+        levels = tuple(levels)
+    if not PAIR_LAUNCHES or not (int(CONV_PRECISION) & 1) or not _same_layout(xs[0], xs[1]) or not _same_layout(dys[0], dys[1]):
+        return None
+    if xs[0].dtype != torch.float32 or dys[0].dtype != torch.float32:
+        return None
+    Cout = w_shape[0]
+    g, ga, sa, pkey, _ = _plan(2, xs[0], dys[0], Cout, k, s, levels, False, "x", "dy")
+    outs = [o if o is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=xs[0].device) for o in outs]
+    if not (outs[0].is_contiguous() and outs[1].is_contiguous()):
+        return None
+    wsp, wsn = _ws_args(xs[0].device)
+    ev = _prof_begin()
+    rc = L.lib().otal_conv_wgrad_pair(ga, sa, _pp(*xs), _pp(*dys), _pp(*outs), int(CONV_PRECISION), wsp, wsn, L.stream())
+    if rc == L.E_UNSUPPORTED:
+        return None
+    L.check(rc, "otal_conv_wgrad_pair")
+    if _DEFER:
+        _after_wgrad(xs[0].device)
+    _prof_end(ev, "wgrad", g, 2)
+    return outs
+
+
+def gn_relu_forward_pair(xs, gammas, betas, groups=32, eps=1e-5, relu=True, levels=None):
+    """[(y0, stats0), (y1, stats1)] in one launch, or None."""
+    if not PAIR_LAUNCHES or not _same_layout(xs[0], xs[1]) or not xs[0].is_contiguous():
+        return None
+    L.require_device(*xs, *gammas, *betas)
+    B, C, T = xs[0].shape
+    nlev, lev = _lev_arg(levels)
+    ys = [torch.empty_like(x) for x in xs]
+    stats = [torch.empty((B, groups, nlev, 2), dtype=torch.float32, device=x.device) for x in xs]
+    rc = L.lib().otal_gn_relu_fwd_pair(_pp(*xs), _pp(*gammas), _pp(*betas), _pp(*ys), _pp(*stats), B, C, T, groups,
+                                       ctypes.c_float(eps), int(relu), nlev, lev, L.stream())
+    if rc == L.E_UNSUPPORTED:
+        return None
+    L.check(rc, "otal_gn_relu_fwd_pair")
+    return list(zip(ys, stats))
+
+
 # ----------------------------------------------------------------------------- GroupNorm + ReLU
 def _lev_arg(levels):
     if levels is None or len(levels) <= 2:
@@ -563,6 +674,12 @@ def gn_relu_backward(dy, x, gamma, beta, stats, groups=32, relu=True, levels=Non
     L.check(L.lib().otal_gn_relu_bwd(L.ptr(dy), ctypes.c_int64(dy.stride(0)), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(stats),
                                      L.ptr(dx), L.ptr(partial), B, C, T, groups, int(relu), nlev, lev, L.stream()),
             "otal_gn_relu_bwd")
+    return (dx,) + _gn_sums(partial, gamma, beta, bias, C, B)
+
+
+def _gn_sums(partial, gamma, beta, bias, C, B):
+    """(d_gamma, d_beta, d_conv_bias) from the backward kernel's per-sample partials: deferred into the gradient arena when
+    a trainer is running (see gn_relu_backward), else summed now."""
     if PENDING_SUMS is not None and bias is not None and GRAD_SLOTS is not None:
         slots = [GRAD_SLOTS.take(t) for t in (gamma, beta, bias)]
         if all(sl is not None for sl in slots):
@@ -570,12 +687,37 @@ def gn_relu_backward(dy, x, gamma, beta, stats, groups=32, relu=True, levels=Non
             # adopting it as .grad (AccumulateGrad steals a gradient only while it holds the sole reference), and the
             # clone -- taken before the deferred sum has run -- would later be copied over the sum
             PENDING_SUMS.append((partial, tuple(sl.data_ptr() for sl in slots), C, B))
-            return dx, slots[0], slots[1], slots[2]
+            return slots[0], slots[1], slots[2]
         for t, sl in zip((gamma, beta, bias), slots):       # hand back what was taken: the plain path returns fresh tensors
             if sl is not None:
                 GRAD_SLOTS.release(t)
     red = partial.sum(0)            # (3,C): d_gamma, d_beta, d_conv_bias -- three contiguous rows, no copies
-    return dx, red[0], red[1], red[2]
+    return red[0], red[1], red[2]
+
+
+def gn_relu_backward_pair(dys, xs, gammas, betas, stats, groups=32, relu=True, levels=None, biases=(None, None)):
+    """Two gn_relu_backward calls of one shape in ONE launch: [(dx, d_gamma, d_beta, d_bias)] * 2, or None."""
+    if not PAIR_LAUNCHES or not _same_layout(xs[0], xs[1]):
+        return None
+    B, C, T = xs[0].shape
+    dys = list(dys)
+    for i in range(2):
+        dy = dys[i]
+        if dy.dim() != 3 or tuple(dy.shape) != (B, C, T) or dy.stride(2) != 1 or dy.stride(1) != T or dy.stride(0) < C * T:
+            dys[i] = dy.contiguous()
+        if not dys[i].is_cuda:
+            raise RuntimeError("opental_amd ops run on the GPU only")
+    L.require_device(*xs, *gammas, *betas, *stats)
+    nlev, lev = _lev_arg(levels)
+    dxs = [torch.empty_like(x) for x in xs]
+    partials = [torch.empty((B, 3, C), dtype=torch.float32, device=x.device) for x in xs]
+    rc = L.lib().otal_gn_relu_bwd_pair(_pp(*dys), (ctypes.c_int64 * 2)(dys[0].stride(0), dys[1].stride(0)), _pp(*xs), _pp(*gammas),
+                                       _pp(*betas), _pp(*stats), _pp(*dxs), _pp(*partials), B, C, T, groups, int(relu), nlev, lev,
+                                       L.stream())
+    if rc == L.E_UNSUPPORTED:
+        return None
+    L.check(rc, "otal_gn_relu_bwd_pair")
+    return [(dxs[i],) + _gn_sums(partials[i], gammas[i], betas[i], biases[i], C, B) for i in range(2)]
 
 
 def flush_pending_sums():

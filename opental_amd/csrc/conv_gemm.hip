@@ -67,6 +67,19 @@ struct ConvArgs {
     unsigned out_bytes, slab_bytes;
     const void* pre;       // persistent prologue region filled earlier (otal_conv_prologue[_batch]); null: build it in the workspace
     int half;              // the large activation operand is STORED as bf16 (fwd: y, dgrad / wgrad: dy); selected kernels only
+    // PAIR launches (otal_conv_*_pair): a second problem of the SAME geometry, strides and options rides in the launch of
+    // the first -- the 1-D pyramid's sibling layers (loc / conf towers, the two ProposalBranches) are latency-bound at
+    // twice the launch floor, so two of them in one grid cost what one does.  pair == 0: the fields below are unused.
+    int pair;
+    const float* x2;       // as x / dy / out / scale / shift / wp / slab / pre, second problem
+    const float* dy2;
+    float* out2;
+    const float* scale2;
+    const float* shift2;
+    const unsigned short* wp2;
+    float* slab2;
+    const void* pre2;
+    const float* w2;
 };
 
 // ---- operand element fetch -------------------------------------------------------------------
@@ -2185,7 +2198,11 @@ __global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const ConvArgs a, int
     __shared__ __attribute__((aligned(16))) unsigned mstart[W1_TC / 2], mend[W1_TC / 2];   // bf16-pair masks: 0 where the tap is cut
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64, split = blockIdx.z;
+    const int tiles_co = (g.Cout + 63) / 64;
+    const bool second = (int)blockIdx.x >= tiles_co;        // pair launch: grid.x = 2 x the output-channel tiles
+    const int co0 = ((int)blockIdx.x - (second ? tiles_co : 0)) * 64, ci0 = blockIdx.y * 64, split = blockIdx.z;
+    const float* const pdy = second ? a.dy2 : a.dy;
+    const float* const px = second ? a.x2 : a.x;
     const int T = g.Ti;
     const int mi = wave & 1, ni = wave >> 1, h8 = (lane >> 5) * 8;
     const unsigned char* arow = sdy + (mi * 32 + (lane & 31)) * W1_PITCH + h8 * 2;
@@ -2198,8 +2215,8 @@ __global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const ConvArgs a, int
     // a workgroup walks `upw` (sample, chunk) units: fewer, fatter split-K slabs (one epilogue and one slab per upw units)
     for (int unit = split * upw; unit < min(units, (split + 1) * upw); ++unit) {
     const int b = unit / nchunks, t0 = (unit - b * nchunks) * W1_TC;
-    const float* dyb = a.dy + (int64_t)b * g.y_bs + t0;
-    const float* xb = a.x + (int64_t)b * g.x_bs + t0;
+    const float* dyb = pdy + (int64_t)b * g.y_bs + t0;
+    const float* xb = px + (int64_t)b * g.x_bs + t0;
     __syncthreads();            // the previous unit's operand reads are done
     // ---- stage dy (64 rows x 128 positions) and x (+ 8 elements of left pad, of which the last is the halo x[t0 - 1])
     for (int idx = tid; idx < 64 * 64; idx += 256) {
@@ -2218,7 +2235,7 @@ __global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const ConvArgs a, int
         const int r = tid & 63, right = tid >> 6;
         const int u = right ? t0 + W1_TC : t0 - 1;
         const bool ok = ci0 + r < g.Cin && u >= 0 && u < T;
-        const float v = ok ? a.x[(int64_t)b * g.x_bs + (int64_t)(ci0 + r) * g.x_cs + u] : 0.f;
+        const float v = ok ? px[(int64_t)b * g.x_bs + (int64_t)(ci0 + r) * g.x_cs + u] : 0.f;
         *reinterpret_cast<unsigned*>(sx + r * W1_PITCH + (right ? 136 : 6) * 2) = right ? cvt_pk_bf16(v, 0.f) : cvt_pk_bf16(0.f, v);
     }
     if (tid < W1_TC / 2) {  // a tap shifted by -1 is cut where t starts a level, one shifted by +1 where t ends one
@@ -2258,7 +2275,7 @@ __global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const ConvArgs a, int
     }
     // slab[split][co][ci * KT + dt]
     const int ci = ci0 + ni * 32 + (lane & 31);
-    float* slab = a.slab + (int64_t)split * a.M * a.N;
+    float* slab = (second ? a.slab2 : a.slab) + (int64_t)split * a.M * a.N;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -2286,14 +2303,21 @@ int launch_wgrad1d(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int upw = upw_env > 0 ? upw_env : 1;      // units per workgroup: measured 1 -> 478.4, 2 -> 475.8, 4 -> 465.7 clips/s
     (void)tiles;
     const int splits = (units + upw - 1) / upw;
-    const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
-    if (!ws || ws_bytes < need) return OTAL_E_UNSUPPORTED;
+    const size_t need = ((size_t)splits * a.M * a.N * sizeof(float) + 255) & ~(size_t)255;
+    if (!ws || ws_bytes < need * (a.pair ? 2 : 1)) return OTAL_E_UNSUPPORTED;
     a.splits = splits; a.k_per_split = 0; a.slab = reinterpret_cast<float*>(ws);
-    const dim3 grid((a.g.Cout + 63) / 64, a.g.Cin / 64, splits);
+    if (a.pair) a.slab2 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + need);
+    const dim3 grid(((a.g.Cout + 63) / 64) * (a.pair ? 2 : 1), a.g.Cin / 64, splits);
     if (a.g.kt == 1) hipLaunchKernelGGL(conv_wgrad1d_kernel<1>, grid, dim3(256), 0, st, a, nchunks, units, upw);
     else hipLaunchKernelGGL(conv_wgrad1d_kernel<3>, grid, dim3(256), 0, st, a, nchunks, units, upw);
     if (int e = otal_launch_status()) return e;
-    return launch_splitk_reduce<MODE_WGRAD>(a, st);
+    if (int e = launch_splitk_reduce<MODE_WGRAD>(a, st)) return e;
+    if (a.pair) {               // the second problem's slabs: its own reduction (recorded with the first's when deferred)
+        ConvArgs b = a;
+        b.slab = a.slab2; b.out = a.out2;
+        return launch_splitk_reduce<MODE_WGRAD>(b, st);
+    }
+    return 0;
 }
 
 // ---- chunked bf16 path: eligibility, workspace layout [chunk table][packed bf16 weights][split-K slabs]
@@ -2884,6 +2908,63 @@ extern "C" int otal_conv_wgrad(const int* geom, const int64_t* strides, const fl
     if (a.half && !a.prec) return OTAL_E_UNSUPPORTED;
     a.pre = prologue;
     return launch_mode<MODE_WGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---- pair launches: two problems of one geometry in one grid (the 1-D temporal layers only: anything else is
+// OTAL_E_UNSUPPORTED and the caller launches the two problems one after the other)
+namespace {
+int pair_geom(ConvArgs& a, const int* geom, const int64_t* strides) {
+    if (int e = fill_geom(a.g, geom)) return e;
+    a.g.x_bs = strides[0]; a.g.x_cs = strides[1]; a.g.y_bs = strides[2]; a.g.y_cs = strides[3];
+    a.pair = 1;
+    return OTAL_OPT("OTAL_CONV_NOPAIR", 0) ? OTAL_E_UNSUPPORTED : 0;
+}
+}  // namespace
+
+extern "C" int otal_conv_fwd_pair(const int* geom, const int64_t* strides, const float* const* x, const float* const* w,
+                                  const float* const* scale, const float* const* shift, float* const* y, int relu, int precision,
+                                  const void* const* prologue, void* ws, size_t ws_bytes, void* stream) {
+    if (!geom || !strides || !x || !w || !y || !x[0] || !x[1] || !w[0] || !w[1] || !y[0] || !y[1]) return OTAL_E_NULL;
+    ConvArgs a = {};
+    if (int e = pair_geom(a, geom, strides)) return e;
+    a.x = x[0]; a.x2 = x[1]; a.w = w[0]; a.w2 = w[1]; a.out = y[0]; a.out2 = y[1];
+    a.scale = scale ? scale[0] : nullptr; a.scale2 = scale ? scale[1] : nullptr;
+    a.shift = shift ? shift[0] : nullptr; a.shift2 = shift ? shift[1] : nullptr;
+    if ((a.scale == nullptr) != (a.scale2 == nullptr) || (a.shift == nullptr) != (a.shift2 == nullptr)) return OTAL_E_NULL;
+    a.M = a.g.Cout; a.N = a.g.B * conv_out_positions(a.g); a.K = a.g.Cin * conv_kvol(a.g);
+    a.flags = relu ? EPI_RELU : 0;
+    a.prec = (precision & 1) ? 1 : 0;
+    a.pre = prologue ? prologue[0] : nullptr; a.pre2 = prologue ? prologue[1] : nullptr;
+    if (!conv1d_tile_eligible(a.g, MODE_FWD, a.prec, a.x, a) || ((uintptr_t)a.x2 & 3)) return OTAL_E_UNSUPPORTED;
+    return launch_conv1d_tile<MODE_FWD>(a, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int otal_conv_dgrad_pair(const int* geom, const int64_t* strides, const float* const* dy, const float* const* w,
+                                    float* const* dx, int precision, const void* const* prologue, void* ws, size_t ws_bytes,
+                                    void* stream) {
+    if (!geom || !strides || !dy || !w || !dx || !dy[0] || !dy[1] || !w[0] || !w[1] || !dx[0] || !dx[1]) return OTAL_E_NULL;
+    ConvArgs a = {};
+    if (int e = pair_geom(a, geom, strides)) return e;
+    a.dy = dy[0]; a.dy2 = dy[1]; a.w = w[0]; a.w2 = w[1]; a.out = dx[0]; a.out2 = dx[1];
+    a.M = a.g.Cin; a.N = a.g.B * conv_in_positions(a.g); a.K = a.g.Cout * conv_kvol(a.g);
+    a.prec = (precision & 1) ? 1 : 0;
+    a.w_natural = (precision & 2) ? 1 : 0;
+    a.pre = prologue ? prologue[0] : nullptr; a.pre2 = prologue ? prologue[1] : nullptr;
+    if (!a.w_natural) return OTAL_E_UNSUPPORTED;            // forward-layout weights only (the prologue re-orders them)
+    if (!conv1d_tile_eligible(a.g, MODE_DGRAD, a.prec, a.dy, a) || ((uintptr_t)a.dy2 & 3)) return OTAL_E_UNSUPPORTED;
+    return launch_conv1d_tile<MODE_DGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int otal_conv_wgrad_pair(const int* geom, const int64_t* strides, const float* const* x, const float* const* dy,
+                                    float* const* dw, int precision, void* ws, size_t ws_bytes, void* stream) {
+    if (!geom || !strides || !x || !dy || !dw || !x[0] || !x[1] || !dy[0] || !dy[1] || !dw[0] || !dw[1]) return OTAL_E_NULL;
+    ConvArgs a = {};
+    if (int e = pair_geom(a, geom, strides)) return e;
+    a.x = x[0]; a.x2 = x[1]; a.dy = dy[0]; a.dy2 = dy[1]; a.out = dw[0]; a.out2 = dw[1];
+    a.M = a.g.Cout; a.N = a.g.Cin * conv_kvol(a.g); a.K = a.g.B * conv_out_positions(a.g);
+    a.prec = (precision & 1) ? 1 : 0;
+    if (!wgrad1d_eligible(a.g, a.prec, a.x, a.dy) || !wgrad1d_eligible(a.g, a.prec, a.x2, a.dy2)) return OTAL_E_UNSUPPORTED;
+    return launch_wgrad1d(a, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // 1 when this geometry has a kernel for the bf16-STORED large operand (precision bit 2): fwd -> y, wgrad / dgrad -> dy.

@@ -48,10 +48,13 @@ __device__ __forceinline__ void for_level(int lane, int nlanes, int cpg, int len
 }
 
 // x,y: (B,C,T); stats out: (B,G,nlev,2) = {mean, rstd}
+// (pair launches, otal_gn_relu_*_pair: grid.y = 2 and `alt` carries the second problem's tensors -- same shapes and options)
+struct GnFwdAlt { const float* x; const float* gamma; const float* beta; float* y; float* stats; };
 __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y,
                                                           float* __restrict__ stats, int C, int T, int G,
-                                                          float eps, int relu, GnLevels L) {
+                                                          float eps, int relu, GnLevels L, GnFwdAlt alt) {
+    if (blockIdx.y) { x = alt.x; gamma = alt.gamma; beta = alt.beta; y = alt.y; stats = alt.stats; }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* buf = reinterpret_cast<float*>(smem);
     float* red = buf + (size_t)(C / G) * T;                      // 8 floats
@@ -114,11 +117,13 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
 
 // dx: (B,C,T); partial: (B,3,C) = {sum dyh*xhat, sum dyh, sum dx} (channel-contiguous rows: summing over b leaves
 // d_gamma, d_beta and the bias gradient as three contiguous vectors)
+struct GnBwdAlt { const float* dy; const float* x; const float* gamma; const float* beta; const float* stats; float* dx; float* partial; int64_t dy_bs; };
 __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ stats, float* __restrict__ dx,
                                                           float* __restrict__ partial, int C, int T, int G, int relu,
-                                                          GnLevels L, int64_t dy_bs) {
+                                                          GnLevels L, int64_t dy_bs, GnBwdAlt alt) {
+    if (blockIdx.y) { dy = alt.dy; x = alt.x; gamma = alt.gamma; beta = alt.beta; stats = alt.stats; dx = alt.dx; partial = alt.partial; dy_bs = alt.dy_bs; }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int cpg = C / G;
     float* xb = reinterpret_cast<float*>(smem);          // x, later xhat
@@ -225,7 +230,23 @@ extern "C" int otal_gn_relu_fwd(const float* x, const float* gamma, const float*
     static bool large_ok = false;
     if (int e = allow_large_lds(gn_relu_fwd_kernel, lds, large_ok)) return e;
     hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G), dim3(256), lds, (hipStream_t)stream,
-                       x, gamma, beta, y, stats, C, T, G, eps, relu, L);
+                       x, gamma, beta, y, stats, C, T, G, eps, relu, L, GnFwdAlt{});
+    return otal_launch_status();
+}
+
+extern "C" int otal_gn_relu_fwd_pair(const float* const* x, const float* const* gamma, const float* const* beta, float* const* y,
+                                     float* const* stats, int B, int C, int T, int G, float eps, int relu, int nlev,
+                                     const int* lev, void* stream) {
+    if (!x || !gamma || !beta || !y || !stats) return OTAL_E_NULL;
+    for (int i = 0; i < 2; ++i) if (!x[i] || !gamma[i] || !beta[i] || !y[i] || !stats[i]) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G) return OTAL_E_SHAPE;
+    GnLevels L;
+    if (int e = fill_levels(L, T, nlev, lev)) return e;
+    const size_t lds = (size_t)(C / G) * T * 4 + 64 + (size_t)(C / G) * 8;
+    if (lds > 64 * 1024) return OTAL_E_UNSUPPORTED;
+    const GnFwdAlt alt = {x[1], gamma[1], beta[1], y[1], stats[1]};
+    hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G, 2), dim3(256), lds, (hipStream_t)stream,
+                       x[0], gamma[0], beta[0], y[0], stats[0], C, T, G, eps, relu, L, alt);
     return otal_launch_status();
 }
 
@@ -243,7 +264,29 @@ extern "C" int otal_gn_relu_bwd(const float* dy, int64_t dy_batch_stride, const 
     static bool large_ok = false;
     if (int e = allow_large_lds(gn_relu_bwd_kernel, lds, large_ok)) return e;
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(256), lds, (hipStream_t)stream,
-                       dy, x, gamma, beta, stats, dx, partial, C, T, G, relu, L, dy_batch_stride);
+                       dy, x, gamma, beta, stats, dx, partial, C, T, G, relu, L, dy_batch_stride, GnBwdAlt{});
+    return otal_launch_status();
+}
+
+extern "C" int otal_gn_relu_bwd_pair(const float* const* dy, const int64_t* dy_batch_stride, const float* const* x,
+                                     const float* const* gamma, const float* const* beta, const float* const* stats,
+                                     float* const* dx, float* const* partial, int B, int C, int T, int G, int relu, int nlev,
+                                     const int* lev, void* stream) {
+    if (!dy || !dy_batch_stride || !x || !gamma || !beta || !stats || !dx || !partial) return OTAL_E_NULL;
+    int64_t bs[2];
+    for (int i = 0; i < 2; ++i) {
+        if (!dy[i] || !x[i] || !gamma[i] || !beta[i] || !stats[i] || !dx[i] || !partial[i]) return OTAL_E_NULL;
+        bs[i] = dy_batch_stride[i] ? dy_batch_stride[i] : (int64_t)C * T;
+        if (bs[i] < (int64_t)C * T) return OTAL_E_SHAPE;
+    }
+    if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G) return OTAL_E_SHAPE;
+    GnLevels L;
+    if (int e = fill_levels(L, T, nlev, lev)) return e;
+    const size_t lds = (size_t)(C / G) * T * 8 + 64 + (size_t)(C / G) * 8;
+    if (lds > 64 * 1024) return OTAL_E_UNSUPPORTED;
+    const GnBwdAlt alt = {dy[1], x[1], gamma[1], beta[1], stats[1], dx[1], partial[1], bs[1]};
+    hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G, 2), dim3(256), lds, (hipStream_t)stream,
+                       dy[0], x[0], gamma[0], beta[0], stats[0], dx[0], partial[0], C, T, G, relu, L, bs[0], alt);
     return otal_launch_status();
 }
 

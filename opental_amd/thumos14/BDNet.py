@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from ..common import ops
 from ..common.i3d_backbone import InceptionI3d
-from ..common.layers import ConvGNReLU, Unit1D, Unit3D
+from ..common.layers import ConvGNReLU, Unit1D, Unit3D, conv_gn_relu_pair
 from ..prop_pooling.boundary_pooling_op import (BoundaryMaxPooling, BoundaryMaxPoolingFunction,
                                                 BoundaryMaxPoolingLevelsFunction)
 
@@ -222,6 +222,21 @@ class CoarsePyramid(nn.Module):
         frame = F.interpolate(p0.unsqueeze(-1), [self.frame_num, 1]).squeeze(-1)   # BDNet.py:324-325
         return feats, self._deconv(frame)
 
+    def _proposal_branches(self, loc_feat, conf_feat, frame_level_feat, segments, frame_segments, lev, roi):
+        """ProposalBranch.forward (BDNet.py:105-113) of the loc and the conf branch, stage by stage: the two branches have
+        the same shapes, so each of their four conv blocks runs as ONE set of launches for both (conv_gn_relu_pair)."""
+        lb, cb = self.loc_proposal_branch, self.conf_proposal_branch
+        short_l, short_c = conv_gn_relu_pair(lb.cur_point_conv, cb.cur_point_conv, loc_feat, conf_feat, lev)
+        lr_l, lr_c = conv_gn_relu_pair(lb.lr_conv, cb.lr_conv, loc_feat, conf_feat, lev)
+        pool_l = BoundaryMaxPoolingLevelsFunction.apply(lr_l, segments, lev, lev)
+        pool_c = BoundaryMaxPoolingLevelsFunction.apply(lr_c, segments, lev, lev)
+        roi_l = roi if roi is not None else lb.pool_frame_level(frame_level_feat, frame_segments, lev)
+        roi_c = roi if roi is not None else cb.pool_frame_level(frame_level_feat, frame_segments, lev)
+        roi_l, roi_c = conv_gn_relu_pair(lb.roi_conv, cb.roi_conv, roi_l, roi_c, lev)
+        prop_l, prop_c = conv_gn_relu_pair(lb.proposal_conv, cb.proposal_conv, torch.cat([roi_l, pool_l, short_l], dim=1),
+                                           torch.cat([roi_c, pool_c, short_c], dim=1), lev)
+        return (prop_l, lr_l), (prop_c, lr_c)
+
     def _drop(self, x):
         return F.dropout(x, p=self.dropout) if self.dropout > 0 else x
 
@@ -236,8 +251,10 @@ class CoarsePyramid(nn.Module):
                     self.conf_proposal_branch.lr_conv(conf_feat)]
         lev = self.levels
         packed = torch.cat(feats, dim=2)                                    # (B,512,126)
-        loc_feat = self.loc_tower[1](self.loc_tower[0](packed, lev), lev)
-        conf_feat = self.conf_tower[1](self.conf_tower[0](packed, lev), lev)
+        # the loc and the conf tower are siblings of one shape: each of their two stages is ONE set of launches for both
+        # (common/layers.py conv_gn_relu_pair; values as of the blocks on their own)
+        l0, c0 = conv_gn_relu_pair(self.loc_tower[0], self.conf_tower[0], packed, packed, lev)
+        loc_feat, conf_feat = conv_gn_relu_pair(self.loc_tower[1], self.conf_tower[1], l0, c0, lev)
         # Head convolutions are level-batched GEMM launches; their tails -- ScaleExp (x fpn stride in the ActivityNet model),
         # the permute(0,2,1).contiguous() of every map and the Dirichlet uncertainty -- are one launch per stage
         # (csrc/heads.hip): the coarse stage here, the refined stage after the proposal branches.
@@ -259,8 +276,8 @@ class CoarsePyramid(nn.Module):
         # compat-gradient mode keeps one pooling per branch: the reference's (buggy) backward runs once per branch, and
         # bwd(g1) + bwd(g2) is only bit-identical to bwd(g1 + g2) for the correct gradient up to fp32 rounding anyway
         roi = None if _bp.COMPAT_REFERENCE_BWD else self.loc_proposal_branch.pool_frame_level(frame_level_feat, frame_segments, lev)
-        loc_prop_feat, loc_lr = self.loc_proposal_branch(loc_feat, frame_level_feat, segments, frame_segments, lev, roi)
-        conf_prop_feat, conf_lr = self.conf_proposal_branch(conf_feat, frame_level_feat, segments, frame_segments, lev, roi)
+        (loc_prop_feat, loc_lr), (conf_prop_feat, conf_lr) = self._proposal_branches(
+            loc_feat, conf_feat, frame_level_feat, segments, frame_segments, lev, roi)
         # The six boundary maps of the output dict are (B,T,C) VIEWS of the channel-major maps (the reference returns
         # permuted copies, BDNet.py:328-331,:392-396; same values): their only consumer, the start / end losses of the
         # training step, reads the channel-major maps in place (ops.BoundaryBCEFunction via OutputDict.boundary_maps).

@@ -934,3 +934,54 @@ def test_boundary_losses_fused_tails_match_calc_bce_loss():
     assert abs(float(gs) - float(ls)) < 1e-5 * abs(float(ls)) and abs(float(ge) - float(le)) < 1e-5 * abs(float(le))
     for u, v in zip(xd, xr):
         close(u.grad, v.grad, tol=1e-4)
+
+
+@pytest.mark.parametrize("k,cin,cout,T,levels", [(3, 512, 512, 126, (0, 64, 96, 112, 120, 124, 126)), (1, 512, 1024, 126, None),
+                                                 (1, 2048, 512, 126, None), (3, 512, 512, 256, None)])
+def test_pair_launches_equal_the_single_launches_bit_for_bit(k, cin, cout, T, levels):
+    """ABI 20: two sibling Conv + GroupNorm + ReLU blocks in one set of launches (ConvGNReLUPairFunction: conv fwd, GN fwd,
+    GN bwd, dgrad, wgrad each carry both problems) give exactly the bits of the two blocks on their own -- outputs,
+    input gradients and every parameter gradient."""
+    from opental_amd.common import ops
+    from opental_amd.common.layers import ConvGNReLU, Unit1D, conv_gn_relu_pair
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        torch.manual_seed(3)
+        blocks = [ConvGNReLU(Unit1D(cin, cout, k, use_bias=True, activation_fn=None), cout).cuda() for _ in range(2)]
+        for b in blocks:
+            with torch.no_grad():
+                b[1].weight.uniform_(0.5, 1.5); b[1].bias.uniform_(-0.3, 0.3)
+        xs = [torch.randn(4, cin, T, device="cuda", requires_grad=True) for _ in range(2)]
+        gys = [torch.randn(4, cout, T, device="cuda") for _ in range(2)]
+
+        def run(pair):
+            for b in blocks:
+                b.zero_grad(set_to_none=True)
+            for x in xs:
+                x.grad = None
+            ops.PAIR_LAUNCHES = pair
+            ys = conv_gn_relu_pair(blocks[0], blocks[1], xs[0], xs[1], levels)
+            torch.autograd.backward(ys, gys)
+            out = [y.detach().clone() for y in ys] + [x.grad.clone() for x in xs]
+            for b in blocks:
+                out += [p.grad.clone() for p in b.parameters()]
+            return out
+        single, paired = run(False), run(True)
+        assert len(single) == len(paired) == 12
+        for a, b in zip(single, paired):
+            assert torch.equal(a, b)
+        # one tensor feeding both blocks (the towers' first stage): autograd adds the two input gradients
+        x = torch.randn(4, cin, T, device="cuda", requires_grad=True)
+        ops.PAIR_LAUNCHES = True
+        y0, y1 = conv_gn_relu_pair(blocks[0], blocks[1], x, x, levels)
+        (y0.sum() + 2 * y1.sum()).backward()
+        g_pair = x.grad.clone()
+        x.grad = None
+        ops.PAIR_LAUNCHES = False
+        y0, y1 = conv_gn_relu_pair(blocks[0], blocks[1], x, x, levels)
+        (y0.sum() + 2 * y1.sum()).backward()
+        assert torch.equal(g_pair, x.grad)
+    finally:
+        ops.CONV_PRECISION = old
+        ops.PAIR_LAUNCHES = True
