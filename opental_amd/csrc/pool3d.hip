@@ -400,6 +400,113 @@ __global__ __launch_bounds__(256) void maxpool333_sep_fwd_kernel(const float* __
         }
 }
 
+// ---- the same pooling with one ROW per thread (planes of 12 x 12 and 6 x 6).  The cell-per-thread kernel above spends
+// ~45 instructions per element on scalar LDS traffic (three passes of 3 reads + 2 writes of one value each) and is VALU /
+// LDS-issue bound at 2.5 - 3 TB/s.  Here a thread owns a whole row of P values: the w pass runs in registers, the h and t
+// passes exchange whole rows through LDS with 16-byte (8-byte for P = 6) accesses -- six times fewer LDS instructions,
+// ~18 VALU instructions per element -- and the row is loaded and stored as vectors.  A workgroup covers TT output planes
+// of one (sample, channel) plus one halo plane on each side (256 / P rows).  Same values and tap bytes as the kernel
+// above: every stage is the FIRST maximum of three with the zero padding taking part.
+template <int P>
+__global__ __launch_bounds__(256) void maxpool333_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  unsigned char* __restrict__ arg, PoolGeom g, int TT) {
+    constexpr int VW = P % 4 == 0 ? 4 : 2, NV = P / VW;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    const int to0 = blockIdx.x * TT;
+    const int tt = min(TT, g.To - to0);
+    const int rows = (tt + 2) * P;
+    float* srm = sm;                                             // [rows][P] row maxima
+    float* spm = sm + (TT + 2) * P * P;                          // [rows][P] plane maxima
+    const int r = tid;
+    const bool act = r < rows;
+    const int tl = r / P, h = r - tl * P;
+    const int ti = to0 - 1 + tl;
+    const float* xb = x + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs;
+    float v[P + 2];
+    v[0] = 0.f; v[P + 1] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const bool in = act && (unsigned)ti < (unsigned)g.Ti;
+        const float* src = xb + ((int64_t)(in ? ti : 0) * P + h) * P + q * VW;
+        if constexpr (VW == 4) {
+            const float4 t4 = in ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[1 + 4 * q] = t4.x; v[2 + 4 * q] = t4.y; v[3 + 4 * q] = t4.z; v[4 + 4 * q] = t4.w;
+        } else {
+            const float2 t2 = in ? *reinterpret_cast<const float2*>(src) : make_float2(0.f, 0.f);
+            v[1 + 2 * q] = t2.x; v[2 + 2 * q] = t2.y;
+        }
+    }
+    auto put = [&](float* dst, const float (&a)[P]) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            if constexpr (VW == 4) *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+            else *reinterpret_cast<float2*>(dst + 2 * q) = make_float2(a[2 * q], a[2 * q + 1]);
+        }
+    };
+    auto get = [&](const float* src, bool ok, float (&a)[P]) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            if constexpr (VW == 4) {
+                const float4 t4 = ok ? *reinterpret_cast<const float4*>(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[4 * q] = t4.x; a[4 * q + 1] = t4.y; a[4 * q + 2] = t4.z; a[4 * q + 3] = t4.w;
+            } else {
+                const float2 t2 = ok ? *reinterpret_cast<const float2*>(src + 2 * q) : make_float2(0.f, 0.f);
+                a[2 * q] = t2.x; a[2 * q + 1] = t2.y;
+            }
+        }
+    };
+    float rm[P], pm[P];
+    unsigned tw = 0, th = 0;
+#pragma unroll
+    for (int w = 0; w < P; ++w) {
+        int k;
+        first_max3(v[w], v[w + 1], v[w + 2], rm[w], k);
+        tw |= (unsigned)k << (2 * w);
+    }
+    if (act) put(srm + r * P, rm);
+    __syncthreads();
+    if (act) {
+        float up[P], dn[P];
+        get(srm + (r - 1) * P, h > 0, up);
+        get(srm + (r + 1) * P, h < P - 1, dn);
+#pragma unroll
+        for (int w = 0; w < P; ++w) {
+            int k;
+            first_max3(up[w], rm[w], dn[w], pm[w], k);
+            th |= (unsigned)k << (2 * w);
+        }
+        put(spm + r * P, pm);
+    }
+    __syncthreads();
+    if (act && tl >= 1 && tl <= tt) {
+        float before[P], after[P], out[P];
+        get(spm + (r - P) * P, true, before);
+        get(spm + (r + P) * P, true, after);
+        unsigned bytes[P / 4 + 1] = {};
+#pragma unroll
+        for (int w = 0; w < P; ++w) {
+            int k;
+            first_max3(before[w], pm[w], after[w], out[w], k);
+            const unsigned byte = ((tw >> (2 * w)) & 3u) | (((th >> (2 * w)) & 3u) << 2) | ((unsigned)k << 4);
+            bytes[w >> 2] |= byte << (8 * (w & 3));
+        }
+        const int64_t p = ((int64_t)(to0 + tl - 1) * P + h) * P;
+        put(y + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p, out);
+        unsigned char* ab = arg + (int64_t)bc * g.To * P * P + p;
+        if constexpr (P % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < P / 4; ++q) reinterpret_cast<unsigned*>(ab)[q] = bytes[q];
+        } else {                                                // P = 6: rows of 6 bytes, 2-byte aligned
+#pragma unroll
+            for (int q = 0; q < P / 2; ++q)
+                reinterpret_cast<unsigned short*>(ab)[q] = (unsigned short)((bytes[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+        }
+    }
+}
+
 constexpr int POOL_SEP_ELEMS = 1152;     // input elements per backward workgroup (8 planes of 12x12, 32 of 6x6, 128 of 3x3)
 // V4: every tensor is 16-byte aligned and the plane size a multiple of 4 -> float4 / uchar4 global accesses (the scalar
 // version issued 27 memory instructions per thread and tile: texture-addresser-bound at 2.5 TB/s)
@@ -498,6 +605,138 @@ __global__ __launch_bounds__(256) void maxpool333_sep_bwd_kernel(const float* __
         if constexpr (V4) *reinterpret_cast<float4*>(dx + xoff + i0) = make_float4(res[0], res[1], res[2], res[3]);
         else dx[xoff + i0] = res[0];
     }
+}
+
+// Backward of the same pools with one ROW of the input per thread: the t stage reads the dy / tap rows of the three output
+// planes that can point into the row (staged once per workgroup in LDS), the h stage exchanges the plane-stage gradient
+// rows through LDS, the w stage and the fused ReLU / BN mask run in registers; every global access is a vector.  Same
+// sums in the same order as maxpool333_sep_bwd_kernel (ascending tap per stage).
+template <int P>
+__global__ __launch_bounds__(256) void maxpool333_rows_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                                  float* __restrict__ dx, PoolGeom g, int TI, int accumulate,
+                                                                  const float* __restrict__ emask, const float* __restrict__ escale) {
+    constexpr int VW = P % 4 == 0 ? 4 : 2, NV = P / VW, TB = P % 4 == 0 ? P : 8;      // tap row pitch in LDS (bytes)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    const int ti0 = blockIdx.x * TI;
+    const int tin = min(TI, g.Ti - ti0);
+    const int rows = (tin + 2) * P;
+    float* sdy = sm;                                             // [rows][P] dy of output planes ti0-1 .. ti0+tin
+    float* sgp = sm + (TI + 2) * P * P;                          // [rows][P] gradient w.r.t. the plane maxima
+    unsigned char* stp = reinterpret_cast<unsigned char*>(sgp + (TI + 2) * P * P);      // [rows][TB] tap bytes (0xff: no plane)
+    const int r = tid;
+    const bool act = r < rows;
+    const int tl = r / P, h = r - tl * P;
+    const int to = ti0 - 1 + tl;                                 // the output plane this thread stages / the input plane it owns
+    const bool inside = act && tl >= 1 && tl <= tin;
+    const int64_t xoff = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)(inside ? to : 0) * P + h) * P;
+    auto getg = [&](const float* src, bool ok, float (&a)[P]) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            if constexpr (VW == 4) {
+                const float4 t4 = ok ? *reinterpret_cast<const float4*>(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[4 * q] = t4.x; a[4 * q + 1] = t4.y; a[4 * q + 2] = t4.z; a[4 * q + 3] = t4.w;
+            } else {
+                const float2 t2 = ok ? *reinterpret_cast<const float2*>(src + 2 * q) : make_float2(0.f, 0.f);
+                a[2 * q] = t2.x; a[2 * q + 1] = t2.y;
+            }
+        }
+    };
+    auto put = [&](float* dst, const float (&a)[P]) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            if constexpr (VW == 4) *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+            else *reinterpret_cast<float2*>(dst + 2 * q) = make_float2(a[2 * q], a[2 * q + 1]);
+        }
+    };
+    auto taps = [&](const unsigned char* src, unsigned (&t)[3]) {   // a tap row as bytes packed into words
+        if constexpr (P % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < P / 4; ++q) t[q] = reinterpret_cast<const unsigned*>(src)[q];
+        } else {
+            t[0] = reinterpret_cast<const unsigned*>(src)[0]; t[1] = reinterpret_cast<const unsigned*>(src)[1]; t[2] = 0;
+        }
+    };
+    // epilogue operands first: their latency hides behind the LDS stages
+    float mk[P], old[P];
+    getg(emask + xoff, inside && emask != nullptr, mk);
+    getg(dx + xoff, inside && accumulate, old);
+    {   // stage this thread's dy row and tap row
+        float d[P];
+        const bool in = act && (unsigned)to < (unsigned)g.To;
+        const int64_t p = ((int64_t)(in ? to : 0) * P + h) * P;
+        getg(dy + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p, in, d);
+        if (act) put(sdy + r * P, d);
+        const unsigned char* ab = arg + (int64_t)bc * g.To * P * P + p;
+        if (act) {
+            if constexpr (P % 4 == 0) {
+#pragma unroll
+                for (int q = 0; q < P / 4; ++q)
+                    reinterpret_cast<unsigned*>(stp + r * TB)[q] = in ? reinterpret_cast<const unsigned*>(ab)[q] : 0xffffffffu;
+            } else {
+                unsigned lo = 0xffffffffu, hi = 0xffffffffu;
+                if (in) {
+                    const unsigned short* a16 = reinterpret_cast<const unsigned short*>(ab);
+                    lo = (unsigned)a16[0] | ((unsigned)a16[1] << 16);
+                    hi = (unsigned)a16[2] | 0xffff0000u;
+                }
+                reinterpret_cast<unsigned*>(stp + r * TB)[0] = lo;
+                reinterpret_cast<unsigned*>(stp + r * TB)[1] = hi;
+            }
+        }
+    }
+    __syncthreads();
+    auto tap_of = [&](const unsigned (&t)[3], int w) -> unsigned { return (t[w >> 2] >> (8 * (w & 3))) & 0xffu; };
+    float gp[P];
+    unsigned town[3];
+    if (inside) {   // through the t stage: output planes to + 1 - dt, dt = 0, 1, 2
+        float d0[P], d1[P], d2[P];
+        unsigned t0[3], t2[3];
+        getg(sdy + (r + P) * P, true, d0); getg(sdy + r * P, true, d1); getg(sdy + (r - P) * P, true, d2);
+        taps(stp + (r + P) * TB, t0); taps(stp + r * TB, town); taps(stp + (r - P) * TB, t2);
+#pragma unroll
+        for (int w = 0; w < P; ++w) {
+            float s_ = 0.f;
+            s_ += ((tap_of(t0, w) >> 4) & 3u) == 0u ? d0[w] : 0.f;
+            s_ += ((tap_of(town, w) >> 4) & 3u) == 1u ? d1[w] : 0.f;
+            s_ += ((tap_of(t2, w) >> 4) & 3u) == 2u ? d2[w] : 0.f;
+            gp[w] = s_;
+        }
+        put(sgp + r * P, gp);
+    }
+    __syncthreads();
+    if (!inside) return;
+    float gr[P];
+    {   // through the h stage: plane-max cells h + 1 - dh of the same plane
+        float gu[P], gd[P];
+        unsigned tu[3] = {}, td[3] = {};
+        getg(sgp + (r + 1) * P, h + 1 < P, gd);                 // dh = 0: row h + 1
+        getg(sgp + (r - 1) * P, h >= 1, gu);                    // dh = 2: row h - 1
+        if (h + 1 < P) taps(stp + (r + 1) * TB, td);
+        if (h >= 1) taps(stp + (r - 1) * TB, tu);
+#pragma unroll
+        for (int w = 0; w < P; ++w) {
+            float s_ = 0.f;
+            if (h + 1 < P) s_ += ((tap_of(td, w) >> 2) & 3u) == 0u ? gd[w] : 0.f;
+            s_ += ((tap_of(town, w) >> 2) & 3u) == 1u ? gp[w] : 0.f;
+            if (h >= 1) s_ += ((tap_of(tu, w) >> 2) & 3u) == 2u ? gu[w] : 0.f;
+            gr[w] = s_;
+        }
+    }
+    const float esc = emask ? escale[c] : 1.f;
+    float res[P];
+#pragma unroll
+    for (int w = 0; w < P; ++w) {   // through the w stage: row-max cells w + 1 - dw of the same row
+        float s_ = 0.f;
+        if (w + 1 < P) s_ += (tap_of(town, w + 1 < P ? w + 1 : w) & 3u) == 0u ? gr[w + 1 < P ? w + 1 : w] : 0.f;
+        s_ += (tap_of(town, w) & 3u) == 1u ? gr[w] : 0.f;
+        if (w >= 1) s_ += (tap_of(town, w >= 1 ? w - 1 : 0) & 3u) == 2u ? gr[w >= 1 ? w - 1 : 0] : 0.f;
+        if (emask) s_ = mk[w] > 0.f ? s_ * esc : 0.f;            // ReLU / BN backward of the pooled layer
+        res[w] = old[w] + s_;
+    }
+    put(dx + xoff, res);
 }
 
 // ---- MaxPool3d_2a / 3a (kernel (1,3,3), stride (1,2,2)) and MaxPool3d_4a ((3,3,3) / (2,2,2)): SAME padding = one zero
@@ -765,6 +1004,16 @@ static int pool_fwd(const int* geom, const int64_t* strides, const float* x, flo
         while (tt > 1 && need(tt) > POOL_LDS_BUDGET) --tt;
         const dim3 grid((g.To + tt - 1) / tt, g.B * g.C);
         const int vec = (g.x_bs % 4 == 0 && g.x_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
+        const bool vy = g.y_bs % 4 == 0 && g.y_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(argtap) & 3) == 0;
+        if (vec && vy && (P == 12 || P == 6) && !OTAL_OPT("OTAL_POOL_NOROWS", 0)) {     // one row per thread
+            const int TT = 256 / P - 2;
+            const dim3 rgrid((g.To + TT - 1) / TT, g.B * g.C);
+            const size_t lds = (size_t)2 * (TT + 2) * P * P * sizeof(float);
+            if (P == 12) hipLaunchKernelGGL(maxpool333_rows_fwd_kernel<12>, rgrid, dim3(256), lds, st_, x, y, argtap, g, TT);
+            else hipLaunchKernelGGL(maxpool333_rows_fwd_kernel<6>, rgrid, dim3(256), lds, st_, x, y, argtap, g, TT);
+            return otal_launch_status();
+        }
         if (P == 12) hipLaunchKernelGGL(maxpool333_sep_fwd_kernel<12>, grid, dim3(256), need(tt), st_, x, y, argtap, g, tt, vec);
         else if (P == 6) hipLaunchKernelGGL(maxpool333_sep_fwd_kernel<6>, grid, dim3(256), need(tt), st_, x, y, argtap, g, tt, vec);
         else hipLaunchKernelGGL(maxpool333_sep_fwd_kernel<3>, grid, dim3(256), need(tt), st_, x, y, argtap, g, tt, vec);
@@ -813,6 +1062,17 @@ static int pool_bwd(const int* geom, const int64_t* strides, const float* dy, co
         const bool v4 = g.Hi != 3 && g.x_bs % 4 == 0 && g.x_cs % 4 == 0 && g.y_bs % 4 == 0 && g.y_cs % 4 == 0 &&
                         ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(out_mask) |
                           reinterpret_cast<uintptr_t>(argtap)) & 15) == 0 && ((int64_t)g.To * PP) % 4 == 0;
+        const bool v2 = g.x_bs % 4 == 0 && g.x_cs % 4 == 0 && g.y_bs % 4 == 0 && g.y_cs % 4 == 0 &&
+                        ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(out_mask) |
+                          reinterpret_cast<uintptr_t>(argtap)) & 15) == 0;
+        if (v2 && (g.Hi == 12 || g.Hi == 6) && !OTAL_OPT("OTAL_POOL_NOROWS", 0)) {      // one input row per thread
+            const int P = g.Hi, TIr = 256 / P - 2, TB = P == 12 ? 12 : 8;
+            const dim3 rgrid((g.Ti + TIr - 1) / TIr, g.B * g.C);
+            const size_t lds = (size_t)2 * (TIr + 2) * P * P * sizeof(float) + (size_t)(TIr + 2) * P * TB;
+            if (P == 12) hipLaunchKernelGGL(maxpool333_rows_bwd_kernel<12>, rgrid, dim3(256), lds, st_, dy, argtap, dx, g, TIr, accumulate, out_mask, out_scale);
+            else hipLaunchKernelGGL(maxpool333_rows_bwd_kernel<6>, rgrid, dim3(256), lds, st_, dy, argtap, dx, g, TIr, accumulate, out_mask, out_scale);
+            return otal_launch_status();
+        }
         if (g.Hi == 12 && v4) hipLaunchKernelGGL((maxpool333_sep_bwd_kernel<12, true>), grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale);
         else if (g.Hi == 6 && v4) hipLaunchKernelGGL((maxpool333_sep_bwd_kernel<6, true>), grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale);
         else if (g.Hi == 12) hipLaunchKernelGGL((maxpool333_sep_bwd_kernel<12, false>), grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale);

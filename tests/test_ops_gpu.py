@@ -985,3 +985,41 @@ def test_pair_launches_equal_the_single_launches_bit_for_bit(k, cin, cout, T, le
     finally:
         ops.CONV_PRECISION = old
         ops.PAIR_LAUNCHES = True
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 45, 12, 12), (1, 4, 128, 12, 12), (2, 8, 83, 6, 6), (1, 16, 64, 6, 6), (1, 4, 3, 12, 12)])
+def test_row_per_thread_333_pool_equals_the_cell_kernel(shape):
+    """maxpool333_rows_fwd_kernel (one row per thread, vector LDS exchange) gives the bits of maxpool333_sep_fwd_kernel --
+    values AND tap bytes -- on planes of 12 x 12 and 6 x 6, tile boundaries and short clips included; ties with the zero
+    padding (ReLU outputs) and NaN included."""
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    g = torch.Generator().manual_seed(shape[2])
+    x = torch.randn(*shape, generator=g).clamp(min=0)          # exact zeros tie with the padding and with each other
+    x[0, 0, shape[2] // 2, 3, 2] = float("nan")
+    xd = x.cuda()
+    try:
+        L.set_option("OTAL_POOL_NOROWS", 1)
+        y0, a0 = ops.maxpool3d_forward(xd, (3, 3, 3), (1, 1, 1))
+        L.set_option("OTAL_POOL_NOROWS", 0)
+        y1, a1 = ops.maxpool3d_forward(xd, (3, 3, 3), (1, 1, 1))
+    finally:
+        L.set_option("OTAL_POOL_NOROWS", 0)
+    assert torch.equal(a0, a1)
+    assert torch.equal(y0.view(torch.int32), y1.view(torch.int32))
+    # backward: the row kernel adds the same terms in the same order (plain store, fused ReLU / BN mask, accumulate)
+    dy = torch.randn(y0.shape, generator=g).cuda()
+    sc = (torch.rand(shape[1], generator=g) + 0.5).cuda()
+    base = torch.randn(*shape, generator=g).cuda()
+    outs = []
+    for rows_off in (1, 0):
+        L.set_option("OTAL_POOL_NOROWS", rows_off)
+        try:
+            plain = ops.maxpool3d_backward(dy, a0, xd.shape, (3, 3, 3), (1, 1, 1))
+            masked = ops.maxpool3d_backward(dy, a0, xd.shape, (3, 3, 3), (1, 1, 1), out_mask=xd, out_scale=sc)
+            acc = ops.maxpool3d_backward(dy, a0, xd.shape, (3, 3, 3), (1, 1, 1), out=base.clone(), accumulate=True, out_mask=xd, out_scale=sc)
+        finally:
+            L.set_option("OTAL_POOL_NOROWS", 0)
+        outs.append((plain, masked, acc))
+    for u, v in zip(*outs):
+        assert torch.equal(u.view(torch.int32), v.view(torch.int32))
