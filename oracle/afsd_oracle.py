@@ -117,9 +117,37 @@ def same_pad(size, k, s):
     return total // 2, total - total // 2
 
 
-def unit1d(x, w, b, stride=1):
+# Operand rounding of the throughput path (BASELINE configs[1] names bf16): the HIP library's bf16 mode rounds BOTH operands
+# of every convolution that runs on the bf16 MFMA to bfloat16 (round to nearest even) while it stages them and accumulates
+# in fp32; the skinny detection heads stay exact fp32 (csrc/headconv.hip).  `with operand_rounding("bf16")` makes this
+# restatement do the same on the CPU -- fp32 convolutions of bf16-rounded operands -- so the bf16 path can be pinned end to
+# end and layer by layer instead of against a loose bf16-vs-fp32 tolerance.  Not part of the reference (which is fp32).
+_ROUND = None
+
+
+class operand_rounding:
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        global _ROUND
+        self.old, _ROUND = _ROUND, self.mode
+        return self
+
+    def __exit__(self, *a):
+        global _ROUND
+        _ROUND = self.old
+
+
+def _r(t):
+    return t.to(torch.bfloat16).to(t.dtype) if _ROUND == "bf16" and t.dtype == torch.float32 else t
+
+
+def unit1d(x, w, b, stride=1, exact=False):
     """Unit1D with activation_fn=None (layers.py:178-214)."""
     f, bk = same_pad(x.shape[2], w.shape[2], stride)
+    if not exact:
+        x, w = _r(x), _r(w)
     return F.conv1d(F.pad(x, [f, bk]), w, b, stride=stride)
 
 
@@ -144,7 +172,7 @@ def _pad3(x, k, s, spatial=True):
 def conv3d_bn_relu(P, prefix, x, k, s):
     """backbone Unit3D (i3d_backbone.py:46-87): SAME pad -> Conv3d(no bias) -> frozen BN
     (eps 1e-3, running stats; BDNet.py:39-49 keeps BN in eval) -> ReLU."""
-    x = F.conv3d(_pad3(x, k, s), P[f"{prefix}.conv3d.weight"], None, stride=s)
+    x = F.conv3d(_pad3(_r(x), k, s), _r(P[f"{prefix}.conv3d.weight"]), None, stride=s)
     x = F.batch_norm(x, P[f"{prefix}.bn.running_mean"], P[f"{prefix}.bn.running_var"],
                      P[f"{prefix}.bn.weight"], P[f"{prefix}.bn.bias"], False, 0.0, 1e-3)
     return F.relu(x)
@@ -229,8 +257,11 @@ def proposal_branch(P, prefix, feat, frame_feat, seg, fseg, compat):
     return fused, lr
 
 
-def _head(P, name, x):
-    return unit1d(x, P[f"{name}.conv1d.weight"], P[f"{name}.conv1d.bias"])
+def _head(P, name, x, cfg=None):
+    # the THUMOS14 heads (1 / 2 / 15 rows) are exact fp32 FMA kernels on the device; the 150-class ActivityNet heads take
+    # the bf16 GEMM path like every other layer
+    exact = cfg is None or cfg.get("num_classes", 16) <= 32
+    return unit1d(x, P[f"{name}.conv1d.weight"], P[f"{name}.conv1d.bias"], exact=exact)
 
 
 def coarse_pyramid(P, f4, f5, cfg=arch.THUMOS, compat=False, keep=None):
@@ -241,16 +272,16 @@ def coarse_pyramid(P, f4, f5, cfg=arch.THUMOS, compat=False, keep=None):
     strides = cfg.get("fpn_strides")
     if cfg.get("two_projections", True):
         # pyramids[0], [1]: Unit3D 'spatial_valid' (temporal k=1 -> no pad) + GN + ReLU (BDNet.py:129-155)
-        x0 = F.conv3d(f4, P[f"{Q}.pyramids.0.0.conv3d.weight"], P[f"{Q}.pyramids.0.0.conv3d.bias"])
+        x0 = F.conv3d(_r(f4), _r(P[f"{Q}.pyramids.0.0.conv3d.weight"]), P[f"{Q}.pyramids.0.0.conv3d.bias"])
         x0 = gn_relu(x0.squeeze(-1).squeeze(-1), P[f"{Q}.pyramids.0.1.weight"], P[f"{Q}.pyramids.0.1.bias"])
-        x1 = F.conv3d(f5, P[f"{Q}.pyramids.1.0.conv3d.weight"], P[f"{Q}.pyramids.1.0.conv3d.bias"])
+        x1 = F.conv3d(_r(f5), _r(P[f"{Q}.pyramids.1.0.conv3d.weight"]), P[f"{Q}.pyramids.1.0.conv3d.bias"])
         x1 = gn_relu(x1.squeeze(-1).squeeze(-1), P[f"{Q}.pyramids.1.1.weight"], P[f"{Q}.pyramids.1.1.bias"])
         x0 = x0 + F.interpolate(x1, x0.shape[2:], mode="nearest")   # BDNet.py:316-319
         feats = [x0, x1]
         x = x1
     else:
         # anet/BDNet.py:130-142,:284-290: one projection of Mixed_5c
-        x = F.conv3d(f5, P[f"{Q}.pyramids.0.0.conv3d.weight"], P[f"{Q}.pyramids.0.0.conv3d.bias"])
+        x = F.conv3d(_r(f5), _r(P[f"{Q}.pyramids.0.0.conv3d.weight"]), P[f"{Q}.pyramids.0.0.conv3d.bias"])
         x = gn_relu(x.squeeze(-1).squeeze(-1), P[f"{Q}.pyramids.0.1.weight"], P[f"{Q}.pyramids.0.1.bias"])
         feats = [x]
     for i in range(len(feats), cfg["layer_num"]):
