@@ -378,6 +378,22 @@ def inference_sharded(device, rank, world, nvid=213):
         ops.CONV_PRECISION = saved
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:               # noqa: BLE001
+        pass
+    sys.stdout.flush()
+
+
+def _mute_stdout():
+    """Nothing may follow the JSON line on stdout (library banners flushed at exit, teardown chatter)."""
+    _flush_c_stdio()
+    fd = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(fd, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -441,6 +457,16 @@ def main():
             dist.init_process_group(backend=backend)
         if dist.get_world_size() != world:
             raise SystemExit(f"RCCL reports {dist.get_world_size()} ranks, expected {world}")
+        # RCCL prints a version / host banner through C stdio when its communicator comes up (at the first collective).
+        # With stdout redirected to a file that text sits in libc's buffer until the process exits -- i.e. it would land
+        # BEHIND the JSON line the driver parses.  Bring the communicator up now, flush libc, and silence the stdout of
+        # every rank but 0 (rank 0 closes its own right after the JSON line).
+        warm = torch.zeros(1, device=device)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
+        _flush_c_stdio()
+        if rank != 0:
+            _mute_stdout()
     from opental_amd.common import ops as _ops
     _ops.CONV_PRECISION = 1 if args.dtype == "bf16" else 0
     if anet:
@@ -677,6 +703,7 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0:
+        _flush_c_stdio()
         print(json.dumps({
             "metric": "clips/sec training step, 768-frame ActivityNet1.3 clips" if anet else
                       "clips/sec training step, 256-frame THUMOS14 clips", "value": round(value, 3),
@@ -701,7 +728,8 @@ def main():
                                   "one captured HIP graph per step") if graphed else "eager launches"},
             "roofline": roofline, "hbm_kernels": hbm,
             "other_configs": extra if extra is not None else ({"inference": infer_n} if infer_n is not None else None),
-            "cpu_baseline": cpu}))
+            "cpu_baseline": cpu}), flush=True)
+        _mute_stdout()
     if world > 1 or force_dist:
         dist.barrier()              # every rank leaves together (rank 0 was busy with the roofline steps)
         dist.destroy_process_group()

@@ -17,6 +17,17 @@ def pytest_configure(config):
 def golden_dir():
     return GOLDEN
 
+
+@pytest.fixture(autouse=True)
+def _restore_global_config():
+    """The drivers (python -m opental_amd.{thumos14,anet}.train / test) install their parsed yaml as the process-wide config,
+    as the reference's `from AFSD.common.config import config` does; model builders without an explicit cfg read it.  A test
+    that ran a driver must not leave e.g. the ActivityNet class count behind for the THUMOS14 tests that follow."""
+    from opental_amd.common import config as C
+    saved = C._config
+    yield
+    C._config = saved
+
 # let small test shapes reach the direct 3x3x3 kernel (the product default keeps it for grids that fill the chip)
 import os as _os
 _os.environ.setdefault("OTAL_CONV_DIRECT_MINTILES", "1")
