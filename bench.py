@@ -668,15 +668,23 @@ def main():
                     "launches_per_step": tot_n // 2, "avg_launch_us": round(tot_t / tot_n * 1e6, 1),
                     "conv_time_ms_per_step": round(tot_t / 2 * 1e3, 2),
                     "by_mode_TFLOPs": {k: round(e[0] / e[1] / 1e12, 2) for k, e in by.items()}}
-        # ... the committed rocprofv3 --pmc passes over this very command (tools/pmc_step.sh) supply it for the default workload
-        pmc = os.path.join(REPO, "profiles", "r02b_pmc_step_traffic.json")
-        if os.path.exists(pmc) and args.dtype == "bf16" and not anet and args.batch == 8 and not args.ssl:
-            with open(pmc) as f:
+        # ... the committed rocprofv3 --pmc passes over this very command (tools/pmc_step.sh) supply it for the default
+        # workload -- as long as the kernels and the launch path are still the ones that were profiled (tools/source_stamp.py)
+        pmcs = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_pmc_step_traffic.json"))
+        if pmcs and args.dtype == "bf16" and not anet and args.batch == 8 and not args.ssl:
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            from source_stamp import source_stamp
+            with open(os.path.join(REPO, "profiles", pmcs[-1])) as f:
                 t = json.load(f)
-            roofline["traffic"] = int(t["conv_traffic_MB_per_launch"] * 1e6)
-            roofline["traffic_note"] = ("bytes of HBM traffic per convolution launch, FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 "
-                                        "--pmc passes over this command (profiles/r02b_pmc_step_traffic.txt); whole step "
-                                        f"{t['step_traffic_MB'] / 1e3:.1f} GB")
+            now = source_stamp()
+            if t.get("source_stamp") == now:
+                roofline["traffic"] = int(t["conv_traffic_MB_per_launch"] * 1e6)
+                roofline["traffic_note"] = ("bytes of HBM traffic per convolution launch, FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 "
+                                            f"--pmc passes over this command (profiles/{pmcs[-1][:-5]}.txt, measured on source stamp {now}: "
+                                            f"the tree running now); whole step {t['step_traffic_MB'] / 1e3:.1f} GB")
+            else:
+                roofline["traffic_note"] = (f"null: profiles/{pmcs[-1]} was measured on source stamp {t.get('source_stamp')}, this tree is "
+                                            f"{now} (kernels or launch path changed since: re-run tools/pmc_step.sh)")
     hbm = None
     if rank == 0 and world == 1 and not args.no_hbm_kernels and not anet:
         # the bandwidth-bound kernel classes in isolation, at the shapes of this step: algorithmic bytes / launch time

@@ -1287,6 +1287,8 @@ struct PrepDesc {
     ConvGeom g;
     int M, Mpad, C, kvol, K, Kp, nchunk, kwv, natural, mode;
     int direct;            // 1: the weight pack of conv3_direct_kernel ([Mpad][C/16][3][9][16] bf16) instead of a chunk-path prologue
+    FastDiv fh, fk;        // host-built exact division by the bf16 pairs per packed row and by kvol (a runtime division is
+                           // ~40 VALU instructions per packed pair: most of the pack kernels' time)
 };
 
 template <int MODE>
@@ -1311,8 +1313,9 @@ __device__ __forceinline__ void prep_chunks_body(const PrepDesc& d, unsigned bid
         }
         const unsigned half = (unsigned)Kp / 2;
         const unsigned pairs = (unsigned)Mpad * half;           // < 2^31 (checked by the launcher): 32-bit index math --
-        for (unsigned p = (unsigned)gid; p < pairs; p += nblk * 256u) {    // a 64-bit division is ~80 VALU instructions
-            const int m = (int)(p / half), k = (int)(p - (unsigned)m * half) * 2;
+        const FastDiv fh = d.fh;
+        for (unsigned p = (unsigned)gid; p < pairs; p += nblk * 256u) {
+            const int m = (int)fd_div(fh, p), k = (int)(p - (unsigned)m * half) * 2;
             float v[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -1342,13 +1345,14 @@ __device__ __forceinline__ void prep_chunks_body(const PrepDesc& d, unsigned bid
     }
     const unsigned half = (unsigned)Kp / 2;
     const unsigned pairs = (unsigned)Mpad * half;
+    const FastDiv fh = d.fh, fk = d.fk;
     for (unsigned p = (unsigned)gid; p < pairs; p += nblk * 256u) {
-        const int m = (int)(p / half), k = (int)(p - (unsigned)m * half) * 2;
+        const int m = (int)fd_div(fh, p), k = (int)(p - (unsigned)m * half) * 2;
         float v[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int kk = k + i;
-            const int j = kk >> 3, cb = j / kvol, tap = j - cb * kvol, c = cb * 8 + (kk & 7);
+            const int j = kk >> 3, cb = (int)fd_div(fk, (unsigned)j), tap = j - cb * kvol, c = cb * 8 + (kk & 7);
             // source layout: [m][c][tap] (forward W, or the packed W^T of DGRAD) / natural W seen from DGRAD: [c][m][tap]
             const int64_t si = natural ? ((int64_t)c * M + m) : ((int64_t)m * C + c);
             v[i] = (m < M && kk < K) ? wsrc[si * kvol + tap] : 0.f;
@@ -1364,11 +1368,11 @@ __global__ __launch_bounds__(256) void prep_chunks_kernel(const PrepDesc d) { pr
 // DGRAD (natural layout W (Cout, Cin, 27)): A[m = ci][..] = w[co = cb*16+c][ci][2-dt][2-dh][2-dw]
 template <int MODE>
 __device__ __forceinline__ void pack_direct_body(unsigned* __restrict__ wp, const float* __restrict__ w, int M, int Mpad, int C, int natural,
-                                                 unsigned bid, unsigned nblk) {
+                                                 unsigned bid, unsigned nblk, const FastDiv fh) {
     const int Ktot = C * 27;
     const unsigned hk = (unsigned)Ktot / 2, pairs = (unsigned)Mpad * hk;       // < 2^31: 32-bit index math
     for (unsigned p = bid * 256u + threadIdx.x; p < pairs; p += nblk * 256u) {
-        const int m = (int)(p / hk), k = (int)(p - (unsigned)m * hk) * 2;
+        const int m = (int)fd_div(fh, p), k = (int)(p - (unsigned)m * hk) * 2;
         float v[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1398,8 +1402,8 @@ __global__ __launch_bounds__(256) void prep_chunks_batch_kernel(const PrepDesc* 
     const PrepDesc& d = descs[lo];
     const unsigned bid = (unsigned)(b - starts[lo]), nblk = (unsigned)(starts[lo + 1] - starts[lo]);
     if (d.direct) {
-        if (d.mode == MODE_FWD) pack_direct_body<MODE_FWD>(d.wp, d.wsrc, d.M, d.Mpad, d.C, d.natural, bid, nblk);
-        else pack_direct_body<MODE_DGRAD>(d.wp, d.wsrc, d.M, d.Mpad, d.C, d.natural, bid, nblk);
+        if (d.mode == MODE_FWD) pack_direct_body<MODE_FWD>(d.wp, d.wsrc, d.M, d.Mpad, d.C, d.natural, bid, nblk, d.fh);
+        else pack_direct_body<MODE_DGRAD>(d.wp, d.wsrc, d.M, d.Mpad, d.C, d.natural, bid, nblk, d.fh);
         return;
     }
     if (d.mode == MODE_FWD) prep_chunks_body<MODE_FWD>(d, bid, nblk);
@@ -1959,8 +1963,8 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
 
 template <int MODE>
 __global__ __launch_bounds__(256) void pack_direct_kernel(unsigned* __restrict__ wp, const float* __restrict__ w, int M, int Mpad,
-                                                          int C, int natural) {
-    pack_direct_body<MODE>(wp, w, M, Mpad, C, natural, blockIdx.x, gridDim.x);
+                                                          int C, int natural, FastDiv fh) {
+    pack_direct_body<MODE>(wp, w, M, Mpad, C, natural, blockIdx.x, gridDim.x, fh);
 }
 
 // ---- Conv3d_1a_7x7 forward, direct: 7x7x7 taps, stride 2, THREE input channels on a 96-wide plane.
@@ -2365,6 +2369,8 @@ static void fill_prep_desc(PrepDesc& d, const ConvArgs& a, int2* ctab, unsigned 
     d.M = a.M; d.Mpad = (a.M + BMsel - 1) / BMsel * BMsel; d.C = C; d.kvol = conv_kvol(a.g);
     d.K = a.K; d.Kp = chunk_kp(a.K); d.nchunk = d.Kp / 8 + CHUNK_PAD; d.kwv = kwv ? 1 : 0; d.natural = a.w_natural; d.mode = MODE;
     d.direct = 0;
+    d.fh = make_fastdiv((uint32_t)(d.Kp / 2));
+    d.fk = make_fastdiv((uint32_t)d.kvol);
 }
 static inline unsigned prep_blocks(const PrepDesc& d) {
     // the pack kernels index with 32 bits: a weight matrix of 2^31 bf16 pairs (8 GB) is refused (0 blocks = launch error)
@@ -2381,8 +2387,8 @@ static inline unsigned prep_blocks(const PrepDesc& d) {
 }
 static void launch_prep(const PrepDesc& d, hipStream_t st) {
     if (d.direct) {
-        if (d.mode == MODE_FWD) hipLaunchKernelGGL((pack_direct_kernel<MODE_FWD>), dim3(prep_blocks(d)), dim3(256), 0, st, d.wp, d.wsrc, d.M, d.Mpad, d.C, d.natural);
-        else hipLaunchKernelGGL((pack_direct_kernel<MODE_DGRAD>), dim3(prep_blocks(d)), dim3(256), 0, st, d.wp, d.wsrc, d.M, d.Mpad, d.C, d.natural);
+        if (d.mode == MODE_FWD) hipLaunchKernelGGL((pack_direct_kernel<MODE_FWD>), dim3(prep_blocks(d)), dim3(256), 0, st, d.wp, d.wsrc, d.M, d.Mpad, d.C, d.natural, d.fh);
+        else hipLaunchKernelGGL((pack_direct_kernel<MODE_DGRAD>), dim3(prep_blocks(d)), dim3(256), 0, st, d.wp, d.wsrc, d.M, d.Mpad, d.C, d.natural, d.fh);
         return;
     }
     if (d.mode == MODE_FWD) hipLaunchKernelGGL((prep_chunks_kernel<MODE_FWD>), dim3(prep_blocks(d)), dim3(256), 0, st, d);
@@ -2655,7 +2661,7 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         const int64_t pairs = (int64_t)Mpad * C * 27 / 2;
         const int blocks = (int)((pairs + 255) / 256 < 2048 ? (pairs + 255) / 256 : 2048);
         hipLaunchKernelGGL((pack_direct_kernel<MODE>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<unsigned*>(ws), a.w,
-                           a.M, Mpad, C, a.w_natural);
+                           a.M, Mpad, C, a.w_natural, make_fastdiv((uint32_t)(C * 27 / 2)));
         if (int e = otal_launch_status()) return e;
     }
     DirectArgs d;
@@ -3059,6 +3065,7 @@ extern "C" int otal_conv_prologue(const int* geom, const int64_t* strides, int m
         const int BM = direct_bm(a.M);
         d.wp = reinterpret_cast<unsigned*>(region); d.wsrc = w; d.g = a.g; d.M = a.M; d.Mpad = (a.M + BM - 1) / BM * BM;
         d.C = mode == MODE_FWD ? a.g.Cin : a.g.Cout; d.natural = a.w_natural; d.mode = mode; d.direct = 1;
+        d.fh = make_fastdiv((uint32_t)(d.C * 27 / 2));
         launch_prep(d, st);
         if (int e = otal_launch_status()) return e > 0 ? -100 - e : e;
         if (host_desc) memcpy(host_desc, &d, sizeof(d));

@@ -36,7 +36,7 @@ struct ConvGeom {
 struct FastDiv {
     uint32_t d, mul, sh, one;   // one = 0xffffffff marks d == 1 (identity), else 0; branch-free at run time
 };
-inline FastDiv make_fastdiv(uint32_t d) {
+OTAL_HD FastDiv make_fastdiv(uint32_t d) {
     FastDiv f;
     f.d = d;
     f.one = 0;

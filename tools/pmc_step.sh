@@ -49,6 +49,9 @@ lines.append(f"{'whole step':16s} {sum(cnt.values()) / steps:13.1f} {'':17s} {''
 conv = res["classes"]["conv gemm"]
 res["conv_traffic_MB_per_launch"] = round((conv["fetch_x2_MB"] + conv["write_MB"]) / conv["launches_per_step"], 2)
 res["step_traffic_MB"] = round(gt, 1)
+sys.path.insert(0, "tools")
+from source_stamp import source_stamp
+res["source_stamp"] = source_stamp()      # bench.py quotes these figures only for the tree they were measured on
 lines.append("")
 lines.append(f"convolution GEMM kernels: {res['conv_traffic_MB_per_launch']} MB of HBM traffic per launch on average")
 open(out + ".txt", "w").write("\n".join(lines) + "\n")

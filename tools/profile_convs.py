@@ -17,12 +17,12 @@ def main():
     rows = []
     orig = ops._prof_end
 
-    def tagged(ev, mode, g):
+    def tagged(ev, mode, g, problems=1):       # problems = 2: a pair launch (two sibling layers in one grid)
         if ev is None:
             return
         end = torch.cuda.Event(enable_timing=True); end.record()
         B, Cin, Cout = g[0], g[1], g[2]
-        flops = 2.0 * B * Cout * g[6] * g[7] * g[8] * Cin * g[9] * g[10] * g[11]
+        flops = 2.0 * B * Cout * g[6] * g[7] * g[8] * Cin * g[9] * g[10] * g[11] * problems
         rows.append((mode, tuple(g[:18]), flops, ev, end))
     ops._prof_end = tagged
     ops.CONV_PROFILE = []
