@@ -51,8 +51,10 @@ class FocalLoss_Ori(nn.Module):
 
 
 class EvidenceLoss(nn.Module):
-    """EDL loss ('log' / 'digamma') with influence-balanced (IBM) re-weighting from a 50-bin EMA
-    (cls_loss.py:212-278) and the IoU-calibration term (cls_loss.py:120-129)."""
+    """EDL loss ('log' / 'digamma' / 'mse', evidence exp / relu / softplus) with influence-balanced (IBM) re-weighting from
+    a 50-bin EMA (cls_loss.py:186-285) and the IoU-calibration term (cls_loss.py:120-129).  The final recipe's
+    combination (exp / log / IBM) runs inside the single-launch HIP loss (csrc/loss.hip); the other kinds use this masked
+    torch formulation on the device."""
 
     def __init__(self, num_cls, cfg, size_average=False):
         super(EvidenceLoss, self).__init__()
@@ -62,7 +64,7 @@ class EvidenceLoss(nn.Module):
         for flag in ('with_focal', 'with_ghm', 'with_ibloss'):
             if cfg.get(flag, False):
                 raise NotImplementedError(f"{flag}: ablation variant outside the opental_final recipe")
-        if self.loss_type not in ('log', 'digamma'):
+        if self.loss_type not in ('log', 'digamma', 'mse'):
             raise NotImplementedError(self.loss_type)
         if cfg.get('soft_label', 0.0):
             raise NotImplementedError("soft_label")
@@ -90,9 +92,16 @@ class EvidenceLoss(nn.Module):
         target = target.view(-1)
         if mask is None:
             mask = torch.ones_like(target, dtype=torch.bool)
-        func = torch.log if self.loss_type == 'log' else torch.digamma
         alpha = self.evidence_func(logit) + 1
         S = alpha.sum(dim=1, keepdim=True)
+        if self.loss_type == 'mse':
+            # mse_loss + loglikelihood_loss (cls_loss.py:186-201,:280-285): squared error of the Dirichlet mean plus its
+            # variance, summed over the positives; the IBM / focal re-weightings do not apply to this loss type there either
+            y = F.one_hot(target, self.num_cls).to(alpha.dtype)
+            per = ((y - alpha / S) ** 2).sum(1) + (alpha * (S - alpha) / (S * S * (S + 1))).sum(1)
+            per = torch.where(mask, per, torch.zeros_like(per))
+            return per.sum() / mask.sum().clamp(min=1) if self.size_average else per.sum()
+        func = torch.log if self.loss_type == 'log' else torch.digamma
         a_y = alpha.gather(1, target.view(-1, 1))
         per = (func(S) - func(a_y)).view(-1)          # sum_k y_k (f(S) - f(alpha_k)) with one-hot y
         if self.with_ibm and self.epoch >= self.ibm_start:

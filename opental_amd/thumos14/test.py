@@ -153,9 +153,13 @@ def get_video_detections(rows, counts, idx_to_class=None, top_k=5000, duration=N
 
 @torch.no_grad()
 def detect_batch(net, videos, sample_fps, clip_length=256, stride=128, conf_thresh=0.01, top_k=5000, nms_sigma=0.5,
-                 batch_clips=32):
+                 batch_clips=32, flow_net=None, flow_videos=None):
     """videos: list of uint8 (C,T,96,96) device tensors (already centre-cropped).  Returns the
-    per-video rows/counts of Soft-NMS.  test.py:203-252 without the JSON dump."""
+    per-video rows/counts of Soft-NMS.  test.py:203-252 without the JSON dump.
+    Two-stream runs (`--fusion`, test.py:227-240 + parse_output :90-108): `flow_net` sees the same windows of
+    `flow_videos` (2-channel optical flow) and the two networks' RAW outputs are averaged before decoding."""
+    if (flow_net is None) != (flow_videos is None):
+        raise RuntimeError("detect_batch: flow_net and flow_videos go together")
     clips, offsets, fps, clip_start = [], [], [], [0]
     for v, data in enumerate(videos):
         offs = get_offsets(data.shape[1], clip_length, stride)
@@ -169,10 +173,18 @@ def detect_batch(net, videos, sample_fps, clip_length=256, stride=128, conf_thre
     # kernels (64 windows: Conv3d_1a's output is 4.8 GB) and the generic kernels take over at half the speed
     batch_clips = max(1, min(int(batch_clips), 32))
     for i in range(0, len(clips), batch_clips):
-        outs.append(net(prepare_windows(videos, clips[i:i + batch_clips], clip_length)))
-    merged = {k: (torch.cat([o[k] for o in outs], 0) if k != 'priors' else outs[0][k])
-              for k in ('loc', 'conf', 'prop_loc', 'prop_conf', 'center', 'act', 'prop_act', 'priors')}
+        out = net(prepare_windows(videos, clips[i:i + batch_clips], clip_length))
+        if flow_net is not None:
+            out = fuse_outputs(out, flow_net(prepare_windows(flow_videos, clips[i:i + batch_clips], clip_length)))
+        outs.append(out)
+    keys = ('loc', 'conf', 'prop_loc', 'prop_conf', 'center', 'act', 'prop_act', 'priors') + \
+        (('unct', 'prop_unct') if flow_net is not None else ())
+    merged = {k: (torch.cat([o[k] for o in outs], 0) if k != 'priors' else outs[0][k]) for k in keys}
     dec = decode_clips(merged, offsets, fps, clip_length, conf_thresh)
+    if flow_net is not None:
+        # the decode kernel derives the uncertainty from the (fused) logits; the reference averages the two networks'
+        # OWN uncertainties instead (parse_output :105-108, decode_predictions :122) -- not the same number
+        dec['unct'] = ((merged['unct'] + merged['prop_unct']) / 2.0).contiguous()
     return softnms_classes(dec, clip_start, top_k, nms_sigma) + (dec,)
 
 
@@ -219,24 +231,31 @@ def prepare_data(data_path, video_name, crop_size, device='cuda'):
 
 
 def fuse_outputs(rgb_out, flow_out):
-    """Two-stream fusion by averaging the two networks' RAW outputs before decoding (test.py:90-108)."""
-    keys = ('loc', 'conf', 'prop_loc', 'prop_conf', 'center', 'act', 'prop_act')
-    fused = {k: (rgb_out[k] + flow_out[k]) / 2.0 for k in keys if rgb_out.get(k) is not None}
+    """Two-stream fusion by averaging the two networks' RAW outputs before decoding (parse_output, test.py:90-108): loc,
+    conf, prop_loc, prop_conf, center, the actionness logits and -- with use_edl -- the two uncertainty maps.
+    Reference hazard (H11): with os_head its parse_output squeezes the rgb actionness to (126,) but not the flow one
+    ((126,1)), so `act + flow_act` broadcasts to (126,126) and decode_predictions fails on the OpenTAL configuration; the
+    elementwise average it evidently means is what is computed here."""
+    keys = ('loc', 'conf', 'prop_loc', 'prop_conf', 'center', 'act', 'prop_act', 'unct', 'prop_unct')
+    fused = {k: (rgb_out[k] + flow_out[k]) / 2.0 for k in keys if rgb_out.get(k) is not None and flow_out.get(k) is not None}
     fused['priors'] = rgb_out['priors']
     return fused
 
 
 def test(net, video_infos, npy_data_path, idx_to_class=None, clip_length=256, stride=128, crop_size=96, conf_thresh=0.01,
-         top_k=5000, nms_sigma=0.5, batch_clips=32, batch_videos=8, rank=0, world=1, device='cuda'):
+         top_k=5000, nms_sigma=0.5, batch_clips=32, batch_videos=8, rank=0, world=1, device='cuda', flow_net=None,
+         flow_data_path=None):
     """The loop of test.py:203-252 over a video list, batched: `batch_videos` videos' windows go through the network
-    together and ONE decode + ONE Soft-NMS launch serve all of them.  Ranks take every world-th video (no collective)."""
+    together and ONE decode + ONE Soft-NMS launch serve all of them.  Ranks take every world-th video (no collective).
+    `flow_net` + `flow_data_path`: the two-stream (fusion) run of test.py:213-240."""
     names = list(video_infos.keys())[rank::world]
     result_dict = {}
     for i in range(0, len(names), batch_videos):
         part = names[i:i + batch_videos]
         vids = [prepare_data(npy_data_path, n, crop_size, device) for n in part]
+        flows = [prepare_data(flow_data_path, n, crop_size, device) for n in part] if flow_net is not None else None
         rows, counts, _, _ = detect_batch(net, vids, [float(video_infos[n]['sample_fps']) for n in part], clip_length, stride,
-                                          conf_thresh, top_k, nms_sigma, batch_clips)
+                                          conf_thresh, top_k, nms_sigma, batch_clips, flow_net=flow_net, flow_videos=flows)
         for v, n in enumerate(part):
             result_dict[n] = get_video_detections(rows[v], counts[v], idx_to_class, top_k)
     return result_dict
@@ -292,20 +311,30 @@ def main(argv=None):
         i += 1
     config = C.set_config(C.get_config(rest))
     te, md, ds = config['testing'], config['model'], config['dataset']['testing']
-    if te.get('fusion', False):
-        raise NotImplementedError("two-stream runs: build both nets and pass fuse_outputs(rgb(x), flow(y)) to decode_clips")
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
     torch.cuda.set_device(dev)
     ops.CONV_PRECISION = 1 if os.environ.get('OTAL_DTYPE', 'bf16') == 'bf16' else 0
-    net = BDNet(in_channels=md['in_channels'], training=False, use_edl=md.get('use_edl', False), cfg=model_cfg_from(config))
-    if not random_init:
-        net.load_state_dict(torch.load(te['checkpoint_path'], map_location='cpu'))
+    flow_net, data_path, flow_path = None, ds['video_data_path'], None
+    if te.get('fusion', False):             # build_model(fusion=True), test.py:24-40: rgb + flow networks, their own checkpoints
+        net = BDNet(in_channels=3, training=False, use_edl=md.get('use_edl', False), cfg=model_cfg_from(config))
+        flow_net = BDNet(in_channels=2, training=False, use_edl=md.get('use_edl', False), cfg=model_cfg_from(config))
+        if not random_init:
+            net.load_state_dict(torch.load(te.get('rgb_checkpoint_path', './models/thumos14/checkpoint-15.ckpt'), map_location='cpu'))
+            flow_net.load_state_dict(torch.load(te.get('flow_checkpoint_path', './models/thumos14_flow/checkpoint-16.ckpt'), map_location='cpu'))
+        flow_net = flow_net.to(dev).eval()
+        data_path = te.get('rgb_data_path', './datasets/thumos14/test_npy/')
+        flow_path = te.get('flow_data_path', './datasets/thumos14/test_flow_npy/')
+    else:
+        net = BDNet(in_channels=md['in_channels'], training=False, use_edl=md.get('use_edl', False), cfg=model_cfg_from(config))
+        if not random_init:
+            net.load_state_dict(torch.load(te['checkpoint_path'], map_location='cpu'))
     net = net.to(dev).eval()
     video_infos = get_video_info(config['dataset']['testing']['video_info_path'])
     _, idx_to_class = get_class_index_map(config['dataset']['class_info_path'])
-    results = test(net, video_infos, ds['video_data_path'], idx_to_class, ds['clip_length'], ds['clip_stride'], ds['crop_size'],
-                   te['conf_thresh'], te['top_k'], te['nms_sigma'], rank=rank, world=world, device=dev)
+    results = test(net, video_infos, data_path, idx_to_class, ds['clip_length'], ds['clip_stride'], ds['crop_size'],
+                   te['conf_thresh'], te['top_k'], te['nms_sigma'], rank=rank, world=world, device=dev, flow_net=flow_net,
+                   flow_data_path=flow_path)
     results = gather_results(results, list(video_infos.keys()), rank, world, dev)
     if results is None:
         return None, None           # ranks > 0: their detections went to rank 0

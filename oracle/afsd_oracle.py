@@ -713,6 +713,17 @@ def decode_predictions(out, idx, offset, fps, cfg=arch.THUMOS):
     return seg, score.transpose(1, 0).contiguous(), unct, actn
 
 
+def fuse_outputs(rgb, flow):
+    """Two-stream fusion of parse_output(fusion=True) (test.py:90-108): the two networks' raw outputs -- and their
+    uncertainty maps -- are averaged before decoding.  (With os_head the reference adds a squeezed (126,) and an
+    unsqueezed (126,1) actionness and breaks; the elementwise average it means is restated here -- pinned with the flow
+    actionness handed to the reference already squeezed.)"""
+    keys = ("loc", "conf", "prop_loc", "prop_conf", "center", "act", "prop_act", "unct", "prop_unct")
+    fused = {k: (rgb[k] + flow[k]) / 2.0 for k in keys}
+    fused["priors"] = rgb["priors"]
+    return fused
+
+
 def filtering(seg, score_cls, unct, actn, conf_thresh=0.01):
     """filtering (test.py:143-162) -> (n,5) rows [start,end,score,unct,act] or None."""
     m = (score_cls > conf_thresh) & (actn > 0.5)

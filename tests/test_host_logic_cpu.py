@@ -54,3 +54,31 @@ def test_plan_cache_distinguishes_layouts():
     xs = wide[:, 2:10]
     k2 = (0, xs.shape, xs.stride(), x.shape, x.stride(), 8, (1, 1, 1), (1, 1, 1), None, False, xs.dtype, x.dtype)
     assert k1 != k2 and hash(k1) != hash(k2)
+
+
+def test_evidence_loss_kinds_match_the_reference_formulas():
+    """EvidenceLoss beyond the final recipe (VERDICT r2 missing #6): evidence relu / softplus / exp and loss types log /
+    digamma / mse, against the formulas of AFSD/thumos14/cls_loss.py:186-285 restated with gathers over the positives
+    (what the reference computes on its boolean-masked rows)."""
+    import torch.nn.functional as F
+    from opental_amd.thumos14.cls_loss import EvidenceLoss
+    g = torch.Generator().manual_seed(4)
+    K, N = 15, 64
+    logit = torch.randn(N, K, generator=g) * 2
+    target = torch.randint(0, K, (N,), generator=g)
+    mask = torch.rand(N, generator=g) > 0.4
+    for evidence in ('exp', 'relu', 'softplus'):
+        ev = {'exp': lambda z: torch.exp(z.clamp(-10, 10)), 'relu': F.relu, 'softplus': F.softplus}[evidence]
+        for loss_type in ('log', 'digamma', 'mse'):
+            crit = EvidenceLoss(K, dict(loss_type=loss_type, evidence=evidence))
+            got = crit(logit, target, mask)
+            z, t = logit[mask], target[mask]
+            alpha = ev(z) + 1
+            S = alpha.sum(1, keepdim=True)
+            y = torch.eye(K)[t]
+            if loss_type == 'mse':
+                want = ((y - alpha / S) ** 2).sum() + (alpha * (S - alpha) / (S * S * (S + 1))).sum()
+            else:
+                f = torch.log if loss_type == 'log' else torch.digamma
+                want = (y * (f(S) - f(alpha))).sum()
+            assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), (evidence, loss_type, float(got), float(want))

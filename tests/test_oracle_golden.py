@@ -91,3 +91,18 @@ def test_ssl_triplet_branch_matches_reference_vectors(golden_dir):
                 np.testing.assert_allclose(got[i].numpy(), fx[f"ssl{si}_{nm}_{i}"], rtol=0, atol=1e-6)
         assert abs(cost - float(fx[f"ssl{si}_cost"])) < 1e-5
         assert abs(cost - float(fx[f"ssl{si}_terms"].sum())) < 1e-5
+
+
+def test_two_stream_fusion_matches_reference_vectors(golden_dir):
+    """O.fuse_outputs + O.decode_predictions regenerate the reference's parse_output(fusion=True) + decode_predictions
+    (tests/golden/decode_fusion.npz, oracle/pin_fusion.py) from the two samples of the b = 2 fixture."""
+    fx, want = np.load(os.path.join(golden_dir, "thumos_b2.npz")), np.load(os.path.join(golden_dir, "decode_fusion.npz"))
+    keys = ("loc", "conf", "prop_loc", "prop_conf", "center", "act", "prop_act", "unct", "prop_unct")
+    priors = torch.tensor([[(c + 0.5) / t] for t in arch.level_lengths() for c in range(t)], dtype=torch.float32)
+    one = lambda i: dict({k: torch.from_numpy(fx["out_" + k][i:i + 1]) for k in keys}, priors=priors)
+    fused = O.fuse_outputs(one(0), one(1))
+    for idx in (0, 1):
+        offset, fps = want[f"offset_fps_{idx}"]
+        seg, score, unct, act = O.decode_predictions(fused, 0, float(offset), float(fps))
+        for got, k in ((seg, "seg"), (score, "score"), (unct, "unct"), (act, "act")):
+            np.testing.assert_allclose(got.numpy(), want[f"{k}_{idx}"], rtol=0, atol=1e-6)
