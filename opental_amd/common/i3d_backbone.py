@@ -286,19 +286,25 @@ class I3DFeaturesFunction(Function):
         x = x.contiguous()
         sc = lambda i: scale[offs[i]:offs[i + 1]]
         sh = lambda i: shift[offs[i]:offs[i + 1]]
-        tape, found = [], {}
+        tape, found, half_grads = [], {}, {}
         cur = x
         cur_scale = None            # bn scale vector of the tensor `cur` when it is a conv/mixed output
         for si, step in enumerate(plan):
             kind, name = step[0], step[-1]
             if kind == "conv":
                 _, wi, k, s, _ = step
-                # a convolution whose output only feeds a strided pool (Conv3d_1a -> MaxPool3d_2a) may store it as bf16:
-                # the pool commutes with the rounding the next convolution applies to its operand anyway
-                half = (si == 0 and not x.requires_grad and name not in endpoints and si + 1 < len(plan) and plan[si + 1][0] == "pool"
-                        and tuple(plan[si + 1][1]) == (1, 3, 3) and tuple(plan[si + 1][2]) == (1, 2, 2)
-                        and ops.half_storage_ok(0, tuple(cur.shape), weights[wi].shape[0], k, s)
-                        and ops.half_storage_ok(2, tuple(cur.shape), weights[wi].shape[0], k, s))
+                # a convolution whose output only feeds a strided (1,3,3)/(1,2,2) pool -- Conv3d_1a -> MaxPool3d_2a, Conv3d_2c ->
+                # MaxPool3d_3a -- may store it as bf16: the pool commutes with the rounding the next convolution applies to its
+                # operand anyway, and the pool keeps the layer's ReLU mask as sign bits.  For the FIRST layer (no data gradient)
+                # the gradient of that tensor is stored as bf16 too (its only consumer, the weight gradient, rounds it anyway);
+                # deeper layers keep fp32 gradients.
+                pooled_next = (name not in endpoints and si + 1 < len(plan) and plan[si + 1][0] == "pool"
+                               and tuple(plan[si + 1][1]) == (1, 3, 3) and tuple(plan[si + 1][2]) == (1, 2, 2)
+                               and ops.half_storage_ok(0, tuple(cur.shape), weights[wi].shape[0], k, s))
+                grad_half = (pooled_next and si == 0 and not x.requires_grad
+                             and ops.half_storage_ok(2, tuple(cur.shape), weights[wi].shape[0], k, s))
+                half = pooled_next and (grad_half or (si > 0 and ops.HALF_ACT_DIRECT))
+                half_grads[si + 1] = grad_half
                 y = ops.conv_forward(cur, weights[wi], k, s, scale=sc(wi), shift=sh(wi), relu=True, half_out=half)
                 tape.append(("conv", wi, k, s, cur, y, cur_scale, sc(wi)))
                 cur, cur_scale = y, sc(wi)
@@ -307,7 +313,7 @@ class I3DFeaturesFunction(Function):
                 # a pool behind a conv + ReLU: let the forward kernel keep that layer's ReLU mask as sign bits, so that the
                 # backward pass does not re-read the 4-byte activations only for their sign
                 y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=cur_scale is not None)
-                tape.append(("pool", k, s, cur, (arg, bits), cur_scale, None))
+                tape.append(("pool", k, s, cur, (arg, bits, half_grads.get(si, False)), cur_scale, None))
                 cur, cur_scale = y, None
             else:
                 _, w0, oc, _ = step
@@ -407,8 +413,8 @@ class I3DFeaturesFunction(Function):
                     dcur = ops.conv_dgrad(dcur, weights[wi], xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, dcur),
                                           out_mask=xin if in_scale is not None else None, out_scale=in_scale)
             elif step[0] == "pool":
-                _, k, s, xin, (arg, bits), in_scale, _ = step
-                if xin.dtype == torch.bfloat16:             # bf16-stored activation: its gradient is stored the same way
+                _, k, s, xin, (arg, bits, grad_half), in_scale, _ = step
+                if grad_half:                               # Conv3d_1a's bf16-stored output: its gradient is stored the same way
                     dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out_scale=in_scale, out_signbits=bits, half_out=True)
                 else:
                     dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, dcur),

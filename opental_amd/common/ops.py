@@ -29,6 +29,10 @@ CONV_PRECISION = 0
 # bf16 STORAGE of the largest activations in the bf16-operand mode (Conv3d_1a's output and its gradient: the tensors are
 # only ever consumed through bf16 roundings, so the forward values do not change).  False: fp32 tensors everywhere.
 HALF_STORAGE = os.environ.get("OTAL_HALF_STORAGE", "1") != "0"
+# ... and of the outputs of direct 3x3x3 layers that only feed a strided pool (Conv3d_2c -> MaxPool3d_3a).  OFF by default:
+# measured 11.66 vs 11.68 ms per step (within noise: the layer is MFMA/LDS-bound, not store-bound), while the pool ties the
+# rounding creates move Conv3d_1a's weight gradient further (cosine 0.989 vs 0.997 with the fp32-stored run).
+HALF_ACT_DIRECT = os.environ.get("OTAL_HALF_ACT_DIRECT", "0") != "0"
 
 
 def _prof_begin():

@@ -1958,6 +1958,48 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
         store(buf ^ 1, sn);
         __syncthreads();
     }
+    if constexpr (MODE == MODE_FWD) {
+        if (a.half) {
+            // bf16-STORED output (a layer that only feeds a strided max-pool: Conv3d_2c -> MaxPool3d_3a; the pool commutes with
+            // the monotonic rounding, so the forward values do not change): scale / shift / ReLU, transpose through LDS (the
+            // operand tiles are dead: BM rows x BNP positions of bf16 + 16 bytes of pitch fit in them), 16-byte runs
+            // along the positions -- half the bytes of the fp32 epilogue, which ran at the HBM write rate with idle matrix pipes.
+            constexpr int PT = BNP * 2 + 16;
+            static_assert(BM * PT + BM * 8 <= 2 * BM * PA + 2 * SPAN_MAX * PX, "staging tile fits in the operand buffers");
+            unsigned char* tile = dsm;
+            float* rows = reinterpret_cast<float*>(dsm + BM * PT);
+            for (int r = tid; r < BM; r += DNT) {
+                const int m = m0 + r;
+                rows[2 * r] = (m < a.M && a.scale) ? a.scale[m] : 1.f;
+                rows[2 * r + 1] = (m < a.M && a.shift) ? a.shift[m] : 0.f;
+            }
+            __syncthreads();
+            const bool relu = (a.flags & EPI_RELU) != 0;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int nl = (wave * WN + j) * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        float v = acc[i][j][r] * rows[2 * lr] + rows[2 * lr + 1];
+                        if (relu) v = fmaxf(v, 0.f);
+                        *reinterpret_cast<unsigned short*>(tile + lr * PT + nl * 2) = (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);
+                    }
+                }
+            __syncthreads();
+            unsigned short* yh = reinterpret_cast<unsigned short*>(a.out);
+            const int64_t ybase = (int64_t)bsm * g.y_bs + p0;
+            for (int p = tid; p < BM * (BNP / 8); p += DNT) {
+                const int row = p / (BNP / 8), q = p - row * (BNP / 8);
+                if (m0 + row >= a.M || n0 + q * 8 >= a.N) continue;
+                const uint4 v = *reinterpret_cast<const uint4*>(tile + row * PT + q * 16);
+                *reinterpret_cast<uint4*>(yh + ybase + (int64_t)(m0 + row) * g.y_cs + q * 8) = v;
+            }
+            return;
+        }
+    }
     store_acc<MODE, WM, WN, BM>(a, acc, m0, n0, 0, wave * WN * 32, lane, 0, reinterpret_cast<float*>(smA(0)));
 }
 
@@ -2729,8 +2771,10 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
             const int e = launch_proj_fwd(a, ws, ws_bytes, st);
             if (e != OTAL_E_UNSUPPORTED) return e;
         }
-        if (a.half && !OTAL_OPT("OTAL_CONV_NO1A", 0)) {     // bf16-stored y: Conv3d_1a only
-            if (conv1a_direct_eligible(a.g, MODE, a.prec, a.x) && conv1a_half_out_ok(a.g, a.out)) return launch_conv1a_direct(a, ws, ws_bytes, st);
+        if (a.half) {       // bf16-stored y: Conv3d_1a's direct kernel and the direct 3x3x3 kernel
+            if (!OTAL_OPT("OTAL_CONV_NO1A", 0) && conv1a_direct_eligible(a.g, MODE, a.prec, a.x) && conv1a_half_out_ok(a.g, a.out))
+                return launch_conv1a_direct(a, ws, ws_bytes, st);
+            if (direct_eligible(a.g, MODE, a.prec, a.M) && conv1a_half_out_ok(a.g, a.out)) return launch_direct<MODE>(a, ws, ws_bytes, st);
             return OTAL_E_UNSUPPORTED;
         }
         if (conv1a_direct_eligible(a.g, MODE, a.prec, a.x)) return launch_conv1a_direct(a, ws, ws_bytes, st);
@@ -2980,7 +3024,10 @@ extern "C" int otal_conv_half_storage(const int* geom, const int64_t* strides, i
     if (!geom || !strides || fill_geom(a.g, geom) || !(precision & 1)) return 0;
     a.g.x_bs = strides[0]; a.g.x_cs = strides[1]; a.g.y_bs = strides[2]; a.g.y_cs = strides[3];
     if (a.g.y_bs % 8 || a.g.y_cs % 8) return 0;
-    if (mode == MODE_FWD) return conv1a_direct_eligible(a.g, MODE_FWD, 1, nullptr) && !OTAL_OPT("OTAL_CONV_NO1A", 0) ? 1 : 0;
+    if (mode == MODE_FWD) {
+        if (conv1a_direct_eligible(a.g, MODE_FWD, 1, nullptr) && !OTAL_OPT("OTAL_CONV_NO1A", 0)) return 1;
+        return direct_eligible(a.g, MODE_FWD, 1, a.g.Cout) && !OTAL_OPT("OTAL_CONV_NODIRECT_HALF", 0) ? 1 : 0;
+    }
     if (mode == MODE_WGRAD) return conv1a_wgrad_eligible(a.g, 1, nullptr, nullptr) ? 1 : 0;
     return 0;
 }

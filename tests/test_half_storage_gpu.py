@@ -35,10 +35,28 @@ def test_conv1a_bf16_output_is_the_rounded_fp32_output(shape, cout):
     y16 = ops.conv_forward(x, w, (7, 7, 7), (2, 2, 2), scale=sc, shift=sh, relu=True, half_out=True)
     assert y16.dtype == torch.bfloat16 and y16.shape == y32.shape
     assert torch.equal(y16, _rne(y32))
-    assert not ops.half_storage_ok(0, (1, 64, 8, 24, 24), 192, (3, 3, 3), (1, 1, 1))      # other layers: fp32 tensors
+    assert not ops.half_storage_ok(0, (1, 64, 8, 24, 24), 64, (1, 1, 1), (1, 1, 1))       # other kernels: fp32 tensors
     with pytest.raises(RuntimeError):
-        ops.conv_forward(torch.randn(1, 64, 4, 24, 24, device="cuda"), torch.randn(64, 64, 3, 3, 3, device="cuda"), (3, 3, 3), (1, 1, 1),
+        ops.conv_forward(torch.randn(1, 64, 4, 24, 24, device="cuda"), torch.randn(64, 64, 1, 1, 1, device="cuda"), (1, 1, 1), (1, 1, 1),
                          half_out=True)
+
+
+@pytest.mark.parametrize("shape,cout", [((2, 64, 8, 24, 24), 192), ((1, 64, 4, 8, 16), 192), ((1, 32, 2, 16, 8), 96),
+                                        ((1, 96, 16, 12, 12), 208)])
+def test_direct_3x3x3_bf16_output_is_the_rounded_fp32_output(shape, cout):
+    """Conv3d_2c -> MaxPool3d_3a: the LDS-direct 3x3x3 kernel's bf16 epilogue (affine + ReLU, rounded to nearest even)."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape) + cout)
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    w = torch.from_numpy((rs.randn(cout, shape[1], 3, 3, 3) * 0.05).astype(np.float32)).cuda()
+    sc = torch.from_numpy((rs.rand(cout) + 0.5).astype(np.float32)).cuda()
+    sh = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    if not ops.half_storage_ok(0, shape, cout, (3, 3, 3), (1, 1, 1)):
+        pytest.skip("geometry not served by the direct kernel")
+    y16 = ops.conv_forward(x, w, (3, 3, 3), (1, 1, 1), scale=sc, shift=sh, relu=True, half_out=True)
+    y32 = ops.conv_forward(x, w, (3, 3, 3), (1, 1, 1), scale=sc, shift=sh, relu=True)      # same kernel, fp32 epilogue
+    assert y16.dtype == torch.bfloat16 and y16.shape == y32.shape
+    assert torch.equal(y16, _rne(y32))
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 6, 48, 48), (1, 3, 2, 6, 8)])
