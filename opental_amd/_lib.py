@@ -48,9 +48,14 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+STREAM_OVERRIDE = None      # a raw stream handle: launches go there instead of torch's current stream (ops.SideWgrads)
+
+
 def stream():
     """The raw HIP stream torch is currently launching on (side streams and graph capture included).  Goes through the
     C bindings directly: torch.cuda.current_stream() builds a Stream object (~10 us) and this runs ~110 times per step."""
+    if STREAM_OVERRIDE is not None:
+        return ctypes.c_void_p(STREAM_OVERRIDE)
     try:
         return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
     except AttributeError:          # private bindings moved: the public (slower) route

@@ -53,9 +53,10 @@ def _prof_end(ev, mode, g, problems=1):
     CONV_PROFILE.append((mode, flops, ev, end))
 
 
-def workspace(device):
-    """One split-K scratch buffer per device; launches on a stream are serialised, so sharing is safe."""
-    key = (device.type, device.index)
+def workspace(device, side=False):
+    """One split-K scratch buffer per device and stream (the main stream's, and the weight-gradient side stream's --
+    SideWgrads); launches on a stream are serialised, so sharing within one is safe."""
+    key = (device.type, device.index, side)
     ws = _WORKSPACE.get(key)
     if ws is None:
         ws = torch.empty(WORKSPACE_TOTAL, dtype=torch.uint8, device=device)
@@ -65,16 +66,23 @@ def workspace(device):
 
 # ---- deferred weight-gradient reductions (include/opental_hip.h: otal_conv_defer_reduces).  While a trainer's backward
 # runs, the split-K reduce of a weight gradient is recorded instead of launched; its slabs stay in the workspace and every
-# later launch works BEHIND them (_WS_CURSOR); flush_reduces() runs all recorded reductions as one launch -- called when
-# the backbone announces a module's gradients (grads_ready), at the trainer's bucket flushes, and when the slabs fill up.
+# later launch on that stream works BEHIND them (_WS_CURSOR); flush_reduces() runs all recorded reductions as one launch --
+# called when the backbone announces a module's gradients (grads_ready), at the trainer's bucket flushes, and when the
+# slabs fill up.  The library keeps ONE list of recorded reductions, so all of them sit on one stream at a time
+# (_DEFER_OWNER: (side workspace?, torch stream or None = the current one)); a weight gradient issued on the other stream
+# flushes them first.
 _DEFER = False
-_WS_CURSOR = 0
+_WS_CURSOR = [0, 0]         # main / side workspace
+_WS_SIDE = False            # True while SideWgrads issues a launch on its stream
+_SIDE_NOW = None            # ... and that torch stream
+_DEFER_OWNER = None
 
 
 def _ws_args(device):
     """(pointer, size) of the workspace a launch may use now."""
-    ws = workspace(device)
-    return ctypes.c_void_p(ws.data_ptr() + _WS_CURSOR), ctypes.c_size_t(min(ws.numel() - _WS_CURSOR, WORKSPACE_BYTES))
+    ws = workspace(device, _WS_SIDE)
+    cur = _WS_CURSOR[_WS_SIDE]
+    return ctypes.c_void_p(ws.data_ptr() + cur), ctypes.c_size_t(min(ws.numel() - cur, WORKSPACE_BYTES))
 
 
 def defer_reduces(on):
@@ -86,22 +94,88 @@ def defer_reduces(on):
 
 
 def flush_reduces():
-    global _WS_CURSOR
-    if _DEFER and _WS_CURSOR:
-        L.check(L.lib().otal_conv_flush_reduces(L.stream()), "otal_conv_flush_reduces")
-    _WS_CURSOR = 0
+    """Run the recorded reductions on the stream their slabs were written on; when that is not the stream the caller
+    launches on, the caller's stream waits for them."""
+    global _DEFER_OWNER
+    own = _DEFER_OWNER
+    if _DEFER and own is not None:
+        stream = own[1]
+        if stream is None:
+            L.check(L.lib().otal_conv_flush_reduces(L.stream()), "otal_conv_flush_reduces")
+        else:
+            L.check(L.lib().otal_conv_flush_reduces(ctypes.c_void_p(stream.cuda_stream)), "otal_conv_flush_reduces")
+            if L.STREAM_OVERRIDE != stream.cuda_stream:
+                torch.cuda.current_stream().wait_stream(stream)
+    _DEFER_OWNER = None
+    _WS_CURSOR[0] = _WS_CURSOR[1] = 0
 
 
 def _after_wgrad(device):
     """Advance the workspace cursor past the slabs a deferred reduction still needs; flush when they pile up."""
-    global _WS_CURSOR
+    global _DEFER_OWNER
     lib = L.lib()
     lib.otal_conv_deferred_end.restype = ctypes.c_size_t
     end = int(lib.otal_conv_deferred_end())
     if end:
-        _WS_CURSOR = (end - workspace(device).data_ptr() + 255) & ~255
-        if _WS_CURSOR > WORKSPACE_TOTAL - WORKSPACE_BYTES:
+        _DEFER_OWNER = (_WS_SIDE, _SIDE_NOW)
+        _WS_CURSOR[_WS_SIDE] = (end - workspace(device, _WS_SIDE).data_ptr() + 255) & ~255
+        if _WS_CURSOR[_WS_SIDE] > WORKSPACE_TOTAL - WORKSPACE_BYTES:
             flush_reduces()
+
+
+# ---- weight gradients on a second HIP stream.  Inside a multi-layer backward node the weight gradient of a layer and its
+# data gradient only share their INPUT (dy): the data-gradient chain is the critical path, the weight gradients hang off
+# it.  Most of the backbone's layers work on 6x6 / 3x3 planes and cannot fill 256 CUs on their own (split-K and ~40 us
+# launches at 50-250 TFLOP/s), so the two families run on two streams and share the chip.  Results are bit-identical:
+# same kernels, same order within each family.
+WGRAD_STREAM = os.environ.get("OTAL_WGRAD_STREAM", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        prio = int(os.environ.get("OTAL_WGRAD_STREAM_PRIORITY", "0"))
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=prio)
+    return st
+
+
+class SideWgrads:
+    """wgrad(...) = conv_wgrad(...) issued on the side stream behind everything the main stream has been given so far;
+    join() makes the main stream wait for all of them (and runs their recorded reductions).  The caller keeps x alive
+    until join(); dy is kept here (the caching allocator would otherwise hand its block to a later main-stream launch
+    while the side stream still reads it)."""
+
+    def __init__(self, device):
+        self.on = WGRAD_STREAM and CONV_PROFILE is None and device.type == "cuda"
+        self.keep = []
+        if self.on:
+            self.main = torch.cuda.current_stream(device)
+            self.side = _side_stream(device)
+
+    def wgrad(self, x, dy, w_shape, k, s, out=None):
+        global _WS_SIDE, _SIDE_NOW
+        if not self.on:
+            return conv_wgrad(x, dy, w_shape, k, s, out=out)
+        if _DEFER_OWNER is not None and not _DEFER_OWNER[0]:
+            flush_reduces()                 # reductions recorded on the main stream: run them there first
+        self.side.wait_stream(self.main)
+        _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = True, self.side, self.side.cuda_stream
+        try:
+            dw = conv_wgrad(x, dy, w_shape, k, s, out=out)
+        finally:
+            _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = False, None, None
+        self.keep.append(dy)
+        return dw
+
+    def join(self):
+        if self.on and self.keep:
+            if _DEFER and _DEFER_OWNER is not None and _DEFER_OWNER[0]:
+                flush_reduces()             # on the side stream; the main stream waits behind them
+            else:
+                self.main.wait_stream(self.side)
+            self.keep.clear()
 
 
 def _as5(t):
@@ -514,8 +588,8 @@ def conv_wgrad(x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None,
         out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device)
     if not out.is_contiguous():
         raise RuntimeError("dw must be contiguous")
-    if _DEFER and accumulate:
-        flush_reduces()             # a recorded reduction may still be on its way to this very buffer
+    if _DEFER and (accumulate or (_DEFER_OWNER is not None and _DEFER_OWNER[0] != _WS_SIDE)):
+        flush_reduces()             # a recorded reduction may still be on its way to this very buffer / sits on the other stream
     wsp, wsn = _ws_args(x.device)
     ev = _prof_begin()
     prec = int(CONV_PRECISION)
@@ -611,6 +685,8 @@ def conv_wgrad_pair(xs, dys, w_shape, k, s, levels=None, outs=(None, None)):
     outs = [o if o is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=xs[0].device) for o in outs]
     if not (outs[0].is_contiguous() and outs[1].is_contiguous()):
         return None
+    if _DEFER and _DEFER_OWNER is not None and _DEFER_OWNER[0] != _WS_SIDE:
+        flush_reduces()
     wsp, wsn = _ws_args(xs[0].device)
     ev = _prof_begin()
     rc = L.lib().otal_conv_wgrad_pair(ga, sa, _pp(*xs), _pp(*dys), _pp(*outs), int(CONV_PRECISION), wsp, wsn, L.stream())

@@ -43,3 +43,41 @@ def test_repeated_forward_backward_is_bit_identical(batch, iters, prec):
             assert torch.equal(cur[1], first[1]), f"run {it}: {int((cur[1] != first[1]).sum())} gradient elements differ"
     finally:
         ops.CONV_PRECISION = old
+
+
+@pytest.mark.parametrize("batch,prec", [(2, 1), (1, 0)])
+def test_weight_gradients_on_the_side_stream_change_nothing(batch, prec):
+    """ops.SideWgrads: the backbone's weight gradients run on a second stream beside the data-gradient chain.  Same
+    kernels in the same order within each family: cost and gradient arena equal the one-stream run's, bit for bit, on
+    every repetition (a missing wait between the two streams would show up as a differing run)."""
+    import bench
+    from opental_amd.common import ops
+    old = (ops.CONV_PRECISION, ops.WGRAD_STREAM)
+    ops.CONV_PRECISION = prec
+    try:
+        dev = torch.device("cuda", 0)
+        tr = bench.build_trainer(dev)
+        clips, targets, scores = bench.synth_batch(batch, 1000, dev)
+        ibm = tr._ibm_state()
+        ibm0 = None if ibm is None else ibm.detach().clone()
+        runs = []
+        for side in (False, True, True, False, True, True, True, True):
+            ops.WGRAD_STREAM = side
+            if ibm0 is not None:
+                tr._ibm_state().copy_(ibm0)
+            tr.arena.grad.zero_()
+            ops.activate_prologues(tr._prologues)
+            try:
+                cost, _ = tr.compute_cost(clips, targets, scores)
+                tr.begin_backward(early=True)
+                cost.backward()
+                tr.end_backward()
+            finally:
+                ops.deactivate_prologues(); ops.GRAD_SLOTS = None; ops.GRAD_READY = None
+            torch.cuda.synchronize()
+            runs.append((side, float(cost.detach()), tr.arena.grad.detach().clone()))
+        for side, c, g in runs[1:]:
+            assert c == runs[0][1]
+            assert torch.equal(g, runs[0][2]), f"side={side}: {int((g != runs[0][2]).sum())} gradient elements differ"
+    finally:
+        ops.CONV_PRECISION, ops.WGRAD_STREAM = old
