@@ -377,8 +377,10 @@ class I3DFeaturesFunction(Function):
             return torch.empty(tuple(shape), dtype=like.dtype, device=like.device)
 
         # weight gradients run on a second stream beside the data-gradient chain (ops.SideWgrads); the main stream joins
-        # them where a module's gradients are announced and at the end of the node
-        side = ops.SideWgrads(weights[0].device)
+        # them where a data-parallel trainer hands a module's gradients to RCCL (grads_ready -> bucket flush), at the end
+        # of the node, or -- a single-GPU trainer writing into its arena -- not before the optimizer step
+        side = ops.side_wgrads(weights[0].device)
+        in_slots = True
         dcur = None
         cloned = True               # False while dcur still aliases an incoming gradient tensor
         for pos in range(len(tape), 0, -1):
@@ -408,13 +410,15 @@ class I3DFeaturesFunction(Function):
             first = pos == 1
             if step[0] == "conv":
                 _, wi, k, s, xin, y, in_scale, _ = step
-                dws[wi] = side.wgrad(xin, dcur, weights[wi].shape, k, s, out=ops.grad_slot(weights[wi]))
+                slot = ops.grad_slot(weights[wi])
+                in_slots = in_slots and slot is not None
+                dws[wi] = side.wgrad(xin, dcur, weights[wi].shape, k, s, out=slot)
                 if first and not need_dx:
                     dcur = None
                 else:
                     dcur = ops.conv_dgrad(dcur, weights[wi], xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, dcur),
                                           out_mask=xin if in_scale is not None else None, out_scale=in_scale)
-                side.join()
+                side.flush()
                 ops.grads_ready([(weights[wi], dws[wi])])
             elif step[0] == "pool":
                 _, k, s, xin, (arg, bits, grad_half), in_scale, _ = step
@@ -433,21 +437,27 @@ class I3DFeaturesFunction(Function):
                 sl = (slice(0, c1), slice(c1, c2), slice(c2, c3), slice(c3, Y.shape[1]))
                 for a, b, hid, sli, dst in ((w0 + 1, w0 + 2, h1, sl[1], Zg[:, :o1]), (w0 + 3, w0 + 4, h2, sl[2], Zg[:, o1:o13])):
                     g = dY[:, sli]
-                    dws[b] = side.wgrad(hid, g, weights[b].shape, THREE, ONE, out=ops.grad_slot(weights[b]))
+                    slot = ops.grad_slot(weights[b])
+                    in_slots = in_slots and slot is not None
+                    dws[b] = side.wgrad(hid, g, weights[b].shape, THREE, ONE, out=slot)
                     ops.conv_dgrad(g, weights[b], hid.shape, THREE, ONE, out=dst, out_mask=hid, out_scale=sc(a))
                 gf = Zg[:, :o13 + c1]       # gradients of the fused 1x1 outputs: dh1, dh2, dY[:, :c1]
-                dwf = side.wgrad(xin, gf, wf.shape, ONE, ONE, out=ops.grad_slot(wf))
+                slot = ops.grad_slot(wf)
+                in_slots = in_slots and slot is not None
+                dwf = side.wgrad(xin, gf, wf.shape, ONE, ONE, out=slot)
                 dws[w0 + 1], dws[w0 + 3], dws[w0] = dwf[:o1], dwf[o1:o13], dwf[o13:]
                 ops.conv_dgrad(gf, wf, xin.shape, ONE, ONE, out=dX, out_mask=xm, out_scale=in_scale)
                 g3 = dY[:, sl[3]]
-                dws[w0 + 5] = side.wgrad(pm, g3, weights[w0 + 5].shape, ONE, ONE, out=ops.grad_slot(weights[w0 + 5]))
+                slot = ops.grad_slot(weights[w0 + 5])
+                in_slots = in_slots and slot is not None
+                dws[w0 + 5] = side.wgrad(pm, g3, weights[w0 + 5].shape, ONE, ONE, out=slot)
                 dpm = ops.conv_dgrad(g3, weights[w0 + 5], pm.shape, ONE, ONE)
                 ops.maxpool3d_backward(dpm, argm, xin.shape, THREE, ONE, out=dX, accumulate=True,
                                        out_mask=xm, out_scale=in_scale)
                 dcur = dX
-                side.join()
+                side.flush()
                 ops.grads_ready([(weights[w0 + q], dws[w0 + q]) for q in range(6)])      # this module's six weights are final
-        side.join()
+        side.node_end(in_slots)
         ctx.tape = None
         ctx.outs = None
         dx = dcur if need_dx else None

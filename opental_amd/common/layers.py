@@ -39,8 +39,11 @@ class ConvSameFunction(Function):
         if ctx.needs_input_grad[0]:
             dx = (ops.conv_dgrad_collapse(dy, w, x.shape) if ops.is_full_collapse(x.shape, k, s, sv)
                   else ops.conv_dgrad(dy, w, x.shape, k, s, spatial_valid=sv, levels=lev))
-        dw = (ops.conv_wgrad(x, dy, w.shape, k, s, spatial_valid=sv, levels=lev, out=ops.grad_slot(w))
-              if ctx.needs_input_grad[1] else None)
+        dw = None
+        if ctx.needs_input_grad[1]:         # on the weight-gradient stream, beside the data gradient (ops.SideWgrads)
+            slot, side = ops.grad_slot(w), ops.side_wgrads(x.device)
+            dw = side.wgrad(x, dy, w.shape, k, s, spatial_valid=sv, levels=lev, out=slot)
+            side.node_end(slot is not None)
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=[0] + list(range(2, dy.dim())))
@@ -74,7 +77,9 @@ class ConvGNReLUFunction(Function):
         if ctx.needs_input_grad[0]:
             dx = (ops.conv_dgrad_collapse(dc5, w, x.shape) if ops.is_full_collapse(x.shape, k, s, sv)
                   else ops.conv_dgrad(dc5, w, x.shape, k, s, spatial_valid=sv, levels=lev))
-        dw = ops.conv_wgrad(x, dc5, w.shape, k, s, spatial_valid=sv, levels=lev, out=ops.grad_slot(w))
+        slot, side = ops.grad_slot(w), ops.side_wgrads(x.device)
+        dw = side.wgrad(x, dc5, w.shape, k, s, spatial_valid=sv, levels=lev, out=slot)
+        side.node_end(slot is not None)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -113,9 +118,11 @@ class ConvGNReLUPairFunction(Function):
             if dxs is None:
                 dxs = [ops.conv_dgrad(dc, w, x0.shape, k, s, levels=lev) for dc, w in ((dc0, w0), (dc1, w1))]
         slots = (ops.grad_slot(w0), ops.grad_slot(w1))
-        dws = ops.conv_wgrad_pair((x0, x1), (dc0, dc1), w0.shape, k, s, lev, slots)
+        side = ops.side_wgrads(x0.device)
+        dws = side.wgrad_pair((x0, x1), (dc0, dc1), w0.shape, k, s, lev, slots)
         if dws is None:
-            dws = [ops.conv_wgrad(x, dc, w0.shape, k, s, levels=lev, out=o) for x, dc, o in ((x0, dc0, slots[0]), (x1, dc1, slots[1]))]
+            dws = [side.wgrad(x, dc, w0.shape, k, s, levels=lev, out=o) for x, dc, o in ((x0, dc0, slots[0]), (x1, dc1, slots[1]))]
+        side.node_end(slots[0] is not None and slots[1] is not None)
         return (dxs[0], dxs[1], dws[0], dws[1], db0, db1, dg0, dg1, dbe0, dbe1, None, None, None, None, None)
 
 

@@ -93,9 +93,16 @@ def defer_reduces(on):
     _DEFER = bool(on)
 
 
-def flush_reduces():
+def _stream_wait(stream):
+    """torch's current stream waits for what `stream` has been given so far (works inside a graph capture)."""
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    ev.wait()
+
+
+def flush_reduces(wait=True):
     """Run the recorded reductions on the stream their slabs were written on; when that is not the stream the caller
-    launches on, the caller's stream waits for them."""
+    launches on, the caller's stream waits for them (unless wait=False: the caller joins the side stream later)."""
     global _DEFER_OWNER
     own = _DEFER_OWNER
     if _DEFER and own is not None:
@@ -104,8 +111,8 @@ def flush_reduces():
             L.check(L.lib().otal_conv_flush_reduces(L.stream()), "otal_conv_flush_reduces")
         else:
             L.check(L.lib().otal_conv_flush_reduces(ctypes.c_void_p(stream.cuda_stream)), "otal_conv_flush_reduces")
-            if L.STREAM_OVERRIDE != stream.cuda_stream:
-                torch.cuda.current_stream().wait_stream(stream)
+            if wait and L.STREAM_OVERRIDE != stream.cuda_stream:
+                _stream_wait(stream)
     _DEFER_OWNER = None
     _WS_CURSOR[0] = _WS_CURSOR[1] = 0
 
@@ -123,59 +130,89 @@ def _after_wgrad(device):
             flush_reduces()
 
 
-# ---- weight gradients on a second HIP stream.  Inside a multi-layer backward node the weight gradient of a layer and its
-# data gradient only share their INPUT (dy): the data-gradient chain is the critical path, the weight gradients hang off
-# it.  Most of the backbone's layers work on 6x6 / 3x3 planes and cannot fill 256 CUs on their own (split-K and ~40 us
-# launches at 50-250 TFLOP/s), so the two families run on two streams and share the chip.  Results are bit-identical:
-# same kernels, same order within each family.
+# ---- weight gradients on a second HIP stream.  The weight gradient of a layer and its data gradient only share their
+# INPUT (dy): the data-gradient chain is the critical path of the backward pass, the weight gradients hang off it, and
+# nothing on the main stream reads them before the trainer's bucket flush / optimizer step.  Most of the layers work on
+# 6x6 / 3x3 planes or 1-D maps and cannot fill 256 CUs on their own (split-K, ~20-40 us launches at 50-250 TFLOP/s), so the
+# two families run on two streams and share the chip.  Results are bit-identical: same kernels, same order within each
+# family.
 WGRAD_STREAM = os.environ.get("OTAL_WGRAD_STREAM", "1") != "0"
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    key = (device.type, device.index)
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        prio = int(os.environ.get("OTAL_WGRAD_STREAM_PRIORITY", "0"))
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=prio)
-    return st
+# True while a trainer's single-use backward runs (DetectorTrainer.begin_backward(early=True)): weight gradients written
+# into their arena slots are joined by the trainer (bucket flushes of a data-parallel run, end_backward), not at the end
+# of each autograd node.
+SIDE_DEFER_JOIN = False
+_SIDES = {}
 
 
 class SideWgrads:
     """wgrad(...) = conv_wgrad(...) issued on the side stream behind everything the main stream has been given so far;
-    join() makes the main stream wait for all of them (and runs their recorded reductions).  The caller keeps x alive
-    until join(); dy is kept here (the caching allocator would otherwise hand its block to a later main-stream launch
-    while the side stream still reads it)."""
+    join() makes the main (= torch's current) stream wait for all of them and for their recorded reductions.  x and dy are
+    kept alive until join(): the caching allocator would otherwise hand their blocks to later main-stream launches while
+    the side stream still reads them."""
 
     def __init__(self, device):
-        self.on = WGRAD_STREAM and CONV_PROFILE is None and device.type == "cuda"
+        prio = int(os.environ.get("OTAL_WGRAD_STREAM_PRIORITY", "0"))
+        self.side = torch.cuda.Stream(device=device, priority=prio)
         self.keep = []
-        if self.on:
-            self.main = torch.cuda.current_stream(device)
-            self.side = _side_stream(device)
 
-    def wgrad(self, x, dy, w_shape, k, s, out=None):
+    @property
+    def on(self):
+        return WGRAD_STREAM and CONV_PROFILE is None
+
+    def _issue(self, fn, tensors):
         global _WS_SIDE, _SIDE_NOW
-        if not self.on:
-            return conv_wgrad(x, dy, w_shape, k, s, out=out)
         if _DEFER_OWNER is not None and not _DEFER_OWNER[0]:
             flush_reduces()                 # reductions recorded on the main stream: run them there first
-        self.side.wait_stream(self.main)
+        ev = torch.cuda.Event()
+        ev.record()                         # torch's current stream: dy's producer is on it
+        self.side.wait_event(ev)
         _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = True, self.side, self.side.cuda_stream
         try:
-            dw = conv_wgrad(x, dy, w_shape, k, s, out=out)
+            out = fn()
         finally:
             _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = False, None, None
-        self.keep.append(dy)
-        return dw
+        self.keep.append(tensors)
+        return out
+
+    def wgrad(self, x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None):
+        if not self.on:
+            return conv_wgrad(x, dy, w_shape, k, s, spatial_valid=spatial_valid, levels=levels, out=out)
+        return self._issue(lambda: conv_wgrad(x, dy, w_shape, k, s, spatial_valid=spatial_valid, levels=levels, out=out), (x, dy))
+
+    def wgrad_pair(self, xs, dys, w_shape, k, s, levels=None, outs=(None, None)):
+        if not self.on:
+            return conv_wgrad_pair(xs, dys, w_shape, k, s, levels, outs)
+        return self._issue(lambda: conv_wgrad_pair(xs, dys, w_shape, k, s, levels, outs), (xs, dys))
+
+    def flush(self):
+        """Run the reductions recorded so far (one launch on the side stream); nobody waits."""
+        if _DEFER and _DEFER_OWNER is not None and _DEFER_OWNER[0]:
+            flush_reduces(wait=False)
 
     def join(self):
-        if self.on and self.keep:
-            if _DEFER and _DEFER_OWNER is not None and _DEFER_OWNER[0]:
-                flush_reduces()             # on the side stream; the main stream waits behind them
-            else:
-                self.main.wait_stream(self.side)
+        if self.keep:
+            self.flush()
+            _stream_wait(self.side)
             self.keep.clear()
+
+    def node_end(self, in_slots):
+        """End of an autograd node: its weight gradients are handed to autograd, which may add them to earlier ones on the
+        main stream -- unless they sit in the trainer's arena slots and the trainer joins (SIDE_DEFER_JOIN)."""
+        if not (SIDE_DEFER_JOIN and in_slots):
+            self.join()
+
+
+def side_wgrads(device):
+    key = (device.type, device.index)
+    sd = _SIDES.get(key)
+    if sd is None:
+        sd = _SIDES[key] = SideWgrads(device)
+    return sd
+
+
+def side_join():
+    for sd in _SIDES.values():
+        sd.join()
 
 
 def _as5(t):

@@ -271,7 +271,11 @@ class DetectorTrainer:
             return
         self._flushed[b] = True
         a = self.arena
-        ops.flush_reduces()                             # recorded weight-gradient reductions: one launch
+        # recorded weight-gradient reductions: one launch, on the stream the weight gradients run on (ops.SideWgrads).  Only
+        # a data-parallel run reads the bucket now (all-reduce): it joins that stream; otherwise end_backward does
+        ops.flush_reduces(wait=self.collectives)
+        if self.collectives:
+            ops.side_join()
         ops.flush_pending_sums()                        # deferred GroupNorm batch sums land in their arena slices: one launch
         dst, src = [], []
         for i in a.bucket_members[b]:
@@ -309,6 +313,7 @@ class DetectorTrainer:
         self._slots.reset()
         ops.GRAD_SLOTS = self._slots                # weight gradients are written straight into the arena
         ops.GRAD_READY = self._grads_ready
+        ops.SIDE_DEFER_JOIN = early                 # ... on a second stream that end_backward / the bucket flushes join
         # GroupNorm's batch sums are deferred to the bucket flushes -- unless a parameter may be used twice in this backward
         # (ssl step): a second gradient would be accumulated into the arena slice before the deferred sum is written there
         ops.PENDING_SUMS = [] if early else None
@@ -327,6 +332,8 @@ class DetectorTrainer:
         all-reduces, and leave every .grad aliasing its arena slice."""
         self._drain(force=True)
         ops.defer_reduces(False)                        # flushes what is still recorded
+        ops.side_join()                                 # the weight gradients' stream: everything after this reads them
+        ops.SIDE_DEFER_JOIN = False
         ops.flush_pending_sums()
         ops.PENDING_SUMS = None
         ops.GRAD_SLOTS = None
@@ -407,6 +414,7 @@ class DetectorTrainer:
             ops.GRAD_SLOTS = None
             ops.GRAD_READY = None
             ops.PENDING_SUMS = None
+            ops.SIDE_DEFER_JOIN = False
             ops.defer_reduces(False)
         self.step_count += 1
         self.optimizer_update()
@@ -477,6 +485,7 @@ class DetectorTrainer:
             ops.GRAD_SLOTS = None
             ops.GRAD_READY = None
             ops.PENDING_SUMS = None
+            ops.SIDE_DEFER_JOIN = False
             ops.defer_reduces(False)
         a = self.arena
         keep = self._stash_skipped()
@@ -585,6 +594,7 @@ class DetectorTrainer:
                     self._flush_bucket(self._flush_order[self._cursor])      # stragglers of phase 1 -> arena (copies only)
                     self._cursor += 1
                 gcut = cut_leaf.grad
+                ops.side_join()                     # a capture ends with every forked stream joined
             with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
                 torch.autograd.backward(stem_out, grad_tensors=gcut, inputs=phase2)
                 self.end_backward()
@@ -596,6 +606,7 @@ class DetectorTrainer:
             ops.GRAD_SLOTS = None
             ops.GRAD_READY = None
             ops.PENDING_SUMS = None
+            ops.SIDE_DEFER_JOIN = False
             ops.defer_reduces(False)
             self._pending = None
         if self._skipped:
