@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 20
+#define OTAL_ABI_VERSION 21
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -52,6 +52,11 @@ const char* otal_error_string(int code);
  * calls getenv; otal_set_option changes it at run time, otal_get_option reads it (dflt when it was never set). */
 int otal_set_option(const char* name, int value);
 int otal_get_option(const char* name, int dflt);
+/* Stream fork / join for callers that spread independent launches of this library over several HIP streams (the host
+ * side runs weight gradients beside the data-gradient chain): everything given to `waiter` after the call runs behind
+ * what `signaler` has been given so far.  One hipEventRecord + hipStreamWaitEvent on an event of an internal ring
+ * (no timing); legal while the streams are being captured into a hipGraph (the waiter joins the capture). */
+int otal_stream_wait(void* waiter, void* signaler);
 
 /* ------------------------------------------------------------------ BoundaryMaxPooling ----
  * out[n,c,k] = max_{i in [l,r]} in[n,c,i];  (l,r) = clamp(trunc(seg[n,k,2*(c>=C/2)+{0,1}]), 0, T-1);

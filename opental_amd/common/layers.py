@@ -120,8 +120,6 @@ class ConvGNReLUPairFunction(Function):
         slots = (ops.grad_slot(w0), ops.grad_slot(w1))
         side = ops.side_wgrads(x0.device)
         dws = side.wgrad_pair((x0, x1), (dc0, dc1), w0.shape, k, s, lev, slots)
-        if dws is None:
-            dws = [side.wgrad(x, dc, w0.shape, k, s, levels=lev, out=o) for x, dc, o in ((x0, dc0, slots[0]), (x1, dc1, slots[1]))]
         side.node_end(slots[0] is not None and slots[1] is not None)
         return (dxs[0], dxs[1], dws[0], dws[1], db0, db1, dg0, dg1, dbe0, dbe1, None, None, None, None, None)
 

@@ -95,9 +95,7 @@ def defer_reduces(on):
 
 def _stream_wait(stream):
     """torch's current stream waits for what `stream` has been given so far (works inside a graph capture)."""
-    ev = torch.cuda.Event()
-    ev.record(stream)
-    ev.wait()
+    L.check(L.lib().otal_stream_wait(L.stream(), ctypes.c_void_p(stream.cuda_stream)), "otal_stream_wait")
 
 
 def flush_reduces(wait=True):
@@ -141,57 +139,88 @@ WGRAD_STREAM = os.environ.get("OTAL_WGRAD_STREAM", "1") != "0"
 # into their arena slots are joined by the trainer (bucket flushes of a data-parallel run, end_backward), not at the end
 # of each autograd node.
 SIDE_DEFER_JOIN = False
+SIDE_IN_GRAPH = os.environ.get("OTAL_WGRAD_STREAM_IN_GRAPH", "0") != "0"      # experiments only
 _SIDES = {}
 
 
 class SideWgrads:
-    """wgrad(...) = conv_wgrad(...) issued on the side stream behind everything the main stream has been given so far;
-    join() makes the main (= torch's current) stream wait for all of them and for their recorded reductions.  x and dy are
-    kept alive until join(): the caching allocator would otherwise hand their blocks to later main-stream launches while
-    the side stream still reads them."""
+    """wgrad(...) RECORDS conv_wgrad(...) and returns its destination; issue() launches what has been recorded on the side
+    stream, behind everything the main stream has been given so far (one fork per chunk of layers: a fork is two HIP calls,
+    and switching streams between consecutive launches costs the runtime more than staying on one), followed by ONE launch
+    for the chunk's recorded split-K reductions; join() issues and makes the main (= torch's current) stream wait.  x and
+    dy are kept alive until join(): the caching allocator would otherwise hand their blocks to later main-stream launches
+    while the side stream still reads them.  Nothing on the main stream may modify a recorded dy before join() -- the
+    backward passes below never write to a gradient tensor after its producer."""
+    CHUNK = int(os.environ.get("OTAL_WGRAD_CHUNK", "4"))
 
     def __init__(self, device):
         prio = int(os.environ.get("OTAL_WGRAD_STREAM_PRIORITY", "0"))
         self.side = torch.cuda.Stream(device=device, priority=prio)
+        self._raw = ctypes.c_void_p(self.side.cuda_stream)
+        self.pending = []
         self.keep = []
 
     @property
     def on(self):
-        return WGRAD_STREAM and CONV_PROFILE is None
-
-    def _issue(self, fn, tensors):
-        global _WS_SIDE, _SIDE_NOW
-        if _DEFER_OWNER is not None and not _DEFER_OWNER[0]:
-            flush_reduces()                 # reductions recorded on the main stream: run them there first
-        ev = torch.cuda.Event()
-        ev.record()                         # torch's current stream: dy's producer is on it
-        self.side.wait_event(ev)
-        _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = True, self.side, self.side.cuda_stream
-        try:
-            out = fn()
-        finally:
-            _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = False, None, None
-        self.keep.append(tensors)
-        return out
+        # not inside a graph capture: a replayed hipGraph runs its branches one after the other (measured at b = 1, 2, 8:
+        # 0.06-0.2 ms per step SLOWER with the fork than without), so only eager launches gain from the second stream
+        return WGRAD_STREAM and CONV_PROFILE is None and (SIDE_IN_GRAPH or not torch.cuda.is_current_stream_capturing())
 
     def wgrad(self, x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None):
         if not self.on:
             return conv_wgrad(x, dy, w_shape, k, s, spatial_valid=spatial_valid, levels=levels, out=out)
-        return self._issue(lambda: conv_wgrad(x, dy, w_shape, k, s, spatial_valid=spatial_valid, levels=levels, out=out), (x, dy))
+        if out is None:
+            out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device)
+        # the recorded call writes through an ALIAS: a second reference to the returned tensor itself would stop autograd
+        # from adopting it as the parameter's .grad (AccumulateGrad clones a gradient somebody else still holds -- here a
+        # clone of memory the weight gradient has not been written to yet)
+        dst = out.detach()
+        self.pending.append(lambda: conv_wgrad(x, dy, w_shape, k, s, spatial_valid=spatial_valid, levels=levels, out=dst))
+        self.keep.append((x, dy))
+        return out
 
     def wgrad_pair(self, xs, dys, w_shape, k, s, levels=None, outs=(None, None)):
+        """Two sibling layers: the pair launch, or two launches where the library has no pair kernel."""
         if not self.on:
-            return conv_wgrad_pair(xs, dys, w_shape, k, s, levels, outs)
-        return self._issue(lambda: conv_wgrad_pair(xs, dys, w_shape, k, s, levels, outs), (xs, dys))
+            r = conv_wgrad_pair(xs, dys, w_shape, k, s, levels, outs)
+            return r if r is not None else [conv_wgrad(x, dc, w_shape, k, s, levels=levels, out=o) for x, dc, o in zip(xs, dys, outs)]
+        outs = [o if o is not None else torch.empty(tuple(w_shape), dtype=xs[0].dtype, device=xs[0].device) for o in outs]
+        dsts = [o.detach() for o in outs]       # aliases, as in wgrad()
+
+        def run():
+            if conv_wgrad_pair(xs, dys, w_shape, k, s, levels, dsts) is None:
+                for x, dc, o in zip(xs, dys, dsts):
+                    conv_wgrad(x, dc, w_shape, k, s, levels=levels, out=o)
+        self.pending.append(run)
+        self.keep.append((xs, dys))
+        return outs
+
+    def issue(self):
+        global _WS_SIDE, _SIDE_NOW
+        if not self.pending:
+            return
+        if _DEFER_OWNER is not None and not _DEFER_OWNER[0]:
+            flush_reduces()                 # reductions recorded on the main stream: run them there first
+        raw = self._raw
+        L.check(L.lib().otal_stream_wait(raw, L.stream()), "otal_stream_wait")      # torch's current stream: the dy producers are on it
+        _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = True, self.side, raw.value
+        try:
+            for fn in self.pending:
+                fn()
+            if _DEFER and _DEFER_OWNER is not None:
+                flush_reduces(wait=False)   # this chunk's reductions: one launch, on the side stream
+        finally:
+            _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = False, None, None
+            self.pending.clear()
 
     def flush(self):
-        """Run the reductions recorded so far (one launch on the side stream); nobody waits."""
-        if _DEFER and _DEFER_OWNER is not None and _DEFER_OWNER[0]:
-            flush_reduces(wait=False)
+        """A good place to cut (a backbone module is complete): issue when a chunk's worth of layers is waiting."""
+        if len(self.pending) >= self.CHUNK:
+            self.issue()
 
     def join(self):
         if self.keep:
-            self.flush()
+            self.issue()
             _stream_wait(self.side)
             self.keep.clear()
 
@@ -200,6 +229,8 @@ class SideWgrads:
         main stream -- unless they sit in the trainer's arena slots and the trainer joins (SIDE_DEFER_JOIN)."""
         if not (SIDE_DEFER_JOIN and in_slots):
             self.join()
+        else:
+            self.flush()
 
 
 def side_wgrads(device):

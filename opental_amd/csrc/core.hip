@@ -69,3 +69,24 @@ extern "C" int otal_get_option(const char* name, int dflt) {
     if (!name) return dflt;
     return *otal_option_slot(name, dflt);
 }
+
+// ---- stream fork / join ---------------------------------------------------------------------------------------------
+// A ring of events: hipStreamWaitEvent takes the event's state at the time of the call, so an event may be recorded again
+// once its wait has been issued.
+extern "C" int otal_stream_wait(void* waiter, void* signaler) {
+    constexpr int RING = 64;
+    static hipEvent_t ring[RING];
+    static int made = 0, next = 0;
+    static std::mutex m;
+    if (waiter == signaler) return 0;
+    std::lock_guard<std::mutex> lock(m);
+    if (made < RING && next == made) {
+        if (hipError_t e = hipEventCreateWithFlags(&ring[made], hipEventDisableTiming)) return (int)e;
+        ++made;
+    }
+    hipEvent_t ev = ring[next];
+    next = (next + 1) % RING;
+    if (hipError_t e = hipEventRecord(ev, (hipStream_t)signaler)) return (int)e;
+    if (hipError_t e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0)) return (int)e;
+    return 0;
+}

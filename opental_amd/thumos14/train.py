@@ -331,9 +331,9 @@ class DetectorTrainer:
         """Call after cost.backward(): flush the buckets that did not complete (unused parameters), wait for the
         all-reduces, and leave every .grad aliasing its arena slice."""
         self._drain(force=True)
-        ops.defer_reduces(False)                        # flushes what is still recorded
         ops.side_join()                                 # the weight gradients' stream: everything after this reads them
         ops.SIDE_DEFER_JOIN = False
+        ops.defer_reduces(False)                        # flushes what is still recorded
         ops.flush_pending_sums()
         ops.PENDING_SUMS = None
         ops.GRAD_SLOTS = None
