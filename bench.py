@@ -202,10 +202,15 @@ def extras(device, batch):
         tr = build_trainer(device)
         b = synth_batch(1, 1000, device)
         eager = _timed_steps(tr, b, 20, 5)
-        tr.capture_step(*b)                         # one clip per step is launch-bound: the step replays from ONE HIP graph
+        # one clip per step is launch-bound: the step replays from captured HIP graphs -- a sequence of them on two streams
+        # (main lane | weight-gradient lane, DetectorTrainer.capture_step(lanes=True)); the one-graph step is timed beside it
+        tr.capture_step(*b)
+        one = _timed_steps(tr, b, 30, 10)
+        tr.capture_step(*b, warmup=0, lanes=True)
         dt = _timed_steps(tr, b, 100, 20)           # 20 warm-up + 100 timed steps
         return {"clips_per_s": round(1 / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": 1, "steps": 100, "warmup": 20,
-                "launch": "one captured HIP graph per step", "eager_ms_per_step": round(eager * 1e3, 3),
+                "launch": "lane graphs: a sequence of captured HIP graphs per step on two streams", "eager_ms_per_step": round(eager * 1e3, 3),
+                "one_graph_ms_per_step": round(one * 1e3, 3),
                 "what": "BASELINE configs[1] at the yaml's own batch_size: 1 (configs/thumos14_opental_final.yaml), bf16 operands"}
 
     def ssl():
@@ -224,11 +229,11 @@ def extras(device, batch):
         nb = getattr(tr, "yaml_batch", 2)
         b = synth_batch(nb, 1000, device, frames=768, classes=150, score_rows=3)
         eager = _timed_steps(tr, b, 6, 3)
-        tr.capture_step(*b)                         # two clips per step: the host cannot issue ~400 launches in the step's GPU time
+        tr.capture_step(*b, lanes=True)             # two clips per step: the host cannot issue ~400 launches in the step's GPU time
         dt = _timed_steps(tr, b, 10, 3)
         best = min(eager, dt)
         return {"clips_per_s": round(nb / best, 1), "ms_per_step": round(best * 1e3, 2), "batch": nb,
-                "launch": "one captured HIP graph per step" if dt <= eager else "eager launches",
+                "launch": "lane graphs (captured HIP graphs on two streams)" if dt <= eager else "eager launches",
                 "eager_ms_per_step": round(eager * 1e3, 2), "graph_ms_per_step": round(dt * 1e3, 2),
                 "what": "BASELINE configs[3]: configs/anet_opental.yaml (read through opental_amd.anet.train.build_training), 768-frame "
                         "clips, 150 classes, the yaml's per-GPU batch"}
@@ -411,7 +416,7 @@ def main():
                     help="thumos14 = the headline workload (BASELINE configs[1]/[2]); anet = configs[3], 768-frame clips")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
                     help="arithmetic type of the convolution GEMMs (BASELINE.json configs[1]: bf16); f32 = parity path")
-    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+    ap.add_argument("--graph", choices=["auto", "on", "off", "lanes"], default="auto",
                     help="replay the training step from one captured HIP graph (auto: fall back to eager launches if capture fails)")
     ap.add_argument("--ssl", action="store_true",
                     help="also run the self-supervised triplet branch every step (train.py:237-242 runs it when flags[0]): a second "
@@ -535,7 +540,9 @@ def main():
     # of a step takes < 90 % of the step, eager launches it is, only a host-bound step is captured; several ranks -- both
     # forms are built and TIMED (MAX over ranks) and the faster one runs.  Decisions and the outcome of the capture are
     # agreed between the ranks (MAX / MIN all-reduce), so all ranks replay or none does.
-    want_graph = args.graph == "on"
+    want_graph = args.graph in ("on", "lanes")
+    lanes = args.graph in ("lanes", "auto")     # auto: the lane graphs where a capture is wanted at all
+    lanes_note = "a sequence of captured HIP graphs per step on two streams (main lane / weight-gradient lane)"
     # A step that issues RCCL collectives is never captured as ONE graph: ProcessGroupNCCL's watchdog thread queries the
     # events of the all-reduces it was handed, and a query of an event recorded in a capturing stream is an error
     # (hipErrorCapturedEvent) that takes the process down (measured with one forced rank).  Data-parallel runs capture the
@@ -569,9 +576,9 @@ def main():
     if want_graph:
         ok = 1
         try:
-            trainer.capture_step(clips, targets, scores, split=multi)
+            trainer.capture_step(clips, targets, scores, split=multi and not lanes, lanes=lanes)
         except Exception as e:                      # noqa: BLE001 -- any capture failure means eager launches
-            if args.graph == "on":
+            if args.graph in ("on", "lanes"):
                 raise
             ok = 0
             torch.cuda.synchronize()
@@ -581,22 +588,24 @@ def main():
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             ok = int(okt)
         graphed = bool(ok)
-        if graphed and multi and launch_probe is not None:
-            # the two-graph step must actually beat the eager one it replaces (both timed here, MAX over ranks); otherwise
+        if graphed and launch_probe is not None:
+            # the captured step must actually beat the eager one it replaces (both timed here, MAX over ranks); otherwise
             # back to eager launches
             for _ in range(2):
                 trainer.step(clips, targets, scores)
             barrier()
-            trainer.measure_exposed, trainer.exposed_events = True, []
+            trainer.measure_exposed, trainer.exposed_events = multi, []
             t = time.perf_counter()
             for _ in range(6):
                 trainer.step(clips, targets, scores)
             torch.cuda.synchronize()
             tt = torch.tensor([(time.perf_counter() - t) / 6], device=device, dtype=torch.float64)
             trainer.measure_exposed = False
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            launch_probe["two_graph_ms"] = round(float(tt[0]) * 1e3, 3)
-            launch_probe["allreduce_exposed_ms_two_graph"] = exposed_of(trainer.exposed_events)
+            if multi:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            launch_probe["lane_graphs_ms" if lanes else "two_graph_ms"] = round(float(tt[0]) * 1e3, 3)
+            if multi:
+                launch_probe["allreduce_exposed_ms_graphs"] = exposed_of(trainer.exposed_events)
             if float(tt[0]) * 1e3 > launch_probe["eager_ms"]:
                 graphed = False
         if not graphed:
@@ -739,7 +748,8 @@ def main():
                                          "exposed = compute-stream wait for the collectives after backward" % nbuckets,
                        "allreduce_exposed_ms": None if exposed_ms is None else round(exposed_ms, 3),
                        "ssl_branch": bool(args.ssl), "launch_probe": launch_probe,
-                       "launch": ("two captured HIP graphs per step, the gradient all-reduces issued between them" if multi else
+                       "launch": (lanes_note if lanes else
+                                  "two captured HIP graphs per step, the gradient all-reduces issued between them" if multi else
                                   "one captured HIP graph per step") if graphed else "eager launches"},
             "roofline": roofline, "hbm_kernels": hbm,
             "other_configs": extra if extra is not None else ({"inference": infer_n} if infer_n is not None else None),

@@ -8,6 +8,7 @@ in place instead of through torch.cat.
 import bisect
 import ctypes
 import os
+import warnings
 
 import torch
 
@@ -143,6 +144,77 @@ SIDE_IN_GRAPH = os.environ.get("OTAL_WGRAD_STREAM_IN_GRAPH", "0") != "0"      # 
 _SIDES = {}
 
 
+class LanePlan:
+    """A training step captured as a SEQUENCE of HIP graphs on two lanes.  A replayed hipGraph runs its branches one after
+    the other, so a fork inside one captured graph buys nothing; graphs launched on two STREAMS do run side by side.  The
+    step is therefore cut wherever SideWgrads issues a chunk of weight gradients: the main lane's launches up to the cut
+    are one graph, the chunk is a second graph for the side stream, and the main lane continues in a third.  Replay: main
+    graphs go to the caller's stream in order; a side graph is launched on the side stream behind the main graph that
+    precedes it (one event) and runs beside the main graphs that follow; ("join",) makes the main stream wait for the side
+    stream; ("call", fn) entries are host actions between graphs (collectives of a data-parallel run).  All graphs share
+    one memory pool: the captures never overlap, and every tensor a side graph reads is kept alive until the capture is
+    complete (`keep`), so no later main-lane allocation can land on it."""
+
+    def __init__(self, side_stream):
+        self.entries = []
+        self.pool = None
+        self.cur = None
+        self.side = side_stream
+        self.keep = []
+
+    def begin_main(self):
+        g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        g.capture_begin(pool=self.pool, capture_error_mode="relaxed")
+        self.cur = g
+
+    def end_main(self):
+        if self.cur is not None:
+            with warnings.catch_warnings():         # two cuts in a row leave an empty graph between them: harmless
+                warnings.simplefilter("ignore")
+                self.cur.capture_end()
+            self.entries.append(("main", self.cur))
+            self.cur = None
+
+    def side_chunk(self, run):
+        self.end_main()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(self.side):
+            g.capture_begin(pool=self.pool, capture_error_mode="relaxed")
+            try:
+                run()
+            finally:
+                g.capture_end()
+        self.entries.append(("side", g))
+        self.begin_main()
+
+    def cut(self, entry):
+        """A host action between two main graphs."""
+        self.end_main()
+        self.entries.append(entry)
+        self.begin_main()
+
+    def replay(self):
+        lib, main = L.lib(), L.stream()
+        side_raw = ctypes.c_void_p(self.side.cuda_stream)
+        for e in self.entries:
+            kind = e[0]
+            if kind == "main":
+                e[1].replay()
+            elif kind == "side":
+                L.check(lib.otal_stream_wait(side_raw, main), "otal_stream_wait")
+                with torch.cuda.stream(self.side):
+                    e[1].replay()
+            elif kind == "join":
+                L.check(lib.otal_stream_wait(main, side_raw), "otal_stream_wait")
+            else:
+                e[1]()
+
+
+LANES = None        # the LanePlan being captured (DetectorTrainer.capture_step(lanes=True)), or None
+
+
 class SideWgrads:
     """wgrad(...) RECORDS conv_wgrad(...) and returns its destination; issue() launches what has been recorded on the side
     stream, behind everything the main stream has been given so far (one fork per chunk of layers: a fork is two HIP calls,
@@ -164,7 +236,8 @@ class SideWgrads:
     def on(self):
         # not inside a graph capture: a replayed hipGraph runs its branches one after the other (measured at b = 1, 2, 8:
         # 0.06-0.2 ms per step SLOWER with the fork than without), so only eager launches gain from the second stream
-        return WGRAD_STREAM and CONV_PROFILE is None and (SIDE_IN_GRAPH or not torch.cuda.is_current_stream_capturing())
+        return WGRAD_STREAM and CONV_PROFILE is None and (LANES is not None or SIDE_IN_GRAPH
+                                                          or not torch.cuda.is_current_stream_capturing())
 
     def wgrad(self, x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None):
         if not self.on:
@@ -196,22 +269,28 @@ class SideWgrads:
         return outs
 
     def issue(self):
-        global _WS_SIDE, _SIDE_NOW
         if not self.pending:
             return
         if _DEFER_OWNER is not None and not _DEFER_OWNER[0]:
             flush_reduces()                 # reductions recorded on the main stream: run them there first
         raw = self._raw
+
+        def run():
+            global _WS_SIDE, _SIDE_NOW
+            _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = True, self.side, raw.value
+            try:
+                for fn in self.pending:
+                    fn()
+                if _DEFER and _DEFER_OWNER is not None:
+                    flush_reduces(wait=False)   # this chunk's reductions: one launch, on the side stream
+            finally:
+                _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = False, None, None
+                self.pending.clear()
+        if LANES is not None:               # capture: the chunk becomes a graph of its own (LanePlan)
+            LANES.side_chunk(run)
+            return
         L.check(L.lib().otal_stream_wait(raw, L.stream()), "otal_stream_wait")      # torch's current stream: the dy producers are on it
-        _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = True, self.side, raw.value
-        try:
-            for fn in self.pending:
-                fn()
-            if _DEFER and _DEFER_OWNER is not None:
-                flush_reduces(wait=False)   # this chunk's reductions: one launch, on the side stream
-        finally:
-            _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = False, None, None
-            self.pending.clear()
+        run()
 
     def flush(self):
         """A good place to cut (a backbone module is complete): issue when a chunk's worth of layers is waiting."""
@@ -221,7 +300,11 @@ class SideWgrads:
     def join(self):
         if self.keep:
             self.issue()
-            _stream_wait(self.side)
+            if LANES is not None:
+                LANES.cut(("join",))
+                LANES.keep.extend(self.keep)
+            else:
+                _stream_wait(self.side)
             self.keep.clear()
 
     def node_end(self, in_slots):
@@ -244,6 +327,11 @@ def side_wgrads(device):
 def side_join():
     for sd in _SIDES.values():
         sd.join()
+
+
+def side_issue():
+    for sd in _SIDES.values():
+        sd.issue()
 
 
 def _as5(t):

@@ -291,9 +291,20 @@ class DetectorTrainer:
             torch._foreach_copy_(dst, src)
         if self.collectives and not self._capturing:
             self._issue_allreduce(b)
+        elif self.collectives and ops.LANES is not None:
+            # lane capture: the bucket's weight gradients become a side graph here, and the replay issues the all-reduce
+            # right behind it, from the side stream (the main lane does not wait for them)
+            ops.side_issue()
+            ops.LANES.cut(("call", lambda b=b: self._issue_allreduce(b, side=True)))
 
-    def _issue_allreduce(self, b):
+    def _issue_allreduce(self, b, side=False):
         lo, hi = self.arena.buckets[b]
+        if side:        # behind everything both lanes have been given: RCCL's stream then waits for the side stream only
+            sd = ops.side_wgrads(self.arena.grad.device)
+            ops.L.check(ops.L.lib().otal_stream_wait(sd._raw, ops.L.stream()), "otal_stream_wait")
+            with torch.cuda.stream(sd.side):
+                self._works.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
         self._works.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def begin_backward(self, early=True):
@@ -318,9 +329,15 @@ class DetectorTrainer:
         # (ssl step): a second gradient would be accumulated into the arena slice before the deferred sum is written there
         ops.PENDING_SUMS = [] if early else None
         ops.defer_reduces(early and ops.CONV_PROFILE is None)     # split-K reduces of weight gradients: batched (per-op timing: at once)
-        if self.collectives and not self._capturing and self._ibm_state() is not None:
+        if self.collectives and self._ibm_state() is not None:
             # the loss kernel updated the IBM EMA in the forward pass: its 50-float average travels under the backward
-            self._ibm_work = dist.all_reduce(self._ibm_state(), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if not self._capturing:
+                self._issue_ibm()
+            elif ops.LANES is not None:
+                ops.LANES.cut(("call", self._issue_ibm))
+
+    def _issue_ibm(self):
+        self._ibm_work = dist.all_reduce(self._ibm_state(), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _ibm_state(self):
         if getattr(self.criterion, 'cls_loss_type', None) == 'edl' and getattr(self.criterion.cls_loss, 'with_ibm', False):
@@ -341,6 +358,8 @@ class DetectorTrainer:
         self._pending = None
         for p, v in zip(self.arena.params, self.arena.grad_views):
             p.grad = v
+        if self.collectives and self._capturing and ops.LANES is not None:
+            ops.LANES.cut(("call", self._finish_allreduce))     # lane capture: the waits sit between the last two graphs
         self._finish_allreduce()
 
     def _issue_used_mask(self):
@@ -398,7 +417,7 @@ class DetectorTrainer:
             if self._graph_key == self._capture_key():
                 return self._replay(clips, targets, scores)
             stale = True            # a baked-in host scalar changed (learning rate, IBM switch): eager now, capture again
-            was_split = self._graph[0] == "split"
+            was_split, was_lanes = self._graph[0] == "split", self._graph[0] == "lanes"
             self._graph = None
         # an eager step next to a captured graph (ssl branch) must not touch the descriptor buffers the graph replays
         # from: it works on its own prologue cache
@@ -419,7 +438,7 @@ class DetectorTrainer:
         self.step_count += 1
         self.optimizer_update()
         if stale:
-            self.capture_step(clips, targets, scores, warmup=0, split=was_split)
+            self.capture_step(clips, targets, scores, warmup=0, split=was_split, lanes=was_lanes)
         return cost.detach(), losses
 
     def _eager_prologues(self):
@@ -496,7 +515,7 @@ class DetectorTrainer:
         self._restore_skipped(keep)
         return cost.detach(), losses
 
-    def capture_step(self, clips, targets, scores, warmup=2, split=False):
+    def capture_step(self, clips, targets, scores, warmup=2, split=False, lanes=False):
         """Capture forward + losses + backward (+ gradient all-reduce) + Adam for inputs of these shapes.
 
         The captured launches bake in every host-side scalar of the step; the only one that changes per step --
@@ -505,6 +524,8 @@ class DetectorTrainer:
         `warmup` eager steps run first on a side stream (they are real optimisation steps)."""
         dev = clips.device
         self._graph = None
+        if lanes:
+            return self._capture_lanes(clips, targets, scores, warmup)
         if split:
             return self._capture_split(clips, targets, scores, warmup)
         if self.collectives:
@@ -540,6 +561,63 @@ class DetectorTrainer:
         # the captured prologue launch reads these descriptor buffers by raw pointer: they live as long as the graph
         self._graph_keepalive = (self._prologues.dev_descs, self._prologues.dev_starts)
         return self
+
+    # ---- the step as a SEQUENCE of HIP graphs on two lanes (ops.LanePlan): the main lane (forward, losses, the data-gradient
+    # chain, Adam) and the weight-gradient lane.  A replayed hipGraph runs its branches one after the other, so the one-graph
+    # step loses the overlap of the two families that eager launches get from two streams; eager launches in turn leave the
+    # GPU waiting for the host in the pyramid / head region (~240 launches of 3-30 us).  Here the host issues ~40 graph
+    # launches per step, the weight gradients of chunk k run beside the main lane's chunk k+1, and a data-parallel run
+    # issues each bucket's all-reduce between two graphs, behind the side graph that completes the bucket.
+    def _capture_lanes(self, clips, targets, scores, warmup):
+        import gc
+        dev = clips.device
+        self._bias_corr = torch.zeros(2, dtype=torch.float32, device=dev)
+        clone = lambda t: None if t is None else ([u.clone() for u in t] if isinstance(t, (list, tuple)) else t.clone())
+        static = tuple(clone(t) for t in (clips, targets, scores))
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cap):
+            for _ in range(warmup):                 # eager steps (real ones): regions, workspaces and plans exist afterwards
+                self.step(*static)
+        torch.cuda.current_stream(dev).wait_stream(cap)
+        ops.activate_prologues(self._prologues)     # upload the descriptors of regions created by the warm-up
+        ops.deactivate_prologues()
+        torch.cuda.synchronize(dev)
+        gc.collect()
+        torch.cuda.empty_cache()
+        plan = ops.LanePlan(ops.side_wgrads(dev).side)
+        self._set_bias(self.step_count + 1)
+        self._capturing = True
+        ops.LANES = plan
+        try:
+            # the capture of a main graph ends and the next begins INSIDE the backward pass: autograd has to run it on this
+            # thread (a stream capture is ended by the thread that began it)
+            with torch.cuda.stream(cap), torch.autograd.set_multithreading_enabled(False):
+                plan.begin_main()
+                try:
+                    out = self._graph_body(*static)
+                finally:
+                    plan.end_main()
+        finally:
+            ops.LANES = None
+            self._capturing = False
+            self._pending = None
+        if self._skipped:
+            raise RuntimeError("capture_step(lanes=True): a parameter received no gradient; use eager launches")
+        self._graph = ("lanes", plan, static, out)
+        self._graph_key = self._capture_key()
+        self._graph_keepalive = (self._prologues.dev_descs, self._prologues.dev_starts)
+        return self
+
+    def _replay_lanes(self, clips, targets, scores):
+        _, plan, static, out = self._graph
+        self._copy_inputs(static, (clips, targets, scores))
+        self._skipped = []
+        self.step_count += 1
+        self._set_bias(self.step_count)
+        plan.replay()
+        return out
 
     # ---- the data-parallel step as TWO HIP graphs with the collectives between them
     # graph 1: forward, losses, backward down to the cut behind MaxPool3d_4a (97 % of the parameters' gradients final);
@@ -674,6 +752,8 @@ class DetectorTrainer:
     def _replay(self, clips, targets, scores):
         if self._graph[0] == "split":
             return self._replay_split(clips, targets, scores)
+        if self._graph[0] == "lanes":
+            return self._replay_lanes(clips, targets, scores)
         graph, static, out = self._graph
         self._copy_inputs(static, (clips, targets, scores))
         self.step_count += 1

@@ -162,6 +162,85 @@ def test_two_graph_data_parallel_step_equals_eager_steps_on_one_rccl_rank():
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+@pytest.mark.parametrize("batch", [1, 4])
+def test_lane_graph_step_equals_eager_steps(batch):
+    """DetectorTrainer.capture_step(lanes=True): the step as a sequence of HIP graphs on two streams (main lane | weight
+    gradients, ops.LanePlan).  Same kernels, same order within each lane, every cross-lane dependency an event between two
+    graph launches: parameters and Adam moments after k replayed steps are BIT-IDENTICAL to k eager steps, on every one of
+    several runs (a missing dependency between the lanes would show as a differing run)."""
+    import bench
+    from opental_amd.common import ops
+    dev = torch.device("cuda", 0)
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        clips, targets, scores = bench.synth_batch(batch, 1000, dev)
+
+        def run(lanes):
+            tr = bench.build_trainer(dev, seed=5)
+            tr.lr = 1e-4
+            done = 0
+            if lanes:
+                tr.capture_step(clips, targets, scores, warmup=1, lanes=True)       # the warm-up step is a real step
+                assert tr._graph[0] == "lanes" and sum(e[0] == "side" for e in tr._graph[1].entries) >= 3
+                done = 1
+            costs = [float(tr.step(clips, targets, scores)[0]) for _ in range(5 - done)]
+            torch.cuda.synchronize()
+            assert tr.step_count == 5
+            return tr.arena.flat.detach().clone(), tr.arena.m.detach().clone(), costs
+        pe, me, ce = run(False)
+        for _ in range(3):
+            pl, ml, cl = run(True)
+            assert torch.equal(pe, pl) and torch.equal(me, ml), float((pe - pl).abs().max())
+            assert ce[-len(cl):] == cl, (ce, cl)
+    finally:
+        ops.CONV_PRECISION = old
+
+
+def test_lane_graph_data_parallel_step_equals_eager_steps_on_one_rccl_rank():
+    """The lane-graph step of a data-parallel run: each bucket's all-reduce is issued BETWEEN two graphs, from the side
+    stream, behind the side graph that completes the bucket; the waits sit in front of the last graph (Adam).  On one
+    forced RCCL rank (child process) the parameters after k replayed steps are bit-identical to k eager data-parallel
+    steps."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import os, sys, torch
+        import torch.distributed as dist
+        sys.path.insert(0, os.getcwd())
+        import bench
+        from opental_amd.common import ops
+        ops.CONV_PRECISION = 1
+        dev = torch.device("cuda", 0)
+        dist.init_process_group(backend="nccl", device_id=dev)
+        clips, targets, scores = bench.synth_batch(4, 1000, dev)
+        def run(mode):
+            tr = bench.build_trainer(dev, seed=5, force_collectives=True)
+            tr.lr = 1e-4
+            done = 0
+            if mode == "lanes":
+                tr.capture_step(clips, targets, scores, warmup=1, lanes=True)
+                assert tr._graph[0] == "lanes"
+                kinds = [e[0] for e in tr._graph[1].entries]
+                assert kinds.count("call") >= len(tr.arena.buckets) + 1, kinds
+                done = 1
+            costs = [float(tr.step(clips, targets, scores)[0]) for _ in range(4 - done)]
+            torch.cuda.synchronize()
+            return tr.arena.flat.detach().clone(), tr.arena.m.detach().clone(), costs, tr.step_count
+        pe, me, ce, ne = run("eager")
+        pl, ml, cl, nl = run("lanes")
+        assert ne == nl == 4, (ne, nl)
+        assert torch.equal(pe, pl) and torch.equal(me, ml), float((pe - pl).abs().max())
+        assert ce[-len(cl):] == cl, (ce, cl)
+        print("OK", cl)
+        dist.destroy_process_group()
+    ''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 def test_trainer_arena_gradients_equal_plain_autograd(prec):
     """Everything the trainer does to gradients on their way into the flat arena -- weight gradients written in place
