@@ -329,13 +329,28 @@ class I3DFeaturesFunction(Function):
                 wf = _fused_weight(weights[w0 + 1].detach(), weights[w0 + 3].detach(), weights[w0].detach())
                 scf, shf = _fused_affine(scale, shift, offs, w0)
                 ops.conv_forward(cur, wf, ONE, ONE, scale=scf, shift=shf, relu=True, out=Z[:, :o13 + c1])
-                ops.conv_forward(h1, weights[w0 + 2], THREE, ONE, scale=sc(w0 + 2), shift=sh(w0 + 2), relu=True,
-                                 out=Y[:, c1:c2])
-                ops.conv_forward(h2, weights[w0 + 4], THREE, ONE, scale=sc(w0 + 4), shift=sh(w0 + 4), relu=True,
-                                 out=Y[:, c2:c3])
-                pm, argm = ops.maxpool3d_forward(cur, THREE, ONE)
-                ops.conv_forward(pm, weights[w0 + 5], ONE, ONE, scale=sc(w0 + 5), shift=sh(w0 + 5), relu=True,
-                                 out=Y[:, c3:])
+                # the two small branches (3x3x3 on h2; pool + 1x1) run on the branch lane beside the large 3x3x3 on h1: on
+                # the 6x6 / 3x3 planes none of them fills the chip alone
+                lane = ops.branch_lane(cur.device)
+                if lane.on:
+                    lane.fork()
+                    with lane:
+                        ops.conv_forward(h2, weights[w0 + 4], THREE, ONE, scale=sc(w0 + 4), shift=sh(w0 + 4), relu=True,
+                                         out=Y[:, c2:c3])
+                        pm, argm = ops.maxpool3d_forward(cur, THREE, ONE)
+                        ops.conv_forward(pm, weights[w0 + 5], ONE, ONE, scale=sc(w0 + 5), shift=sh(w0 + 5), relu=True,
+                                         out=Y[:, c3:])
+                    ops.conv_forward(h1, weights[w0 + 2], THREE, ONE, scale=sc(w0 + 2), shift=sh(w0 + 2), relu=True,
+                                     out=Y[:, c1:c2])
+                    lane.join()
+                else:
+                    ops.conv_forward(h1, weights[w0 + 2], THREE, ONE, scale=sc(w0 + 2), shift=sh(w0 + 2), relu=True,
+                                     out=Y[:, c1:c2])
+                    ops.conv_forward(h2, weights[w0 + 4], THREE, ONE, scale=sc(w0 + 4), shift=sh(w0 + 4), relu=True,
+                                     out=Y[:, c2:c3])
+                    pm, argm = ops.maxpool3d_forward(cur, THREE, ONE)
+                    ops.conv_forward(pm, weights[w0 + 5], ONE, ONE, scale=sc(w0 + 5), shift=sh(w0 + 5), relu=True,
+                                     out=Y[:, c3:])
                 out_scale = _cat_cached(_OUT_SCALE, scale, w0, [sc(w0), sc(w0 + 2), sc(w0 + 4), sc(w0 + 5)])
                 tape.append(("mixed", w0, (c1, c2, c3), cur, h1, h2, pm, argm, Y, cur_scale, (wf, o1, o13), out_scale))
                 cur, cur_scale = Y, out_scale

@@ -73,8 +73,8 @@ def workspace(device, side=False):
 # (_DEFER_OWNER: (side workspace?, torch stream or None = the current one)); a weight gradient issued on the other stream
 # flushes them first.
 _DEFER = False
-_WS_CURSOR = [0, 0]         # main / side workspace
-_WS_SIDE = False            # True while SideWgrads issues a launch on its stream
+_WS_CURSOR = [0, 0, 0]      # main / weight-gradient side / branch lane workspace
+_WS_SIDE = 0                # 1 while SideWgrads issues a launch on its stream, 2 inside a BranchLane block
 _SIDE_NOW = None            # ... and that torch stream
 _DEFER_OWNER = None
 
@@ -113,7 +113,7 @@ def flush_reduces(wait=True):
             if wait and L.STREAM_OVERRIDE != stream.cuda_stream:
                 _stream_wait(stream)
     _DEFER_OWNER = None
-    _WS_CURSOR[0] = _WS_CURSOR[1] = 0
+    _WS_CURSOR[0] = _WS_CURSOR[1] = 0           # (the branch lane never holds recorded reductions: its cursor stays 0)
 
 
 def _after_wgrad(device):
@@ -277,14 +277,14 @@ class SideWgrads:
 
         def run():
             global _WS_SIDE, _SIDE_NOW
-            _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = True, self.side, raw.value
+            _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = 1, self.side, raw.value
             try:
                 for fn in self.pending:
                     fn()
                 if _DEFER and _DEFER_OWNER is not None:
                     flush_reduces(wait=False)   # this chunk's reductions: one launch, on the side stream
             finally:
-                _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = False, None, None
+                _WS_SIDE, _SIDE_NOW, L.STREAM_OVERRIDE = 0, None, None
                 self.pending.clear()
         if LANES is not None:               # capture: the chunk becomes a graph of its own (LanePlan)
             LANES.side_chunk(run)
@@ -316,6 +316,50 @@ class SideWgrads:
             self.flush()
 
 
+# ---- a third stream for independent branches of the main lane (the Inception modules' small branches run beside the large
+# one: common/i3d_backbone.py).  with lane: ... issues this library's launches on the lane's stream, with the lane's own
+# workspace; fork() / join() are one event each.
+BRANCH_LANE = os.environ.get("OTAL_BRANCH_LANE", "1") != "0"
+_BRANCHES = {}
+
+
+class BranchLane:
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self._raw = ctypes.c_void_p(self.stream.cuda_stream)
+        self._saved = None
+
+    @property
+    def on(self):
+        return BRANCH_LANE and CONV_PROFILE is None
+
+    def fork(self):
+        """The lane continues behind everything torch's current stream has been given so far."""
+        L.check(L.lib().otal_stream_wait(self._raw, L.stream()), "otal_stream_wait")
+
+    def join(self):
+        L.check(L.lib().otal_stream_wait(L.stream(), self._raw), "otal_stream_wait")
+
+    def __enter__(self):
+        global _WS_SIDE
+        self._saved = (_WS_SIDE, L.STREAM_OVERRIDE)
+        _WS_SIDE, L.STREAM_OVERRIDE = 2, self._raw.value
+        return self
+
+    def __exit__(self, *exc):
+        global _WS_SIDE
+        _WS_SIDE, L.STREAM_OVERRIDE = self._saved
+        return False
+
+
+def branch_lane(device):
+    key = (device.type, device.index)
+    b = _BRANCHES.get(key)
+    if b is None:
+        b = _BRANCHES[key] = BranchLane(device)
+    return b
+
+
 def side_wgrads(device):
     key = (device.type, device.index)
     sd = _SIDES.get(key)
@@ -332,6 +376,11 @@ def side_join():
 def side_issue():
     for sd in _SIDES.values():
         sd.issue()
+
+
+def side_busy():
+    """True when weight gradients have been given to a side stream since its last join."""
+    return any(sd.keep for sd in _SIDES.values())
 
 
 def _as5(t):

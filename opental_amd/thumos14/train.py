@@ -271,11 +271,12 @@ class DetectorTrainer:
             return
         self._flushed[b] = True
         a = self.arena
-        # recorded weight-gradient reductions: one launch, on the stream the weight gradients run on (ops.SideWgrads).  Only
-        # a data-parallel run reads the bucket now (all-reduce): it joins that stream; otherwise end_backward does
-        ops.flush_reduces(wait=self.collectives)
+        # The bucket's weight gradients run on the side stream (ops.SideWgrads), some still waiting to be issued.  Nothing
+        # on the main stream reads them before the optimizer step: a data-parallel run issues what is waiting and hands the
+        # bucket to RCCL FROM the side stream (below), so the main stream's data-gradient chain never waits for them.
         if self.collectives:
-            ops.side_join()
+            ops.side_issue()
+        ops.flush_reduces(wait=False)                   # reductions recorded on the main stream (side stream off): one launch
         ops.flush_pending_sums()                        # deferred GroupNorm batch sums land in their arena slices: one launch
         dst, src = [], []
         for i in a.bucket_members[b]:
@@ -290,11 +291,10 @@ class DetectorTrainer:
         if dst:
             torch._foreach_copy_(dst, src)
         if self.collectives and not self._capturing:
-            self._issue_allreduce(b)
+            self._issue_allreduce(b, side=ops.side_busy())
         elif self.collectives and ops.LANES is not None:
-            # lane capture: the bucket's weight gradients become a side graph here, and the replay issues the all-reduce
-            # right behind it, from the side stream (the main lane does not wait for them)
-            ops.side_issue()
+            # lane capture: the bucket's weight gradients became a side graph above, and the replay issues the all-reduce
+            # right behind it, from the side stream
             ops.LANES.cut(("call", lambda b=b: self._issue_allreduce(b, side=True)))
 
     def _issue_allreduce(self, b, side=False):
