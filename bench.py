@@ -536,10 +536,9 @@ def main():
 
     # Launch mode.  The step is GPU-bound since the loss / gradient hand-over stopped issuing ~800 tiny kernels: eager
     # launches and a replayed HIP graph give the same throughput when the host has slack.  `auto` checks for that slack on
-    # every rank (the probe steps are ordinary data-parallel steps, all ranks take part): one GPU -- if issuing the launches
-    # of a step takes < 90 % of the step, eager launches it is, only a host-bound step is captured; several ranks -- both
-    # forms are built and TIMED (MAX over ranks) and the faster one runs.  Decisions and the outcome of the capture are
-    # agreed between the ranks (MAX / MIN all-reduce), so all ranks replay or none does.
+    # every rank (the probe steps are ordinary data-parallel steps, all ranks take part) and reports it; both forms -- eager
+    # launches and the lane graphs -- are then built and TIMED (MAX over ranks) and the faster one runs.  Decisions and the
+    # outcome of the capture are agreed between the ranks (MAX / MIN all-reduce), so all ranks replay or none does.
     want_graph = args.graph in ("on", "lanes")
     lanes = args.graph in ("lanes", "auto")     # auto: the lane graphs where a capture is wanted at all
     lanes_note = "a sequence of captured HIP graphs per step on two streams (main lane / weight-gradient lane)"
@@ -572,7 +571,9 @@ def main():
         if multi:
             launch_probe["host_issue_ms_per_rank"] = per_rank_issue
             launch_probe["allreduce_exposed_ms_eager"] = exposed_of(trainer.exposed_events)
-        want_graph = multi or t_issue > 0.9 * t_total
+        # the lane graphs also overlap what eager launches cannot (the weight pack beside Conv3d_1a's forward, Adam beside the
+        # stem's weight gradients): always built, kept only if measured faster than the eager steps (below)
+        want_graph = True
     if want_graph:
         ok = 1
         try:

@@ -2611,6 +2611,10 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
 static inline int direct_bm(int M) {
     if (M % 96 == 0) return 96;
     if (M % 64 == 0) return 64;
+    // 16 .. 32 rows (data gradient of the Inception b2b layers: M = Cin = 16 / 24 / 32; forward of Mixed_3b.b2b): one 32-row
+    // MFMA tile per wave.  LDS-read-bound (9 weight + 9 position fragments per 9 MFMAs), but these layers are tiny and ran
+    // on the gather kernel at 25 .. 90 us for 0.1 .. 1 GFLOP of work per sample
+    if (M <= 32 && !OTAL_OPT("OTAL_CONV_DIRECT_NO32", 0)) return 32;
     const int pad64 = (M + 63) / 64 * 64;
     return (pad64 - M) * 100 <= M * OTAL_OPT("OTAL_CONV_DIRECT_PAD", 34) ? 64 : 0;     // accept <= 34 % padded rows (Mixed_4e: 144 -> 192)
 }
@@ -2620,7 +2624,9 @@ static inline int direct_bnp(const ConvGeom& g, int M) {
     const int BM = direct_bm(M);
     if (!BM) return 0;
     const int64_t tm = (M + BM - 1) / BM, NP = (int64_t)g.B * conv_out_positions(g);
-    const int min_tiles = OTAL_OPT("OTAL_CONV_DIRECT_MINTILES", 192);
+    // (140: the 144 tiles of a one-M-tile layer on the 6x6 planes still take the 128-position form -- Mixed_4b / 4e b2b forward
+    //  17.5 -> 10.1 us, 27.6 -> 12.9 us, Mixed_4b b1b data gradient 71 -> 54 us against the gather kernel; tools/micro_planes6.py)
+    const int min_tiles = OTAL_OPT("OTAL_CONV_DIRECT_MINTILES", 140);
     // 512 positions (two tiles per wave: the weight fragments are shared, the kernel turns MFMA-bound) when that still gives
     // every CU two rounds of workgroups and the tile stays inside one sample
     // (96-row tiles only: a 64-row tile of 256 positions fits TWICE per CU -- 16 waves -- and measured faster than one 512 tile)
@@ -2718,6 +2724,7 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if (bnp == 128) {
         const dim3 grid(a.N / 128, tm, 1);
         if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 128, 1>), grid, dim3(256), (direct_lds_bytes<96, 128>()), st, d);
+        else if (BM == 32) hipLaunchKernelGGL((conv3_direct_kernel<32, MODE, 128, 1>), grid, dim3(256), (direct_lds_bytes<32, 128>()), st, d);
         else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 128, 1>), grid, dim3(256), (direct_lds_bytes<64, 128>()), st, d);
         return otal_launch_status();
     }
@@ -2727,12 +2734,13 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         return launch_direct512<64, MODE>(d, grid, st);
     }
     const dim3 grid(a.N / 256, tm, 1);
-    if (OTAL_OPT("OTAL_CONV_DIRECT_256X2", 0) == 1) {
+    if (OTAL_OPT("OTAL_CONV_DIRECT_256X2", 0) == 1 && BM != 32) {
         if (BM == 96) return launch_direct256x2<96, MODE>(d, grid, st);
         return launch_direct256x2<64, MODE>(d, grid, st);
     }
     if (OTAL_OPT("OTAL_CONV_DIRECT_256X2", 0) == 2 && BM == 96) return launch_direct256d<96, MODE>(d, grid, st);
     if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<96, 256>()), st, d);
+    else if (BM == 32) hipLaunchKernelGGL((conv3_direct_kernel<32, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<32, 256>()), st, d);
     else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<64, 256>()), st, d);
     return otal_launch_status();
 }

@@ -1,6 +1,8 @@
 """GPU parity of the dense ops (through the C ABI) against the CPU oracle / torch-CPU fp32:
 implicit-GEMM conv (fwd, dgrad, wgrad; SAME pads, strides, split-K, channel slices, level packing,
 fused epilogues), GroupNorm+ReLU, MaxPool3dSamePadding, proposal windows (bit-exact), Adam."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -771,6 +773,52 @@ def test_direct_conv_two_position_tiles_per_wave(shape, cout):
     close(res[0][0], yref)
     close(res[0][1], dxref)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout,min_tiles", [
+    ((2, 32, 64, 6, 6), 128, 30),      # Mixed_4f.b2b: dgrad M = 32 on 128-position tiles (18 tiles of 256 < 30 <= 36 of 128), fwd M = 128
+    ((2, 24, 64, 6, 6), 64, 30),       # Mixed_4c.b2b: dgrad M = 24 (rows 24 .. 31 are padding); fwd: gather kernel (Cin % 16)
+    ((1, 16, 32, 12, 12), 32, 1),      # Mixed_3b.b2b: dgrad M = 16 AND fwd M = 32, 256-position tiles
+    ((2, 48, 8, 8, 8), 16, 1)])        # fwd M = 16, dgrad M = 48 (64-row tile, padded)
+def test_direct_conv_32_row_tiles(shape, cout, min_tiles):
+    """conv3_direct_kernel<32, MODE, 128 / 256, 1> (one 32-row MFMA tile per wave: the data gradient of the Inception b2b
+    layers, M = Cin = 16 / 24 / 32, and forward layers with <= 32 output channels): forward with scale / shift / ReLU and the
+    masked data gradient equal the fp32 convolution of the bf16-rounded operands (1e-4 of scale), and the gather kernel
+    (OTAL_CONV_NODIRECT) to summation-order accuracy."""
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape) + cout)
+    B, cin, T, H, W = shape
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    w = torch.from_numpy((rs.randn(cout, cin, 3, 3, 3) / np.sqrt(cin * 27)).astype(np.float32)).cuda()
+    sc = torch.from_numpy((rs.rand(cout) + 0.5).astype(np.float32)).cuda()
+    sh = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    sci = torch.from_numpy((rs.rand(cin) + 0.5).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rs.randn(B, cout, T, H, W).astype(np.float32)).cuda()
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        res = []
+        L.set_option("OTAL_CONV_DIRECT_MINTILES", min_tiles)
+        for nodirect in (0, 1):
+            L.set_option("OTAL_CONV_NODIRECT", nodirect)
+            y = ops.conv_forward(x, w, (3, 3, 3), (1, 1, 1), scale=sc, shift=sh, relu=True)
+            dx = ops.conv_dgrad(dy, w, x.shape, (3, 3, 3), (1, 1, 1), out_mask=x, out_scale=sci)
+            res.append((y, dx))
+    finally:
+        L.set_option("OTAL_CONV_NODIRECT", 0)
+        L.set_option("OTAL_CONV_DIRECT_MINTILES", int(os.environ.get("OTAL_CONV_DIRECT_MINTILES", "140")))     # conftest: 1
+        ops.CONV_PRECISION = old
+    xr = _bf16_round(x.cpu()).requires_grad_(True)
+    yr = F.conv3d(xr, _bf16_round(w.cpu()), padding=1)
+    yr.backward(_bf16_round(dy.cpu()))
+    yref = (yr.detach() * sc.cpu().view(1, -1, 1, 1, 1) + sh.cpu().view(1, -1, 1, 1, 1)).clamp(min=0)
+    dxref = xr.grad * (x.cpu() > 0) * sci.cpu().view(1, -1, 1, 1, 1)
+    for y, dx in res:
+        close(y, yref)
+        close(dx, dxref)
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * float(dxref.abs().max())
 
 
 @pytest.mark.gpu
