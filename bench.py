@@ -611,6 +611,12 @@ def main():
                 graphed = False
         if not graphed:
             trainer.drop_graph()
+    inputs_note = "resident in HBM"
+    if graphed and trainer.static_inputs() is not None:
+        # the synthetic batch is resident in HBM either way; a captured step replays from ITS buffers, and a producer that
+        # fills those (the clip kernel writes wherever it is told to) saves the device-to-device copy of the batch
+        clips, targets, scores = trainer.static_inputs()
+        inputs_note = "resident in HBM, in the captured step's input buffers (no per-step copy of the batch)"
     for _ in range(args.warmup):
         trainer.step(clips, targets, scores, *ssl_args)
     replicas_ok = replica_check("after the warm-up steps")
@@ -748,7 +754,7 @@ def main():
                                          "the backward pass (the backbone hands its finished layers over while it runs); "
                                          "exposed = compute-stream wait for the collectives after backward" % nbuckets,
                        "allreduce_exposed_ms": None if exposed_ms is None else round(exposed_ms, 3),
-                       "ssl_branch": bool(args.ssl), "launch_probe": launch_probe,
+                       "ssl_branch": bool(args.ssl), "inputs": inputs_note, "launch_probe": launch_probe,
                        "launch": (lanes_note if lanes else
                                   "two captured HIP graphs per step, the gradient all-reduces issued between them" if multi else
                                   "one captured HIP graph per step") if graphed else "eager launches"},
