@@ -23,6 +23,7 @@
 #include "conv_index.h"
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace {
 
@@ -1760,7 +1761,12 @@ struct DirectArgs {
 // The dense pitch brings a 96 x 256 tile of four waves under 80 KB: TWO workgroups per CU that are not barrier-coupled, so
 // one's staging / store / epilogue phases run under the other's MFMAs (the 8-wave 512-position tile leaves the matrix
 // pipes idle in those phases: ~12 us of epilogue per 50 us tile on Conv3d_2c).
-template <int BM, int MODE, int BNP, int WN, int PX = 48, int MINW = 1>
+// XPF2: the gathered positions travel TWO K steps ahead of their use (two register sets, K loop unrolled by two) instead of
+// one; the weights stay one step ahead (they are L2 hits).  Costs 8 * X_ITERS registers (the 96 x 512 forward variant lands
+// on exactly 256, no spills), so only the one-workgroup-per-CU variants take it.  Worth 1 .. 5 % per launch, not the ~19 %
+// a per-tile budget of Conv3d_2c forward had attributed to load stalls (48 us per tile = 24 MFMA at the sustained clock +
+// 12 epilogue + 3 first loads + "9 waiting for positions"): one step of cover was nearly enough.
+template <int BM, int MODE, int BNP, int WN, int PX = 48, int MINW = 1, bool XPF2 = false>
 __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const DirectArgs d) {
     constexpr int DNT = BNP * 2 / WN;                       // one wave per 32 * WN positions
     constexpr int WM = BM / 32, PA = 304, SPAN_MAX = BNP + 52;
@@ -1827,10 +1833,11 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
         const int p = tid + DNT * j;
         avo[j] = (unsigned)(((m0 + p / 18) * d.Ktot * 2) + (p % 18) * 16);
     }
-    unsigned rx[X_ITERS][2][4];
+    unsigned rxs[XPF2 ? 2 : 1][X_ITERS][2][4];
     Words4 ra[A_PIECES];
     const int nsteps = (d.C >> 4) * 3;
-    auto load_x = [&](int s) {
+    auto load_x = [&](int s, auto SET) {
+        unsigned (&rx)[X_ITERS][2][4] = rxs[decltype(SET)::value];
         const int cb = s / 3, dt = s - cb * 3;
         const unsigned so = (unsigned)(((int64_t)cb * 16 * scs + (int64_t)(dt - 1) * HW) * 4);
 #pragma unroll
@@ -1849,7 +1856,8 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
             if ((BM * 18) % DNT == 0 || tid + DNT * j < BM * 18)
                 ra[j] = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rw, avo[j], s * 288, 0));
     };
-    auto store = [&](int buf, int s) {
+    auto store = [&](int buf, int s, auto SET) {
+        unsigned (&rx)[X_ITERS][2][4] = rxs[decltype(SET)::value];
         const int cb = s / 3, dt = s - cb * 3;
         const unsigned so = (unsigned)(((int64_t)cb * 16 * scs + (int64_t)(dt - 1) * HW) * 4);
 #pragma unroll
@@ -1889,9 +1897,12 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_x(0);
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, XPF2 ? 1 : 0>;
+    load_x(0, Set0{});
     load_a(0);
-    store(0, 0);
+    store(0, 0, Set0{});
+    if constexpr (XPF2) load_x(nsteps > 1 ? 1 : 0, Set1{});     // step 1's positions: in flight while step 0 computes
     __syncthreads();
     const int xpos = wave * WN * 32 + (lane & 31) + W + 1;                               // this lane's first position in the span
     const int xrow = xpos * PX + (lane >> 5) * 16;
@@ -1917,10 +1928,14 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
         const bool ok = ((tmask[j] >> dt) & 1u) && ((hwmask[j] >> g9) & 1u);
         return *reinterpret_cast<const bf16x8*>(ok ? src : smZero);
     };
-    for (int s = 0; s < nsteps; ++s) {
+    // one K step; CUR = the register set that holds the positions of step s + 1 when XPF2 (loaded during step s - 1: stored
+    // to LDS at the end of this step), while the loads of step s + 2 go to the other set; without XPF2 there is one set,
+    // loaded and stored within the step
+    auto kstep = [&](int s, auto CUR, auto OTHER) {
         const int buf = s & 1;
         const int dt = s % 3;
         const int sn = s + 1 < nsteps ? s + 1 : s;          // the prefetch past the end re-reads the last step
+        const int sx = XPF2 ? (s + 2 < nsteps ? s + 2 : nsteps - 1) : sn;
         bf16x8 avA[WM], bvA[WN], avB[WM], bvB[WN];
 #pragma unroll
         for (int i = 0; i < WM; ++i) avA[i] = frag_a(buf, 0, i);
@@ -1928,7 +1943,7 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
         for (int j = 0; j < WN; ++j) bvA[j] = frag_b(buf, dt, 0, j);
 #pragma unroll
         for (int g9 = 0; g9 < 9; ++g9) {
-            if (g9 == 0) load_x(sn);
+            if (g9 == 0) load_x(sx, OTHER);
             if (g9 == 1) load_a(sn);
             bf16x8 (&av)[WM] = (g9 & 1) ? avB : avA;
             bf16x8 (&bv)[WN] = (g9 & 1) ? bvB : bvA;
@@ -1955,8 +1970,16 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        store(buf ^ 1, sn);
+        store(buf ^ 1, sn, CUR);
         __syncthreads();
+    };
+    if constexpr (XPF2) {
+        for (int s = 0; s < nsteps; s += 2) {
+            kstep(s, Set1{}, Set0{});
+            if (s + 1 < nsteps) kstep(s + 1, Set0{}, Set1{});
+        }
+    } else {
+        for (int s = 0; s < nsteps; ++s) kstep(s, Set0{}, Set0{});
     }
     if constexpr (MODE == MODE_FWD) {
         if (a.half) {
@@ -2682,17 +2705,17 @@ static int launch_direct256d(const DirectArgs& d, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((conv3_direct_kernel<BM, MODE, 256, 1, 32, 4>), grid, dim3(512), lds, st, d);
     return otal_launch_status();
 }
-template <int BM, int MODE>
+template <int BM, int MODE, bool XPF2 = false>
 static int launch_direct512(const DirectArgs& d, dim3 grid, hipStream_t st) {
     constexpr int lds = direct_lds_bytes<BM, 512>();
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_direct_kernel<BM, MODE, 512, 2>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_direct_kernel<BM, MODE, 512, 2, 48, 1, XPF2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL((conv3_direct_kernel<BM, MODE, 512, 2>), grid, dim3(512), lds, st, d);
+    hipLaunchKernelGGL((conv3_direct_kernel<BM, MODE, 512, 2, 48, 1, XPF2>), grid, dim3(512), lds, st, d);
     return otal_launch_status();
 }
 
@@ -2728,8 +2751,17 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 128, 1>), grid, dim3(256), (direct_lds_bytes<64, 128>()), st, d);
         return otal_launch_status();
     }
+    // positions two K steps ahead (XPF2): bit 0 -- 96 x 256 tiles, and 64 x 256 tiles when the grid has at most one workgroup
+    // per CU (the variant is one workgroup per CU instead of two: it only pays where nobody would share the CU anyway);
+    // bit 1 -- 96 x 512 (forward); bit 2 -- every 64 x 256 launch.  Measured (tools/xpf_sweep.sh): Conv3d_2c fwd 505 -> 499 us,
+    // Mixed_3c.b1b fwd 239 -> 232, Mixed_3b.b1b dgrad 158 -> 150, Mixed_4c .. 4f b1b dgrad 309 -> 285 (sum); with bit 2
+    // Conv3d_2c dgrad 476 -> 558 and the 64-row forward launches +15 %: the load latency was NOT what these tiles wait for
+    const int xpf2 = OTAL_OPT("OTAL_CONV_DIRECT_XPF2", 3);
     if (bnp == 512) {           // two position tiles per wave (dynamic LDS: 112 KB)
         const dim3 grid(a.N / 512, tm, 1);
+        if constexpr (MODE == MODE_FWD) {
+            if (BM == 96 && (xpf2 & 2)) return launch_direct512<96, MODE, true>(d, grid, st);
+        }
         if (BM == 96) return launch_direct512<96, MODE>(d, grid, st);
         return launch_direct512<64, MODE>(d, grid, st);
     }
@@ -2739,7 +2771,9 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         return launch_direct256x2<64, MODE>(d, grid, st);
     }
     if (OTAL_OPT("OTAL_CONV_DIRECT_256X2", 0) == 2 && BM == 96) return launch_direct256d<96, MODE>(d, grid, st);
-    if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<96, 256>()), st, d);
+    if (BM == 96 && (xpf2 & 1)) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256, 1, 48, 1, true>), grid, dim3(512), (direct_lds_bytes<96, 256>()), st, d);
+    else if (BM == 64 && ((xpf2 & 4) || ((xpf2 & 1) && (int64_t)grid.x * grid.y <= 256))) hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 256, 1, 48, 1, true>), grid, dim3(512), (direct_lds_bytes<64, 256>()), st, d);
+    else if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<96, 256>()), st, d);
     else if (BM == 32) hipLaunchKernelGGL((conv3_direct_kernel<32, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<32, 256>()), st, d);
     else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<64, 256>()), st, d);
     return otal_launch_status();

@@ -776,6 +776,49 @@ def test_direct_conv_two_position_tiles_per_wave(shape, cout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout", [((2, 16, 8, 8, 8), 96),       # 3 K steps (odd: the unrolled loop's tail), 96 x 256 tiles
+                                        ((1, 48, 4, 24, 24), 64),      # 9 K steps forward; data gradient: 12 steps, M = 48
+                                        ((1, 96, 8, 24, 24), 192),     # 96 x 512 forward tiles (two position tiles per wave)
+                                        ((2, 64, 64, 6, 6), 128),      # 6x6 planes, 64-row tiles, tiles crossing t planes
+                                        ((1, 16, 4, 8, 8), 64)])       # ONE channel block: 3 steps, the second load re-reads step 2
+def test_direct_conv_positions_two_steps_ahead_equal_one_step(shape, cout):
+    """conv3_direct_kernel<..., XPF2 = true> (gathered positions loaded TWO K steps ahead through a second register set, K loop
+    unrolled by two) gives bit for bit what the one-step-ahead kernel gives -- same products, same order -- for odd and even
+    step counts, every tile shape that has the variant (OTAL_CONV_DIRECT_XPF2 = 7 forces all of them), forward with scale /
+    shift / ReLU and masked data gradient; and both equal the fp32 convolution of the bf16-rounded operands."""
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape) + cout)
+    B, cin, T, H, W = shape
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    w = torch.from_numpy((rs.randn(cout, cin, 3, 3, 3) / np.sqrt(cin * 27)).astype(np.float32)).cuda()
+    sc = torch.from_numpy((rs.rand(cout) + 0.5).astype(np.float32)).cuda()
+    sh = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    sci = torch.from_numpy((rs.rand(cin) + 0.5).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rs.randn(B, cout, T, H, W).astype(np.float32)).cuda()
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        res = []
+        L.set_option("OTAL_CONV_DIRECT_MINTILES512", 1)
+        for xpf in (0, 7):
+            L.set_option("OTAL_CONV_DIRECT_XPF2", xpf)
+            y = ops.conv_forward(x, w, (3, 3, 3), (1, 1, 1), scale=sc, shift=sh, relu=True)
+            dx = ops.conv_dgrad(dy, w, x.shape, (3, 3, 3), (1, 1, 1), out_mask=x, out_scale=sci)
+            res.append((y, dx))
+    finally:
+        L.set_option("OTAL_CONV_DIRECT_XPF2", 3)
+        L.set_option("OTAL_CONV_DIRECT_MINTILES512", 512)
+        ops.CONV_PRECISION = old
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    xr = _bf16_round(x.cpu()).requires_grad_(True)
+    yr = F.conv3d(xr, _bf16_round(w.cpu()), padding=1)
+    yr.backward(_bf16_round(dy.cpu()))
+    close(res[1][0], (yr.detach() * sc.cpu().view(1, -1, 1, 1, 1) + sh.cpu().view(1, -1, 1, 1, 1)).clamp(min=0))
+    close(res[1][1], xr.grad * (x.cpu() > 0) * sci.cpu().view(1, -1, 1, 1, 1))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape,cout,min_tiles", [
     ((2, 32, 64, 6, 6), 128, 30),      # Mixed_4f.b2b: dgrad M = 32 on 128-position tiles (18 tiles of 256 < 30 <= 36 of 128), fwd M = 128
     ((2, 24, 64, 6, 6), 64, 30),       # Mixed_4c.b2b: dgrad M = 24 (rows 24 .. 31 are padding); fwd: gather kernel (Cin % 16)
