@@ -64,69 +64,58 @@ class ANETdetection(object):
             class_to_idx[name] = idx + 1
         return class_to_idx
 
-    def _import_ground_truth(self, ground_truth_filename):
-        with open(ground_truth_filename, 'r') as fobj:
+    @staticmethod
+    def _load_json(path, required, what):
+        with open(path, 'r') as fobj:
             data = json.load(fobj)
-        if not all([field in data.keys() for field in self.gt_fields]):
-            raise IOError('Please input a valid ground truth file.')
-        video_lst, t_start, t_end, label = [], [], [], []
-        for videoid, v in data['database'].items():
-            if v['subset'] not in self.subset or videoid in self.blocked_videos:
-                continue
-            for ann in v['annotations']:
-                video_lst.append(videoid)
-                t_start.append(float(ann['segment'][0]))
-                t_end.append(float(ann['segment'][1]))
-                if self.openset:
-                    label.append(self.activity_index.get(ann['label'], 0))
-                else:
-                    assert ann['label'] in self.activity_index, 'Ground truth json contains invalid class: %s' % (ann['label'])
-                    label.append(self.activity_index[ann['label']])
-        gt = {'video-id': np.array(video_lst, dtype=object), 't-start': np.array(t_start, dtype=np.float64),
-              't-end': np.array(t_end, dtype=np.float64), 'label': np.array(label, dtype=np.int64)}
+        if any(field not in data for field in required):
+            raise IOError('Please input a valid %s file.' % what)
+        return data
+
+    def _import_ground_truth(self, ground_truth_filename):
+        """eval_detection.py:101-147 -> column arrays.  Every annotation of every video of the requested subsets is one row;
+        a label outside the known classes is 0 ('__unknown__') in the open-set protocol and an error in the closed-set one."""
+        database = self._load_json(ground_truth_filename, self.gt_fields, 'ground truth')['database']
+        rows = [(vid, ann) for vid, v in database.items()
+                if v['subset'] in self.subset and vid not in self.blocked_videos for ann in v['annotations']]
+        if not self.openset:
+            for _, ann in rows:
+                assert ann['label'] in self.activity_index, 'Ground truth json contains invalid class: %s' % (ann['label'])
+        video_lst = [vid for vid, _ in rows]
+        seg = np.array([ann['segment'][:2] for _, ann in rows], dtype=np.float64).reshape(-1, 2)
+        gt = {'video-id': np.array(video_lst, dtype=object), 't-start': seg[:, 0].copy(), 't-end': seg[:, 1].copy(),
+              'label': np.array([self.activity_index.get(ann['label'], 0) for _, ann in rows], dtype=np.int64)}
         return gt, video_lst
 
+    # out-of-distribution score of one detection under each scoring rule (eval_detection.py:183-196); a detection whose
+    # score falls below ood_threshold is relabelled '__unknown__' in the open-set protocol
+    OOD_SCORES = {
+        'uncertainty': lambda r: r['uncertainty'],
+        'confidence': lambda r: 1 - r['score'],
+        'uncertainty_actionness': lambda r: r['uncertainty'] * r['actionness'],
+        'a_by_inv_u': lambda r: r['actionness'] / (1 - r['uncertainty'] + 1e-6),
+        'u_by_inv_a': lambda r: r['uncertainty'] / (1 - r['actionness'] + 1e-6),
+        'half_au': lambda r: 0.5 * (r['actionness'] + 1) * r['uncertainty'],
+    }
+
     def _import_prediction(self, prediction_filename):
-        with open(prediction_filename, 'r') as fobj:
-            data = json.load(fobj)
-        if not all([field in data.keys() for field in self.pred_fields]):
-            raise IOError('Please input a valid prediction file.')
-        known_videos = set(self.video_lst)
-        video_lst, t_start, t_end, label, score, ood = [], [], [], [], [], []
-        for videoid, v in data['results'].items():
-            if videoid in self.blocked_videos or videoid not in known_videos:
-                continue
-            for result in v:
-                if result['label'] not in self.activity_index:
-                    continue
-                s = self.ood_scoring
-                if s == 'uncertainty':
-                    res_score = result['uncertainty']
-                elif s == 'confidence':
-                    res_score = 1 - result['score']
-                elif s == 'uncertainty_actionness':
-                    res_score = result['uncertainty'] * result['actionness']
-                elif s == 'a_by_inv_u':
-                    res_score = result['actionness'] / (1 - result['uncertainty'] + 1e-6)
-                elif s == 'u_by_inv_a':
-                    res_score = result['uncertainty'] / (1 - result['actionness'] + 1e-6)
-                elif s == 'half_au':
-                    res_score = 0.5 * (result['actionness'] + 1) * result['uncertainty']
-                else:
-                    raise NotImplementedError(s)
-                if self.openset and self.ood_threshold is not None and res_score < self.ood_threshold:
-                    lab = self.activity_index['__unknown__']
-                else:
-                    lab = self.activity_index[result['label']]
-                video_lst.append(videoid)
-                t_start.append(float(result['segment'][0]))
-                t_end.append(float(result['segment'][1]))
-                label.append(lab)
-                score.append(result['score'])
-                ood.append(res_score)
-        return {'video-id': np.array(video_lst, dtype=object), 't-start': np.array(t_start, dtype=np.float64),
-                't-end': np.array(t_end, dtype=np.float64), 'label': np.array(label, dtype=np.int64),
-                'score': np.array(score, dtype=np.float64), 'ood_score': np.array(ood, dtype=np.float64)}
+        """eval_detection.py:149-219 -> column arrays: detections of videos without ground truth and detections of classes
+        outside the index are dropped, in file order."""
+        results = self._load_json(prediction_filename, self.pred_fields, 'prediction')['results']
+        if self.ood_scoring not in self.OOD_SCORES:
+            raise NotImplementedError(self.ood_scoring)
+        ood_of = self.OOD_SCORES[self.ood_scoring]
+        known_videos = set(self.video_lst) - set(self.blocked_videos)
+        rows = [(vid, r) for vid, dets in results.items() if vid in known_videos
+                for r in dets if r['label'] in self.activity_index]
+        ood = np.array([ood_of(r) for _, r in rows], dtype=np.float64)
+        label = np.array([self.activity_index[r['label']] for _, r in rows], dtype=np.int64)
+        if self.openset and self.ood_threshold is not None:
+            label[ood < self.ood_threshold] = self.activity_index['__unknown__']
+        seg = np.array([r['segment'][:2] for _, r in rows], dtype=np.float64).reshape(-1, 2)
+        return {'video-id': np.array([vid for vid, _ in rows], dtype=object), 't-start': seg[:, 0].copy(),
+                't-end': seg[:, 1].copy(), 'label': label,
+                'score': np.array([r['score'] for _, r in rows], dtype=np.float64), 'ood_score': ood}
 
     @staticmethod
     def _rows(table, mask):

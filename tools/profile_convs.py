@@ -10,8 +10,12 @@ def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     ops.CONV_PRECISION = int(os.environ.get("OTAL_PREC", "1"))
     dev = torch.device("cuda", 0)
-    tr = bench.build_trainer(dev)
-    clips, targets, scores = bench.synth_batch(batch, 1000, dev)
+    if os.environ.get("OTAL_RECIPE") == "anet":         # configs/anet_opental.yaml: 768-frame clips, 150 classes
+        tr = bench.build_anet_trainer(dev)
+        clips, targets, scores = bench.synth_batch(batch, 1000, dev, frames=768, classes=150, score_rows=3)
+    else:
+        tr = bench.build_trainer(dev)
+        clips, targets, scores = bench.synth_batch(batch, 1000, dev)
     for _ in range(2):
         tr.step(clips, targets, scores)
     rows = []
