@@ -11,6 +11,8 @@ LAYERS = {
     "4f_b1b": ((8, 160, 64, 6, 6), 320, (3, 3, 3), (1, 1, 1)),
     "3b_b0": ((8, 192, 128, 12, 12), 64, (1, 1, 1), (1, 1, 1)),
     "2b": ((8, 64, 128, 24, 24), 64, (1, 1, 1), (1, 1, 1)),
+    "3c_1x1": ((8, 256, 128, 12, 12), 288, (1, 1, 1), (1, 1, 1)),     # Mixed_3c: the fused [b1a | b2a | b0] launch
+    "4e_1x1": ((8, 512, 64, 6, 6), 288, (1, 1, 1), (1, 1, 1)),
     "tower": ((8, 512, 126), 512, (3, 1, 1), (1, 1, 1)),
 }
 
