@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 21
+#define OTAL_ABI_VERSION 22
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -383,6 +383,21 @@ int otal_detection_loss(const float* loc, const float* conf, const float* prop_l
                         float clip_length, float overlap_thresh, int ibm_active, int num_bins, float momentum,
                         int iou_aware, int cls_mode, float focal_alpha, float* losses, float* grads, float* scratch,
                         void* stream);
+
+/* The same for the ActivityNet1.3 recipe (ABI 22): AFSD/anet/multisegment_loss.py:87-301 with anet/cls_loss.py:78-246
+ * (EvidenceLoss 'log', exp evidence, the closed-form influence-balanced weight 1 / (|z|_1 exp(ibm_coeff g) + 1e-10) whose
+ * |z|_1 carries gradient, IoU calibration as each sample's mean) and :249-296 (ActionnessLoss with its rank hinge:
+ * act_weight, act_margin).  Every term is evaluated per sample, normalised by that sample's counts and averaged over the
+ * batch: one workgroup per sample + a seven-sum launch.  priors2 (K,2) = [centre, pyramid level]; level_bounds (nlev,2) =
+ * the per-level (lower, upper] bounds on max(left, right) in frames (multisegment_loss.py:11); K <= 1024, nlev <= 8.
+ * losses, grads: as otal_detection_loss (gradients already divided by B; otal_detection_loss_bwd applies);
+ * scratch: 8 * B floats.  No state (this recipe's IBM weight has no EMA). */
+int otal_detection_loss_anet(const float* loc, const float* conf, const float* prop_loc, const float* prop_conf,
+                             const float* center, const float* act, const float* prop_act, const float* priors2,
+                             const float* gt, const unsigned char* gvalid, int B, int K, int C, int G,
+                             float clip_length, float overlap_thresh, const float* level_bounds, int nlev,
+                             int ibm_active, float ibm_coeff, int iou_aware, float act_weight, float act_margin,
+                             float* losses, float* grads, float* scratch, void* stream);
 
 /* Backward of otal_detection_loss in one launch: the gradients w.r.t. the seven head outputs from the stored per-loss
  * gradients (`grads` as written by otal_detection_loss) and the incoming gradients of the seven losses g7[i] (device

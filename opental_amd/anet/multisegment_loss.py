@@ -15,6 +15,7 @@ from ..thumos14.multisegment_loss import _tiou, iou_loss, pad_targets  # noqa: F
 from .cls_loss import ActionnessLoss, EvidenceLoss, FocalLoss_Ori
 
 bounds = [[0, 30], [15, 60], [30, 120], [60, 240], [96, 768], [256, 768]]
+FUSED = True      # one workgroup per sample (csrc/loss.hip) for the recipe's settings; False forces the torch formulation
 
 
 class MultiSegmentLoss(nn.Module):
@@ -77,9 +78,25 @@ class MultiSegmentLoss(nn.Module):
         prop_loc_t = (loc_t - loc) / (0.5 * w)
         return loc_t, conf_t, prop_loc_t, prop_conf_t, iou
 
+    def _fused_ok(self, loc, conf, priors):
+        """The HIP loss of this recipe (csrc/loss.hip, otal_detection_loss_anet) covers what configs/anet_opental.yaml trains
+        with; other settings stay on the torch formulation below."""
+        cl = self.cls_loss
+        return (FUSED and loc.is_cuda and loc.dtype == torch.float32 and priors.shape[0] <= 1024 and priors.shape[1] == 2
+                and self.cls_loss_type == 'edl' and cl.loss_type == 'log' and cl.evidence == 'exp' and not cl.size_average
+                and cl.num_cls == conf.shape[-1] and not self.act_loss.size_average)
+
     def forward(self, predictions, targets, pre_locs=None):
         loc, conf, prop_loc, prop_conf, center, priors, act, prop_act = predictions
         B, K = loc.shape[0], priors.shape[0]
+        if self._fused_ok(loc, conf, priors):
+            from ..common.ops import AnetDetectionLossFunction
+            gt, valid = pad_targets(targets, loc.device) if isinstance(targets, (list, tuple)) else targets
+            cl = self.cls_loss
+            return AnetDetectionLossFunction.apply(
+                loc, conf, prop_loc, prop_conf, center.reshape(B, K), act.reshape(B, K), prop_act.reshape(B, K), priors, gt, valid,
+                bounds, float(self.clip_length), float(self.overlap_thresh), bool(cl.with_ibm and cl.epoch >= cl.ibm_start),
+                float(cl.coeff), bool(self.iou_aware), float(self.act_loss.weight), float(self.act_loss.margin))
         loc_t, conf_t, prop_loc_t, prop_conf_t, iou_pred = self.match(loc.detach(), priors, targets)
         pos, prop_pos = conf_t > 0, prop_conf_t > 0
         zero = loc.new_zeros(())

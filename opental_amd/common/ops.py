@@ -1195,6 +1195,40 @@ class DetectionLossFunction(torch.autograd.Function):
         return (d_loc, d_conf, d_pl, d_pconf, d_cen, d_act, d_pact) + (None,) * 12
 
 
+class AnetDetectionLossFunction(torch.autograd.Function):
+    """The seven terms of the ActivityNet1.3 MultiSegmentLoss (per-sample normalisation) and all their gradients from one
+    workgroup per sample + a seven-sum launch (csrc/loss.hip: otal_detection_loss_anet); backward = the shared
+    otal_detection_loss_bwd."""
+
+    @staticmethod
+    def forward(ctx, loc, conf, prop_loc, prop_conf, center, act, prop_act, priors2, gt, gvalid, level_bounds,
+                clip_length, overlap, ibm_active, ibm_coeff, iou_aware, act_weight, act_margin):
+        B, K, C = conf.shape
+        G = gt.shape[1]
+        tens = [t.contiguous().float() for t in (loc, conf, prop_loc, prop_conf, center, act, prop_act, priors2, gt)]
+        L.require_device(*tens)
+        gv = gvalid.contiguous().to(torch.uint8)
+        lib = L.lib()
+        lib.otal_detection_loss_grad_floats.restype = ctypes.c_size_t
+        ng = lib.otal_detection_loss_grad_floats(B, K, C)
+        losses = torch.empty(7, dtype=torch.float32, device=loc.device)
+        grads = torch.empty(ng, dtype=torch.float32, device=loc.device)
+        scratch = torch.empty(8 * B, dtype=torch.float32, device=loc.device)
+        nlev = len(level_bounds)
+        lbs = (ctypes.c_float * (2 * nlev))(*[float(v) for row in level_bounds for v in row])
+        L.check(lib.otal_detection_loss_anet(*[L.ptr(t) for t in tens], L.ptr(gv), B, K, C, G, ctypes.c_float(clip_length),
+                                             ctypes.c_float(overlap), lbs, nlev, int(ibm_active), ctypes.c_float(ibm_coeff),
+                                             int(iou_aware), ctypes.c_float(act_weight), ctypes.c_float(act_margin),
+                                             L.ptr(losses), L.ptr(grads), L.ptr(scratch), L.stream()), "otal_detection_loss_anet")
+        ctx.save_for_backward(grads)
+        ctx.dims = (B, K, C)
+        return tuple(losses[i] for i in range(7))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return DetectionLossFunction.backward(ctx, *gs)[:7] + (None,) * 11
+
+
 # ----------------------------------------------------------------------------- head output tails
 class HeadOutputsFunction(torch.autograd.Function):
     """permute / ScaleExp / Dirichlet uncertainty of all detection-head maps in one launch (csrc/heads.hip).

@@ -401,6 +401,308 @@ __global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
     }
 }
 
+
+// =================================================================================================
+// ActivityNet1.3 recipe (AFSD/anet/multisegment_loss.py:87-301, anet/cls_loss.py:78-296): every term is evaluated PER SAMPLE
+// and normalised by that sample's own counts before the mean over the batch, so a workgroup owns ONE sample (K anchors,
+// 189 for 768-frame clips; up to 150 classes) and a second tiny launch sums the B x 7 terms in sample order.  What differs
+// from the THUMOS14 kernel above and is reproduced: per-level regression bounds on max(left, right) in the matching
+// (:69-84, :156-166); refined-stage positives use min(overlap_thresh, best tIoU among the sample's positives) (:178-184);
+// smooth-L1 for the refinement (:206); the influence-balanced weight is the closed form 1 / (|z|_1 exp(coeff g) + 1e-10)
+// with |z|_1 NOT detached (cls_loss.py:137, :225-232; no EMA state); the actionness loss keeps its rank hinge (weight 0.1);
+// the IoU calibration is each sample's own mean.  Gradients use the layout of otal_detection_loss, already divided by B.
+// It replaced ~250 ATen launches of this package's own torch formulation of that file (2.4 ms of kernel time per step).
+constexpr int LA = 256;             // threads per sample
+constexpr int MAX_KA = 1024;        // anchors per sample
+constexpr int MAX_LEVELS_A = 8;
+
+struct AnetLossArgs {
+    const float *loc, *conf, *prop_loc, *prop_conf, *center, *act, *prop_act, *priors, *gt;   // priors (K,2): centre, level
+    const unsigned char* gvalid;
+    float* terms;                   // (B, 8): the seven per-sample terms
+    float* grads;
+    int B, K, C, G;
+    float clip, overlap;
+    int ibm_active, iou_aware;
+    float coeff, act_weight, act_margin;
+    float lb[MAX_LEVELS_A], rb[MAX_LEVELS_A];
+    int nlev;
+};
+
+__device__ float bsum256(float v, float* red) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    red[t] = v;
+    __syncthreads();
+    for (int s = LA / 2; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+// maximum and the FIRST index that holds it (torch.max(dim) backward sends the gradient to one index; ties are measure-zero)
+__device__ float bmax256(float v, int idx, float* red, int* redi, int* arg) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    red[t] = v; redi[t] = idx;
+    __syncthreads();
+    for (int s = LA / 2; s > 0; s >>= 1) {
+        if (t < s) {
+            const float o = red[t + s];
+            const int oi = redi[t + s];
+            if (o > red[t] || (o == red[t] && oi < redi[t])) { red[t] = o; redi[t] = oi; }
+        }
+        __syncthreads();
+    }
+    const float r = red[0];
+    if (arg) *arg = redi[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(LA) void detection_loss_anet_kernel(const AnetLossArgs a) {
+    __shared__ float red[LA];
+    __shared__ int redi[LA];
+    __shared__ float s_lt0[MAX_KA], s_lt1[MAX_KA], s_iou[MAX_KA], s_pl0[MAX_KA], s_pl1[MAX_KA], s_pred[MAX_KA];
+    __shared__ short s_ct[MAX_KA], s_pct[MAX_KA];
+    __shared__ unsigned char s_used[MAX_KA];
+    const int t = threadIdx.x, b = blockIdx.x;
+    const int K = a.K, C = a.C, A = a.B * a.K;
+    float* g_loc_l = a.grads;
+    float* g_loc_ct = g_loc_l + 2 * (size_t)A;
+    float* g_pl_pl = g_loc_ct + 2 * (size_t)A;
+    float* g_pl_ct = g_pl_pl + 2 * (size_t)A;
+    float* g_conf = g_pl_ct + 2 * (size_t)A;
+    float* g_pconf = g_conf + (size_t)A * C;
+    float* g_center = g_pconf + (size_t)A * C;
+    float* g_act = g_center + A;
+    float* g_pact = g_act + A;
+
+    // ---- matching (anet/multisegment_loss.py:144-188), no gradient
+    const float big = a.clip * 2.f;
+    float npos_f = 0.f, my_best = -INFINITY;
+    for (int k = t; k < K; k += LA) {
+        const int i = b * K + k;
+        const float c = a.priors[2 * k];
+        int lvl = (int)a.priors[2 * k + 1];
+        lvl = lvl < 0 ? 0 : (lvl >= a.nlev ? a.nlev - 1 : lvl);
+        const float lb = a.lb[lvl], rb = a.rb[lvl];
+        float best_area = 0.f;
+        int best = 0;
+        for (int g = 0; g < a.G; ++g) {
+            const float left = (c - a.gt[(b * a.G + g) * 3]) * a.clip, right = (a.gt[(b * a.G + g) * 3 + 1] - c) * a.clip;
+            const float far = fmaxf(left, right);
+            float area = left + right;
+            if (left < 0.f || right < 0.f || far <= lb || far > rb || !a.gvalid[b * a.G + g]) area = big;
+            if (g == 0 || area < best_area) { best_area = area; best = g; }     // first minimum, like torch.min
+        }
+        const float g0 = a.gt[(b * a.G + best) * 3], g1 = a.gt[(b * a.G + best) * 3 + 1], lab = a.gt[(b * a.G + best) * 3 + 2];
+        const float lt0 = (c - g0) * a.clip, lt1 = (g1 - c) * a.clip;
+        const int conf_t = best_area >= big ? 0 : (int)lab;
+        const float p0 = a.loc[2 * i], p1 = a.loc[2 * i + 1];
+        const TIoU q = tiou_grad(p0, p1, lt0, lt1);
+        const float w = p0 + p1;
+        s_lt0[k] = lt0; s_lt1[k] = lt1; s_ct[k] = (short)conf_t; s_iou[k] = q.iou;
+        s_pl0[k] = (lt0 - p0) / (0.5f * w); s_pl1[k] = (lt1 - p1) / (0.5f * w);
+        if (conf_t > 0) { npos_f += 1.f; my_best = fmaxf(my_best, q.iou); }
+    }
+    const float npos = bsum256(npos_f, red);
+    const float best_iou = bmax256(my_best, t, red, redi, nullptr);
+    const float thr = npos > 0.f ? fminf(best_iou, a.overlap) : a.overlap;
+    float nppos_f = 0.f;
+    for (int k = t; k < K; k += LA) {
+        const int pct = s_iou[k] < thr ? 0 : (int)s_ct[k];
+        s_pct[k] = (short)pct;
+        nppos_f += pct > 0 ? 1.f : 0.f;
+    }
+    const float nppos = bsum256(nppos_f, red);
+    const float Nf = fmaxf(npos, 1.f), PNf = fmaxf(nppos, 1.f);
+
+    // ---- classification: EvidenceLoss 'log' with exp evidence (anet/cls_loss.py:120-141), per sample
+    float loss_cls[2];
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* logits = pass == 0 ? a.conf : a.prop_conf;
+        float* gout = pass == 0 ? g_conf : g_pconf;
+        const float norm = (pass == 0 ? Nf : PNf) * (float)a.B;
+        float part = 0.f;
+        for (int k = t; k < K; k += LA) {
+            const int i = b * K + k;
+            const int tgt = pass == 0 ? (int)s_ct[k] : (int)s_pct[k];
+            const float* z = logits + (size_t)i * C;
+            float* gz = gout + (size_t)i * C;
+            if (tgt > 0) {
+                const int y = tgt - 1;
+                float S = 0.f, ay = 1.f, l1 = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    const float al = expf(fminf(fmaxf(z[c], -10.f), 10.f)) + 1.f;
+                    S += al;
+                    l1 += fabsf(z[c]);
+                    if (c == y) ay = al;
+                }
+                const float per0 = logf(S) - logf(ay);
+                float invD = 1.f, dfn = 0.f;            // per = per0 * invD;  d per / d |z|_1 = dfn
+                if (a.ibm_active) {
+                    const float e = expf(a.coeff * fabsf(1.f / ay - (float)C / S));       // exp(coeff * g), g detached
+                    const float D = l1 * e + 1e-10f;
+                    invD = 1.f / D;
+                    dfn = -per0 * e / (D * D);
+                }
+                part += per0 * invD;
+                for (int c = 0; c < C; ++c) {
+                    const float zc = z[c];
+                    const float da = (zc >= -10.f && zc <= 10.f) ? expf(zc) : 0.f;     // clamp backward is inclusive
+                    const float sg = zc > 0.f ? 1.f : (zc < 0.f ? -1.f : 0.f);
+                    gz[c] = ((1.f / S - (c == y ? 1.f / ay : 0.f)) * da * invD + dfn * sg) / norm;
+                }
+            } else {
+                for (int c = 0; c < C; ++c) gz[c] = 0.f;
+            }
+        }
+        loss_cls[pass] = bsum256(part, red) / (pass == 0 ? Nf : PNf);
+    }
+
+    // ---- IoU calibration on prop_conf: this sample's mean over its K anchors (anet/multisegment_loss.py:259-261)
+    if (a.iou_aware) {
+        float part = 0.f;
+        const float norm = (float)K * (float)a.B;
+        for (int k = t; k < K; k += LA) {
+            const int i = b * K + k;
+            float iou = s_iou[k];
+            if (iou < 0.f) iou = 1e-3f;
+            const float* z = a.prop_conf + (size_t)i * C;
+            float S = 0.f;
+            for (int c = 0; c < C; ++c) S += expf(fminf(fmaxf(z[c], -10.f), 10.f)) + 1.f;
+            const float u = (float)C / S;
+            part += -iou * logf(1.f - u) - (1.f - iou) * logf(u);
+            const float dreg_du = iou / (1.f - u) - (1.f - iou) / u;
+            float* gz = g_pconf + (size_t)i * C;
+            for (int c = 0; c < C; ++c) {
+                const float zc = z[c];
+                const float da = (zc >= -10.f && zc <= 10.f) ? expf(zc) : 0.f;
+                gz[c] += dreg_du * (-(float)C / (S * S)) * da / norm;
+            }
+        }
+        loss_cls[1] += bsum256(part, red) / (float)K;
+    }
+
+    // ---- localisation (GIoU over positives), refined smooth-L1, quality BCE with the non-detached tIoU target
+    float pl = 0.f, ppl = 0.f, pct = 0.f;
+    const float nN = Nf * (float)a.B, nPN = PNf * (float)a.B;
+    for (int k = t; k < K; k += LA) {
+        const int i = b * K + k;
+        const bool pos = s_ct[k] > 0, ppos = s_pct[k] > 0;
+        const float p0 = a.loc[2 * i], p1 = a.loc[2 * i + 1], t0 = s_lt0[k], t1 = s_lt1[k];
+        float dl0 = 0.f, dl1 = 0.f, dct_l0 = 0.f, dct_l1 = 0.f, dct_p0 = 0.f, dct_p1 = 0.f, dcen = 0.f;
+        if (pos) {
+            const TIoU q = tiou_grad(p0, p1, t0, t1);
+            const float hull = fmaxf(p0, t0) + fmaxf(p1, t1);
+            const float hc = fmaxf(hull, F_EPS), hlive = hull >= F_EPS ? 1.f : 0.f;
+            pl += 1.f - (q.iou - (hull - q.uni) / hc);
+            const float dh0 = dmax_da(p0, t0), dh1 = dmax_da(p1, t1);
+            const float du0 = 1.f - dmin_da(p0, t0), du1 = 1.f - dmin_da(p1, t1);
+            dl0 = (-q.d0 + ((dh0 - du0) * hc - (hull - q.uni) * dh0 * hlive) / (hc * hc)) / nN;
+            dl1 = (-q.d1 + ((dh1 - du1) * hc - (hull - q.uni) * dh1 * hlive) / (hc * hc)) / nN;
+            const float w = p0 + p1, r0 = a.prop_loc[2 * i], r1 = a.prop_loc[2 * i + 1];
+            const float c0 = 0.5f * w * r0 + p0, c1 = 0.5f * w * r1 + p1;
+            const TIoU qq = tiou_grad(c0, c1, t0, t1);
+            const float qv = fmaxf(qq.iou, 0.f), qlive = qq.iou >= 0.f ? 1.f : 0.f;
+            const float x = a.center[i];
+            const float ex = expf(-fabsf(x));
+            pct += fmaxf(x, 0.f) - x * qv + log1pf(ex);
+            const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+            dcen = ((x >= 0.f ? 1.f : 0.f) - qv - sg * ex / (1.f + ex)) / nN;
+            const float gq0 = -x * qlive * qq.d0 / nN, gq1 = -x * qlive * qq.d1 / nN;
+            dct_p0 = gq0 * 0.5f * w; dct_p1 = gq1 * 0.5f * w;
+            const float common = 0.5f * (gq0 * r0 + gq1 * r1);
+            dct_l0 = common + gq0; dct_l1 = common + gq1;
+        }
+        float dpp0 = 0.f, dpp1 = 0.f;
+        if (ppos) {
+            const float e0 = a.prop_loc[2 * i] - s_pl0[k], e1 = a.prop_loc[2 * i + 1] - s_pl1[k];
+            const float d0 = fabsf(e0), d1 = fabsf(e1);
+            ppl += (d0 < 1.f ? 0.5f * d0 * d0 : d0 - 0.5f) + (d1 < 1.f ? 0.5f * d1 * d1 : d1 - 0.5f);
+            dpp0 = (d0 < 1.f ? e0 : (e0 > 0.f ? 1.f : -1.f)) / nPN;
+            dpp1 = (d1 < 1.f ? e1 : (e1 > 0.f ? 1.f : -1.f)) / nPN;
+        }
+        g_loc_l[2 * i] = dl0; g_loc_l[2 * i + 1] = dl1;
+        g_loc_ct[2 * i] = dct_l0; g_loc_ct[2 * i + 1] = dct_l1;
+        g_pl_pl[2 * i] = dpp0; g_pl_pl[2 * i + 1] = dpp1;
+        g_pl_ct[2 * i] = dct_p0; g_pl_ct[2 * i + 1] = dct_p1;
+        g_center[i] = dcen;
+    }
+    const float loss_l = bsum256(pl, red) / Nf;
+    const float loss_pl = bsum256(ppl, red) / PNf;
+    const float loss_ct = bsum256(pct, red) / Nf;
+
+    // ---- positive-unlabelled actionness BCE with the rank hinge (anet/cls_loss.py:249-296), per sample
+    float loss_a[2];
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* pred = (pass == 0 ? a.act : a.prop_act) + (size_t)b * K;
+        float* gout = (pass == 0 ? g_act : g_pact) + (size_t)b * K;
+        const short* tg = pass == 0 ? s_ct : s_pct;
+        const int np = (int)(pass == 0 ? npos : nppos), nn = K - np;
+        const int top_m = min(np, nn) - 1;
+        __syncthreads();
+        for (int k = t; k < K; k += LA) s_pred[k] = pred[k];
+        __syncthreads();
+        float used_f = 0.f, nmax = -INFINITY, pmax = -INFINITY;
+        int nmax_i = 0x7fffffff;
+        for (int k = t; k < K; k += LA) {
+            const bool pos = tg[k] > 0;
+            bool used = true;
+            const float x = s_pred[k];
+            if (!pos && top_m > 0) {        // rank among the negatives: ascending score, ties by index
+                int rank = 0;
+                for (int j = 0; j < K; ++j)
+                    if (!(tg[j] > 0)) rank += (s_pred[j] < x || (s_pred[j] == x && j < k)) ? 1 : 0;
+                used = rank < top_m;
+            }
+            s_used[k] = used ? 1 : 0;
+            used_f += used ? 1.f : 0.f;
+            if (pos) pmax = fmaxf(pmax, x);
+            else if (x > nmax) { nmax = x; nmax_i = k; }
+        }
+        const float cnt = bsum256(used_f, red);
+        int arg_n = 0;
+        const float neg_max = bmax256(nmax, nmax_i, red, redi, &arg_n);
+        const float pos_max = bmax256(pmax, t, red, redi, nullptr);
+        // torch: where(neg, pred, -finfo.max).max(); with no negative / positive the hinge's argument is hugely negative or
+        // the hinge is switched off by top_m <= 0 anyway
+        float hinge = 0.f, dh = 0.f;
+        if (top_m > 0 && a.act_weight != 0.f) {
+            const float v = a.act_margin - neg_max + pos_max;
+            if (v >= 0.f) { hinge = a.act_weight * v; dh = -a.act_weight; }
+        }
+        const float normA = cnt * (float)a.B;
+        float part = 0.f;
+        for (int k = t; k < K; k += LA) {
+            const float x = s_pred[k], y = tg[k] > 0 ? 1.f : 0.f;
+            float gx = 0.f;
+            if (s_used[k]) {
+                part += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+                gx = (1.f / (1.f + expf(-x)) - y) / normA;
+            }
+            if (dh != 0.f && k == arg_n) gx += dh / normA;
+            gout[k] = gx;
+        }
+        loss_a[pass] = (bsum256(part, red) + hinge) / cnt;
+    }
+    if (t == 0) {
+        float* o = a.terms + 8 * b;
+        o[0] = loss_l; o[1] = loss_cls[0]; o[2] = loss_pl; o[3] = loss_cls[1]; o[4] = loss_ct; o[5] = loss_a[0]; o[6] = loss_a[1];
+    }
+}
+
+__global__ void detection_loss_anet_finish_kernel(const float* __restrict__ terms, float* __restrict__ losses, int B) {
+    const int i = threadIdx.x;
+    if (i >= 7) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += terms[8 * b + i];      // sample order, as the reference's python loop
+    losses[i] = s / (float)B;
+}
+
 }  // namespace
 
 extern "C" size_t otal_detection_loss_scratch_floats(int B, int K) { return (size_t)B * K * SCR; }
@@ -431,6 +733,29 @@ extern "C" int otal_detection_loss(const float* loc, const float* conf, const fl
     return otal_launch_status();
 }
 
+
+extern "C" int otal_detection_loss_anet(const float* loc, const float* conf, const float* prop_loc, const float* prop_conf,
+                                        const float* center, const float* act, const float* prop_act, const float* priors2,
+                                        const float* gt, const unsigned char* gvalid, int B, int K, int C, int G,
+                                        float clip_length, float overlap_thresh, const float* level_bounds, int nlev,
+                                        int ibm_active, float ibm_coeff, int iou_aware, float act_weight, float act_margin,
+                                        float* losses, float* grads, float* scratch, void* stream) {
+    if (!loc || !conf || !prop_loc || !prop_conf || !center || !act || !prop_act || !priors2 || !gt || !gvalid ||
+        !level_bounds || !losses || !grads || !scratch) return OTAL_E_NULL;
+    if (B <= 0 || K <= 0 || C <= 0 || G <= 0 || nlev <= 0) return OTAL_E_SHAPE;
+    if (K > MAX_KA || nlev > MAX_LEVELS_A) return OTAL_E_UNSUPPORTED;
+    AnetLossArgs a;
+    a.loc = loc; a.conf = conf; a.prop_loc = prop_loc; a.prop_conf = prop_conf; a.center = center; a.act = act;
+    a.prop_act = prop_act; a.priors = priors2; a.gt = gt; a.gvalid = gvalid; a.terms = scratch; a.grads = grads;
+    a.B = B; a.K = K; a.C = C; a.G = G; a.clip = clip_length; a.overlap = overlap_thresh;
+    a.ibm_active = ibm_active; a.iou_aware = iou_aware; a.coeff = ibm_coeff; a.act_weight = act_weight; a.act_margin = act_margin;
+    a.nlev = nlev;
+    for (int l = 0; l < MAX_LEVELS_A; ++l) { a.lb[l] = l < nlev ? level_bounds[2 * l] : 0.f; a.rb[l] = l < nlev ? level_bounds[2 * l + 1] : 0.f; }
+    hipLaunchKernelGGL(detection_loss_anet_kernel, dim3(B), dim3(LA), 0, (hipStream_t)stream, a);
+    if (int e = otal_launch_status()) return e;
+    hipLaunchKernelGGL(detection_loss_anet_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, losses, B);
+    return otal_launch_status();
+}
 
 // ---- backward of the fused detection loss: the seven head gradients from the stored per-loss gradients and the incoming
 // scalar gradients of the seven losses, in ONE launch (the autograd formulation is 9 multiplies and 2 adds = 11 launches).

@@ -194,3 +194,58 @@ def test_detect_batch_equals_the_per_video_order(golden_dir):
         assert got[v] == ref
         total += len(ref)
     assert total > 0
+
+
+@pytest.mark.parametrize("case", ["mixed", "no_targets_in_one_sample", "single_positive_level", "ibm_off"])
+def test_fused_anet_loss_equals_the_torch_formulation(case):
+    """otal_detection_loss_anet (one workgroup per sample: matching with per-level bounds, EvidenceLoss with the closed-form
+    influence-balanced weight, smooth-L1 refinement, quality BCE with the non-detached tIoU target, positive-unlabelled
+    actionness BCE with its rank hinge, per-sample IoU calibration, per-sample normalisation) against this package's torch
+    formulation of AFSD/anet/multisegment_loss.py -- which oracle/pin_anet.py pins to the reference with delta 0: the seven
+    terms to 2e-5 and the gradient of a weighted sum w.r.t. every head output to 2e-5 of its scale.  Cases: three samples
+    with 1-4 targets; a sample without any target (no positives: N = 1, thresholds fall back); targets that only one
+    pyramid level accepts; the IBM weight off (epoch < ibm_start)."""
+    from opental_amd.anet import multisegment_loss as M
+    rs = np.random.RandomState({"mixed": 1, "no_targets_in_one_sample": 2, "single_positive_level": 3, "ibm_off": 4}[case])
+    B, C = 3, 150
+    lens = [96, 48, 24, 12, 6, 3]
+    K = sum(lens)
+    pri = np.concatenate([np.stack([(np.arange(t) + 0.5) / t, np.full(t, i)], 1) for i, t in enumerate(lens)]).astype(np.float32)
+    priors = torch.from_numpy(pri).cuda()
+
+    def seg(a, b, lab):
+        return [a / 768.0, b / 768.0, float(lab)]
+    if case == "single_positive_level":
+        targets = [np.array([seg(100, 140, 5)], np.float32), np.array([seg(300, 330, 9), seg(500, 540, 2)], np.float32),
+                   np.array([seg(20, 60, 150)], np.float32)]
+    else:
+        targets = [np.array([seg(50, 250, 3), seg(400, 430, 17), seg(600, 760, 150), seg(300, 320, 1)], np.float32),
+                   np.array([seg(10, 700, 42)], np.float32),
+                   np.array([seg(200, 260, 7), seg(220, 500, 8)], np.float32)]
+    if case == "no_targets_in_one_sample":
+        targets[1] = np.zeros((0, 3), np.float32)
+    targets = [torch.from_numpy(t).cuda() for t in targets]
+    mk = lambda *shape, scale=1.0: (torch.from_numpy((rs.randn(*shape) * scale).astype(np.float32)).cuda())
+    loc0 = torch.from_numpy(np.abs(rs.randn(B, K, 2)).astype(np.float32) * 40 + 5).cuda()
+    inputs = [loc0, mk(B, K, C, scale=2.0), mk(B, K, 2, scale=0.8), mk(B, K, C, scale=2.0), mk(B, K, 1), mk(B, K, 1), mk(B, K, 1)]
+    wsum = torch.tensor([1.0, 0.7, 1.3, 0.9, 1.1, 0.6, 1.2], device="cuda")
+
+    def run(fused):
+        M.FUSED = fused
+        crit = M.MultiSegmentLoss(C, 0.6, 1.0, cls_loss_type='edl', edl_config=EDL, os_head=True).cuda()
+        crit.cls_loss.epoch = 0 if case == "ibm_off" else 12
+        xs = [t.clone().requires_grad_(True) for t in inputs]
+        loc, conf, pl, pc, cen, act, pact = xs
+        terms = crit([loc, conf, pl, pc, cen, priors, act, pact], targets)
+        (torch.stack([v.reshape(()) for v in terms]) * wsum).sum().backward()
+        return np.array([float(v.detach()) for v in terms]), [x.grad.detach().cpu().numpy() for x in xs]
+    try:
+        t_ref, g_ref = run(False)
+        t_hip, g_hip = run(True)
+    finally:
+        M.FUSED = True
+    assert np.isfinite(t_hip).all()
+    assert (np.abs(t_hip - t_ref) <= 2e-5 * np.maximum(1.0, np.abs(t_ref))).all(), (t_hip, t_ref)
+    for name, a, b in zip(("loc", "conf", "prop_loc", "prop_conf", "center", "act", "prop_act"), g_hip, g_ref):
+        scale = max(float(np.abs(b).max()), 1e-12)
+        assert float(np.abs(a - b).max()) <= 2e-5 * scale + 1e-9, (name, float(np.abs(a - b).max()), scale)
