@@ -412,7 +412,8 @@ __global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
 // with |z|_1 NOT detached (cls_loss.py:137, :225-232; no EMA state); the actionness loss keeps its rank hinge (weight 0.1);
 // the IoU calibration is each sample's own mean.  Gradients use the layout of otal_detection_loss, already divided by B.
 // It replaced ~250 ATen launches of this package's own torch formulation of that file (2.4 ms of kernel time per step).
-constexpr int LA = 256;             // threads per sample
+constexpr int LA = 1024;            // threads per sample: FOUR lanes per anchor -- the class loops (150 classes, five passes
+constexpr int LQ = LA / 4;          // with an exp each) are split over them and finished with two shuffles; 256 anchors per sweep
 constexpr int MAX_KA = 1024;        // anchors per sample
 constexpr int MAX_LEVELS_A = 8;
 
@@ -429,7 +430,12 @@ struct AnetLossArgs {
     int nlev;
 };
 
-__device__ float bsum256(float v, float* red) {
+__device__ __forceinline__ float quad_sum(float v) {        // sum over the four lanes of an anchor (same wave)
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
+__device__ float bsumA(float v, float* red) {
     const int t = threadIdx.x;
     __syncthreads();
     red[t] = v;
@@ -443,7 +449,7 @@ __device__ float bsum256(float v, float* red) {
     return r;
 }
 // maximum and the FIRST index that holds it (torch.max(dim) backward sends the gradient to one index; ties are measure-zero)
-__device__ float bmax256(float v, int idx, float* red, int* redi, int* arg) {
+__device__ float bmaxA(float v, int idx, float* red, int* redi, int* arg) {
     const int t = threadIdx.x;
     __syncthreads();
     red[t] = v; redi[t] = idx;
@@ -469,6 +475,8 @@ __global__ __launch_bounds__(LA) void detection_loss_anet_kernel(const AnetLossA
     __shared__ short s_ct[MAX_KA], s_pct[MAX_KA];
     __shared__ unsigned char s_used[MAX_KA];
     const int t = threadIdx.x, b = blockIdx.x;
+    const int q4 = t >> 2, sub = t & 3;             // anchor slot of this lane and its share of the class / rank loops
+    const bool lead = sub == 0;                     // per-anchor scalar work and partial sums: one lane of the four
     const int K = a.K, C = a.C, A = a.B * a.K;
     float* g_loc_l = a.grads;
     float* g_loc_ct = g_loc_l + 2 * (size_t)A;
@@ -508,8 +516,8 @@ __global__ __launch_bounds__(LA) void detection_loss_anet_kernel(const AnetLossA
         s_pl0[k] = (lt0 - p0) / (0.5f * w); s_pl1[k] = (lt1 - p1) / (0.5f * w);
         if (conf_t > 0) { npos_f += 1.f; my_best = fmaxf(my_best, q.iou); }
     }
-    const float npos = bsum256(npos_f, red);
-    const float best_iou = bmax256(my_best, t, red, redi, nullptr);
+    const float npos = bsumA(npos_f, red);
+    const float best_iou = bmaxA(my_best, t, red, redi, nullptr);
     const float thr = npos > 0.f ? fminf(best_iou, a.overlap) : a.overlap;
     float nppos_f = 0.f;
     for (int k = t; k < K; k += LA) {
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(LA) void detection_loss_anet_kernel(const AnetLossA
         s_pct[k] = (short)pct;
         nppos_f += pct > 0 ? 1.f : 0.f;
     }
-    const float nppos = bsum256(nppos_f, red);
+    const float nppos = bsumA(nppos_f, red);
     const float Nf = fmaxf(npos, 1.f), PNf = fmaxf(nppos, 1.f);
 
     // ---- classification: EvidenceLoss 'log' with exp evidence (anet/cls_loss.py:120-141), per sample
@@ -527,20 +535,24 @@ __global__ __launch_bounds__(LA) void detection_loss_anet_kernel(const AnetLossA
         float* gout = pass == 0 ? g_conf : g_pconf;
         const float norm = (pass == 0 ? Nf : PNf) * (float)a.B;
         float part = 0.f;
-        for (int k = t; k < K; k += LA) {
-            const int i = b * K + k;
-            const int tgt = pass == 0 ? (int)s_ct[k] : (int)s_pct[k];
+        for (int k0 = 0; k0 < K; k0 += LQ) {            // (uniform trip count: the shuffles below need all four lanes)
+            const int k = k0 + q4;
+            const bool live = k < K;
+            const int i = b * K + (live ? k : 0);
+            const int tgt = !live ? 0 : (pass == 0 ? (int)s_ct[k] : (int)s_pct[k]);
             const float* z = logits + (size_t)i * C;
             float* gz = gout + (size_t)i * C;
-            if (tgt > 0) {
-                const int y = tgt - 1;
-                float S = 0.f, ay = 1.f, l1 = 0.f;
-                for (int c = 0; c < C; ++c) {
+            const int y = tgt - 1;
+            float S = 0.f, ay = 0.f, l1 = 0.f;
+            if (tgt > 0)
+                for (int c = sub; c < C; c += 4) {
                     const float al = expf(fminf(fmaxf(z[c], -10.f), 10.f)) + 1.f;
                     S += al;
                     l1 += fabsf(z[c]);
                     if (c == y) ay = al;
                 }
+            S = quad_sum(S); l1 = quad_sum(l1); ay = quad_sum(ay);
+            if (tgt > 0) {
                 const float per0 = logf(S) - logf(ay);
                 float invD = 1.f, dfn = 0.f;            // per = per0 * invD;  d per / d |z|_1 = dfn
                 if (a.ibm_active) {
@@ -549,42 +561,48 @@ __global__ __launch_bounds__(LA) void detection_loss_anet_kernel(const AnetLossA
                     invD = 1.f / D;
                     dfn = -per0 * e / (D * D);
                 }
-                part += per0 * invD;
-                for (int c = 0; c < C; ++c) {
+                if (lead) part += per0 * invD;
+                for (int c = sub; c < C; c += 4) {
                     const float zc = z[c];
                     const float da = (zc >= -10.f && zc <= 10.f) ? expf(zc) : 0.f;     // clamp backward is inclusive
                     const float sg = zc > 0.f ? 1.f : (zc < 0.f ? -1.f : 0.f);
                     gz[c] = ((1.f / S - (c == y ? 1.f / ay : 0.f)) * da * invD + dfn * sg) / norm;
                 }
-            } else {
-                for (int c = 0; c < C; ++c) gz[c] = 0.f;
+            } else if (live) {
+                for (int c = sub; c < C; c += 4) gz[c] = 0.f;
             }
         }
-        loss_cls[pass] = bsum256(part, red) / (pass == 0 ? Nf : PNf);
+        loss_cls[pass] = bsumA(part, red) / (pass == 0 ? Nf : PNf);
     }
 
     // ---- IoU calibration on prop_conf: this sample's mean over its K anchors (anet/multisegment_loss.py:259-261)
     if (a.iou_aware) {
         float part = 0.f;
         const float norm = (float)K * (float)a.B;
-        for (int k = t; k < K; k += LA) {
-            const int i = b * K + k;
-            float iou = s_iou[k];
+        for (int k0 = 0; k0 < K; k0 += LQ) {
+            const int k = k0 + q4;
+            const bool live = k < K;
+            const int i = b * K + (live ? k : 0);
+            float iou = live ? s_iou[k] : 0.f;
             if (iou < 0.f) iou = 1e-3f;
             const float* z = a.prop_conf + (size_t)i * C;
             float S = 0.f;
-            for (int c = 0; c < C; ++c) S += expf(fminf(fmaxf(z[c], -10.f), 10.f)) + 1.f;
-            const float u = (float)C / S;
-            part += -iou * logf(1.f - u) - (1.f - iou) * logf(u);
-            const float dreg_du = iou / (1.f - u) - (1.f - iou) / u;
-            float* gz = g_pconf + (size_t)i * C;
-            for (int c = 0; c < C; ++c) {
-                const float zc = z[c];
-                const float da = (zc >= -10.f && zc <= 10.f) ? expf(zc) : 0.f;
-                gz[c] += dreg_du * (-(float)C / (S * S)) * da / norm;
+            if (live)
+                for (int c = sub; c < C; c += 4) S += expf(fminf(fmaxf(z[c], -10.f), 10.f)) + 1.f;
+            S = quad_sum(S);
+            if (live) {
+                const float u = (float)C / S;
+                if (lead) part += -iou * logf(1.f - u) - (1.f - iou) * logf(u);
+                const float dreg_du = iou / (1.f - u) - (1.f - iou) / u;
+                float* gz = g_pconf + (size_t)i * C;
+                for (int c = sub; c < C; c += 4) {
+                    const float zc = z[c];
+                    const float da = (zc >= -10.f && zc <= 10.f) ? expf(zc) : 0.f;
+                    gz[c] += dreg_du * (-(float)C / (S * S)) * da / norm;
+                }
             }
         }
-        loss_cls[1] += bsum256(part, red) / (float)K;
+        loss_cls[1] += bsumA(part, red) / (float)K;
     }
 
     // ---- localisation (GIoU over positives), refined smooth-L1, quality BCE with the non-detached tIoU target
@@ -632,9 +650,9 @@ __global__ __launch_bounds__(LA) void detection_loss_anet_kernel(const AnetLossA
         g_pl_ct[2 * i] = dct_p0; g_pl_ct[2 * i + 1] = dct_p1;
         g_center[i] = dcen;
     }
-    const float loss_l = bsum256(pl, red) / Nf;
-    const float loss_pl = bsum256(ppl, red) / PNf;
-    const float loss_ct = bsum256(pct, red) / Nf;
+    const float loss_l = bsumA(pl, red) / Nf;
+    const float loss_pl = bsumA(ppl, red) / PNf;
+    const float loss_ct = bsumA(pct, red) / Nf;
 
     // ---- positive-unlabelled actionness BCE with the rank hinge (anet/cls_loss.py:249-296), per sample
     float loss_a[2];
@@ -649,27 +667,30 @@ __global__ __launch_bounds__(LA) void detection_loss_anet_kernel(const AnetLossA
         __syncthreads();
         float used_f = 0.f, nmax = -INFINITY, pmax = -INFINITY;
         int nmax_i = 0x7fffffff;
-        for (int k = t; k < K; k += LA) {
-            const bool pos = tg[k] > 0;
-            bool used = true;
-            const float x = s_pred[k];
-            if (!pos && top_m > 0) {        // rank among the negatives: ascending score, ties by index
-                int rank = 0;
-                for (int j = 0; j < K; ++j)
+        for (int k0 = 0; k0 < K; k0 += LQ) {
+            const int k = k0 + q4;
+            const bool live = k < K;
+            const bool pos = live && tg[k] > 0;
+            const float x = live ? s_pred[k] : 0.f;
+            int rank = 0;
+            if (live && !pos && top_m > 0)      // rank among the negatives: ascending score, ties by index; a quarter per lane
+                for (int j = sub; j < K; j += 4)
                     if (!(tg[j] > 0)) rank += (s_pred[j] < x || (s_pred[j] == x && j < k)) ? 1 : 0;
-                used = rank < top_m;
+            rank += __shfl_xor(rank, 1);
+            rank += __shfl_xor(rank, 2);
+            if (live && lead) {
+                const bool used = pos || top_m <= 0 || rank < top_m;
+                s_used[k] = used ? 1 : 0;
+                used_f += used ? 1.f : 0.f;
+                if (pos) pmax = fmaxf(pmax, x);
+                else if (x > nmax) { nmax = x; nmax_i = k; }
             }
-            s_used[k] = used ? 1 : 0;
-            used_f += used ? 1.f : 0.f;
-            if (pos) pmax = fmaxf(pmax, x);
-            else if (x > nmax) { nmax = x; nmax_i = k; }
         }
-        const float cnt = bsum256(used_f, red);
+        const float cnt = bsumA(used_f, red);
         int arg_n = 0;
-        const float neg_max = bmax256(nmax, nmax_i, red, redi, &arg_n);
-        const float pos_max = bmax256(pmax, t, red, redi, nullptr);
-        // torch: where(neg, pred, -finfo.max).max(); with no negative / positive the hinge's argument is hugely negative or
-        // the hinge is switched off by top_m <= 0 anyway
+        const float neg_max = bmaxA(nmax, nmax_i, red, redi, &arg_n);
+        const float pos_max = bmaxA(pmax, t, red, redi, nullptr);
+        // torch: where(neg, pred, -finfo.max).max(); with no negative / positive the hinge is switched off by top_m <= 0
         float hinge = 0.f, dh = 0.f;
         if (top_m > 0 && a.act_weight != 0.f) {
             const float v = a.act_margin - neg_max + pos_max;
@@ -687,7 +708,7 @@ __global__ __launch_bounds__(LA) void detection_loss_anet_kernel(const AnetLossA
             if (dh != 0.f && k == arg_n) gx += dh / normA;
             gout[k] = gx;
         }
-        loss_a[pass] = (bsum256(part, red) + hinge) / cnt;
+        loss_a[pass] = (bsumA(part, red) + hinge) / cnt;
     }
     if (t == 0) {
         float* o = a.terms + 8 * b;
