@@ -1367,6 +1367,25 @@ def head_convs(levels, items):
                                    *maps, *[c.weight for _, _, c in heads], *[c.bias for _, _, c in heads])
 
 
+HC_MAX_ROWS = 21        # csrc/headconv.hip: output channels of all fused heads on one input map
+
+
+def head_convs_mixed(levels, items, run_one):
+    """The heads of a stage where some are too wide for the fused launches (the 150-class heads of the ActivityNet model):
+    the skinny ones (1 / 2 output channels) still share ONE forward and TWO backward launches, only the wide ones run as
+    convolutions of their own (`run_one(x, unit)`).  Returns the raw maps in the order of `items`, or None when not even the
+    skinny subset fits (the caller then runs every head by itself)."""
+    wide = [unit.conv1d.out_channels > HC_MAX_ROWS for _, unit in items]
+    if not any(wide) or all(wide):
+        return None
+    small = [it for it, w in zip(items, wide) if not w]
+    fused = head_convs(levels, small)
+    if fused is None:
+        return None
+    fused = list(fused)
+    return [run_one(x, unit) if w else fused.pop(0) for (x, unit), w in zip(items, wide)]
+
+
 # ----------------------------------------------------------------------------- boundary (start / end) losses
 class BoundaryBCEFunction(torch.autograd.Function):
     """(loss_start, loss_end) = calc_bce_loss on the two channel halves of x (B,C,T), read in place (x may be a slice along

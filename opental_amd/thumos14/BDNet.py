@@ -265,6 +265,8 @@ class CoarsePyramid(nn.Module):
         if self.os_head:
             stage.append((conf_feat, self.actionness_head))
         raws = ops.head_convs(lev, stage)
+        if raws is None:            # wide heads (150 classes): the skinny ones still share the fused launches
+            raws = ops.head_convs_mixed(lev, stage, lambda x, head: head(x, lev))
         raws = list(raws) if raws is not None else [head(x, lev) for x, head in stage]
         res = ops.HeadOutputsFunction.apply(tuple(lev), self.fpn_strides, (1, um, 0)[:len(raws)], *scales, *raws)
         loc, conf = res[0], res[1]
@@ -292,8 +294,11 @@ class CoarsePyramid(nn.Module):
         stage = [(loc_prop_feat, self.prop_loc_head), (self._drop(conf_prop_feat), self.prop_conf_head), (loc_prop_feat, self.center_head)]
         if self.os_head:
             stage.append((conf_prop_feat, self.prop_actionness_head))
+        one = lambda x, head: head(x, lev) if head._kernel_shape != 1 else head(x)
         raws = ops.head_convs(lev, stage)
-        raws = list(raws) if raws is not None else [head(x, lev) if head._kernel_shape != 1 else head(x) for x, head in stage]
+        if raws is None:
+            raws = ops.head_convs_mixed(lev, stage, one)
+        raws = list(raws) if raws is not None else [one(x, head) for x, head in stage]
         res = ops.HeadOutputsFunction.apply(tuple(lev), None, (0, um, 0, 0)[:len(raws)], *[h.detach() for h in scales], *raws)
         prop_loc, prop_conf, center = res[0], res[1], res[2]
         prop_act = res[3] if self.os_head else None
