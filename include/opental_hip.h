@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OTAL_ABI_VERSION 22
+#define OTAL_ABI_VERSION 23
 
 /* argument errors */
 #define OTAL_E_NULL      (-1)  /* null pointer */
@@ -114,7 +114,15 @@ int otal_bmp_bwd_levels(const void* grad_out, const void* in, const float* seg, 
  *                parameter, strides stay in ELEMENTS.  Only geometries for which otal_conv_half_storage() returns 1
  *                (16-byte aligned pointer, y strides multiples of 8); anything else is OTAL_E_UNSUPPORTED.  The values
  *                are the ones the consumer's bf16 operand rounding produces from the fp32 tensor, so the forward
- *                results do not change; the backbone uses it for Conv3d_1a's output and its gradient (604 MB each). */
+ *                results do not change; the backbone uses it for Conv3d_1a's output and its gradient (604 MB each).
+ *            bit 3 (value 8), with bits 0 and 2 (ABI 23): the tensor on the layer's INPUT side is stored as bf16 as well
+ *                (otal_conv_fwd: x; otal_conv_wgrad: x; otal_conv_dgrad: dx) -- every activation and data gradient between two
+ *                backbone layers is then a bf16 tensor (half the bytes; operands, accumulators and results are those of the
+ *                fp32-tensor kernels fed with the same bf16 values, outputs rounded to nearest even once).  No accumulate.
+ *            bit 4 (value 16), otal_conv_dgrad with bit 3: out_mask is a bf16 tensor (the activation itself) -- required
+ *                whenever out_mask is given together with bit 3.
+ *                otal_conv_half_storage(geom, strides, mode, precision incl. bit 3) says whether a kernel exists
+ *                (16-byte aligned pointers; batch / channel strides and positions per sample multiples of 8). */
 int otal_conv_half_storage(const int* geom, const int64_t* strides, int mode, int precision);
 size_t otal_conv_workspace_bytes(const int* geom, int mode);
 
@@ -244,6 +252,26 @@ int otal_maxpool3d_fwd_signbits_h(const int* geom, const int64_t* strides, const
                                   unsigned char* argtap, unsigned char* signbits, void* stream);
 int otal_maxpool3d_bwd_signbits_h(const int* geom, const int64_t* strides, const float* dy, const unsigned char* argtap,
                                   void* dx_bf16, const unsigned char* signbits, const float* out_scale, void* stream);
+/* The general bf16-storage forms (ABI 23).  `io` says which tensors are STORED as bf16 (strides stay in elements).
+ *   _fwd_io  io: bit 0 x, bit 1 y.  1 = _fwd_signbits_h; 3 = both: the strided 3x3 pools ((1,3,3)/(1,2,2), (3,3,3)/(2,2,2)) and
+ *            the 3x3x3 / stride-1 branch pools on 12 x 12 and 6 x 6 planes.  A max-pool commutes with the monotonic bf16
+ *            rounding and its winners are copied, not rounded: the output equals the fp32 pool's output rounded once.
+ *   _bwd_io  io: bit 0 dx, bit 1 dy, bit 2 out_mask.  1 = _bwd_signbits_h; 3 / 7 = all of them: strided pools with the sign-bit
+ *            mask and a plain store; branch pools with a bf16 out_mask tensor, `accumulate` = read the bf16 dx, add this
+ *            pool's contribution in fp32, round to nearest even once (the second producer of an Inception module's input
+ *            gradient, AFSD/common/i3d_backbone.py:116-121 under autograd).
+ * signbits / out_mask / out_scale nullable as in the fp32 entry points; anything else is OTAL_E_UNSUPPORTED. */
+int otal_maxpool3d_fwd_io(const int* geom, const int64_t* strides, const void* x, void* y, unsigned char* argtap,
+                          unsigned char* signbits, int io, void* stream);
+int otal_maxpool3d_bwd_io(const int* geom, const int64_t* strides, const void* dy, const unsigned char* argtap, void* dx,
+                          int accumulate, const void* out_mask, const float* out_scale, const unsigned char* signbits, int io,
+                          void* stream);
+/* fp32 <-> bf16 storage conversion of a (B, C, P) map (dense positions, batch / channel strides in elements: channel slices of
+ * a concat buffer): the boundary between the backbone's bf16-stored tensors and the fp32 tensors around them (the endpoints
+ * handed to the pyramid, AFSD/thumos14/BDNet.py:307-308, and their gradients).  to_bf16 != 0: fp32 -> bf16, round to nearest
+ * even; 0: bf16 -> fp32, exact.  P, the strides: multiples of 8; pointers 16-byte aligned. */
+int otal_convert_storage(const void* src, int64_t src_bs, int64_t src_cs, void* dst, int64_t dst_bs, int64_t dst_cs,
+                         int to_bf16, int B, int C, int P, void* stream);
 
 /* ------------------------------------------------------------------ head output tails ----
  * Everything between the head convolutions and CoarsePyramid's outputs (AFSD/thumos14/BDNet.py:337-353,:399-412,:538-556;

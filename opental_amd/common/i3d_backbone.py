@@ -177,7 +177,8 @@ class InceptionI3d(nn.Module):
             # in two phases -- everything down to the cut, then the stem (Conv3d_1a .. Mixed_3c: a third of the backward's
             # GPU time, 3 % of the parameters) -- and all-reduces the first phase's gradients while the second runs
             # (thumos14/train.py, capture_step(split=True)).  The cut tensor is a pool output: its gradient is raw.
-            (stem_out,) = I3DFeaturesFunction.apply(x, plan[:cut], (plan[cut - 1][-1],), scale, shift, offs, *weights)
+            # ("=": the cut tensor is handed over as the stem stores it -- bf16 when ops.HALF_STORAGE is on)
+            (stem_out,) = I3DFeaturesFunction.apply(x, plan[:cut], ("=" + plan[cut - 1][-1],), scale, shift, offs, *weights)
             self.stem_out = cut_in = stem_out
             if self.detach_cut and torch.is_grad_enabled() and stem_out.requires_grad:
                 # the trunk reads a LEAF copy of the cut tensor (same storage): backward(cost) then stops at the cut and
@@ -272,6 +273,49 @@ def _fused_affine(scale, shift, offs, w0):
     return hit[0], hit[1]
 
 
+_HALF_OK = {}
+
+
+def _pool_half_ok(shape, k, s):
+    """A max-pool that has bf16-tensor kernels (csrc/pool3d.hip): the strided 3x3 pools and the 12x12 / 6x6 branch pools."""
+    _, _, T, H, W = shape
+    k, s = tuple(k), tuple(s)
+    if k[1:] == (3, 3) and s[1:] == (2, 2) and H % 2 == 0 and W % 4 == 0:
+        return (k[0], s[0]) == (1, 1) or ((k[0], s[0]) == (3, 2) and T % 2 == 0)
+    return k == THREE and s == ONE and H == W and H in (12, 6)
+
+
+def _conv_half_ok(shape, cout, k, first=False):
+    """A stride-1 convolution whose forward, data gradient (unless it is the network's first layer) and weight gradient all
+    have bf16-tensor kernels for this geometry."""
+    modes = (0, 2) if first else (0, 1, 2)
+    return all(ops.half_storage_ok(m, tuple(shape), cout, k, ONE, both=True) for m in modes)
+
+
+def _step_half_ok(step, shape, weights):
+    """May this plan step run on bf16-STORED tensors (input of `shape`, its own intermediates, its output)?"""
+    key = (step[0], tuple(shape), step[1:-1] if step[0] != "conv" else (tuple(weights[step[1]].shape), step[2], step[3]), ops.HALF_CHAIN,
+           int(ops.CONV_PRECISION), ops.HALF_STORAGE)
+    hit = _HALF_OK.get(key)
+    if hit is None:
+        B, C, T, H, W = shape
+        if not (ops.HALF_CHAIN and ops.HALF_STORAGE and int(ops.CONV_PRECISION) & 1):
+            hit = False
+        elif step[0] == "conv":
+            hit = tuple(step[3]) == ONE and _conv_half_ok(shape, weights[step[1]].shape[0], tuple(step[2]))
+        elif step[0] == "pool":
+            hit = _pool_half_ok(shape, step[1], step[2])
+        else:
+            oc = step[2]
+            hit = (_conv_half_ok(shape, oc[1] + oc[3] + oc[0], ONE) and _conv_half_ok((B, oc[1], T, H, W), oc[2], THREE)
+                   and _conv_half_ok((B, oc[3], T, H, W), oc[4], THREE) and _pool_half_ok(shape, THREE, ONE)
+                   and _conv_half_ok(shape, oc[5], ONE))
+        if len(_HALF_OK) > 512:
+            _HALF_OK.clear()
+        _HALF_OK[key] = hit
+    return hit
+
+
 class I3DFeaturesFunction(Function):
     """Forward + hand-written backward tape of the whole backbone.
 
@@ -279,7 +323,18 @@ class I3DFeaturesFunction(Function):
     step is already multiplied by (Z > 0) * bn_scale[channel] ("dz"), because every kernel that
     contributes to it (the consumers' dgrad GEMMs, max-pool backward) applies that factor in its
     store epilogue.  The producer's wgrad / dgrad GEMMs therefore read ONE tensor per operand
-    instead of gradient + activation.  Gradients of pool outputs are raw."""
+    instead of gradient + activation.  Gradients of pool outputs are raw.
+
+    bf16 STORAGE (ops.HALF_STORAGE + ops.HALF_CHAIN, bf16-operand mode).  Every consumer of a backbone activation rounds it
+    to bf16 while staging it (convolutions) or commutes with that rounding (max-pools), and every consumer of a data
+    gradient is a convolution's bf16 operand loader: between Conv3d_1a and the last module whose planes the bf16-tensor
+    kernels cover (Mixed_4f: 6 x 6), activations AND data gradients are therefore STORED as bf16 -- half the HBM bytes of
+    the 1x1x1 layers and the pools, which stream at the memory rate, with forward values that do not change by a bit.
+    Backward: a bf16-stored gradient holds exactly what its consumers would have rounded the fp32 tensor to, except where a
+    tensor has two producers (a module's input gradient: the fused 1x1 data gradient stores, the branch pool's backward
+    adds -- read bf16, add in fp32, round once).  Where the region ends (an endpoint handed to the pyramid, a step without
+    bf16-tensor kernels) a ("cvt") tape entry converts: bf16 -> fp32 forward, fp32 -> bf16 backward -- so gradients from
+    outside always meet on the fp32 side."""
 
     @staticmethod
     def forward(ctx, x, plan, endpoints, scale, shift, offs, *weights):
@@ -289,9 +344,29 @@ class I3DFeaturesFunction(Function):
         tape, found, half_grads = [], {}, {}
         cur = x
         cur_scale = None            # bn scale vector of the tensor `cur` when it is a conv/mixed output
+        BF = torch.bfloat16
+        need_grad = any(ctx.needs_input_grad)      # (grad mode is off inside forward(): ask what autograd will request)
+        raw_out = {e[1:] for e in endpoints if e.startswith("=")}       # "=name": handed over as stored (a bf16 hand-over
+        endpoints = tuple(e.lstrip("=") for e in endpoints)             #  between the two nodes of a split backward)
+
+        def leave_half():
+            """bf16-stored `cur` -> an fp32 copy; the tape entry converts the gradient back."""
+            nonlocal cur
+            cur32 = ops.convert_storage(cur, torch.float32)
+            tape.append(("cvt", cur, cur32, cur_scale))
+            cur = cur32
+
         for si, step in enumerate(plan):
             kind, name = step[0], step[-1]
-            if kind == "conv":
+            if cur.dtype == BF and not _step_half_ok(step, cur.shape, weights):
+                leave_half()
+            chain = cur.dtype == BF
+            if kind == "conv" and chain:
+                _, wi, k, s, _ = step
+                y = ops.conv_forward(cur, weights[wi], k, s, scale=sc(wi), shift=sh(wi), relu=True)
+                tape.append(("conv", wi, k, s, cur, y, cur_scale, sc(wi)))
+                cur, cur_scale = y, sc(wi)
+            elif kind == "conv":
                 _, wi, k, s, _ = step
                 # a convolution whose output only feeds a strided (1,3,3)/(1,2,2) pool -- Conv3d_1a -> MaxPool3d_2a, Conv3d_2c ->
                 # MaxPool3d_3a -- may store it as bf16: the pool commutes with the rounding the next convolution applies to its
@@ -304,6 +379,11 @@ class I3DFeaturesFunction(Function):
                 grad_half = (pooled_next and si == 0 and not x.requires_grad
                              and ops.half_storage_ok(2, tuple(cur.shape), weights[wi].shape[0], k, s))
                 half = pooled_next and (grad_half or (si > 0 and ops.HALF_ACT_DIRECT))
+                # ... and with the bf16 chain on, the first layer's bf16 output starts it whatever follows
+                if (not half and si == 0 and not x.requires_grad and ops.HALF_CHAIN and si + 1 < len(plan) and name not in endpoints
+                        and ops.half_storage_ok(0, tuple(cur.shape), weights[wi].shape[0], k, s)
+                        and ops.half_storage_ok(2, tuple(cur.shape), weights[wi].shape[0], k, s)):
+                    half = True
                 half_grads[si + 1] = grad_half
                 y = ops.conv_forward(cur, weights[wi], k, s, scale=sc(wi), shift=sh(wi), relu=True, half_out=half)
                 tape.append(("conv", wi, k, s, cur, y, cur_scale, sc(wi)))
@@ -312,7 +392,10 @@ class I3DFeaturesFunction(Function):
                 _, k, s, _ = step
                 # a pool behind a conv + ReLU: let the forward kernel keep that layer's ReLU mask as sign bits, so that the
                 # backward pass does not re-read the 4-byte activations only for their sign
-                y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=cur_scale is not None)
+                if chain:
+                    y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=True, half_out=True)
+                else:
+                    y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=cur_scale is not None)
                 tape.append(("pool", k, s, cur, (arg, bits, half_grads.get(si, False)), cur_scale, None))
                 cur, cur_scale = y, None
             else:
@@ -337,7 +420,7 @@ class I3DFeaturesFunction(Function):
                     with lane:
                         ops.conv_forward(h2, weights[w0 + 4], THREE, ONE, scale=sc(w0 + 4), shift=sh(w0 + 4), relu=True,
                                          out=Y[:, c2:c3])
-                        pm, argm = ops.maxpool3d_forward(cur, THREE, ONE)
+                        pm, argm = ops.maxpool3d_forward(cur, THREE, ONE, half_out=chain)
                         ops.conv_forward(pm, weights[w0 + 5], ONE, ONE, scale=sc(w0 + 5), shift=sh(w0 + 5), relu=True,
                                          out=Y[:, c3:])
                     ops.conv_forward(h1, weights[w0 + 2], THREE, ONE, scale=sc(w0 + 2), shift=sh(w0 + 2), relu=True,
@@ -348,14 +431,21 @@ class I3DFeaturesFunction(Function):
                                      out=Y[:, c1:c2])
                     ops.conv_forward(h2, weights[w0 + 4], THREE, ONE, scale=sc(w0 + 4), shift=sh(w0 + 4), relu=True,
                                      out=Y[:, c2:c3])
-                    pm, argm = ops.maxpool3d_forward(cur, THREE, ONE)
+                    pm, argm = ops.maxpool3d_forward(cur, THREE, ONE, half_out=chain)
                     ops.conv_forward(pm, weights[w0 + 5], ONE, ONE, scale=sc(w0 + 5), shift=sh(w0 + 5), relu=True,
                                      out=Y[:, c3:])
                 out_scale = _cat_cached(_OUT_SCALE, scale, w0, [sc(w0), sc(w0 + 2), sc(w0 + 4), sc(w0 + 5)])
                 tape.append(("mixed", w0, (c1, c2, c3), cur, h1, h2, pm, argm, Y, cur_scale, (wf, o1, o13), out_scale))
                 cur, cur_scale = Y, out_scale
             if name in endpoints:
-                found[name] = (cur, len(tape))
+                if cur.dtype == BF and name not in raw_out:
+                    if need_grad or si + 1 == len(plan):
+                        leave_half()                        # the region ends here: gradients from outside meet on the fp32 side
+                        found[name] = (cur, len(tape))
+                    else:                                   # no gradient will come back: a copy for the caller, the chain goes on
+                        found[name] = (ops.convert_storage(cur, torch.float32), len(tape))
+                else:
+                    found[name] = (cur, len(tape))
         missing = [e for e in endpoints if e not in found]
         if missing:
             raise RuntimeError(f"unknown endpoints {missing}")
@@ -382,7 +472,8 @@ class I3DFeaturesFunction(Function):
 
         def out_grad_buffer(p, shape, like):
             """Where the gradient w.r.t. the OUTPUT of tape step p (1-based; 0 = the network input) is written.  For a
-            mixed step it is the tail of a larger buffer, so that the fused 1x1 backward reads one channel range."""
+            mixed step it is the tail of a larger buffer, so that the fused 1x1 backward reads one channel range.
+            `like`: a tensor of the dtype the gradient is stored in (= the dtype of that output)."""
             if p >= 1 and tape[p - 1][0] == "mixed":
                 o13 = tape[p - 1][10][2]
                 B, ct, T, H, W = shape
@@ -423,7 +514,12 @@ class I3DFeaturesFunction(Function):
                 continue
             step = tape[pos - 1]
             first = pos == 1
-            if step[0] == "conv":
+            if step[0] == "cvt":
+                # the fp32 gradient of the converted copy -> the bf16 gradient of the stored tensor (already masked / scaled
+                # by its producers when that tensor is a conv / mixed output: the convention does not change at the seam)
+                _, xh, _, _ = step
+                dcur = ops.convert_storage(dcur.contiguous(), xh.dtype, out=out_grad_buffer(pos - 1, xh.shape, xh))
+            elif step[0] == "conv":
                 _, wi, k, s, xin, y, in_scale, _ = step
                 slot = ops.grad_slot(weights[wi])
                 in_slots = in_slots and slot is not None
@@ -431,23 +527,27 @@ class I3DFeaturesFunction(Function):
                 if first and not need_dx:
                     dcur = None
                 else:
-                    dcur = ops.conv_dgrad(dcur, weights[wi], xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, dcur),
+                    dcur = ops.conv_dgrad(dcur, weights[wi], xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, xin),
                                           out_mask=xin if in_scale is not None else None, out_scale=in_scale)
                 side.flush()
                 ops.grads_ready([(weights[wi], dws[wi])])
             elif step[0] == "pool":
                 _, k, s, xin, (arg, bits, grad_half), in_scale, _ = step
-                if grad_half:                               # Conv3d_1a's bf16-stored output: its gradient is stored the same way
+                if dcur.dtype == torch.bfloat16:            # bf16 chain: dy, dx and the (sign-bit) mask alike
+                    masked = in_scale is not None and bits is not None
+                    dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, xin),
+                                                  out_scale=in_scale if masked else None, out_signbits=bits if masked else None)
+                elif grad_half:                             # Conv3d_1a's bf16-stored output: its gradient is stored the same way
                     dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out_scale=in_scale, out_signbits=bits, half_out=True)
                 else:
-                    dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, dcur),
+                    dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, xin),
                                                   out_mask=xin if (in_scale is not None and bits is None) else None,
                                                   out_scale=in_scale, out_signbits=bits)
             else:
                 _, w0, (c1, c2, c3), xin, h1, h2, pm, argm, Y, in_scale, (wf, o1, o13), _ = step
                 Zg = zg.pop(pos)            # [dh1 | dh2 | dY]; dcur is its tail
                 dY = Zg[:, o13:]
-                dX = out_grad_buffer(pos - 1, xin.shape, dcur)
+                dX = out_grad_buffer(pos - 1, xin.shape, xin)
                 xm = xin if in_scale is not None else None
                 sl = (slice(0, c1), slice(c1, c2), slice(c2, c3), slice(c3, Y.shape[1]))
                 for a, b, hid, sli, dst in ((w0 + 1, w0 + 2, h1, sl[1], Zg[:, :o1]), (w0 + 3, w0 + 4, h2, sl[2], Zg[:, o1:o13])):

@@ -34,6 +34,10 @@ HALF_STORAGE = os.environ.get("OTAL_HALF_STORAGE", "1") != "0"
 # measured 11.66 vs 11.68 ms per step (within noise: the layer is MFMA/LDS-bound, not store-bound), while the pool ties the
 # rounding creates move Conv3d_1a's weight gradient further (cosine 0.989 vs 0.997 with the fp32-stored run).
 HALF_ACT_DIRECT = os.environ.get("OTAL_HALF_ACT_DIRECT", "0") != "0"
+# ... and (round 4) of EVERY activation and data gradient between Conv3d_1a and the last backbone module the bf16-tensor kernels
+# cover (Mixed_4f): precision bit 3 of the C ABI, otal_maxpool3d_*_io (common/i3d_backbone.py: "bf16 STORAGE").  The forward
+# values do not change; gradients change only where a tensor has two producers (one more bf16 rounding).
+HALF_CHAIN = os.environ.get("OTAL_HALF_CHAIN", "1") != "0"
 
 
 def _prof_begin():
@@ -243,7 +247,7 @@ class SideWgrads:
         if not self.on:
             return conv_wgrad(x, dy, w_shape, k, s, spatial_valid=spatial_valid, levels=levels, out=out)
         if out is None:
-            out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device)
+            out = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
         # the recorded call writes through an ALIAS: a second reference to the returned tensor itself would stop autograd
         # from adopting it as the parameter's .grad (AccumulateGrad clones a gradient somebody else still holds -- here a
         # clone of memory the weight gradient has not been written to yet)
@@ -577,8 +581,9 @@ def _out_positions(x, Cout, k, s, levels, spatial_valid):
     return _make_geom(B, Cin, Cout, (Ti, Hi, Wi), k, s, levels, spatial_valid)[1]
 
 
-def half_storage_ok(mode, x_shape, cout, k, s):
-    """True when the library has a kernel for this geometry with the large operand (fwd: y, wgrad: dy) stored as bf16."""
+def half_storage_ok(mode, x_shape, cout, k, s, both=False):
+    """True when the library has a kernel for this geometry with the large operand (fwd: y, wgrad: dy) stored as bf16;
+    both=True: with the tensors on BOTH sides of the layer stored as bf16 (precision bit 3)."""
     if not (HALF_STORAGE and int(CONV_PRECISION) & 1) or len(x_shape) != 5:
         return False
     k, s = _k3(k), _k3(s)
@@ -587,16 +592,19 @@ def half_storage_ok(mode, x_shape, cout, k, s):
     ga = (ctypes.c_int * len(g))(*g)
     P = outn[0] * outn[1] * outn[2]
     sa = (ctypes.c_int64 * 4)(Cin * Ti * Hi * Wi, Ti * Hi * Wi, cout * P, P)
-    return bool(L.lib().otal_conv_half_storage(ga, sa, int(mode), int(CONV_PRECISION)))
+    return bool(L.lib().otal_conv_half_storage(ga, sa, int(mode), int(CONV_PRECISION) | (12 if both else 0)))
 
 
 def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=False, levels=None, out=None, half_out=False):
     """y = act(scale * conv_SAME(x, w) + shift).  x (B,Cin,T[,H,W]); w (Cout,Cin,*k).
-    half_out: y is STORED as bf16 (half_storage_ok(0, ...) geometries only)."""
+    half_out: y is STORED as bf16 (half_storage_ok(0, ...) geometries only).  A bfloat16 x (a bf16-STORED activation of the
+    backbone, HALF_STORAGE) implies a bfloat16 y: precision bits 2 and 3 of the C ABI."""
     k, s = _k3(k), _k3(s)
     if levels is not None:
         levels = tuple(levels)
     Cout = w.shape[0]
+    if x.dtype == torch.bfloat16:
+        return _conv_forward_half(x, w, k, s, scale, shift, relu, spatial_valid, levels, out)
     if out is None:
         outn = _out_positions(x, Cout, k, s, levels, spatial_valid)
         out = torch.empty((x.shape[0], Cout) + (outn if x.dim() == 5 else outn[:1]),
@@ -613,6 +621,26 @@ def conv_forward(x, w, k, s, scale=None, shift=None, relu=False, spatial_valid=F
     L.check(L.lib().otal_conv_fwd(ga, sa, L.ptr(x), L.ptr(w), _opt(scale), _opt(shift), L.ptr(out), int(relu),
                                   prec | (4 if half_out else 0), pre, wsp, wsn, L.stream()),
             "otal_conv_fwd")
+    _prof_end(ev, "fwd", g)
+    return out
+
+
+def _conv_forward_half(x, w, k, s, scale, shift, relu, spatial_valid, levels, out):
+    Cout = w.shape[0]
+    if out is None:
+        outn = _out_positions(x, Cout, k, s, levels, spatial_valid)
+        out = torch.empty((x.shape[0], Cout) + (outn if x.dim() == 5 else outn[:1]), dtype=torch.bfloat16, device=x.device)
+    if out.dtype != torch.bfloat16 or not (int(CONV_PRECISION) & 1):
+        raise RuntimeError("conv_forward: a bfloat16 x needs a bfloat16 y and the bf16-operand mode")
+    g, ga, sa, pkey, _ = _plan(0, x, out, Cout, k, s, levels, spatial_valid, "x", "y")
+    if not w.is_contiguous():
+        raise RuntimeError("weights must be contiguous")
+    wsp, wsn = _ws_args(x.device)
+    ev = _prof_begin()
+    prec = int(CONV_PRECISION)
+    pre = _prologue(0, ga, sa, pkey, w, prec)
+    L.check(L.lib().otal_conv_fwd(ga, sa, L.ptr(x), L.ptr(w), _opt(scale), _opt(shift), L.ptr(out), int(relu),
+                                  prec | 12, pre, wsp, wsn, L.stream()), "otal_conv_fwd (bf16 tensors)")
     _prof_end(ev, "fwd", g)
     return out
 
@@ -641,8 +669,11 @@ def conv_dgrad(dy, w, x_shape, k, s, spatial_valid=False, levels=None, out=None,
         out = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
     elif tuple(out.shape) != tuple(x_shape):
         raise RuntimeError(f"conv_dgrad: out has shape {tuple(out.shape)}, expected {tuple(x_shape)}")
-    if out.dtype != torch.float32 or dy.dtype != torch.float32:
-        raise RuntimeError("conv_dgrad: float32 tensors")
+    half = dy.dtype == torch.bfloat16                       # bf16-stored gradients (HALF_STORAGE): dy, dx and the mask alike
+    if out.dtype != dy.dtype or not (half or dy.dtype == torch.float32):
+        raise RuntimeError("conv_dgrad: float32 tensors, or bfloat16 dy / dx / out_mask together")
+    if half and (accumulate or not (int(CONV_PRECISION) & 1)):
+        raise RuntimeError("conv_dgrad: bfloat16 tensors need the bf16-operand mode and a plain store")
     g, ga, sa, pkey, xlay = _plan(1, out, dy, Cout, k, s, levels, spatial_valid, "dx", "dy")
     prec = int(CONV_PRECISION)
     if wt is None:          # hand the forward-layout weight over; the launch re-orders it in its own prologue
@@ -652,9 +683,11 @@ def conv_dgrad(dy, w, x_shape, k, s, spatial_valid=False, levels=None, out=None,
     ev = _prof_begin()
     if out_mask is not None:
         m5 = _as5(out_mask)
-        if (tuple(m5.shape), _bs(m5)) != xlay or out_mask.dtype != torch.float32:
-            raise RuntimeError("out_mask must share dx's shape and layout")
+        if (tuple(m5.shape), _bs(m5)) != xlay or out_mask.dtype != dy.dtype:
+            raise RuntimeError("out_mask must share dx's shape, layout and dtype")
     pre = _prologue(1, ga, sa, pkey, wt, prec) if (prec & 2) else None     # regions are keyed on the live weight tensor
+    if half:
+        prec |= 12 | (16 if out_mask is not None else 0)
     L.check(L.lib().otal_conv_dgrad(ga, sa, L.ptr(dy), L.ptr(wt), L.ptr(out),
                                     int(accumulate), _opt(out_mask), _opt(out_scale), prec, pre,
                                     wsp, wsn, L.stream()),
@@ -784,13 +817,14 @@ def conv_wgrad(x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None,
         levels = tuple(levels)
     Cout = w_shape[0]
     half_dy = dy.dtype == torch.bfloat16                    # bf16-stored gradient (maxpool3d_backward(half_out=True))
-    if x.dtype != torch.float32 or not (half_dy or dy.dtype == torch.float32):
-        raise RuntimeError("conv_wgrad: float32 x, float32 or bfloat16 dy")
+    half_x = x.dtype == torch.bfloat16                      # ... and a bf16-stored activation (HALF_STORAGE): only with a bf16 dy
+    if not (half_x or x.dtype == torch.float32) or not (half_dy or dy.dtype == torch.float32) or (half_x and not half_dy):
+        raise RuntimeError("conv_wgrad: float32 x with a float32 or bfloat16 dy, or both bfloat16")
     g, ga, sa, pkey, _ = _plan(2, x, dy, Cout, k, s, levels, spatial_valid, "x", "dy")
     if out is None:
         if accumulate:
             raise RuntimeError("accumulate needs an existing buffer")
-        out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device)
+        out = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     if not out.is_contiguous():
         raise RuntimeError("dw must be contiguous")
     if _DEFER and (accumulate or (_DEFER_OWNER is not None and _DEFER_OWNER[0] != _WS_SIDE)):
@@ -798,9 +832,9 @@ def conv_wgrad(x, dy, w_shape, k, s, spatial_valid=False, levels=None, out=None,
     wsp, wsn = _ws_args(x.device)
     ev = _prof_begin()
     prec = int(CONV_PRECISION)
-    pre = None if half_dy else _prologue(2, ga, sa, pkey, x, prec)
+    pre = _prologue(2, ga, sa, pkey, x, prec) if (half_x or not half_dy) else None
     L.check(L.lib().otal_conv_wgrad(ga, sa, L.ptr(x), L.ptr(dy), L.ptr(out),
-                                    int(accumulate), prec | (4 if half_dy else 0), pre, wsp, wsn, L.stream()),
+                                    int(accumulate), prec | (4 if half_dy else 0) | (8 if half_x else 0), pre, wsp, wsn, L.stream()),
             "otal_conv_wgrad")
     if _DEFER:
         _after_wgrad(x.device)
@@ -1030,12 +1064,30 @@ def _pool_geom(x5, k, s):
     return [B, C, Ti, Hi, Wi, *outs, *k, *s, *pads], tuple(outs)
 
 
-def maxpool3d_forward(x, k, s, out=None, signbits=False):
+def maxpool3d_forward(x, k, s, out=None, signbits=False, half_out=False):
     """(y, winner bytes) -- with signbits=True (y, winner bytes, sign bits of x or None): the strided 3x3 pools can hand
-    the ReLU mask of their input to the backward pass as one bit per element (maxpool3d_backward(out_signbits=...))."""
+    the ReLU mask of their input to the backward pass as one bit per element (maxpool3d_backward(out_signbits=...)).
+    half_out (bfloat16 x only): y is STORED as bf16 too (otal_maxpool3d_fwd_io, io = 3)."""
     x5 = _as5(x)
     g, outn = _pool_geom(x5, k, s)
     B, C = x5.shape[:2]
+    if half_out:
+        if x5.dtype != torch.bfloat16:
+            raise RuntimeError("maxpool3d_forward(half_out): a bfloat16 input (winners are copied, not rounded)")
+        if out is None:
+            out = torch.empty((B, C) + outn, dtype=torch.bfloat16, device=x.device)
+        arg = torch.empty((B, C) + outn, dtype=torch.uint8, device=x.device)
+        _check(x5, "x", torch.bfloat16); _check(out, "y", torch.bfloat16)
+        ga, sa = _geom_arrays(g, x5, out)
+        lib = L.lib()
+        bits = None
+        if signbits:
+            lib.otal_maxpool3d_signbits_bytes.restype = ctypes.c_size_t
+            nbytes = int(lib.otal_maxpool3d_signbits_bytes(ga, sa))
+            if nbytes:
+                bits = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        L.check(lib.otal_maxpool3d_fwd_io(ga, sa, L.ptr(x5), L.ptr(out), L.ptr(arg), _opt(bits), 3, L.stream()), "otal_maxpool3d_fwd_io")
+        return (out, arg, bits) if signbits else (out, arg)
     if out is None:
         out = torch.empty((B, C) + outn, dtype=x.dtype, device=x.device)
     arg = torch.empty((B, C) + outn, dtype=torch.uint8, device=x.device)
@@ -1070,7 +1122,25 @@ def maxpool3d_forward(x, k, s, out=None, signbits=False):
 
 def maxpool3d_backward(dy, arg, x_shape, k, s, out=None, accumulate=False, out_mask=None, out_scale=None, out_signbits=None,
                        half_out=False):
-    """half_out: dx is STORED as bf16 (sign-bit mask, no accumulate) for conv_wgrad's bf16-dy kernels."""
+    """half_out: dx is STORED as bf16 (sign-bit mask, no accumulate) for conv_wgrad's bf16-dy kernels.
+    A bfloat16 dy (HALF_STORAGE) implies a bfloat16 dx and, when given, a bfloat16 out_mask (otal_maxpool3d_bwd_io)."""
+    if dy.dtype == torch.bfloat16:
+        if out is None:
+            if accumulate:
+                raise RuntimeError("accumulate needs an existing buffer")
+            out = torch.empty(tuple(x_shape), dtype=torch.bfloat16, device=dy.device)
+        g, outn = _pool_geom(out, k, s)
+        _check(out, "dx", torch.bfloat16); _check(dy, "dy", torch.bfloat16)
+        if tuple(dy.shape[2:]) != outn or not arg.is_contiguous():
+            raise RuntimeError("maxpool3d_backward: shape mismatch")
+        if out_mask is not None and (tuple(out_mask.shape) != tuple(out.shape) or out_mask.stride() != out.stride()
+                                     or out_mask.dtype != torch.bfloat16):
+            raise RuntimeError("out_mask must share dx's shape, layout and dtype")
+        ga, sa = _geom_arrays(g, out, dy)
+        L.check(L.lib().otal_maxpool3d_bwd_io(ga, sa, L.ptr(dy), L.ptr(arg), L.ptr(out), int(accumulate), _opt(out_mask),
+                                              _opt(out_scale), _opt(out_signbits), 3 | (4 if out_mask is not None else 0), L.stream()),
+                "otal_maxpool3d_bwd_io")
+        return out
     if half_out:
         if accumulate or out_mask is not None or out_signbits is None or out is not None:
             raise RuntimeError("maxpool3d_backward(half_out): plain store with the sign-bit mask only")
@@ -1102,6 +1172,24 @@ def maxpool3d_backward(dy, arg, x_shape, k, s, out=None, accumulate=False, out_m
         raise RuntimeError("out_mask must share dx's shape and layout")
     L.check(L.lib().otal_maxpool3d_bwd(ga, sa, L.ptr(dy), L.ptr(arg), L.ptr(out), int(accumulate),
                                        _opt(out_mask), _opt(out_scale), L.stream()), "otal_maxpool3d_bwd")
+    return out
+
+
+def convert_storage(src, dtype, out=None):
+    """A (B,C,T,H,W) / (B,C,T) map (dense positions; may be a channel slice) converted between float32 and bfloat16 STORAGE
+    (otal_convert_storage): the boundary between the backbone's bf16-stored tensors and the fp32 tensors around them."""
+    s5 = _as5(src)
+    if out is None:
+        out = torch.empty(tuple(src.shape), dtype=dtype, device=src.device)
+    o5 = _as5(out)
+    if {src.dtype, out.dtype} != {torch.float32, torch.bfloat16} or tuple(o5.shape) != tuple(s5.shape):
+        raise RuntimeError("convert_storage: float32 <-> bfloat16, same shape")
+    _check(s5, "src", s5.dtype); _check(o5, "dst", o5.dtype)
+    B, C, T, H, W = s5.shape
+    (sb, sc), (db, dc) = _bs(s5), _bs(o5)
+    L.check(L.lib().otal_convert_storage(L.ptr(s5), ctypes.c_int64(sb), ctypes.c_int64(sc), L.ptr(o5), ctypes.c_int64(db),
+                                         ctypes.c_int64(dc), int(out.dtype == torch.bfloat16), B, C, T * H * W, L.stream()),
+            "otal_convert_storage")
     return out
 
 

@@ -22,6 +22,19 @@ def sources():
     return sorted(glob.glob(os.path.join(HERE, "*.hip")))
 
 
+def _includes(src, seen=None):
+    """Files of this directory that `src` includes, directly or through another file (conv_gemm_half.hip includes
+    conv_gemm.hip, which includes the .inc files)."""
+    import re
+    seen = set() if seen is None else seen
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(src).read(), flags=re.M):
+        path = os.path.join(HERE, name)
+        if os.path.exists(path) and path not in seen:
+            seen.add(path)
+            _includes(path, seen)
+    return seen
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -38,7 +51,7 @@ def build(force=False, verbose=True):
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
+        if force or _stale(obj, [src] + headers + sorted(_includes(src))):
             cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -25,6 +25,20 @@
 #include <cstring>
 #include <type_traits>
 
+// This file is compiled TWICE (csrc/build.py): part 0 = the C entry points, the dispatch and every kernel that works on fp32
+// tensors; part 1 (conv_gemm_half.hip defines OTAL_CONV_PART 1 and includes this file) = the instantiations of the same
+// kernel templates for bf16-STORED activations / gradients (template flag H), reached through otal_conv::launch_half().
+// Two translation units halve the build's critical path; the kernels themselves exist once, as source.
+#ifndef OTAL_CONV_PART
+#define OTAL_CONV_PART 0
+#endif
+
+namespace otal_conv {
+struct ConvArgs;
+// part 1's dispatcher: the launch for bf16-stored tensors (a.half / a.xhalf set), or OTAL_E_UNSUPPORTED
+__attribute__((visibility("hidden"))) int launch_half(int mode, ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st);
+}  // namespace otal_conv
+
 namespace {
 
 constexpr int NT = 256;
@@ -33,7 +47,8 @@ enum { EPI_RELU = 1, EPI_ACCUM = 2, DBG_NOLOAD = 4, DBG_NOSTORE = 8, DBG_NOBARRI
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct ConvArgs {
+}  // namespace
+struct otal_conv::ConvArgs {
     ConvGeom g;
     ConvFastDiv fd;        // host-built exact fast-division constants (no runtime integer divides)
     const float* x;        // FWD/WGRAD: input activations
@@ -81,7 +96,14 @@ struct ConvArgs {
     float* slab2;
     const void* pre2;
     const float* w2;
+    // bf16 STORAGE of the tensors around a backbone layer (ops.HALF_STORAGE; part 1 of this file).  Strides stay in ELEMENTS.
+    //   half  : the tensor on the layer's OUTPUT side is bf16 -- fwd: y; dgrad / wgrad: dy
+    //   xhalf : the tensor on its INPUT side is bf16          -- fwd: x; dgrad: dx; wgrad: x
+    //   mhalf : dgrad: `emask` is bf16 (it has dx's layout)
+    int xhalf, mhalf;
 };
+namespace {
+using otal_conv::ConvArgs;
 
 // ---- operand element fetch -------------------------------------------------------------------
 // Every gather loads UNCONDITIONALLY: an out-of-range element reads a device zero word instead of
@@ -167,6 +189,20 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {     // v_c
     const hw_f32x2 f = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f, hw_bf16x2));
 }
+
+// ---- helpers of the bf16-STORED tensors (template flag H).  Two words that each hold the bf16 values of two neighbouring
+// positions (lo | hi << 16), one word per channel: the pair (channel a, channel b) of the LOW / HIGH position -- one v_perm_b32
+// each, where the fp32 tensors need one v_cvt_pk_bf16_f32: the transposition "positions along the load, channels along the
+// MFMA operand" costs the same VALU work as the conversion it replaces.
+__device__ __forceinline__ unsigned pair_lo(unsigned ch_a, unsigned ch_b) { return __builtin_amdgcn_perm(ch_b, ch_a, 0x05040100u); }
+__device__ __forceinline__ unsigned pair_hi(unsigned ch_a, unsigned ch_b) { return __builtin_amdgcn_perm(ch_b, ch_a, 0x07060302u); }
+// (value > 0) of a bf16 bit pattern, as all-ones / zero for the half word it sits in: positive, not zero, not NaN
+__device__ __forceinline__ bool bf16_pos(unsigned bits16) { return bits16 - 1u < 0x7f80u; }
+__device__ __forceinline__ unsigned bf16_relu_mask2(unsigned w) {            // per half word of w: 0xffff where its bf16 is > 0
+    return (bf16_pos(w & 0xffffu) ? 0x0000ffffu : 0u) | (bf16_pos(w >> 16) ? 0xffff0000u : 0u);
+}
+__device__ __forceinline__ float bf16lo_f32(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi_f32(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {     // round to nearest even, lo in bits 0..15
     unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
@@ -329,6 +365,84 @@ __device__ __forceinline__ void store_acc(const ConvArgs& a, const f32x16 (&acc)
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, vo[r], 0, 0);
+        }
+    }
+}
+
+// Epilogue for a bf16-STORED output (H kernels; FWD: y, DGRAD: dx).  The fp32 epilogue above issues sixteen 4-byte stores
+// per MFMA tile and lane -- and, for a masked data gradient, sixteen 4-byte mask loads in front of them: on the 1x1x1
+// layers that was 45 - 65 % of the launch.  Here the tile is finished in registers (folded BN / ReLU, or the
+// producer's BN scale), rounded to nearest even ONCE, transposed through LDS (the operand tiles are dead) and written as
+// 16-byte runs of eight positions; the ReLU mask of a data gradient is the bf16 activation itself, read with the same
+// 16-byte pieces.  Positions: n = b * P + p with P % 8 == 0 (checked on the host), so a run never leaves its sample and is
+// contiguous whatever the convolution's stride.  No split-K here (slabs stay fp32: store_acc), no accumulate.
+// `lds`: at least BM * (BN * 2 + 16) + BM * 8 bytes.
+template <int MODE, int WM, int WN, int BM, int BN>
+__device__ __forceinline__ void store_acc_h(const ConvArgs& a, const f32x16 (&acc)[WM][WN], int m0, int n0, int wm0, int wn0,
+                                            int lane, unsigned char* lds, int nthreads) {
+    static_assert(MODE != MODE_WGRAD, "weight gradients are fp32");
+    constexpr int PT = BN * 2 + 16;
+    const ConvGeom& g = a.g;
+    float* rows = reinterpret_cast<float*>(lds + BM * PT);
+    __syncthreads();        // every wave is done reading the operand tiles
+    for (int r = threadIdx.x; r < BM; r += nthreads) {
+        const int m = m0 + r;
+        float s0 = 1.f, s1 = 0.f;
+        if (m < a.M) {
+            if constexpr (MODE == MODE_FWD) { if (a.scale) s0 = a.scale[m]; if (a.shift) s1 = a.shift[m]; }
+            else { if (a.escale) s0 = a.escale[m]; }
+        }
+        rows[2 * r] = s0; rows[2 * r + 1] = s1;
+    }
+    __syncthreads();
+    const bool relu = (a.flags & EPI_RELU) != 0;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int nl = wn0 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[i][j][r];
+                if constexpr (MODE == MODE_FWD) {
+                    v = v * rows[2 * lr] + rows[2 * lr + 1];
+                    if (relu) v = fmaxf(v, 0.f);
+                } else {
+                    v *= rows[2 * lr];
+                }
+                *reinterpret_cast<unsigned short*>(lds + lr * PT + nl * 2) = (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);
+            }
+        }
+    __syncthreads();
+    unsigned short* const out = reinterpret_cast<unsigned short*>(a.out);
+    const unsigned short* const mk = (MODE == MODE_DGRAD) ? reinterpret_cast<const unsigned short*>(a.emask) : nullptr;
+    const int64_t bs = MODE == MODE_FWD ? g.y_bs : g.x_bs, cs = MODE == MODE_FWD ? g.y_cs : g.x_cs;
+    const FastDiv fP = a.fd.P;                                          // DGRAD: the host admits stride-1 SAME layers only (in = out positions)
+    constexpr int PIECES = BM * (BN / 8);
+    for (int p0 = threadIdx.x; p0 < PIECES; p0 += 2 * nthreads) {     // two pieces per trip: both mask loads in flight together
+        int64_t off[2];
+        bool ok[2];
+        Words4 v[2], m4[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = p0 + u * nthreads;
+            const int row = p / (BN / 8), q = p - row * (BN / 8);
+            const int m = m0 + row, n = n0 + q * 8;
+            ok[u] = p < PIECES && m < a.M && n < a.N;
+            const uint32_t b = fd_div(fP, ok[u] ? (uint32_t)n : 0u);
+            off[u] = ok[u] ? (int64_t)b * bs + (int64_t)m * cs + (int64_t)((uint32_t)n - b * fP.d) : 0;
+            v[u] = *reinterpret_cast<const Words4*>(lds + (ok[u] ? row : 0) * PT + (ok[u] ? q : 0) * 16);
+            if (mk) m4[u] = *reinterpret_cast<const Words4*>(mk + off[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ok[u]) continue;
+            if (mk) {
+                v[u].a &= bf16_relu_mask2(m4[u].a); v[u].b &= bf16_relu_mask2(m4[u].b);
+                v[u].c &= bf16_relu_mask2(m4[u].c); v[u].d &= bf16_relu_mask2(m4[u].d);
+            }
+            *reinterpret_cast<Words4*>(out + off[u]) = v[u];
         }
     }
 }
@@ -703,15 +817,24 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const ConvArgs a) {
 // accumulators in VGPRs (106 / 164 registers, no spills).  The 1x1x1 layers these kernels mostly serve are latency-bound
 // per workgroup (8 .. 26 K steps between a cold first load and a 16-store epilogue): Mixed_3c fused 1x1 forward
 // 101 -> 94 us.  (The 128-row variant spills at three per CU: left at two.)
-template <int BM, int WM, int WN, int MODE, int CW, bool KWV = false>
+// H: the gathered tensor (FWD: x, DGRAD: dy) and the output are STORED as bf16 (ConvArgs::half / xhalf).  A load of CW positions
+// is CW * 2 bytes (b64 / b32 / b16 for CW 4 / 2 / 1 -- raw-buffer loads are legal at 2-byte aligned addresses on gfx950 and
+// return correct data, tools/ubench/align2probe.hip; plain global loads are NOT: they drop address bit 1); the values go to
+// LDS as they are (pair_lo / pair_hi transpose "positions along the load" into "channels along the operand" for the price
+// of the conversion they replace), so the MFMA operands -- and with them every accumulator -- are bit for bit those of the
+// fp32-tensor kernel fed with the same bf16 values; the epilogue is store_acc_h.  Split-K slabs stay fp32.
+template <int BM, int WM, int WN, int MODE, int CW, bool KWV = false, bool H = false>
 __global__ __launch_bounds__(NT, KWV ? 1 : (BM == 96 ? 4 : (BM == 192 ? 3 : 1))) void conv_gemm_bf16c_kernel(const ConvArgs a) {
-    static_assert(!KWV || (CW == 1 && MODE == MODE_FWD), "kw-vector mode");
+    static_assert(!KWV || (CW == 1 && MODE == MODE_FWD && !H), "kw-vector mode");
     constexpr int BN = 128, BK = 32, KP = 40;
+    constexpr int ESZ = H ? 2 : 4;                           // bytes per element of the gathered tensor
     constexpr int PB = CW == 4 ? 36 : (CW == 2 ? 72 : 0);   // LDS row-block pitch of the position permutation
     constexpr int B_ROWS = CW == 1 ? BN : (CW - 1) * PB + BN / CW;
     constexpr int A_PIECES = (BM * 4 + NT - 1) / NT;        // 16-byte weight pieces per thread per K step
-    __shared__ __attribute__((aligned(16))) unsigned short smA[2][BM * KP];
-    __shared__ __attribute__((aligned(16))) unsigned short smB[2][B_ROWS * KP];
+    constexpr int OPER_BYTES = 2 * (BM + B_ROWS) * KP * 2, EPI_BYTES = H ? BM * (BN * 2 + 16) + BM * 8 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_[OPER_BYTES > EPI_BYTES ? OPER_BYTES : EPI_BYTES];
+    unsigned short (*const smA)[BM * KP] = reinterpret_cast<unsigned short (*)[BM * KP]>(smem_);
+    unsigned short (*const smB)[B_ROWS * KP] = reinterpret_cast<unsigned short (*)[B_ROWS * KP]>(smem_ + 2 * BM * KP * 2);
 
     const ConvGeom& g = a.g;
     const ConvFastDiv& fd = a.fd;
@@ -726,8 +849,8 @@ __global__ __launch_bounds__(NT, KWV ? 1 : (BM == 96 ? 4 : (BM == 192 ? 3 : 1)))
     const int k_end = min(a.Kp, k_begin + a.k_per_split);
     const int nk = (k_end - k_begin) / BK;                  // Kp and k_per_split are multiples of 32
 
-    const float* src = MODE == MODE_FWD ? a.x : a.dy;
-    const int cs_bytes = (int)((MODE == MODE_FWD ? g.x_cs : g.y_cs) * 4);
+    const float* src = MODE == MODE_FWD ? a.x : a.dy;       // (H: bf16 data behind the float pointer; offsets below are in elements)
+    const int cs_bytes = (int)((MODE == MODE_FWD ? g.x_cs : g.y_cs) * ESZ);
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)a.src_bytes, 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, (int)a.wp_bytes, 0x00020000);
 
@@ -749,7 +872,7 @@ __global__ __launch_bounds__(NT, KWV ? 1 : (BM == 96 ? 4 : (BM == 192 ? 3 : 1)))
             pd = dec_pos_fd(n < a.N ? n : 0, fd.Ti, fd.Hi, fd.Wi);
             an = anchor_of_input(g, src, pd, n < a.N);
         }
-        voff0 = (unsigned)((an.base - src) * 4);            // may be "negative": the sum with a valid tap offset is not
+        voff0 = (unsigned)((an.base - src) * ESZ);          // may be "negative": the sum with a valid tap offset is not
         vmask = an.mask;
         if constexpr (CW > 1) {
             voff0 += (unsigned)((CW == 4 ? (lane >> 5) * 4 : 0) * cs_bytes);
@@ -773,7 +896,10 @@ __global__ __launch_bounds__(NT, KWV ? 1 : (BM == 96 ? 4 : (BM == 192 ? 3 : 1)))
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 ra[A_PIECES];
-    float rb[16];                                           // CW 1: [chunk h][k i]; CW 4: [k i][pos j]; CW 2: [k i][pos j]
+    float rb[H ? 1 : 16];                                   // CW 1: [chunk h][k i]; CW 4: [k i][pos j]; CW 2: [k i][pos j]
+    unsigned rh[H ? 16 : 1];                                // H: the loaded words -- CW 4: [k i][2]; CW 2: [k i]; CW 1: [chunk h][k i], one bf16 each
+    // byte offset of a chunk-table entry: the table is built for 4-byte elements
+    auto tab_off = [](unsigned long long e) { return H ? (unsigned)((int)(unsigned)e >> 1) : (unsigned)e; };
     auto loadA = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < A_PIECES; ++j)
@@ -805,14 +931,16 @@ __global__ __launch_bounds__(NT, KWV ? 1 : (BM == 96 ? 4 : (BM == 192 ? 3 : 1)))
             r[4] = __builtin_bit_cast(float, v1.a); r[5] = __builtin_bit_cast(float, v1.b);
             r[6] = __builtin_bit_cast(float, v1.c); r[7] = __builtin_bit_cast(float, v1.d);
         } else if constexpr (CW == 1) {                    // h-th 8-k chunk of this thread's 16
-            const unsigned ex = (unsigned)ce[h], ey = (unsigned)(ce[h] >> 32);
+            const unsigned ex = tab_off(ce[h]), ey = (unsigned)(ce[h] >> 32);
             const unsigned sel = (vmask & ey) == ey ? 0xffffffffu : 0u;
             const unsigned vo = ((voff0 + ex) & sel) | (a.src_bytes & ~sel);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                rb[8 * h + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * cs_bytes, 0));
+            for (int i = 0; i < 8; ++i) {
+                if constexpr (H) rh[8 * h + i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, i * cs_bytes, 0);
+                else rb[8 * h + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * cs_bytes, 0));
+            }
         } else if (h == 0) {
-            const unsigned ex = (unsigned)ce[0], ey = (unsigned)(ce[0] >> 32);
+            const unsigned ex = tab_off(ce[0]), ey = (unsigned)(ce[0] >> 32);
             const unsigned eth = ey & 0x8000ffffu;                 // t / h bits (+ the never-valid bit of padding entries)
             const unsigned sel = (vmask & eth) == eth ? 0xffffffffu : 0u;
             const unsigned vo = ((voff0 + ex) & sel) | (a.src_bytes & ~sel);
@@ -821,7 +949,12 @@ __global__ __launch_bounds__(NT, KWV ? 1 : (BM == 96 ? 4 : (BM == 192 ? 3 : 1)))
             for (int i = 0; i < NL; ++i) {
                 // (the loaded vector is bit-cast to a plain struct: hipcc 7.2 miscompiles element access combined with
                 //  bit operations on the builtin's vector result -- elements 1 and 2 come back as element 0)
-                if constexpr (CW == 4) {
+                if constexpr (H && CW == 4) {
+                    const Words2 v = __builtin_bit_cast(Words2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, i * cs_bytes, 0));
+                    rh[2 * i] = v.a; rh[2 * i + 1] = v.b;
+                } else if constexpr (H) {
+                    rh[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * cs_bytes, 0);
+                } else if constexpr (CW == 4) {
                     const Words4 v = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, i * cs_bytes, 0));
                     rb[4 * i] = __builtin_bit_cast(float, v.a); rb[4 * i + 1] = __builtin_bit_cast(float, v.b);
                     rb[4 * i + 2] = __builtin_bit_cast(float, v.c); rb[4 * i + 3] = __builtin_bit_cast(float, v.d);
@@ -849,6 +982,48 @@ __global__ __launch_bounds__(NT, KWV ? 1 : (BM == 96 ? 4 : (BM == 192 ? 3 : 1)))
                     for (int j = 1; j < 8; ++j) {          // (the second vector's immediate offset does not wrap either)
                         const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? wrap_add(vo, 4u * j) : a.src_bytes, 0, 0);
                         r[j] = neg ? __builtin_bit_cast(float, v & keepw[j]) : r[j];
+                    }
+                }
+            }
+        } else if constexpr (CW > 1 && H) {
+            const unsigned ex = tab_off(ce[0]), ey = (unsigned)(ce[0] >> 32);
+            const unsigned eth = ey & 0x8000ffffu;
+            const unsigned dwb = (ey >> 16) & 0xffu;
+            const bool below = (dwb & ((1u << g.pw) - 1u)) != 0u, above = (dwb >> (g.pw + 1)) != 0u;
+            const unsigned sneg = (MODE == MODE_FWD ? below : above) ? 0xffffffffu : 0u;
+            const unsigned spos = (MODE == MODE_FWD ? above : below) ? 0xffffffffu : 0u;
+            const unsigned keepL = ~(keepL_thr & sneg) | 0xffff0000u;      // first position = low half of a load's first word
+            const unsigned keepR = ~(keepR_thr & spos) | 0x0000ffffu;      // last position = high half of its last word
+            const unsigned sel = (vmask & eth) == eth ? 0xffffffffu : 0u;
+            const unsigned vo = ((voff0 + ex) & sel) | (a.src_bytes & ~sel);
+            constexpr int NL = 16 / CW, WPL = CW / 2;                     // loads per K step, words per load
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                rh[WPL * i] &= keepL;
+                rh[WPL * i + WPL - 1] &= keepR;
+            }
+            // The bounds check works on DWORDS of the access: a vector that starts 2 bytes in front of the tensor is rejected
+            // as a whole, and one whose last dword straddles the tensor's end loses that dword's in-range half (a tap shifted
+            // by one element makes the vector 2-byte aligned).  Both happen for a handful of lanes per launch: wave-uniform
+            // branch, the elements re-fetched one by one (an element outside the tensor reads 0 by itself).
+            // (the end case concerns ONE of the thread's channels: the check adds the load's channel offset i * cs_bytes)
+            const bool neg = vo >= 0xfffffff0u;
+            const unsigned gap = a.src_bytes + 2u - 2u * CW - vo;          // the load of channel i straddles the end iff gap == i * cs_bytes
+            bool any = neg;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) any = any || (vo < a.src_bytes && gap == (unsigned)(i * cs_bytes));
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    const bool fix = neg || (vo < a.src_bytes && gap == (unsigned)(i * cs_bytes));
+#pragma unroll
+                    for (int w = 0; w < WPL; ++w) {
+                        const unsigned lo = __builtin_amdgcn_raw_buffer_load_b16(rs, fix ? wrap_add(vo, 4u * w) : a.src_bytes, i * cs_bytes, 0);
+                        const unsigned hi = __builtin_amdgcn_raw_buffer_load_b16(rs, fix ? wrap_add(vo, 4u * w + 2u) : a.src_bytes, i * cs_bytes, 0);
+                        unsigned v = lo | (hi << 16);
+                        if (w == 0) v &= keepL;
+                        if (w == WPL - 1) v &= keepR;
+                        rh[WPL * i + w] = fix ? v : rh[WPL * i + w];
                     }
                 }
             }
@@ -895,7 +1070,33 @@ __global__ __launch_bounds__(NT, KWV ? 1 : (BM == 96 ? 4 : (BM == 192 ? 3 : 1)))
             const int p = tid + NT * j;
             if ((BM * 4) % NT == 0 || p < BM * 4) *reinterpret_cast<u32x4*>(As + (p >> 2) * KP + (p & 3) * 8) = ra[j];
         }
-        if constexpr (CW == 1) {
+        if constexpr (H && CW == 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4 pk;
+                pk.x = pair_lo(rh[8 * h], rh[8 * h + 1]); pk.y = pair_lo(rh[8 * h + 2], rh[8 * h + 3]);
+                pk.z = pair_lo(rh[8 * h + 4], rh[8 * h + 5]); pk.w = pair_lo(rh[8 * h + 6], rh[8 * h + 7]);
+                *reinterpret_cast<uint4*>(Bs + b_q * KP + b_kq * 16 + 8 * h) = pk;
+            }
+        } else if constexpr (H && CW == 4) {               // rh[k i][word]: word j >> 1 holds position j in its low / high half
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x2 pk;
+                pk[0] = (j & 1) ? pair_hi(rh[j >> 1], rh[2 + (j >> 1)]) : pair_lo(rh[j >> 1], rh[2 + (j >> 1)]);
+                pk[1] = (j & 1) ? pair_hi(rh[4 + (j >> 1)], rh[6 + (j >> 1)]) : pair_lo(rh[4 + (j >> 1)], rh[6 + (j >> 1)]);
+                *reinterpret_cast<u32x2*>(Bs + (j * PB + b_q) * KP + wave * 8 + (lane >> 5) * 4) = pk;
+            }
+        } else if constexpr (H) {                          // CW 2: rh[k i] = positions (0 | 1 << 16) of channel i
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 pk;
+                pk.x = j ? pair_hi(rh[0], rh[1]) : pair_lo(rh[0], rh[1]);
+                pk.y = j ? pair_hi(rh[2], rh[3]) : pair_lo(rh[2], rh[3]);
+                pk.z = j ? pair_hi(rh[4], rh[5]) : pair_lo(rh[4], rh[5]);
+                pk.w = j ? pair_hi(rh[6], rh[7]) : pair_lo(rh[6], rh[7]);
+                *reinterpret_cast<uint4*>(Bs + (j * PB + b_q) * KP + wave * 8) = pk;
+            }
+        } else if constexpr (CW == 1) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 uint4 pk;
@@ -998,6 +1199,12 @@ __global__ __launch_bounds__(NT, KWV ? 1 : (BM == 96 ? 4 : (BM == 192 ? 3 : 1)))
         return;
     }
 #endif
+    if constexpr (H) {
+        if (a.splits == 1) {
+            store_acc_h<MODE, WM, WN, BM, BN>(a, acc, m0, n0, wm0, wn0, lane, smem_, NT);
+            return;
+        }
+    }
     store_acc<MODE, WM, WN, BM>(a, acc, m0, n0, wm0, wn0, lane, split, reinterpret_cast<float*>(smA[0]));
 }
 
@@ -1020,11 +1227,15 @@ __global__ __launch_bounds__(NT, KWV ? 1 : (BM == 96 ? 4 : (BM == 192 ? 3 : 1)))
 // thread owns the column PAIR (dw = 2i, 2i+1) of one (ci, dt, dh) row: the window's even elements are the operand
 // vector of column 2i, the odd ones of column 2i+1 (columns are padded to 8 per row; EPI_NPAD8 drops the padding).
 // Thread = (pair = tid & 63, position group = wave): 4 dwordx4 per K step, validity of the window's ends by compare.
-template <int BM, int WM, int WN, int CW, bool S2 = false>
+// H: x and dy are STORED as bf16.  A group of CW positions is CW * 2 bytes (b128 / b64 / b32; 2-byte aligned for the taps
+// shifted by one element -- legal for raw-buffer loads, tools/ubench/align2probe.hip) and goes to LDS as loaded: positions ARE
+// the K axis of both operands here, so there is neither a conversion nor a transposition left.  dy pieces carry 8 positions.
+template <int BM, int WM, int WN, int CW, bool S2 = false, bool H = false>
 __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) {
-    static_assert(!S2 || CW == 8, "pair mode works on groups of 8 output positions");
+    static_assert(!S2 || (CW == 8 && !H), "pair mode works on groups of 8 output positions of fp32 tensors");
     constexpr int BN = 128, BK = 32, KP = 40;
-    constexpr int A_PIECES = BM / 32;                       // 16-byte dy pieces (4 positions) per thread per K step
+    constexpr int ESZ = H ? 2 : 4;
+    constexpr int A_PIECES = H ? (BM * 4 + NT - 1) / NT : BM / 32;     // 16-byte dy pieces (4 [H: 8] positions) per thread per K step
     constexpr int NG = S2 ? 1 : 16 / CW;                    // position groups per thread per K step
     __shared__ __attribute__((aligned(16))) unsigned short smA[2][BM * KP];
     __shared__ __attribute__((aligned(16))) unsigned short smB[2][BN * KP];
@@ -1063,33 +1274,42 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
     } else {
         const int n = min(n0 + b_n, a.N - 1);
         const TapDec t = dec_tap_fd(fd, (uint32_t)n);
-        coloff = (unsigned)(((int64_t)t.c * g.x_cs + ((int64_t)t.dt * g.Hi + t.dh) * g.Wi + t.dw) * 4);
+        coloff = (unsigned)(((int64_t)t.c * g.x_cs + ((int64_t)t.dt * g.Hi + t.dh) * g.Wi + t.dw) * ESZ);
         tbits = (1u << t.dt) | (1u << (8 + t.dh));
         thrL = t.dw < g.pw ? 0xffffffffu : 0u;              // this tap reads one element to the left / right of the centre
         thrR = t.dw > g.pw ? 0xffffffffu : 0u;
     }
-    // ---- dy pieces: piece p = tid + 256 j -> row p >> 3, positions (p & 7) * 4 .. + 3 of the K step
+    // ---- dy pieces: piece p = tid + 256 j -> row p >> 3, positions (p & 7) * 4 .. + 3 of the K step (H: row p >> 2, 8 positions)
     unsigned voffA[A_PIECES];
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) {
         const int p = tid + NT * j;
-        const int m = min(m0 + (p >> 3), a.M - 1);
-        voffA[j] = (unsigned)(((int64_t)m * g.y_cs + (p & 7) * 4) * 4);
+        if constexpr (H) {
+            const int m = min(m0 + (p >> 2), a.M - 1);
+            voffA[j] = (unsigned)(((int64_t)m * g.y_cs + (p & 3) * 8) * 2);
+        } else {
+            const int m = min(m0 + (p >> 3), a.M - 1);
+            voffA[j] = (unsigned)(((int64_t)m * g.y_cs + (p & 7) * 4) * 4);
+        }
     }
 
     Words4 ra[A_PIECES];
-    float rb[16];
+    float rb[16];                                           // (unused, and removed by the compiler, when H)
+    unsigned rh[8];                                         // H: the 16 positions of this thread's column as loaded (8 words)
+    // byte offset of a position-table entry: the table is built for 4-byte elements
+    auto tab_off = [](unsigned long long e) { return H ? (unsigned)((int)(unsigned)e >> 1) : (unsigned)e; };     // (offsets may be negative)
     // position -> (sample, position in sample): a K step never leaves its sample (P % 32 == 0)
     auto dy_soff = [&](int k0) {
         const int kc = min(k0, a.K - BK);                   // the prefetch past the end re-reads the last step
         const uint32_t b = fd_div(fd.P, (uint32_t)kc);
-        return (int)(((int64_t)b * g.y_bs + (kc - (int)(b * fd.P.d))) * 4);
+        return (int)(((int64_t)b * g.y_bs + (kc - (int)(b * fd.P.d))) * ESZ);
     };
     auto loadA = [&](int k0) {
         const int so = dy_soff(k0);
 #pragma unroll
         for (int j = 0; j < A_PIECES; ++j)
-            ra[j] = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rdy, voffA[j], so, 0));
+            if (!H || (BM * 4) % NT == 0 || tid + NT * j < BM * 4)
+                ra[j] = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rdy, voffA[j], so, 0));
     };
     // position-table entries of the NEXT K step (64-bit scalar loads, one step ahead)
     const unsigned long long* ptab64 = reinterpret_cast<const unsigned long long*>(a.ptab) + b_kq * NG;
@@ -1133,9 +1353,22 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
         for (int q = 0; q < NG; ++q) pe_next[q] = ptab64[k0 / CW + q];
     };
     auto loadB = [&](int q) {                              // q-th position group of this thread's 16 positions (issue only)
-        const unsigned ex = (unsigned)pe[q], ey = (unsigned)(pe[q] >> 32);
+        const unsigned ex = tab_off(pe[q]), ey = (unsigned)(pe[q] >> 32);
         const unsigned sel = (ey & tbits) == tbits ? 0xffffffffu : 0u;
         const unsigned vo = ((ex + coloff) & sel) | (a.src_bytes & ~sel);
+        if constexpr (H) {
+            unsigned* r = rh + (CW / 2) * q;
+            if constexpr (CW == 8) {
+                const Words4 v = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0));
+                r[0] = v.a; r[1] = v.b; r[2] = v.c; r[3] = v.d;
+            } else if constexpr (CW == 4) {
+                const Words2 v = __builtin_bit_cast(Words2, __builtin_amdgcn_raw_buffer_load_b64(rx, vo, 0, 0));
+                r[0] = v.a; r[1] = v.b;
+            } else {
+                r[0] = __builtin_amdgcn_raw_buffer_load_b32(rx, vo, 0, 0);
+            }
+            return;
+        }
         float* r = rb + CW * q;
         if constexpr (CW == 8) {
             const Words4 v0 = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0));
@@ -1155,6 +1388,35 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
     };
     auto fixB = [&]() {
         if constexpr (S2) { fixB_s2(); return; }
+        if constexpr (H) {
+            constexpr int WPG = CW / 2;                    // words per group
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                const unsigned ex = tab_off(pe[q]), ey = (unsigned)(pe[q] >> 32);
+                const unsigned sel = (ey & tbits) == tbits ? 0xffffffffu : 0u;
+                const unsigned vo = ((ex + coloff) & sel) | (a.src_bytes & ~sel);
+                const unsigned eL = (ey & 0x10000u) ? 0xffffffffu : 0u, eR = (ey & 0x20000u) ? 0xffffffffu : 0u;
+                const unsigned keepL = ~(thrL & eL) | 0xffff0000u, keepR = ~(thrR & eR) | 0x0000ffffu;
+                unsigned* r = rh + WPG * q;
+                r[0] &= keepL;
+                r[WPG - 1] &= keepR;
+                // dword-granular bounds check (see conv_gemm_bf16c_kernel): a group that starts in front of the tensor is
+                // rejected as a whole, a 2-byte aligned one whose last dword straddles the end loses that dword's in-range half
+                const bool fix = vo >= 0xfffffff0u || (vo < a.src_bytes && vo + 2u * CW == a.src_bytes + 2u);
+                if (__builtin_amdgcn_ballot_w64(fix) != 0ull) {
+#pragma unroll
+                    for (int w = 0; w < WPG; ++w) {
+                        const unsigned lo = __builtin_amdgcn_raw_buffer_load_b16(rx, fix ? wrap_add(vo, 4u * w) : a.src_bytes, 0, 0);
+                        const unsigned hi = __builtin_amdgcn_raw_buffer_load_b16(rx, fix ? wrap_add(vo, 4u * w + 2u) : a.src_bytes, 0, 0);
+                        unsigned v = lo | (hi << 16);
+                        if (w == 0) v &= keepL;
+                        if (w == WPG - 1) v &= keepR;
+                        r[w] = fix ? v : r[w];
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             const unsigned ex = (unsigned)pe[q], ey = (unsigned)(pe[q] >> 32);
@@ -1185,15 +1447,22 @@ __global__ __launch_bounds__(NT) void conv_wgrad_bf16v_kernel(const ConvArgs a) 
 #pragma unroll
         for (int j = 0; j < A_PIECES; ++j) {
             const int p = tid + NT * j;
-            Words2 pk;
-            pk.a = cvt_pk_bf16(__builtin_bit_cast(float, ra[j].a), __builtin_bit_cast(float, ra[j].b));
-            pk.b = cvt_pk_bf16(__builtin_bit_cast(float, ra[j].c), __builtin_bit_cast(float, ra[j].d));
-            *reinterpret_cast<Words2*>(As + (p >> 3) * KP + (p & 7) * 4) = pk;
+            if constexpr (H) {
+                if ((BM * 4) % NT == 0 || p < BM * 4) *reinterpret_cast<Words4*>(As + (p >> 2) * KP + (p & 3) * 8) = ra[j];
+            } else {
+                Words2 pk;
+                pk.a = cvt_pk_bf16(__builtin_bit_cast(float, ra[j].a), __builtin_bit_cast(float, ra[j].b));
+                pk.b = cvt_pk_bf16(__builtin_bit_cast(float, ra[j].c), __builtin_bit_cast(float, ra[j].d));
+                *reinterpret_cast<Words2*>(As + (p >> 3) * KP + (p & 7) * 4) = pk;
+            }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             uint4 pk;
-            if constexpr (S2) {     // window order in rb: even elements are column dw0's vector, odd ones column dw0+1's
+            if constexpr (H) {
+                pk.x = rh[4 * h]; pk.y = rh[4 * h + 1]; pk.z = rh[4 * h + 2]; pk.w = rh[4 * h + 3];
+                *reinterpret_cast<uint4*>(Bs + b_n * KP + b_kq * 16 + 8 * h) = pk;
+            } else if constexpr (S2) {     // window order in rb: even elements are column dw0's vector, odd ones column dw0+1's
                 pk.x = cvt_pk_bf16(rb[h], rb[2 + h]);
                 pk.y = cvt_pk_bf16(rb[4 + h], rb[6 + h]);
                 pk.z = cvt_pk_bf16(rb[8 + h], rb[10 + h]);
@@ -1457,7 +1726,22 @@ static inline size_t tab_bytes(int K) { return (((size_t)K + TAB_PAD) * sizeof(i
 // fixed-order reduction of the split-K slabs + the same epilogue.  V consecutive elements per thread (float4 when the
 // slab size allows); the loads of 8 splits are issued together and THEN added in split order -- the sum order (and so the
 // result) is the one of a plain loop, without its one-load-in-flight dependency chain.
-template <int MODE, int V>
+// H (FWD / DGRAD): the output, and the data gradient's ReLU mask, are bf16 tensors (see store_acc_h).
+template <bool H>
+__device__ __forceinline__ bool relu_mask_at(const ConvArgs& a, int64_t off) {
+    if constexpr (H) return bf16_pos(reinterpret_cast<const unsigned short*>(a.emask)[off]);
+    else return a.emask[off] > 0.f;
+}
+template <bool H>
+__device__ __forceinline__ void reduce_store(const ConvArgs& a, int64_t off, float v) {
+    if constexpr (H) reinterpret_cast<unsigned short*>(a.out)[off] = (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);
+    else {
+        if (a.flags & EPI_ACCUM) v += a.out[off];
+        a.out[off] = v;
+    }
+}
+
+template <int MODE, int V, bool H = false>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
     const ConvGeom& g = a.g;
     const int64_t total = (int64_t)a.M * a.N;
@@ -1493,15 +1777,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
                 off = conv_out_offset(g, dec_pos_fd(n, a.fd.To, a.fd.Ho, a.fd.Wo), m);
             } else if (MODE == MODE_DGRAD) {
                 off = conv_in_offset(g, dec_pos_fd(n, a.fd.Ti, a.fd.Hi, a.fd.Wi), m);
-                if (a.emask) v = a.emask[off] > 0.f ? v * a.escale[m] : 0.f;
+                if (a.emask) v = relu_mask_at<H>(a, off) ? v * a.escale[m] : 0.f;
             } else if (a.flags & EPI_NPAD8) {
                 if ((n & 7) >= g.kw) continue;
                 off = (int64_t)m * ((a.N >> 3) * g.kw) + (n >> 3) * g.kw + (n & 7);
             } else {
                 off = idx;
             }
-            if (a.flags & EPI_ACCUM) v += a.out[off];
-            a.out[off] = v;
+            reduce_store<H>(a, off, v);
         }
     }
 }
@@ -1510,7 +1793,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
 // thread walking 500 slabs is a 10 us latency chain.  Here a workgroup owns 64 float4 outputs; its four waves sum a quarter
 // of the slabs each (8 loads in flight, in slab order) and the quarters meet in LDS in a fixed order ((q0 + q1) + (q2 + q3)),
 // so the result is deterministic -- a different, equally valid summation tree than the sequential kernel's.
-template <int MODE>
+template <int MODE, bool H = false>
 __global__ __launch_bounds__(256) void splitk_reduce_tall_kernel(const ConvArgs a) {
     __shared__ float4 part[3][64];
     const ConvGeom& g = a.g;
@@ -1552,15 +1835,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_tall_kernel(const ConvArgs 
             off = conv_out_offset(g, dec_pos_fd(n, a.fd.To, a.fd.Ho, a.fd.Wo), m);
         } else if (MODE == MODE_DGRAD) {
             off = conv_in_offset(g, dec_pos_fd(n, a.fd.Ti, a.fd.Hi, a.fd.Wi), m);
-            if (a.emask) v = a.emask[off] > 0.f ? v * a.escale[m] : 0.f;
+            if (a.emask) v = relu_mask_at<H>(a, off) ? v * a.escale[m] : 0.f;
         } else if (a.flags & EPI_NPAD8) {
             if ((n & 7) >= g.kw) continue;
             off = (int64_t)m * ((a.N >> 3) * g.kw) + (n >> 3) * g.kw + (n & 7);
         } else {
             off = idx;
         }
-        if (a.flags & EPI_ACCUM) v += a.out[off];
-        a.out[off] = v;
+        reduce_store<H>(a, off, v);
     }
 }
 
@@ -1571,10 +1853,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_tall_kernel(const ConvArgs 
 // weight gradients of an Inception module, or the GroupNorm blocks between two bucket flushes of the trainer.  Same
 // summation tree as splitk_reduce_tall_kernel (four quarter sums in slab order, combined (q0+q1)+(q2+q3)): deterministic.
 // Process-global state, used from the one thread that issues the training step.
+}  // namespace
+namespace otal_conv {
 constexpr int DEFER_MAX = 24;
 struct DeferItem { const float* slab; float* out; int64_t total; int splits, flags, N, kw; };
 struct DeferBatch { DeferItem it[DEFER_MAX]; };
-static struct { bool on = false; int n = 0; DeferBatch batch; uintptr_t last_end = 0; } g_defer;
+struct DeferState { bool on = false; int n = 0; DeferBatch batch; uintptr_t last_end = 0; };
+__attribute__((visibility("hidden"))) extern DeferState g_defer;       // ONE list for both parts of this file (defined in part 0)
+}  // namespace otal_conv
+#if OTAL_CONV_PART == 0
+otal_conv::DeferState otal_conv::g_defer;
+#endif
+namespace {
+using otal_conv::DEFER_MAX;
+using otal_conv::DeferItem;
+using otal_conv::DeferBatch;
+using otal_conv::g_defer;
 
 __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const DeferBatch b) {
     __shared__ float4 part[3][64];
@@ -1628,8 +1922,9 @@ static int flush_deferred(hipStream_t st) {
     return otal_launch_status();
 }
 
-template <int MODE>
+template <int MODE, bool H = false>
 static int launch_splitk_reduce(const ConvArgs& a, hipStream_t st) {
+    static_assert(!(H && MODE == MODE_WGRAD), "weight gradients are fp32");
     const int64_t total = (int64_t)a.M * a.N;
     const bool v4 = (total % 4 == 0) && (((uintptr_t)a.slab & 15) == 0);
     if (MODE == MODE_WGRAD) {
@@ -1645,13 +1940,13 @@ static int launch_splitk_reduce(const ConvArgs& a, hipStream_t st) {
     }
     if (v4 && a.splits >= 16 && total <= (1 << 21) && !OTAL_OPT("OTAL_CONV_NOTALLREDUCE", 0)) {
         const int blocks = (int)((total / 4 + 63) / 64);
-        hipLaunchKernelGGL((splitk_reduce_tall_kernel<MODE>), dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((splitk_reduce_tall_kernel<MODE, H>), dim3(blocks), dim3(256), 0, st, a);
         return otal_launch_status();
     }
     const int64_t work = v4 ? total / 4 : total;
     const int blocks = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
-    if (v4) hipLaunchKernelGGL((splitk_reduce_kernel<MODE, 4>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((splitk_reduce_kernel<MODE, 1>), dim3(blocks), dim3(256), 0, st, a);
+    if (v4) hipLaunchKernelGGL((splitk_reduce_kernel<MODE, 4, H>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((splitk_reduce_kernel<MODE, 1, H>), dim3(blocks), dim3(256), 0, st, a);
     return otal_launch_status();
 }
 
@@ -1788,13 +2083,18 @@ struct DirectArgs {
 // on exactly 256, no spills), so only the one-workgroup-per-CU variants take it.  Worth 1 .. 5 % per launch, not the ~19 %
 // a per-tile budget of Conv3d_2c forward had attributed to load stalls (48 us per tile = 24 MFMA at the sustained clock +
 // 12 epilogue + 3 first loads + "9 waiting for positions"): one step of cover was nearly enough.
-template <int BM, int MODE, int BNP, int WN, int PX = 48, int MINW = 1, bool XPF2 = false>
+// H: the gathered tensor and the output are STORED as bf16.  A load item is (EIGHT positions, channel pair): two 16-byte loads,
+// transposed into the [position][16 channels] tile by pair_lo / pair_hi -- half the load instructions of the fp32 form for
+// the same LDS stores, no conversion; the span starts at an even position (W + 2 in front of the tile instead of W + 1) so
+// that every load is 4-byte aligned.  Operands, accumulators and results are those of the fp32-tensor kernel on the same values.
+template <int BM, int MODE, int BNP, int WN, int PX = 48, int MINW = 1, bool XPF2 = false, bool H = false>
 __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const DirectArgs d) {
     constexpr int DNT = BNP * 2 / WN;                       // one wave per 32 * WN positions
-    constexpr int WM = BM / 32, PA = 304, SPAN_MAX = BNP + 52;
+    constexpr int WM = BM / 32, PA = 304, SPAN_MAX = BNP + (H ? 56 : 52);
+    constexpr int ESZ = H ? 2 : 4, XV = H ? 8 : 4;           // bytes per element, positions per load
     static_assert(PX == 48 || PX == 32, "position pitch");
     constexpr int A_PIECES = (BM * 18 + DNT - 1) / DNT;       // 16-byte weight pieces per thread per K step
-    constexpr int X_ITEMS = (SPAN_MAX / 4 + 1) * 8;         // (quad of positions, channel pair) items per K step, upper bound
+    constexpr int X_ITEMS = (SPAN_MAX / XV + 1) * 8;        // (quad [octet] of positions, channel pair) items per K step, upper bound
     constexpr int X_ITERS = (X_ITEMS + DNT - 1) / DNT;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];     // [2][BM * PA] weights, then [2][SPAN_MAX * PX] positions
     unsigned char* const smA0 = dsm;
@@ -1811,7 +2111,8 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
     const TileId tile = xcd_tile(true);
     const int m0 = tile.y * BM, n0 = tile.x * BNP;
     const int W = g.Wi, HW = g.Hi * g.Wi;
-    const int span = BNP + 2 * W + 2, nq = (span + 3) >> 2;
+    const int XO = H ? W + 2 : W + 1;                       // positions staged in front of the tile
+    const int span = BNP + XO + W + 1, nq = (span + XV - 1) / XV;
     const float* src = MODE == MODE_FWD ? a.x : a.dy;
     const int64_t sbs = MODE == MODE_FWD ? g.x_bs : g.y_bs, scs = MODE == MODE_FWD ? g.x_cs : g.y_cs;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)a.src_bytes, 0x00020000);
@@ -1819,7 +2120,7 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
     // the tile lies inside one sample (P % 128 == 0): sample b, first position p0
     const uint32_t bsm = fd_div(fd.P, (uint32_t)n0);
     const int p0 = n0 - (int)(bsm * fd.P.d);
-    const unsigned tile_off = (unsigned)(((int64_t)bsm * sbs + p0 - (W + 1)) * 4);      // byte offset of span element 0 at dt = 1, channel 0
+    const unsigned tile_off = (unsigned)(((int64_t)bsm * sbs + p0 - XO) * ESZ);         // byte offset of span element 0 at dt = 1, channel 0
 
     // this lane's output positions: validity of the 3 + 3 + 3 taps (FWD form; DGRAD uses flipped taps in the pack)
     unsigned tmask[WN], hwmask[WN];
@@ -1845,9 +2146,12 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
         const int item = tid + DNT * i;
         const int cp = item & 7, q = item >> 3;            // channel pair fastest: consecutive lanes write consecutive LDS dwords
         const bool used = q < nq;
-        xvo[i] = used ? tile_off + (unsigned)((2 * cp * scs + 4 * q) * 4) : 0xffffffffu;
-        xlds[i] = PX == 48 ? (4 * q) * PX + cp * 4                 // positions 4q .. 4q+3 share bit 3 = bit 1 of q
-                           : (4 * q) * PX + ((((cp >> 2) ^ (q >> 1)) & 1) << 4) + (cp & 3) * 4;
+        xvo[i] = used ? tile_off + (unsigned)((2 * cp * scs + XV * q) * ESZ) : 0xffffffffu;
+        if constexpr (H)                                           // positions 8q .. 8q+7 share bit 3 = bit 0 of q
+            xlds[i] = PX == 48 ? (8 * q) * PX + cp * 4 : (8 * q) * PX + ((((cp >> 2) ^ q) & 1) << 4) + (cp & 3) * 4;
+        else
+            xlds[i] = PX == 48 ? (4 * q) * PX + cp * 4             // positions 4q .. 4q+3 share bit 3 = bit 1 of q
+                               : (4 * q) * PX + ((((cp >> 2) ^ (q >> 1)) & 1) << 4) + (cp & 3) * 4;
     }
     unsigned avo[A_PIECES];
 #pragma unroll
@@ -1861,13 +2165,13 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
     auto load_x = [&](int s, auto SET) {
         unsigned (&rx)[X_ITERS][2][4] = rxs[decltype(SET)::value];
         const int cb = s / 3, dt = s - cb * 3;
-        const unsigned so = (unsigned)(((int64_t)cb * 16 * scs + (int64_t)(dt - 1) * HW) * 4);
+        const unsigned so = (unsigned)(((int64_t)cb * 16 * scs + (int64_t)(dt - 1) * HW) * ESZ);
 #pragma unroll
         for (int i = 0; i < X_ITERS; ++i) {
             const unsigned vo = xvo[i] == 0xffffffffu ? a.src_bytes : xvo[i] + so;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const Words4 v = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, h ? (int)(scs * 4) : 0, 0));
+                const Words4 v = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, h ? (int)(scs * ESZ) : 0, 0));
                 rx[i][h][0] = v.a; rx[i][h][1] = v.b; rx[i][h][2] = v.c; rx[i][h][3] = v.d;
             }
         }
@@ -1881,7 +2185,7 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
     auto store = [&](int buf, int s, auto SET) {
         unsigned (&rx)[X_ITERS][2][4] = rxs[decltype(SET)::value];
         const int cb = s / 3, dt = s - cb * 3;
-        const unsigned so = (unsigned)(((int64_t)cb * 16 * scs + (int64_t)(dt - 1) * HW) * 4);
+        const unsigned so = (unsigned)(((int64_t)cb * 16 * scs + (int64_t)(dt - 1) * HW) * ESZ);
 #pragma unroll
         for (int i = 0; i < X_ITERS; ++i) {
             if (xvo[i] == 0xffffffffu) continue;
@@ -1891,18 +2195,34 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
             if (__builtin_amdgcn_ballot_w64(neg) != 0ull) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
+                    if constexpr (H) {                  // (loads are 4-byte aligned here: whole words, the first ones out of range)
 #pragma unroll
-                    for (int e = 1; e < 4; ++e) {
-                        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? wrap_add(vo, 4u * e) : a.src_bytes,
-                                                                                 h ? (int)(scs * 4) : 0, 0);
-                        rx[i][h][e] = neg ? v : rx[i][h][e];
+                        for (int e = 1; e < 4; ++e) {
+                            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? wrap_add(vo, 4u * e) : a.src_bytes,
+                                                                                     h ? (int)(scs * ESZ) : 0, 0);
+                            rx[i][h][e] = neg ? v : rx[i][h][e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 1; e < 4; ++e) {
+                            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, neg ? wrap_add(vo, 4u * e) : a.src_bytes,
+                                                                                     h ? (int)(scs * 4) : 0, 0);
+                            rx[i][h][e] = neg ? v : rx[i][h][e];
+                        }
                     }
                 }
             }
+            if constexpr (H) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                *reinterpret_cast<unsigned*>(smX(buf) + xlds[i] + e * PX) =
-                    cvt_pk_bf16(__uint_as_float(rx[i][0][e]), __uint_as_float(rx[i][1][e]));
+                for (int e = 0; e < 8; ++e)
+                    *reinterpret_cast<unsigned*>(smX(buf) + xlds[i] + e * PX) =
+                        (e & 1) ? pair_hi(rx[i][0][e >> 1], rx[i][1][e >> 1]) : pair_lo(rx[i][0][e >> 1], rx[i][1][e >> 1]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    *reinterpret_cast<unsigned*>(smX(buf) + xlds[i] + e * PX) =
+                        cvt_pk_bf16(__uint_as_float(rx[i][0][e]), __uint_as_float(rx[i][1][e]));
+            }
         }
 #pragma unroll
         for (int j = 0; j < A_PIECES; ++j) {
@@ -1926,7 +2246,7 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
     store(0, 0, Set0{});
     if constexpr (XPF2) load_x(nsteps > 1 ? 1 : 0, Set1{});     // step 1's positions: in flight while step 0 computes
     __syncthreads();
-    const int xpos = wave * WN * 32 + (lane & 31) + W + 1;                               // this lane's first position in the span
+    const int xpos = wave * WN * 32 + (lane & 31) + XO;                                  // this lane's first position in the span
     const int xrow = xpos * PX + (lane >> 5) * 16;
     // Fragment reads of tap group g + 1 are issued ONE BY ONE BETWEEN the MFMAs of group g (second register set): the reads'
     // issue slots and their LDS latency then sit inside the matrix pipe's 32-cycle issue intervals instead of in front of a
@@ -2013,47 +2333,58 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
     } else {
         for (int s = 0; s < nsteps; ++s) kstep(s, Set0{}, Set0{});
     }
-    if constexpr (MODE == MODE_FWD) {
-        if (a.half) {
-            // bf16-STORED output (a layer that only feeds a strided max-pool: Conv3d_2c -> MaxPool3d_3a; the pool commutes with
-            // the monotonic rounding, so the forward values do not change): scale / shift / ReLU, transpose through LDS (the
-            // operand tiles are dead: BM rows x BNP positions of bf16 + 16 bytes of pitch fit in them), 16-byte runs
-            // along the positions -- half the bytes of the fp32 epilogue, which ran at the HBM write rate with idle matrix pipes.
-            constexpr int PT = BNP * 2 + 16;
-            static_assert(BM * PT + BM * 8 <= 2 * BM * PA + 2 * SPAN_MAX * PX, "staging tile fits in the operand buffers");
-            unsigned char* tile = dsm;
-            float* rows = reinterpret_cast<float*>(dsm + BM * PT);
-            for (int r = tid; r < BM; r += DNT) {
-                const int m = m0 + r;
+    if ((MODE == MODE_FWD && a.half) || (MODE == MODE_DGRAD && a.xhalf)) {
+        // bf16-STORED output (FWD: y -- H kernels, and the fp32-input layer that only feeds a strided max-pool, which commutes
+        // with the monotonic rounding; DGRAD: dx of the H kernels): scale / shift / ReLU or the producer's BN scale, rounded
+        // once, transposed through LDS (the operand tiles are dead: BM rows x BNP positions of bf16 + 16 bytes of pitch fit in
+        // them), 16-byte runs along the positions; the data gradient's ReLU mask is the bf16 activation, read in the same pieces.
+        constexpr int PT = BNP * 2 + 16;
+        static_assert(BM * PT + BM * 8 <= 2 * BM * PA + 2 * SPAN_MAX * PX, "staging tile fits in the operand buffers");
+        unsigned char* tile = dsm;
+        float* rows = reinterpret_cast<float*>(dsm + BM * PT);
+        __syncthreads();            // (every wave is done with the operand tiles: the K loop ends with a barrier, kept explicit here)
+        for (int r = tid; r < BM; r += DNT) {
+            const int m = m0 + r;
+            if constexpr (MODE == MODE_FWD) {
                 rows[2 * r] = (m < a.M && a.scale) ? a.scale[m] : 1.f;
                 rows[2 * r + 1] = (m < a.M && a.shift) ? a.shift[m] : 0.f;
+            } else {
+                rows[2 * r] = (m < a.M && a.escale) ? a.escale[m] : 1.f;
+                rows[2 * r + 1] = 0.f;
             }
-            __syncthreads();
-            const bool relu = (a.flags & EPI_RELU) != 0;
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    const int nl = (wave * WN + j) * 32 + (lane & 31);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        float v = acc[i][j][r] * rows[2 * lr] + rows[2 * lr + 1];
-                        if (relu) v = fmaxf(v, 0.f);
-                        *reinterpret_cast<unsigned short*>(tile + lr * PT + nl * 2) = (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);
-                    }
-                }
-            __syncthreads();
-            unsigned short* yh = reinterpret_cast<unsigned short*>(a.out);
-            const int64_t ybase = (int64_t)bsm * g.y_bs + p0;
-            for (int p = tid; p < BM * (BNP / 8); p += DNT) {
-                const int row = p / (BNP / 8), q = p - row * (BNP / 8);
-                if (m0 + row >= a.M || n0 + q * 8 >= a.N) continue;
-                const uint4 v = *reinterpret_cast<const uint4*>(tile + row * PT + q * 16);
-                *reinterpret_cast<uint4*>(yh + ybase + (int64_t)(m0 + row) * g.y_cs + q * 8) = v;
-            }
-            return;
         }
+        __syncthreads();
+        const bool relu = MODE == MODE_FWD && (a.flags & EPI_RELU) != 0;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int nl = (wave * WN + j) * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = acc[i][j][r] * rows[2 * lr] + rows[2 * lr + 1];
+                    if (relu) v = fmaxf(v, 0.f);
+                    *reinterpret_cast<unsigned short*>(tile + lr * PT + nl * 2) = (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);
+                }
+            }
+        __syncthreads();
+        unsigned short* yh = reinterpret_cast<unsigned short*>(a.out);
+        const unsigned short* mk = MODE == MODE_DGRAD ? reinterpret_cast<const unsigned short*>(a.emask) : nullptr;
+        const int64_t ocs = MODE == MODE_FWD ? g.y_cs : g.x_cs;
+        const int64_t ybase = (int64_t)bsm * (MODE == MODE_FWD ? g.y_bs : g.x_bs) + p0;
+        for (int p = tid; p < BM * (BNP / 8); p += DNT) {
+            const int row = p / (BNP / 8), q = p - row * (BNP / 8);
+            if (m0 + row >= a.M || n0 + q * 8 >= a.N) continue;
+            Words4 v = *reinterpret_cast<const Words4*>(tile + row * PT + q * 16);
+            const int64_t off = ybase + (int64_t)(m0 + row) * ocs + q * 8;
+            if (mk) {
+                const Words4 m4 = *reinterpret_cast<const Words4*>(mk + off);
+                v.a &= bf16_relu_mask2(m4.a); v.b &= bf16_relu_mask2(m4.b); v.c &= bf16_relu_mask2(m4.c); v.d &= bf16_relu_mask2(m4.d);
+            }
+            *reinterpret_cast<Words4*>(yh + off) = v;
+        }
+        return;
     }
 #ifdef OTAL_DIRECT_ABLATE
     if (a.flags & 64) {         // no epilogue (the accumulators stay live through an impossible store)
@@ -2443,9 +2774,14 @@ static inline size_t chunk_wp_bytes(int M, int BM, int K) {      // + one K step
     return align256(((size_t)((M + BM - 1) / BM * BM) * chunk_kp(K) + 64) * sizeof(unsigned short));
 }
 // extent in bytes of the tensor the gather reads (channel-sliced views: strides come from the caller)
-static inline int64_t gather_extent_bytes(const ConvGeom& g, int mode) {
-    if (mode == MODE_FWD) return 4 * ((int64_t)(g.B - 1) * g.x_bs + (int64_t)(g.Cin - 1) * g.x_cs + conv_in_positions(g));
-    return 4 * ((int64_t)(g.B - 1) * g.y_bs + (int64_t)(g.Cout - 1) * g.y_cs + conv_out_positions(g));
+static inline int64_t gather_extent_bytes(const ConvGeom& g, int mode, int esz = 4) {
+    if (mode == MODE_FWD) return esz * ((int64_t)(g.B - 1) * g.x_bs + (int64_t)(g.Cin - 1) * g.x_cs + conv_in_positions(g));
+    return esz * ((int64_t)(g.B - 1) * g.y_bs + (int64_t)(g.Cout - 1) * g.y_cs + conv_out_positions(g));
+}
+// bf16-stored tensors around a layer (H kernels): 16-byte runs of eight positions must stay inside a sample and be aligned
+static inline bool half_layout_ok(const ConvGeom& g, const void* x, const void* y) {
+    return conv_out_positions(g) % 8 == 0 && conv_in_positions(g) % 8 == 0 && g.x_bs % 8 == 0 && g.x_cs % 8 == 0 &&
+           g.y_bs % 8 == 0 && g.y_cs % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
 }
 static inline bool chunk_eligible(const ConvGeom& g, int mode, int prec) {
     if (!prec || mode == MODE_WGRAD) return false;
@@ -2505,10 +2841,11 @@ static void launch_prep(const PrepDesc& d, hipStream_t st) {
     else hipLaunchKernelGGL((prep_chunks_kernel<MODE_DGRAD>), dim3(prep_blocks(d)), dim3(256), 0, st, d);
 }
 
-template <int MODE>
+template <int MODE, bool H = false>
 int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int C = MODE == MODE_FWD ? a.g.Cin : a.g.Cout;
     const bool kwv = MODE == MODE_FWD && (C % 8) != 0;
+    if (H && (kwv || (a.flags & EPI_ACCUM) || conv_in_positions(a.g) != conv_out_positions(a.g))) return OTAL_E_UNSUPPORTED;
     if (kwv) a.K = a.g.Cin * a.g.kt * a.g.kh * 8;          // kw padded to 8 taps per (ci, dt, dh) row
     const int BMsel = choose_bm(a.M, kwv ? 0 : 1);
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + 127) / 128;
@@ -2531,7 +2868,7 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         ws_bytes -= tb + wb;
     }
     a.ctab = ctab; a.wp = wp;
-    a.src_bytes = (unsigned)gather_extent_bytes(a.g, MODE);
+    a.src_bytes = (unsigned)gather_extent_bytes(a.g, MODE, H ? 2 : 4);
     a.wp_bytes = (unsigned)wb;
     a.fd = make_conv_fastdiv(a.g);
     int splits = choose_splits(tm * tn, a.Kp);
@@ -2555,11 +2892,11 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int cw = chunk_vector_width(a.g);
 #define OTAL_LAUNCH_C(BM_, WM_, WN_)                                                                                   \
     do {                                                                                                               \
-        if (cw == 4) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<BM_, WM_, WN_, MODE, 4>), grid, dim3(NT), 0, st, a);   \
-        else if (cw == 2) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<BM_, WM_, WN_, MODE, 2>), grid, dim3(NT), 0, st, a); \
-        else hipLaunchKernelGGL((conv_gemm_bf16c_kernel<BM_, WM_, WN_, MODE, 1>), grid, dim3(NT), 0, st, a);           \
+        if (cw == 4) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<BM_, WM_, WN_, MODE, 4, false, H>), grid, dim3(NT), 0, st, a);   \
+        else if (cw == 2) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<BM_, WM_, WN_, MODE, 2, false, H>), grid, dim3(NT), 0, st, a); \
+        else hipLaunchKernelGGL((conv_gemm_bf16c_kernel<BM_, WM_, WN_, MODE, 1, false, H>), grid, dim3(NT), 0, st, a);           \
     } while (0)
-    if constexpr (MODE == MODE_FWD) {
+    if constexpr (MODE == MODE_FWD && !H) {
         if (kwv) {
             if (BMsel == 128) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<128, 2, 2, MODE_FWD, 1, true>), grid, dim3(NT), 0, st, a);
             else if (BMsel == 96) hipLaunchKernelGGL((conv_gemm_bf16c_kernel<96, 3, 1, MODE_FWD, 1, true>), grid, dim3(NT), 0, st, a);
@@ -2576,7 +2913,7 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 #undef OTAL_LAUNCH_C
     if (int e = otal_launch_status()) return e;
     if (splits > 1) {
-        return launch_splitk_reduce<MODE>(a, st);
+        return launch_splitk_reduce<MODE, H>(a, st);
     }
     return 0;
 }
@@ -2613,8 +2950,10 @@ static inline size_t ptab_bytes(const ConvGeom& g, int cw) {
     return align256(((size_t)g.B * conv_out_positions(g) / cw + PTAB_PAD) * sizeof(int2));
 }
 
+template <bool H = false>
 int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStream_t st) {
     const bool pair = a.g.sw == 2;
+    if (H && pair) return OTAL_E_UNSUPPORTED;
     if (pair) {                                             // columns padded to 8 per (ci, dt, dh) row
         a.N = a.g.Cin * a.g.kt * a.g.kh * 8;
         a.flags |= EPI_NPAD8;
@@ -2624,8 +2963,8 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
     const size_t tb = ptab_bytes(a.g, cw);
     a.fd = make_conv_fastdiv(a.g);
     a.P = conv_out_positions(a.g);
-    a.src_bytes = (unsigned)gather_extent_bytes(a.g, MODE_FWD);
-    a.dy_bytes = (unsigned)gather_extent_bytes(a.g, MODE_DGRAD);
+    a.src_bytes = (unsigned)gather_extent_bytes(a.g, MODE_FWD, H ? 2 : 4);
+    a.dy_bytes = (unsigned)gather_extent_bytes(a.g, MODE_DGRAD, H ? 2 : 4);
     int2* ptab;
     if (a.pre) {
         ptab = reinterpret_cast<int2*>(const_cast<void*>(a.pre));      // geometry-only table, built once by the caller
@@ -2656,15 +2995,19 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
     const dim3 grid(tn, tm, splits);
 #define OTAL_LAUNCH_W(BM_, WM_, WN_)                                                                                   \
     do {                                                                                                               \
-        if (cw == 8) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<BM_, WM_, WN_, 8>), grid, dim3(NT), 0, st, a);        \
-        else if (cw == 4) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<BM_, WM_, WN_, 4>), grid, dim3(NT), 0, st, a);   \
-        else hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<BM_, WM_, WN_, 2>), grid, dim3(NT), 0, st, a);                \
+        if (cw == 8) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<BM_, WM_, WN_, 8, false, H>), grid, dim3(NT), 0, st, a);        \
+        else if (cw == 4) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<BM_, WM_, WN_, 4, false, H>), grid, dim3(NT), 0, st, a);   \
+        else hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<BM_, WM_, WN_, 2, false, H>), grid, dim3(NT), 0, st, a);                \
     } while (0)
+    if constexpr (!H) {
+        if (pair) {
+            if (BMsel == 128) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<128, 2, 2, 8, true>), grid, dim3(NT), 0, st, a);
+            else if (BMsel == 96) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<96, 3, 1, 8, true>), grid, dim3(NT), 0, st, a);
+            else if (BMsel == 64) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<64, 2, 1, 8, true>), grid, dim3(NT), 0, st, a);
+            else hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<32, 1, 1, 8, true>), grid, dim3(NT), 0, st, a);
+        }
+    }
     if (pair) {
-        if (BMsel == 128) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<128, 2, 2, 8, true>), grid, dim3(NT), 0, st, a);
-        else if (BMsel == 96) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<96, 3, 1, 8, true>), grid, dim3(NT), 0, st, a);
-        else if (BMsel == 64) hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<64, 2, 1, 8, true>), grid, dim3(NT), 0, st, a);
-        else hipLaunchKernelGGL((conv_wgrad_bf16v_kernel<32, 1, 1, 8, true>), grid, dim3(NT), 0, st, a);
     } else if (BMsel == 192) OTAL_LAUNCH_W(192, 6, 1);
     else if (BMsel == 128) OTAL_LAUNCH_W(128, 2, 2);
     else if (BMsel == 96) OTAL_LAUNCH_W(96, 3, 1);
@@ -2723,8 +3066,8 @@ static inline size_t direct_wp_bytes(int M, int C) {
     return align256((size_t)((M + BM - 1) / BM * BM) * C * 27 * 2 + 1024);
 }
 
-template <int BM, int BNP, int PX = 48>
-constexpr int direct_lds_bytes() { return 2 * BM * 304 + 2 * (BNP + 52) * PX + 16; }
+template <int BM, int BNP, int PX = 48, bool H = false>
+constexpr int direct_lds_bytes() { return 2 * BM * 304 + 2 * (BNP + (H ? 56 : 52)) * PX + 16; }
 // four waves x two position tiles, dense LDS pitch: 78 KB (BM = 96) / 59 KB (BM = 64) -> two workgroups per CU
 template <int BM, int MODE>
 static int launch_direct256x2(const DirectArgs& d, dim3 grid, hipStream_t st) {
@@ -2753,22 +3096,23 @@ static int launch_direct256d(const DirectArgs& d, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((conv3_direct_kernel<BM, MODE, 256, 1, 32, 4>), grid, dim3(512), lds, st, d);
     return otal_launch_status();
 }
-template <int BM, int MODE, bool XPF2 = false>
+template <int BM, int MODE, bool XPF2 = false, bool H = false>
 static int launch_direct512(const DirectArgs& d, dim3 grid, hipStream_t st) {
-    constexpr int lds = direct_lds_bytes<BM, 512>();
+    constexpr int lds = direct_lds_bytes<BM, 512, 48, H>();
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_direct_kernel<BM, MODE, 512, 2, 48, 1, XPF2>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_direct_kernel<BM, MODE, 512, 2, 48, 1, XPF2, H>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL((conv3_direct_kernel<BM, MODE, 512, 2, 48, 1, XPF2>), grid, dim3(512), lds, st, d);
+    hipLaunchKernelGGL((conv3_direct_kernel<BM, MODE, 512, 2, 48, 1, XPF2, H>), grid, dim3(512), lds, st, d);
     return otal_launch_status();
 }
 
-template <int MODE>
+template <int MODE, bool H = false>
 int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (H && ((a.g.Wi & 1) || (a.flags & EPI_ACCUM))) return OTAL_E_UNSUPPORTED;       // (4-byte aligned loads need an even row length)
     const int C = MODE == MODE_FWD ? a.g.Cin : a.g.Cout;
     const int BM = direct_bm(a.M);
     const int tm = (a.M + BM - 1) / BM, Mpad = tm * BM;
@@ -2785,7 +3129,7 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     }
     DirectArgs d;
     a.fd = make_conv_fastdiv(a.g);
-    a.src_bytes = (unsigned)gather_extent_bytes(a.g, MODE);
+    a.src_bytes = (unsigned)gather_extent_bytes(a.g, MODE, H ? 2 : 4);
     a.splits = 1; a.k_per_split = 0; a.slab = nullptr;
     set_epilogue_extents<MODE>(a);
 #ifdef OTAL_DIRECT_ABLATE
@@ -2797,9 +3141,9 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int bnp = direct_bnp(a.g, a.M);
     if (bnp == 128) {
         const dim3 grid(a.N / 128, tm, 1);
-        if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 128, 1>), grid, dim3(256), (direct_lds_bytes<96, 128>()), st, d);
-        else if (BM == 32) hipLaunchKernelGGL((conv3_direct_kernel<32, MODE, 128, 1>), grid, dim3(256), (direct_lds_bytes<32, 128>()), st, d);
-        else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 128, 1>), grid, dim3(256), (direct_lds_bytes<64, 128>()), st, d);
+        if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 128, 1, 48, 1, false, H>), grid, dim3(256), (direct_lds_bytes<96, 128, 48, H>()), st, d);
+        else if (BM == 32) hipLaunchKernelGGL((conv3_direct_kernel<32, MODE, 128, 1, 48, 1, false, H>), grid, dim3(256), (direct_lds_bytes<32, 128, 48, H>()), st, d);
+        else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 128, 1, 48, 1, false, H>), grid, dim3(256), (direct_lds_bytes<64, 128, 48, H>()), st, d);
         return otal_launch_status();
     }
     // positions two K steps ahead (XPF2): bit 0 -- 96 x 256 tiles, and 64 x 256 tiles when the grid has at most one workgroup
@@ -2811,22 +3155,24 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if (bnp == 512) {           // two position tiles per wave (dynamic LDS: 112 KB)
         const dim3 grid(a.N / 512, tm, 1);
         if constexpr (MODE == MODE_FWD) {
-            if (BM == 96 && (xpf2 & 2)) return launch_direct512<96, MODE, true>(d, grid, st);
+            if (BM == 96 && (xpf2 & 2)) return launch_direct512<96, MODE, true, H>(d, grid, st);
         }
-        if (BM == 96) return launch_direct512<96, MODE>(d, grid, st);
-        return launch_direct512<64, MODE>(d, grid, st);
+        if (BM == 96) return launch_direct512<96, MODE, false, H>(d, grid, st);
+        return launch_direct512<64, MODE, false, H>(d, grid, st);
     }
     const dim3 grid(a.N / 256, tm, 1);
-    if (OTAL_OPT("OTAL_CONV_DIRECT_256X2", 0) == 1 && BM != 32) {
-        if (BM == 96) return launch_direct256x2<96, MODE>(d, grid, st);
-        return launch_direct256x2<64, MODE>(d, grid, st);
+    if constexpr (!H) {         // experiments: fp32 tensors only
+        if (OTAL_OPT("OTAL_CONV_DIRECT_256X2", 0) == 1 && BM != 32) {
+            if (BM == 96) return launch_direct256x2<96, MODE>(d, grid, st);
+            return launch_direct256x2<64, MODE>(d, grid, st);
+        }
+        if (OTAL_OPT("OTAL_CONV_DIRECT_256X2", 0) == 2 && BM == 96) return launch_direct256d<96, MODE>(d, grid, st);
     }
-    if (OTAL_OPT("OTAL_CONV_DIRECT_256X2", 0) == 2 && BM == 96) return launch_direct256d<96, MODE>(d, grid, st);
-    if (BM == 96 && (xpf2 & 1)) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256, 1, 48, 1, true>), grid, dim3(512), (direct_lds_bytes<96, 256>()), st, d);
-    else if (BM == 64 && ((xpf2 & 4) || ((xpf2 & 1) && (int64_t)grid.x * grid.y <= 256))) hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 256, 1, 48, 1, true>), grid, dim3(512), (direct_lds_bytes<64, 256>()), st, d);
-    else if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<96, 256>()), st, d);
-    else if (BM == 32) hipLaunchKernelGGL((conv3_direct_kernel<32, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<32, 256>()), st, d);
-    else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 256, 1>), grid, dim3(512), (direct_lds_bytes<64, 256>()), st, d);
+    if (BM == 96 && (xpf2 & 1)) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256, 1, 48, 1, true, H>), grid, dim3(512), (direct_lds_bytes<96, 256, 48, H>()), st, d);
+    else if (BM == 64 && ((xpf2 & 4) || ((xpf2 & 1) && (int64_t)grid.x * grid.y <= 256))) hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 256, 1, 48, 1, true, H>), grid, dim3(512), (direct_lds_bytes<64, 256, 48, H>()), st, d);
+    else if (BM == 96) hipLaunchKernelGGL((conv3_direct_kernel<96, MODE, 256, 1, 48, 1, false, H>), grid, dim3(512), (direct_lds_bytes<96, 256, 48, H>()), st, d);
+    else if (BM == 32) hipLaunchKernelGGL((conv3_direct_kernel<32, MODE, 256, 1, 48, 1, false, H>), grid, dim3(512), (direct_lds_bytes<32, 256, 48, H>()), st, d);
+    else hipLaunchKernelGGL((conv3_direct_kernel<64, MODE, 256, 1, 48, 1, false, H>), grid, dim3(512), (direct_lds_bytes<64, 256, 48, H>()), st, d);
     return otal_launch_status();
 }
 
@@ -2836,8 +3182,71 @@ int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 #include "proj_gemm.inc"
 #include "wgrad1x1.inc"
 
+// Which H kernel serves a launch with bf16-stored tensors on both sides (0: none).  fwd / dgrad: 1 direct 3x3x3, 2 chunked;
+// wgrad: 3 direct, 4 wide 1x1, 5 vector (the number is the vector width + 16).  Shared by part 1's dispatcher and part 0's
+// otal_conv_half_storage() query; x / dy may be null (the query has no tensors: alignment is then the caller's contract).
+static inline int half_kernel_kind(const ConvGeom& g, int mode, const void* x, const void* dy) {
+    if (g.nlev > 1 || OTAL_OPT("OTAL_CONV_NOHALF", 0)) return 0;
+    if (conv_out_positions(g) % 8 || conv_in_positions(g) % 8 || g.x_bs % 8 || g.x_cs % 8 || g.y_bs % 8 || g.y_cs % 8) return 0;
+    if (mode == MODE_FWD || mode == MODE_DGRAD) {
+        const int M = mode == MODE_FWD ? g.Cout : g.Cin, C = mode == MODE_FWD ? g.Cin : g.Cout;
+        if (direct_eligible(g, mode, 1, M) && !(g.Wi & 1)) return 1;
+        if (chunk_eligible(g, mode, 1) && C % 8 == 0 && conv_in_positions(g) == conv_out_positions(g)) return 2;
+        return 0;
+    }
+    if (wgrad_direct_eligible(g, 1, x, dy)) return 3;
+    if (wgrad1x1_wide_eligible(g, 1, x, dy)) return 4;
+    if (const int cw = wgrad_vector_width(g, 1)) return 16 + cw;
+    return 0;
+}
+
+#if OTAL_CONV_PART == 1
+// bf16-stored tensors on BOTH sides of a backbone layer (fwd: x and y; dgrad: dy, dx and the ReLU mask; wgrad: x and dy): the H
+// instantiations of the direct 3x3x3, chunked, direct / wide / vector weight-gradient kernels.  Anything else: unsupported.
+}  // namespace
+int otal_conv::launch_half(int mode, ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    const ConvGeom& g = a.g;
+    if (!a.prec || !a.xhalf || !a.half || (a.flags & EPI_ACCUM)) return OTAL_E_UNSUPPORTED;
+    const void* px = mode == MODE_DGRAD ? (const void*)a.out : (const void*)a.x;
+    const void* py = mode == MODE_FWD ? (const void*)a.out : (const void*)a.dy;
+    if ((reinterpret_cast<uintptr_t>(px) | reinterpret_cast<uintptr_t>(py)) & 15) return OTAL_E_UNSUPPORTED;
+    if (mode == MODE_DGRAD && a.emask && (!a.mhalf || (reinterpret_cast<uintptr_t>(a.emask) & 15))) return OTAL_E_UNSUPPORTED;
+    const int kind = half_kernel_kind(g, mode, px, py);
+    // a persistent prologue region holds what the fp32-tensor launch of this geometry would use (prologue_kind): the direct
+    // kernel's weight pack wherever that kernel is eligible -- not what the chunked kernel reads
+    if (kind == 2 && direct_eligible(g, mode, 1, mode == MODE_FWD ? g.Cout : g.Cin)) a.pre = nullptr;
+    if (mode == MODE_FWD) {
+        if (kind == 1) return launch_direct<MODE_FWD, true>(a, ws, ws_bytes, st);
+        if (kind == 2) return launch_chunked<MODE_FWD, true>(a, ws, ws_bytes, st);
+        return OTAL_E_UNSUPPORTED;
+    }
+    if (mode == MODE_DGRAD) {
+        if (kind == 1) return launch_direct<MODE_DGRAD, true>(a, ws, ws_bytes, st);
+        if (kind == 2) return launch_chunked<MODE_DGRAD, true>(a, ws, ws_bytes, st);
+        return OTAL_E_UNSUPPORTED;
+    }
+    if (kind == 3) {
+        const int e = launch_wgrad_direct<true>(a, ws, ws_bytes, st);
+        if (e != OTAL_E_UNSUPPORTED) return e;              // slabs do not fit: the vector kernel
+        if (const int cw = wgrad_vector_width(g, 1)) return launch_wgrad_vector<true>(a, cw, ws, ws_bytes, st);
+        return e;
+    }
+    if (kind == 4) {
+        const int e = launch_wgrad1x1_wide<true>(a, ws, ws_bytes, st);
+        if (e != OTAL_E_UNSUPPORTED) return e;
+        if (const int cw = wgrad_vector_width(g, 1)) return launch_wgrad_vector<true>(a, cw, ws, ws_bytes, st);
+        return e;
+    }
+    if (kind > 16) return launch_wgrad_vector<true>(a, kind - 16, ws, ws_bytes, st);
+    return OTAL_E_UNSUPPORTED;
+}
+namespace {
+#endif
+
+#if OTAL_CONV_PART == 0
 template <int MODE>
 int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (a.xhalf) return otal_conv::launch_half(MODE, a, ws, ws_bytes, st);      // bf16-stored tensors on both sides: part 1
     if constexpr (MODE == MODE_WGRAD) {
         if (conv1a_wgrad_eligible(a.g, a.prec, a.x, a.dy) && (!a.half || a.g.y_bs % 8 + a.g.y_cs % 8 == 0)) {
             const int e = launch_conv1a_wgrad(a, ws, ws_bytes, st);
@@ -2966,9 +3375,11 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     }
     return 0;
 }
+#endif      // OTAL_CONV_PART == 0
 
 }  // namespace
 
+#if OTAL_CONV_PART == 0
 extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
     ConvGeom g;
     if (!geom || fill_geom(g, geom)) return 0;
@@ -3010,7 +3421,9 @@ extern "C" int otal_conv_fwd(const int* geom, const int64_t* strides, const floa
     a.flags = relu ? EPI_RELU : 0;
     a.prec = (precision & 1) ? 1 : 0;
     a.half = (precision & 4) ? 1 : 0;
-    if (a.half && !a.prec) return OTAL_E_UNSUPPORTED;
+    a.xhalf = (precision & 8) ? 1 : 0;
+    if ((a.half || a.xhalf) && !a.prec) return OTAL_E_UNSUPPORTED;
+    if (a.xhalf && !a.half) return OTAL_E_UNSUPPORTED;      // a bf16 x is only served together with a bf16 y
     a.pre = prologue;
     return launch_mode<MODE_FWD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -3031,7 +3444,10 @@ extern "C" int otal_conv_dgrad(const int* geom, const int64_t* strides, const fl
     a.prec = (precision & 1) ? 1 : 0;
     a.w_natural = (precision & 2) ? 1 : 0;
     a.half = (precision & 4) ? 1 : 0;
-    if (a.half && !a.prec) return OTAL_E_UNSUPPORTED;
+    a.xhalf = (precision & 8) ? 1 : 0;
+    a.mhalf = (precision & 16) ? 1 : 0;
+    if ((a.half || a.xhalf || a.mhalf) && !a.prec) return OTAL_E_UNSUPPORTED;
+    if (a.half != a.xhalf || (a.mhalf && !a.xhalf) || (out_mask && a.xhalf && !a.mhalf)) return OTAL_E_UNSUPPORTED;   // all three bf16, or none
     a.pre = prologue;
     return launch_mode<MODE_DGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -3048,7 +3464,9 @@ extern "C" int otal_conv_wgrad(const int* geom, const int64_t* strides, const fl
     a.flags = accumulate ? EPI_ACCUM : 0;
     a.prec = (precision & 1) ? 1 : 0;
     a.half = (precision & 4) ? 1 : 0;
-    if (a.half && !a.prec) return OTAL_E_UNSUPPORTED;
+    a.xhalf = (precision & 8) ? 1 : 0;
+    if ((a.half || a.xhalf) && !a.prec) return OTAL_E_UNSUPPORTED;
+    if (a.xhalf && !a.half) return OTAL_E_UNSUPPORTED;      // a bf16 x is only served together with a bf16 dy
     a.pre = prologue;
     return launch_mode<MODE_WGRAD>(a, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -3117,6 +3535,7 @@ extern "C" int otal_conv_half_storage(const int* geom, const int64_t* strides, i
     if (!geom || !strides || fill_geom(a.g, geom) || !(precision & 1)) return 0;
     a.g.x_bs = strides[0]; a.g.x_cs = strides[1]; a.g.y_bs = strides[2]; a.g.y_cs = strides[3];
     if (a.g.y_bs % 8 || a.g.y_cs % 8) return 0;
+    if (precision & 8) return half_kernel_kind(a.g, mode, nullptr, nullptr) ? 1 : 0;      // bf16 on both sides of the layer
     if (mode == MODE_FWD) {
         if (conv1a_direct_eligible(a.g, MODE_FWD, 1, nullptr) && !OTAL_OPT("OTAL_CONV_NO1A", 0)) return 1;
         return direct_eligible(a.g, MODE_FWD, 1, a.g.Cout) && !OTAL_OPT("OTAL_CONV_NODIRECT_HALF", 0) ? 1 : 0;
@@ -3242,3 +3661,4 @@ extern "C" int otal_conv_defer_reduces(int on) {
 extern "C" size_t otal_conv_deferred_end(void) { return (size_t)g_defer.last_end; }
 extern "C" int otal_conv_deferred_count(void) { return g_defer.n; }
 extern "C" int otal_conv_flush_reduces(void* stream) { return flush_deferred((hipStream_t)stream); }
+#endif      // OTAL_CONV_PART == 0

@@ -121,7 +121,50 @@ __global__ __launch_bounds__(256) void masked_scale_copy_kernel(const float* __r
     }
 }
 
+// fp32 <-> bf16 STORAGE conversion of a (B, C, P) map with dense positions and arbitrary batch / channel strides (channel
+// slices of a concat buffer): the boundary between the backbone's bf16-stored tensors and the fp32 tensors around them.
+// TO_H: fp32 -> bf16, round to nearest even; else bf16 -> fp32 (exact).  Eight positions per thread.
+template <bool TO_H>
+__global__ __launch_bounds__(256) void convert_storage_kernel(const void* __restrict__ src, int64_t sbs, int64_t scs, void* __restrict__ dst,
+                                                              int64_t dbs, int64_t dcs, int C, int P8, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int p = (int)(i % P8) * 8;
+    int64_t r = i / P8;
+    const int c = (int)(r % C);
+    const int64_t b = r / C;
+    const int64_t so = b * sbs + c * scs + p, dofs = b * dbs + c * dcs + p;
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    if constexpr (TO_H) {
+        const float4 a = *reinterpret_cast<const float4*>(static_cast<const float*>(src) + so);
+        const float4 d = *reinterpret_cast<const float4*>(static_cast<const float*>(src) + so + 4);
+        auto pk = [](float lo, float hi) { const f2 f = {lo, hi}; return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf2)); };
+        *reinterpret_cast<uint4*>(static_cast<unsigned short*>(dst) + dofs) = make_uint4(pk(a.x, a.y), pk(a.z, a.w), pk(d.x, d.y), pk(d.z, d.w));
+    } else {
+        const uint4 w = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(src) + so);
+        auto lo = [](unsigned v) { return __uint_as_float(v << 16); };
+        auto hi = [](unsigned v) { return __uint_as_float(v & 0xffff0000u); };
+        float* o = static_cast<float*>(dst) + dofs;
+        *reinterpret_cast<float4*>(o) = make_float4(lo(w.x), hi(w.x), lo(w.y), hi(w.y));
+        *reinterpret_cast<float4*>(o + 4) = make_float4(lo(w.z), hi(w.z), lo(w.w), hi(w.w));
+    }
+}
+
 }  // namespace
+
+extern "C" int otal_convert_storage(const void* src, int64_t src_bs, int64_t src_cs, void* dst, int64_t dst_bs, int64_t dst_cs,
+                                    int to_bf16, int B, int C, int P, void* stream) {
+    if (!src || !dst) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0 || P <= 0) return OTAL_E_SHAPE;
+    if (P % 8 || src_bs % 8 || src_cs % 8 || dst_bs % 8 || dst_cs % 8 ||
+        ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15)) return OTAL_E_UNSUPPORTED;
+    const int64_t total = (int64_t)B * C * (P / 8);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (to_bf16) hipLaunchKernelGGL(convert_storage_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, src_bs, src_cs, dst, dst_bs, dst_cs, C, P / 8, total);
+    else hipLaunchKernelGGL(convert_storage_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, src_bs, src_cs, dst, dst_bs, dst_cs, C, P / 8, total);
+    return otal_launch_status();
+}
 
 extern "C" int otal_proposal_windows(const float* loc, float* seg, float* frame_seg, int B, int nlev,
                                      const int* lev, float frame_num, void* stream) {

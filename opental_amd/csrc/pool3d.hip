@@ -43,6 +43,76 @@ struct PoolShape {
     __device__ __forceinline__ static int sw(const PoolGeom& g) { return KT ? SW : g.sw; }
 };
 
+// ---- bf16-STORED pool tensors (template flag H of the row-per-thread and strided kernels; ops.HALF_STORAGE).  A max-pool
+// commutes with the monotonic rounding, and every consumer of a pooled backbone map rounds its operand to bf16 anyway, so
+// the forward values do not change; backward sums are formed in fp32 and rounded (to nearest even) once, at the store.
+__device__ __forceinline__ float h2f_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h2f_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ unsigned f2h_pair_exact(float lo, float hi) {      // both values ARE bf16 values: no rounding
+    return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned f2h_pair_rne(float lo, float hi) {        // v_cvt_pk_bf16_f32
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf2));
+}
+// a run of N (even) consecutive elements of a fp32 / bf16 tensor <-> registers; `base` is the tensor seen as float*,
+// `off` the ELEMENT offset of the run (a multiple of VW; the caller guarantees the alignment of VW elements)
+template <int N, int VW, bool H>
+__device__ __forceinline__ void load_run(const float* base, int64_t off, bool ok, float (&a)[N]) {
+    static_assert(VW == 4 || VW == 2, "vector width");
+    if constexpr (H) {
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(base) + off;
+#pragma unroll
+        for (int q = 0; q < N / VW; ++q) {
+            if constexpr (VW == 4) {
+                const uint2 t = ok ? *reinterpret_cast<const uint2*>(src + 4 * q) : make_uint2(0u, 0u);
+                a[4 * q] = h2f_lo(t.x); a[4 * q + 1] = h2f_hi(t.x); a[4 * q + 2] = h2f_lo(t.y); a[4 * q + 3] = h2f_hi(t.y);
+            } else {
+                const unsigned t = ok ? *reinterpret_cast<const unsigned*>(src + 2 * q) : 0u;
+                a[2 * q] = h2f_lo(t); a[2 * q + 1] = h2f_hi(t);
+            }
+        }
+    } else {
+        const float* src = base + off;
+#pragma unroll
+        for (int q = 0; q < N / VW; ++q) {
+            if constexpr (VW == 4) {
+                const float4 t4 = ok ? *reinterpret_cast<const float4*>(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[4 * q] = t4.x; a[4 * q + 1] = t4.y; a[4 * q + 2] = t4.z; a[4 * q + 3] = t4.w;
+            } else {
+                const float2 t2 = ok ? *reinterpret_cast<const float2*>(src + 2 * q) : make_float2(0.f, 0.f);
+                a[2 * q] = t2.x; a[2 * q + 1] = t2.y;
+            }
+        }
+    }
+}
+template <int N, int VW, bool H, bool EXACT>
+__device__ __forceinline__ void store_run(float* base, int64_t off, const float (&a)[N]) {
+    if constexpr (H) {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(base) + off;
+#pragma unroll
+        for (int q = 0; q < N / VW; ++q) {
+            if constexpr (VW == 4) {
+                uint2 t;
+                t.x = EXACT ? f2h_pair_exact(a[4 * q], a[4 * q + 1]) : f2h_pair_rne(a[4 * q], a[4 * q + 1]);
+                t.y = EXACT ? f2h_pair_exact(a[4 * q + 2], a[4 * q + 3]) : f2h_pair_rne(a[4 * q + 2], a[4 * q + 3]);
+                *reinterpret_cast<uint2*>(dst + 4 * q) = t;
+            } else {
+                *reinterpret_cast<unsigned*>(dst + 2 * q) = EXACT ? f2h_pair_exact(a[2 * q], a[2 * q + 1]) : f2h_pair_rne(a[2 * q], a[2 * q + 1]);
+            }
+        }
+    } else {
+        float* dst = base + off;
+#pragma unroll
+        for (int q = 0; q < N / VW; ++q) {
+            if constexpr (VW == 4) *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+            else *reinterpret_cast<float2*>(dst + 2 * q) = make_float2(a[2 * q], a[2 * q + 1]);
+        }
+    }
+}
+
 // grid: x over output positions of one (b,c) plane, y = b*C + c
 template <int KT, int KH, int KW, int ST, int SH, int SW>
 __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -407,7 +477,8 @@ __global__ __launch_bounds__(256) void maxpool333_sep_fwd_kernel(const float* __
 // ~18 VALU instructions per element -- and the row is loaded and stored as vectors.  A workgroup covers TT output planes
 // of one (sample, channel) plus one halo plane on each side (256 / P rows).  Same values and tap bytes as the kernel
 // above: every stage is the FIRST maximum of three with the zero padding taking part.
-template <int P>
+// H: x and y are STORED as bf16 (8-byte / 4-byte row pieces); the maxima are taken on the exact fp32 images of the bf16 values.
+template <int P, bool H = false>
 __global__ __launch_bounds__(256) void maxpool333_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                   unsigned char* __restrict__ arg, PoolGeom g, int TT) {
     constexpr int VW = P % 4 == 0 ? 4 : 2, NV = P / VW;
@@ -424,20 +495,14 @@ __global__ __launch_bounds__(256) void maxpool333_rows_fwd_kernel(const float* _
     const bool act = r < rows;
     const int tl = r / P, h = r - tl * P;
     const int ti = to0 - 1 + tl;
-    const float* xb = x + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs;
     float v[P + 2];
     v[0] = 0.f; v[P + 1] = 0.f;
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
+    {
         const bool in = act && (unsigned)ti < (unsigned)g.Ti;
-        const float* src = xb + ((int64_t)(in ? ti : 0) * P + h) * P + q * VW;
-        if constexpr (VW == 4) {
-            const float4 t4 = in ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-            v[1 + 4 * q] = t4.x; v[2 + 4 * q] = t4.y; v[3 + 4 * q] = t4.z; v[4 + 4 * q] = t4.w;
-        } else {
-            const float2 t2 = in ? *reinterpret_cast<const float2*>(src) : make_float2(0.f, 0.f);
-            v[1 + 2 * q] = t2.x; v[2 + 2 * q] = t2.y;
-        }
+        float row[P];
+        load_run<P, VW, H>(x, (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)(in ? ti : 0) * P + h) * P, in, row);
+#pragma unroll
+        for (int w = 0; w < P; ++w) v[1 + w] = row[w];
     }
     auto put = [&](float* dst, const float (&a)[P]) {
 #pragma unroll
@@ -494,7 +559,7 @@ __global__ __launch_bounds__(256) void maxpool333_rows_fwd_kernel(const float* _
             bytes[w >> 2] |= byte << (8 * (w & 3));
         }
         const int64_t p = ((int64_t)(to0 + tl - 1) * P + h) * P;
-        put(y + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p, out);
+        store_run<P, VW, H, true>(y, (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p, out);
         unsigned char* ab = arg + (int64_t)bc * g.To * P * P + p;
         if constexpr (P % 4 == 0) {
 #pragma unroll
@@ -611,7 +676,9 @@ __global__ __launch_bounds__(256) void maxpool333_sep_bwd_kernel(const float* __
 // planes that can point into the row (staged once per workgroup in LDS), the h stage exchanges the plane-stage gradient
 // rows through LDS, the w stage and the fused ReLU / BN mask run in registers; every global access is a vector.  Same
 // sums in the same order as maxpool333_sep_bwd_kernel (ascending tap per stage).
-template <int P>
+// H: dy, dx and the mask are STORED as bf16; an accumulating call reads the bf16 dx, adds this pool's contribution in fp32 and
+// rounds once (the module-input gradient has two producers: the fused 1x1 data gradient stores, this kernel adds).
+template <int P, bool H = false>
 __global__ __launch_bounds__(256) void maxpool333_rows_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
                                                                   float* __restrict__ dx, PoolGeom g, int TI, int accumulate,
                                                                   const float* __restrict__ emask, const float* __restrict__ escale) {
@@ -661,13 +728,13 @@ __global__ __launch_bounds__(256) void maxpool333_rows_bwd_kernel(const float* _
     };
     // epilogue operands first: their latency hides behind the LDS stages
     float mk[P], old[P];
-    getg(emask + xoff, inside && emask != nullptr, mk);
-    getg(dx + xoff, inside && accumulate, old);
+    load_run<P, VW, H>(emask, xoff, inside && emask != nullptr, mk);
+    load_run<P, VW, H>(dx, xoff, inside && accumulate, old);
     {   // stage this thread's dy row and tap row
         float d[P];
         const bool in = act && (unsigned)to < (unsigned)g.To;
         const int64_t p = ((int64_t)(in ? to : 0) * P + h) * P;
-        getg(dy + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p, in, d);
+        load_run<P, VW, H>(dy, (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p, in, d);
         if (act) put(sdy + r * P, d);
         const unsigned char* ab = arg + (int64_t)bc * g.To * P * P + p;
         if (act) {
@@ -736,7 +803,7 @@ __global__ __launch_bounds__(256) void maxpool333_rows_bwd_kernel(const float* _
         if (emask) s_ = mk[w] > 0.f ? s_ * esc : 0.f;            // ReLU / BN backward of the pooled layer
         res[w] = old[w] + s_;
     }
-    put(dx + xoff, res);
+    store_run<P, VW, H, false>(dx, xoff, res);
 }
 
 // ---- MaxPool3d_2a / 3a (kernel (1,3,3), stride (1,2,2)) and MaxPool3d_4a ((3,3,3) / (2,2,2)): SAME padding = one zero
@@ -755,7 +822,8 @@ __device__ __forceinline__ void scan_tap(float v, bool in, int tap, bool first, 
 // byte per thread instead of two float4 of the 4-byte activations (604 MB -> 19 MB for MaxPool3d_2a).
 // XH: the pool INPUT is stored as bf16 (the producing convolution wrote it so): rows are read as 8 + 2 bytes.
 __device__ __forceinline__ float bf16_bits_to_float(unsigned h) { return __uint_as_float(h << 16); }
-template <int KT, bool XH>
+// YH (with XH): the pool OUTPUT is stored as bf16 too -- the winners are bf16 values already, nothing is rounded.
+template <int KT, bool XH, bool YH = false>
 __global__ __launch_bounds__(256) void maxpoolk33_s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 unsigned char* __restrict__ arg, PoolGeom g, FastDiv fW2,
                                                                 unsigned char* __restrict__ signbits) {
@@ -809,7 +877,12 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_fwd_kernel(const float* __r
             scan_tap(e[dt][dh], in && cin, tap + 2, false, b1, w1);
         }
     const int p = ((int)t * g.Ho + ho) * g.Wo + 2 * m;
-    *reinterpret_cast<float2*>(y + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p) = make_float2(b0, b1);
+    if constexpr (YH) {
+        static_assert(XH, "a bf16 pool output needs a bf16 input (the values are copied, not rounded)");
+        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(y) + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p) = f2h_pair_exact(b0, b1);
+    } else {
+        *reinterpret_cast<float2*>(y + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p) = make_float2(b0, b1);
+    }
     *reinterpret_cast<unsigned short*>(arg + (int64_t)bc * g.To * g.Ho * g.Wo + p) = (unsigned short)(w0 | (w1 << 8));
     if (signbits) {             // this thread read the input planes t*ST .. t*ST + ST - 1, rows 2 ho and 2 ho + 1, columns 4m .. 4m+3 in full
 #pragma unroll
@@ -828,7 +901,8 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_fwd_kernel(const float* __r
 
 // XH: dx is STORED as bf16 (round to nearest even -- the rounding the consuming weight-gradient GEMM applies anyway);
 // no accumulate, mask from the sign bits only.
-template <int KT, bool XH>
+// DYH: the incoming gradient dy is STORED as bf16.
+template <int KT, bool XH, bool DYH = false>
 __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
                                                                 float* __restrict__ dx, PoolGeom g, int accumulate,
                                                                 const float* __restrict__ emask, const float* __restrict__ escale,
@@ -867,7 +941,9 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __r
         const int to = KT == 1 ? t : (t >> 1) - pl;
         const bool pin = KT == 1 || (pl == 0 ? true : ((t & 1) == 0 && to >= 0));
         base[pl] = KT == 1 ? 0 : 9 * (pl == 0 ? (t & 1) : 2);
-        const float* dyb = dy + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + (int64_t)(pin ? to : 0) * g.Ho * g.Wo;
+        const int64_t dyo = (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + (int64_t)(pin ? to : 0) * g.Ho * g.Wo;
+        const float* dyb = dy + dyo;
+        const unsigned short* dyh = reinterpret_cast<const unsigned short*>(dy) + dyo;
         const unsigned char* ab = arg + ((int64_t)bc * g.To + (pin ? to : 0)) * g.Ho * g.Wo;
         // D[r][k], A[r][k]: output rows a-1 (r = 0) and a (r = 1), output columns 2m-1, 2m, 2m+1
 #pragma unroll
@@ -876,10 +952,18 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __r
             const int ho = a - 1 + r;
             const bool rin = pin && ho >= 0;
             const int o = rin ? ho * g.Wo + 2 * m : 0;
-            const float2 d2 = *reinterpret_cast<const float2*>(dyb + o);
-            const unsigned t2 = *reinterpret_cast<const unsigned short*>(ab + o);
             const bool lin = rin && m > 0;
-            const float d0 = dyb[lin ? o - 1 : o];
+            float2 d2;
+            float d0;
+            if constexpr (DYH) {
+                const unsigned w2 = *reinterpret_cast<const unsigned*>(dyh + o);
+                d2 = make_float2(h2f_lo(w2), h2f_hi(w2));
+                d0 = h2f_lo(dyh[lin ? o - 1 : o]);
+            } else {
+                d2 = *reinterpret_cast<const float2*>(dyb + o);
+                d0 = dyb[lin ? o - 1 : o];
+            }
+            const unsigned t2 = *reinterpret_cast<const unsigned short*>(ab + o);
             const int t0 = ab[lin ? o - 1 : o];
             D[pl][r][0] = lin ? d0 : 0.f;  A[pl][r][0] = lin ? t0 : 255;
             D[pl][r][1] = rin ? d2.x : 0.f; A[pl][r][1] = rin ? (int)(t2 & 255u) : 255;
@@ -977,18 +1061,23 @@ int bwd_planes(const PoolGeom& g, int& tlo_max, size_t& lds) {
 
 }  // namespace
 
+// io (forward): bit 0 -- x is stored as bf16, bit 1 -- y is stored as bf16 (only together with bit 0)
 static int pool_fwd(const int* geom, const int64_t* strides, const float* x, float* y, unsigned char* argtap,
-                    unsigned char* signbits, void* stream, int half = 0) {
+                    unsigned char* signbits, void* stream, int io = 0) {
     if (!geom || !strides || !x || !y || !argtap) return OTAL_E_NULL;
+    if (io != 0 && io != 1 && io != 3) return OTAL_E_UNSUPPORTED;
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
-    if ((signbits || half) && !strided_k33_kind(g, x, y)) return OTAL_E_UNSUPPORTED;
+    if ((signbits || io == 1) && !strided_k33_kind(g, x, y)) return OTAL_E_UNSUPPORTED;
     if (const int kind = strided_k33_kind(g, x, y)) {
         const int n2 = g.To * g.Ho * (g.Wo / 2);
         const dim3 grid((n2 + 255) / 256, g.B * g.C);
         const FastDiv fW2 = make_fastdiv((uint32_t)(g.Wo / 2));
-        if (half) {             // bf16-stored input (8-byte rows): the (1,3,3)/(1,2,2) pools
+        if (io == 3) {          // bf16 in, bf16 out
+            if (kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_fwd_kernel<1, true, true>), grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
+            else hipLaunchKernelGGL((maxpoolk33_s2_fwd_kernel<3, true, true>), grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
+        } else if (io == 1) {   // bf16-stored input (8-byte rows), fp32 output: the (1,3,3)/(1,2,2) pools
             if (kind != 1) return OTAL_E_UNSUPPORTED;
             hipLaunchKernelGGL((maxpoolk33_s2_fwd_kernel<1, true>), grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
         } else if (kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_fwd_kernel<1, false>), grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
@@ -1006,12 +1095,24 @@ static int pool_fwd(const int* geom, const int64_t* strides, const float* x, flo
         const int vec = (g.x_bs % 4 == 0 && g.x_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
         const bool vy = g.y_bs % 4 == 0 && g.y_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(argtap) & 3) == 0;
+        if (io == 3) {          // bf16 in / out: the row-per-thread kernels (12 x 12, 6 x 6 planes; 16-byte aligned channel planes)
+            const bool ok = (P == 12 || P == 6) && g.x_bs % 8 == 0 && g.x_cs % 8 == 0 && g.y_bs % 8 == 0 && g.y_cs % 8 == 0 &&
+                            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
+                            (reinterpret_cast<uintptr_t>(argtap) & 3) == 0;
+            if (!ok) return OTAL_E_UNSUPPORTED;
+            const int TT = 256 / P - 2;
+            const dim3 rgrid((g.To + TT - 1) / TT, g.B * g.C);
+            const size_t lds = (size_t)2 * (TT + 2) * P * P * sizeof(float);
+            if (P == 12) hipLaunchKernelGGL((maxpool333_rows_fwd_kernel<12, true>), rgrid, dim3(256), lds, st_, x, y, argtap, g, TT);
+            else hipLaunchKernelGGL((maxpool333_rows_fwd_kernel<6, true>), rgrid, dim3(256), lds, st_, x, y, argtap, g, TT);
+            return otal_launch_status();
+        }
         if (vec && vy && (P == 12 || P == 6) && !OTAL_OPT("OTAL_POOL_NOROWS", 0)) {     // one row per thread
             const int TT = 256 / P - 2;
             const dim3 rgrid((g.To + TT - 1) / TT, g.B * g.C);
             const size_t lds = (size_t)2 * (TT + 2) * P * P * sizeof(float);
-            if (P == 12) hipLaunchKernelGGL(maxpool333_rows_fwd_kernel<12>, rgrid, dim3(256), lds, st_, x, y, argtap, g, TT);
-            else hipLaunchKernelGGL(maxpool333_rows_fwd_kernel<6>, rgrid, dim3(256), lds, st_, x, y, argtap, g, TT);
+            if (P == 12) hipLaunchKernelGGL((maxpool333_rows_fwd_kernel<12>), rgrid, dim3(256), lds, st_, x, y, argtap, g, TT);
+            else hipLaunchKernelGGL((maxpool333_rows_fwd_kernel<6>), rgrid, dim3(256), lds, st_, x, y, argtap, g, TT);
             return otal_launch_status();
         }
         if (P == 12) hipLaunchKernelGGL(maxpool333_sep_fwd_kernel<12>, grid, dim3(256), need(tt), st_, x, y, argtap, g, tt, vec);
@@ -1019,6 +1120,7 @@ static int pool_fwd(const int* geom, const int64_t* strides, const float* x, flo
         else hipLaunchKernelGGL(maxpool333_sep_fwd_kernel<3>, grid, dim3(256), need(tt), st_, x, y, argtap, g, tt, vec);
         return otal_launch_status();
     }
+    if (io) return OTAL_E_UNSUPPORTED;      // bf16 tensors: the strided 3x3 pools and the 12 x 12 / 6 x 6 branch pools only
     size_t lds = 0;
     // staging pays when the taps overlap (stride 1: every input is read kvol times); the strided pools read each input
     // ~2 times and were measured faster with direct loads (r01: 230 vs 514 us for the 1x3x3 / (1,2,2) pool)
@@ -1034,23 +1136,29 @@ static int pool_fwd(const int* geom, const int64_t* strides, const float* x, flo
     return otal_launch_status();
 }
 
+// io (backward): bit 0 -- dx is stored as bf16, bit 1 -- dy is stored as bf16, bit 2 -- out_mask is a bf16 tensor
 static int pool_bwd(const int* geom, const int64_t* strides, const float* dy, const unsigned char* argtap, float* dx,
                     int accumulate, const float* out_mask, const float* out_scale, const unsigned char* signbits, void* stream,
-                    int half = 0) {
+                    int io = 0) {
     if (!geom || !strides || !dy || !dx || !argtap) return OTAL_E_NULL;
     if (((out_mask == nullptr) && (signbits == nullptr)) != (out_scale == nullptr)) return OTAL_E_NULL;
     if (out_mask && signbits) return OTAL_E_NULL;
+    const bool all_half = (io & 3) == 3 && (!out_mask || (io & 4));
+    if (io != 0 && io != 1 && !all_half) return OTAL_E_UNSUPPORTED;
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
     hipStream_t st_ = (hipStream_t)stream;
     const int kind = (!out_mask || (reinterpret_cast<uintptr_t>(out_mask) & 15) == 0) ? strided_k33_kind(g, dx, dy) : 0;
-    if ((signbits || half) && !kind) return OTAL_E_UNSUPPORTED;
-    if (half && (kind != 1 || accumulate || out_mask)) return OTAL_E_UNSUPPORTED;      // bf16-stored dx: plain store, sign-bit mask
+    if ((signbits || io == 1) && !kind) return OTAL_E_UNSUPPORTED;
+    if (io == 1 && kind != 1) return OTAL_E_UNSUPPORTED;
+    if (io && kind && (accumulate || out_mask)) return OTAL_E_UNSUPPORTED;      // bf16-stored dx of a strided pool: plain store, sign-bit mask
     if (kind) {
         const int n4 = g.Ti * (g.Hi / 2) * (g.Wi / 4);
         const dim3 grid((n4 + 255) / 256, g.B * g.C);
         const FastDiv fW4 = make_fastdiv((uint32_t)(g.Wi / 4)), fH2 = make_fastdiv((uint32_t)(g.Hi / 2));
-        if (half) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, true>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
+        if (all_half && kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, true, true>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
+        else if (all_half) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<3, true, true>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
+        else if (io == 1) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, true>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
         else if (kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, false>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
         else hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<3, false>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
         return otal_launch_status();
@@ -1065,12 +1173,24 @@ static int pool_bwd(const int* geom, const int64_t* strides, const float* dy, co
         const bool v2 = g.x_bs % 4 == 0 && g.x_cs % 4 == 0 && g.y_bs % 4 == 0 && g.y_cs % 4 == 0 &&
                         ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(out_mask) |
                           reinterpret_cast<uintptr_t>(argtap)) & 15) == 0;
+        if (io) {               // bf16 dy / dx / mask: the row-per-thread kernels (12 x 12, 6 x 6 planes; 16-byte aligned channel planes)
+            const bool ok = all_half && (g.Hi == 12 || g.Hi == 6) && g.x_bs % 8 == 0 && g.x_cs % 8 == 0 && g.y_bs % 8 == 0 && g.y_cs % 8 == 0 &&
+                            ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(out_mask) |
+                              reinterpret_cast<uintptr_t>(argtap)) & 15) == 0;
+            if (!ok) return OTAL_E_UNSUPPORTED;
+            const int P = g.Hi, TIr = 256 / P - 2, TB = P == 12 ? 12 : 8;
+            const dim3 rgrid((g.Ti + TIr - 1) / TIr, g.B * g.C);
+            const size_t lds = (size_t)2 * (TIr + 2) * P * P * sizeof(float) + (size_t)(TIr + 2) * P * TB;
+            if (P == 12) hipLaunchKernelGGL((maxpool333_rows_bwd_kernel<12, true>), rgrid, dim3(256), lds, st_, dy, argtap, dx, g, TIr, accumulate, out_mask, out_scale);
+            else hipLaunchKernelGGL((maxpool333_rows_bwd_kernel<6, true>), rgrid, dim3(256), lds, st_, dy, argtap, dx, g, TIr, accumulate, out_mask, out_scale);
+            return otal_launch_status();
+        }
         if (v2 && (g.Hi == 12 || g.Hi == 6) && !OTAL_OPT("OTAL_POOL_NOROWS", 0)) {      // one input row per thread
             const int P = g.Hi, TIr = 256 / P - 2, TB = P == 12 ? 12 : 8;
             const dim3 rgrid((g.Ti + TIr - 1) / TIr, g.B * g.C);
             const size_t lds = (size_t)2 * (TIr + 2) * P * P * sizeof(float) + (size_t)(TIr + 2) * P * TB;
-            if (P == 12) hipLaunchKernelGGL(maxpool333_rows_bwd_kernel<12>, rgrid, dim3(256), lds, st_, dy, argtap, dx, g, TIr, accumulate, out_mask, out_scale);
-            else hipLaunchKernelGGL(maxpool333_rows_bwd_kernel<6>, rgrid, dim3(256), lds, st_, dy, argtap, dx, g, TIr, accumulate, out_mask, out_scale);
+            if (P == 12) hipLaunchKernelGGL((maxpool333_rows_bwd_kernel<12>), rgrid, dim3(256), lds, st_, dy, argtap, dx, g, TIr, accumulate, out_mask, out_scale);
+            else hipLaunchKernelGGL((maxpool333_rows_bwd_kernel<6>), rgrid, dim3(256), lds, st_, dy, argtap, dx, g, TIr, accumulate, out_mask, out_scale);
             return otal_launch_status();
         }
         if (g.Hi == 12 && v4) hipLaunchKernelGGL((maxpool333_sep_bwd_kernel<12, true>), grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale);
@@ -1080,6 +1200,7 @@ static int pool_bwd(const int* geom, const int64_t* strides, const float* dy, co
         else hipLaunchKernelGGL((maxpool333_sep_bwd_kernel<3, false>), grid, dim3(256), l3, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale);
         return otal_launch_status();
     }
+    if (io) return OTAL_E_UNSUPPORTED;
     size_t lds = 0;
     int tlo_max = 0;
     const int ti = OTAL_OPT("OTAL_POOL_NOLDS", 0) ? 0 : bwd_planes(g, tlo_max, lds);
@@ -1132,4 +1253,19 @@ extern "C" int otal_maxpool3d_bwd_signbits_h(const int* geom, const int64_t* str
                                              void* dx_bf16, const unsigned char* signbits, const float* out_scale, void* stream) {
     if (!signbits || !out_scale) return OTAL_E_NULL;
     return pool_bwd(geom, strides, dy, argtap, static_cast<float*>(dx_bf16), 0, nullptr, out_scale, signbits, stream, 1);
+}
+/* The general bf16-storage forms (ABI 23): `io` says which tensors are STORED as bf16 (pointers through the float* parameters,
+ * strides in elements).  fwd io: bit 0 x, bit 1 y (1: the form above; 3: both -- the strided 3x3 pools and the 3x3x3 branch pools
+ * on 12 x 12 / 6 x 6 planes).  bwd io: bit 0 dx, bit 1 dy, bit 2 out_mask (1: the form above; 3 / 7: all of them -- strided pools
+ * with the sign-bit mask and a plain store; branch pools with a bf16 mask tensor, and `accumulate` = read dx, add in fp32, round
+ * once).  signbits / out_mask nullable as in the fp32 entry points.  Anything else: OTAL_E_UNSUPPORTED. */
+extern "C" int otal_maxpool3d_fwd_io(const int* geom, const int64_t* strides, const void* x, void* y, unsigned char* argtap,
+                                     unsigned char* signbits, int io, void* stream) {
+    return pool_fwd(geom, strides, static_cast<const float*>(x), static_cast<float*>(y), argtap, signbits, stream, io);
+}
+extern "C" int otal_maxpool3d_bwd_io(const int* geom, const int64_t* strides, const void* dy, const unsigned char* argtap, void* dx,
+                                     int accumulate, const void* out_mask, const float* out_scale, const unsigned char* signbits,
+                                     int io, void* stream) {
+    return pool_bwd(geom, strides, static_cast<const float*>(dy), argtap, static_cast<float*>(dx), accumulate,
+                    static_cast<const float*>(out_mask), out_scale, signbits, stream, io);
 }
