@@ -341,7 +341,8 @@ class DetectorTrainer:
 
     def _ibm_state(self):
         if getattr(self.criterion, 'cls_loss_type', None) == 'edl' and getattr(self.criterion.cls_loss, 'with_ibm', False):
-            return self.criterion.cls_loss.weight_accum
+            # (the ActivityNet EvidenceLoss uses the closed-form IBM weight: no cross-step state to average -> None)
+            return getattr(self.criterion.cls_loss, 'weight_accum', None)
         return None
 
     def end_backward(self):

@@ -509,3 +509,46 @@ def test_inference_results_are_gathered_on_rank_0_in_list_order():
     assert res[1] is None
     assert list(res[0].keys()) == [f"v{i}" for i in range(7)]
     assert [res[0][f"v{i}"][0]["score"] for i in range(7)] == [0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0]
+
+
+def _anet_criterion_worker(rank, world, port, q):
+    """Data-parallel steps with the ActivityNet criterion (closed-form IBM weight: no `weight_accum` buffer to average)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from opental_amd.anet.multisegment_loss import MultiSegmentLoss
+        tr, net = _make_trainer(True)
+        edl = dict(evidence='exp', loss_type='log', iou_aware=True, with_ibm=True, ibm_start=10, momentum=0.99, num_bins=50)
+        tr.criterion = MultiSegmentLoss(150, 0.6, 1.0, cls_loss_type='edl', edl_config=edl, os_head=True)
+        assert tr.collectives and tr.criterion.cls_loss.with_ibm and not hasattr(tr.criterion.cls_loss, 'weight_accum')
+        assert tr._ibm_state() is None              # ADVICE r3: this access raised AttributeError under world > 1
+        g = torch.Generator().manual_seed(7)
+        xs = torch.randn(world, 2, 5, 8, generator=g)
+        ys = torch.randn(world, 2, 5, 1, generator=g)
+        for step in range(2):
+            tr.step(xs[rank, step], ys[rank, step], None)
+        q.put((rank, tr.arena.flat.clone(), tr.arena.grad.clone()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_anet_criterion_without_ibm_state_steps_under_data_parallelism():
+    import queue
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_anet_criterion_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    except queue.Empty:
+        res = None
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert res is not None and all(p.exitcode == 0 for p in procs)
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])

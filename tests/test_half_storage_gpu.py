@@ -92,11 +92,16 @@ def test_conv1a_weight_gradient_from_a_bf16_gradient(shape, cout):
     assert torch.equal(dw, dw_ref)          # same bf16 operands, same summation order
 
 
-def test_model_forward_is_unchanged_and_only_the_first_layer_gradient_moves(golden_dir):
-    """HALF_STORAGE on / off: identical features and losses (bit for bit); every weight gradient but Conv3d_1a's identical;
-    Conv3d_1a's differs only where two window elements became equal after rounding (the pool's first-maximum rule then
-    routes the gradient to the other one): cosine 0.997 with the fp32-stored run, against 0.77 between the bf16-operand
-    and the fp32 modes for this layer (test_bf16_compute_mode_stays_close_to_fp32)."""
+def test_model_forward_is_unchanged_and_only_backbone_gradients_move(golden_dir):
+    """HALF_STORAGE on / off (round 4: with ops.HALF_CHAIN every activation and data gradient between Conv3d_1a and Mixed_4f is
+    stored as bf16): identical features and losses, bit for bit -- every consumer rounds its operand to bf16 anyway, max-pools
+    commute with the rounding.  Gradients: everything outside the backbone is identical (computed before the backbone's
+    backward); inside it a bf16-stored gradient is what its consumer's operand loader would have rounded the fp32 tensor to,
+    EXCEPT where a tensor has two producers -- a module's input gradient is stored by the fused 1x1 data gradient and added to
+    by the branch pool's backward (read bf16, add in fp32, round once: one more rounding than the fp32-stored run) -- and where
+    two pool-window elements became equal after rounding (the first-maximum rule then routes the gradient to the other one).
+    Measured cosines with the fp32-stored run: >= 0.995 for every layer, against 0.77 (Conv3d_1a) between the bf16-operand and
+    the fp32 modes (test_bf16_compute_mode_stays_close_to_fp32)."""
     from oracle import arch
     from test_model_gpu import build, _criterion, W
     from opental_amd.common import ops
@@ -123,7 +128,12 @@ def test_model_forward_is_unchanged_and_only_the_first_layer_gradient_moves(gold
         assert torch.equal(o0[k], o1[k]), k
     assert c0 == c1
     moved = [k for k in g0 if not torch.equal(g0[k], g1[k])]
-    assert all("Conv3d_1a" in k for k in moved), moved
+    assert moved and all(k.startswith("backbone.") for k in moved), [k for k in moved if not k.startswith("backbone.")]
+    # Mixed_5b / 5c run on fp32 tensors behind the region's end: their gradients are untouched
+    assert not any("Mixed_5" in k for k in moved), [k for k in moved if "Mixed_5" in k]
+    worst = {}
     for k in moved:
-        cos = float(torch.nn.functional.cosine_similarity(g0[k].flatten(), g1[k].flatten(), dim=0))
+        cos = float(torch.nn.functional.cosine_similarity(g0[k].flatten().double(), g1[k].flatten().double(), dim=0))
+        worst[k] = cos
         assert cos > 0.99, (k, cos)
+    print("bf16-stored vs fp32-stored gradients, lowest cosines:", sorted(worst.items(), key=lambda kv: kv[1])[:4])
