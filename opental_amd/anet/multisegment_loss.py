@@ -78,13 +78,30 @@ class MultiSegmentLoss(nn.Module):
         prop_loc_t = (loc_t - loc) / (0.5 * w)
         return loc_t, conf_t, prop_loc_t, prop_conf_t, iou
 
+    def _bounds_list(self):
+        """The level table of the `level_bounds` BUFFER (the single source of truth of both paths), as host floats."""
+        lb = self.level_bounds
+        key = (lb.data_ptr(), lb._version)
+        if getattr(self, '_bounds_key', None) != key:
+            self._bounds_host, self._bounds_key = lb.detach().cpu().tolist(), key
+        return self._bounds_host
+
     def _fused_ok(self, loc, conf, priors):
         """The HIP loss of this recipe (csrc/loss.hip, otal_detection_loss_anet) covers what configs/anet_opental.yaml trains
         with; other settings stay on the torch formulation below."""
         cl = self.cls_loss
-        return (FUSED and loc.is_cuda and loc.dtype == torch.float32 and priors.shape[0] <= 1024 and priors.shape[1] == 2
+        if not (FUSED and loc.is_cuda and loc.dtype == torch.float32 and priors.shape[0] <= 1024 and priors.shape[1] == 2
                 and self.cls_loss_type == 'edl' and cl.loss_type == 'log' and cl.evidence == 'exp' and not cl.size_average
-                and cl.num_cls == conf.shape[-1] and not self.act_loss.size_average)
+                and cl.num_cls == conf.shape[-1] and cl.num_cls < 32768 and not self.act_loss.size_average
+                and self.level_bounds.shape[0] <= 8):        # (the kernel keeps labels in 16 bits and <= MAX_LEVELS_A = 8 levels)
+            return False
+        # the kernel clamps a prior's level id into the table; the torch path would raise on an out-of-range one: keep the
+        # torch path's behaviour for such priors (checked once per priors tensor -- one host read, not one per step)
+        key = (priors.data_ptr(), priors._version, tuple(priors.shape))
+        if getattr(self, '_lvl_checked', None) != key:
+            self._lvl_ok = bool(0 <= int(priors[:, 1].min()) and int(priors[:, 1].max()) < self.level_bounds.shape[0])
+            self._lvl_checked = key
+        return self._lvl_ok
 
     def forward(self, predictions, targets, pre_locs=None):
         loc, conf, prop_loc, prop_conf, center, priors, act, prop_act = predictions
@@ -95,7 +112,7 @@ class MultiSegmentLoss(nn.Module):
             cl = self.cls_loss
             return AnetDetectionLossFunction.apply(
                 loc, conf, prop_loc, prop_conf, center.reshape(B, K), act.reshape(B, K), prop_act.reshape(B, K), priors, gt, valid,
-                bounds, float(self.clip_length), float(self.overlap_thresh), bool(cl.with_ibm and cl.epoch >= cl.ibm_start),
+                self._bounds_list(), float(self.clip_length), float(self.overlap_thresh), bool(cl.with_ibm and cl.epoch >= cl.ibm_start),
                 float(cl.coeff), bool(self.iou_aware), float(self.act_loss.weight), float(self.act_loss.margin))
         loc_t, conf_t, prop_loc_t, prop_conf_t, iou_pred = self.match(loc.detach(), priors, targets)
         pos, prop_pos = conf_t > 0, prop_conf_t > 0

@@ -133,8 +133,8 @@ def main(argv=None):
                              channels=config['model']['in_channels'], binary_class=config['dataset']['num_classes'] == 2)
     if len(dataset) == 0:
         raise SystemExit("no training videos found under " + str(ds['video_mp4_path']))
-    any_video = dataset.video(dataset.training_list[0]['video_name'])
-    stager = ClipStager(tr['batch_size'], ds['clip_length'], int(any_video.shape[1]), int(any_video.shape[2]), ds['crop_size'],
+    any_shape = dataset.video_shape(dataset.training_list[0]['video_name'])
+    stager = ClipStager(tr['batch_size'], ds['clip_length'], int(any_shape[1]), int(any_shape[2]), ds['crop_size'],
                         device=dev)
     checkpoint_path = tr['checkpoint_path']
     train_state_path = os.path.join(checkpoint_path, 'training')

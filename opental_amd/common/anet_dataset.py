@@ -126,38 +126,73 @@ def ssl_splice(annos, th, clip_length=768, rng=random):
     return fmap, new_annos, True
 
 
+class LazyVideo:
+    """What a decision record carries instead of the pixels: the video's name and shape (read from the .npy HEADER only).
+    The frames are loaded when the stager slices it -- `v[a:b]` -- through the dataset's bounded cache, so deciding a whole
+    epoch up front (thumos14.train.run_one_epoch materialises every rank's batch list) touches no pixel data."""
+    dtype = torch.uint8
+
+    def __init__(self, dataset, name, shape):
+        self._ds, self.name, self.shape = dataset, name, tuple(shape)
+
+    def dim(self):
+        return len(self.shape)
+
+    def __getitem__(self, idx):
+        return self._ds.video(self.name)[idx]
+
+
 class ANET_Dataset:
     """Same constructor arguments as the reference's Dataset (anet_dataset.py:129-153).  `decide(idx)` is `__getitem__`
-    up to the pixels.  Videos are read from <video_dir>/<name>.npy (uint8, (T,H,W,3)) on first use and kept in pinned
-    host memory (the reference re-reads the file for every sample, :218)."""
+    up to the pixels.  Videos are read from <video_dir>/<name>.npy (uint8, (T,H,W,3)) when a batch is SUBMITTED and kept in a
+    bounded least-recently-used cache (`cache_videos`, default 64 = ~1.9 GB of 768 x 112 x 112 x 3 videos; the reference
+    re-reads the file for every sample, :218; ActivityNet1.3 has ~10 k training videos = ~290 GB, which an unbounded cache
+    -- the THUMOS14 pattern of ~200 videos -- would try to hold on every rank)."""
 
     def __init__(self, video_info_path, video_dir, clip_length, crop_size, stride, channels=3, rgb_norm=True, training=True,
-                 binary_class=False, pin=True):
+                 binary_class=False, pin=False, cache_videos=64):
         self.training = training
         video_info = get_video_info(video_info_path, 'training' if training else 'validation')
         self.training_list, self.th = split_videos(video_info, clip_length, video_dir, binary_class)
         self.clip_length, self.crop_size, self.rgb_norm = clip_length, crop_size, rgb_norm
         self.video_dir, self.channels = video_dir, channels
         self._pin = pin
-        self._cache = {}
+        self._cache = {}                # name -> tensor, in least-recently-used order (dicts keep insertion order)
+        self._cap = max(1, int(cache_videos))
+        self._shapes = {}
         if not rgb_norm:
             raise NotImplementedError("the device kernel normalises (rgb_norm=True, the only setting the reference uses)")
 
     def __len__(self):
         return len(self.training_list)
 
+    def video_shape(self, name):
+        """(T, H, W, 3) from the file header: np.load(mmap_mode='r') maps the file without reading the frames."""
+        shp = self._shapes.get(name)
+        if shp is None:
+            m = np.load(os.path.join(self.video_dir, name + '.npy'), mmap_mode='r')
+            if m.dtype != np.uint8 or m.ndim != 4 or m.shape[3] != 3:
+                raise RuntimeError(f"{name}.npy: expected uint8 (T,H,W,3)")
+            shp = self._shapes[name] = tuple(int(d) for d in m.shape)
+            del m
+        return shp
+
     def video(self, name):
-        v = self._cache.get(name)
+        v = self._cache.pop(name, None)
         if v is None:
             v = torch.from_numpy(np.load(os.path.join(self.video_dir, name + '.npy')))
             if v.dtype != torch.uint8 or v.dim() != 4 or v.shape[3] != 3:
                 raise RuntimeError(f"{name}.npy: expected uint8 (T,H,W,3)")
-            v = self._cache[name] = v.pin_memory() if (self._pin and torch.cuda.is_available()) else v
+            if self._pin and torch.cuda.is_available():
+                v = v.pin_memory()
+            while len(self._cache) >= self._cap:            # evict the least recently used (the stager copies frames into
+                self._cache.pop(next(iter(self._cache)))    # its own pinned slots at submit time: nothing points here later)
+        self._cache[name] = v
         return v
 
     def decide(self, idx, rng=random):
         info = self.training_list[idx]
-        video = self.video(info['video_name'])
+        video = LazyVideo(self, info['video_name'], self.video_shape(info['video_name']))
         th = int(self.th[info['video_name']] / 4)                   # :216
         offset = info['offset']
         valid = min(offset + self.clip_length, info['frame_num']) - offset      # :219-221

@@ -177,6 +177,10 @@ def detect_batch(net, videos, sample_fps, clip_length=256, stride=128, conf_thre
         if flow_net is not None:
             out = fuse_outputs(out, flow_net(prepare_windows(flow_videos, clips[i:i + batch_clips], clip_length)))
         outs.append(out)
+    if flow_net is not None and 'unct' not in outs[0]:
+        # fuse_outputs only carries the uncertainty maps when BOTH networks produced them (use_edl + os_head); the reference's
+        # two-stream fusion of a closed-set model (thumos14.yaml) decodes softmax scores, which this decode kernel does not
+        raise NotImplementedError("two-stream fusion needs evidential (use_edl, os_head) networks on both streams")
     keys = ('loc', 'conf', 'prop_loc', 'prop_conf', 'center', 'act', 'prop_act', 'priors') + \
         (('unct', 'prop_unct') if flow_net is not None else ())
     merged = {k: (torch.cat([o[k] for o in outs], 0) if k != 'priors' else outs[0][k]) for k in keys}

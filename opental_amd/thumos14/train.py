@@ -929,7 +929,10 @@ def rank_batches(every, rank, world):
     """The batches of one epoch that rank `rank` of `world` runs: every world-th one of a list truncated to a multiple of
     `world` -- drop_last across ranks.  Every rank must run the SAME number of steps (each step's bucket / IBM / used-mask
     all-reduces need all peers; a rank with one batch more would wait for collectives nobody else issues until the RCCL
-    watchdog aborts the job at the end of the first epoch)."""
+    watchdog aborts the job at the end of the first epoch).  The truncation comes BEFORE a caller's max_steps cut, and every
+    rank materialises the whole list (the sampling decisions draw from one shared random stream, so all ranks must draw all of
+    them to stay aligned; decisions are host-only records -- no pixels, see anet_dataset.LazyVideo).  The per-epoch means a
+    driver prints are this rank's means over its own steps, not global ones."""
     every = list(every)
     every = every[:len(every) // world * world]
     return every[rank::world]

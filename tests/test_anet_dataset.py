@@ -47,6 +47,28 @@ def test_sampling_decisions_match_the_reference_fixture(tmp_path, golden_dir):
     assert flags > 0 and fails > 0
 
 
+def test_deciding_an_epoch_loads_no_frames_and_the_video_cache_is_bounded(tmp_path):
+    """decide() used to load (and pin) every video of the epoch on every rank before the first step.  Decisions
+    need the frame size only -- read from the .npy header -- and the pixels are loaded when the stager slices the record's
+    lazy handle, through a least-recently-used cache of `cache_videos` entries."""
+    from opental_amd.common import anet_dataset as MD
+    root = str(tmp_path)
+    videos = P.write_dataset(root, P.dataset_spec())
+    ds = MD.ANET_Dataset(os.path.join(root, "info.json"), os.path.join(root, "npy"), P.CLIP, P.CROP, P.STRIDE, cache_videos=2)
+    recs = [ds.decide(i) for i in range(len(ds))]
+    assert len(ds._cache) == 0                                  # no frame was read
+    names = []
+    for r in recs:
+        v = r['video']
+        assert isinstance(v, MD.LazyVideo) and v.dtype == torch.uint8 and tuple(v.shape) == tuple(videos[v.name].shape)
+        sl = v[r['offset']: r['offset'] + r['valid']]
+        assert torch.equal(sl, torch.from_numpy(videos[v.name][r['offset']: r['offset'] + r['valid']]))
+        names.append(v.name)
+        assert len(ds._cache) <= 2
+    assert len(set(names)) > 2                                  # more videos than cache entries were touched
+    assert list(ds._cache) == list(dict.fromkeys(reversed(names)))[:2][::-1]      # the two most recently used, oldest first
+
+
 def test_slice_assignment_semantics_of_the_splice():
     """`new[:, a:b] = old[:, c:d]` as torch evaluates it: equal lengths copy, a one-frame source broadcasts, anything
     else is the RuntimeError the reference catches (anet_dataset.py:194-207) -> the splice is given up."""
