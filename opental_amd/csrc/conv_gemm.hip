@@ -1674,7 +1674,12 @@ __device__ __forceinline__ void pack_direct_body(unsigned* __restrict__ wp, cons
             float x = 0.f;
             if (m < M) {
                 if (MODE == MODE_FWD) x = w[((int64_t)m * C + c) * 27 + dt * 9 + g9];
+#ifdef OTAL_BREAK_DGRAD_TAP     // tools/break_dgrad_tap.sh: a deliberately mis-routed data gradient (temporal taps not flipped), to show
+                                // that tests/test_bf16_parity_gpu.py's backward pin fails on it.  Never defined in the product build.
+                else if (natural) x = w[((int64_t)c * M + m) * 27 + dt * 9 + (8 - g9)];
+#else
                 else if (natural) x = w[((int64_t)c * M + m) * 27 + (2 - dt) * 9 + (8 - g9)];
+#endif
                 else x = w[((int64_t)m * C + c) * 27 + (2 - dt) * 9 + (8 - g9)];      // packed W^T (Cin, Cout, 27)
             }
             v[i] = x;

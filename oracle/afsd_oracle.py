@@ -122,25 +122,51 @@ def same_pad(size, k, s):
 # in fp32; the skinny detection heads stay exact fp32 (csrc/headconv.hip).  `with operand_rounding("bf16")` makes this
 # restatement do the same on the CPU -- fp32 convolutions of bf16-rounded operands -- so the bf16 path can be pinned end to
 # end and layer by layer instead of against a loose bf16-vs-fp32 tolerance.  Not part of the reference (which is fp32).
+# grads=True extends it to the BACKWARD pass of the same convolutions: the data- and weight-gradient GEMMs of the HIP path
+# round their gradient operand dy (the gradient w.r.t. the convolution's own output, i.e. behind the frozen-BN scale and
+# the ReLU mask) to bf16 as well -- on the CPU a pass-through node behind each such convolution that rounds the incoming
+# gradient.  stored_until="Mixed_4f" models the bf16 STORAGE of the backbone (ops.HALF_CHAIN): activations between
+# Conv3d_1a and that endpoint exist as bf16 values only, so the max-pools up to it choose their winners among ROUNDED
+# values (forward values unchanged -- max commutes with the rounding -- but ties, and with them the routing of the
+# gradient, are those of the rounded window).
 _ROUND = None
+_ROUND_GRADS = False
+_STORED_UNTIL = None
+_STORED_NOW = False
 
 
 class operand_rounding:
-    def __init__(self, mode):
-        self.mode = mode
+    def __init__(self, mode, grads=False, stored_until=None):
+        self.mode, self.grads, self.stored_until = mode, grads, stored_until
 
     def __enter__(self):
-        global _ROUND
-        self.old, _ROUND = _ROUND, self.mode
+        global _ROUND, _ROUND_GRADS, _STORED_UNTIL
+        self.old = (_ROUND, _ROUND_GRADS, _STORED_UNTIL)
+        _ROUND, _ROUND_GRADS, _STORED_UNTIL = self.mode, self.grads, self.stored_until
         return self
 
     def __exit__(self, *a):
-        global _ROUND
-        _ROUND = self.old
+        global _ROUND, _ROUND_GRADS, _STORED_UNTIL
+        _ROUND, _ROUND_GRADS, _STORED_UNTIL = self.old
 
 
 def _r(t):
     return t.to(torch.bfloat16).to(t.dtype) if _ROUND == "bf16" and t.dtype == torch.float32 else t
+
+
+class _RoundGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y):
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _rg(y):
+    """Behind a bf16-MFMA convolution: its gradient operand dy is rounded in the backward pass (grads=True)."""
+    return _RoundGrad.apply(y) if (_ROUND == "bf16" and _ROUND_GRADS and y.requires_grad) else y
 
 
 def unit1d(x, w, b, stride=1, exact=False):
@@ -148,6 +174,7 @@ def unit1d(x, w, b, stride=1, exact=False):
     f, bk = same_pad(x.shape[2], w.shape[2], stride)
     if not exact:
         x, w = _r(x), _r(w)
+        return _rg(F.conv1d(F.pad(x, [f, bk]), w, b, stride=stride))
     return F.conv1d(F.pad(x, [f, bk]), w, b, stride=stride)
 
 
@@ -172,7 +199,7 @@ def _pad3(x, k, s, spatial=True):
 def conv3d_bn_relu(P, prefix, x, k, s):
     """backbone Unit3D (i3d_backbone.py:46-87): SAME pad -> Conv3d(no bias) -> frozen BN
     (eps 1e-3, running stats; BDNet.py:39-49 keeps BN in eval) -> ReLU."""
-    x = F.conv3d(_pad3(_r(x), k, s), _r(P[f"{prefix}.conv3d.weight"]), None, stride=s)
+    x = _rg(F.conv3d(_pad3(_r(x), k, s), _r(P[f"{prefix}.conv3d.weight"]), None, stride=s))
     x = F.batch_norm(x, P[f"{prefix}.bn.running_mean"], P[f"{prefix}.bn.running_var"],
                      P[f"{prefix}.bn.weight"], P[f"{prefix}.bn.bias"], False, 0.0, 1e-3)
     return F.relu(x)
@@ -180,6 +207,8 @@ def conv3d_bn_relu(P, prefix, x, k, s):
 
 def maxpool3d_same(x, k, s):
     """MaxPool3dSamePadding (layers.py:9-35): ZERO padding (not -inf), then plain max-pool."""
+    if _STORED_NOW:
+        x = _r(x)               # bf16-stored pool input: the winner is the first maximum of the ROUNDED window
     return F.max_pool3d(_pad3(x, k, s), k, s)
 
 
@@ -195,7 +224,9 @@ def mixed(P, prefix, x):
 
 def i3d_features(P, x, endpoints=None):
     """InceptionI3d.extract_features up to Mixed_5c (i3d_backbone.py:335-342)."""
+    global _STORED_NOW
     feats = {}
+    _STORED_NOW = _ROUND == "bf16" and _STORED_UNTIL is not None
     for name, kind, args in arch.I3D_ENDPOINTS:
         if kind == "conv":
             _cin, _cout, k, s = args
@@ -206,6 +237,9 @@ def i3d_features(P, x, endpoints=None):
             x = mixed(P, f"backbone._model.{name}", x)
         if endpoints is None or name in endpoints:
             feats[name] = x
+        if name == _STORED_UNTIL:
+            _STORED_NOW = False
+    _STORED_NOW = False
     return feats
 
 
@@ -272,16 +306,16 @@ def coarse_pyramid(P, f4, f5, cfg=arch.THUMOS, compat=False, keep=None):
     strides = cfg.get("fpn_strides")
     if cfg.get("two_projections", True):
         # pyramids[0], [1]: Unit3D 'spatial_valid' (temporal k=1 -> no pad) + GN + ReLU (BDNet.py:129-155)
-        x0 = F.conv3d(_r(f4), _r(P[f"{Q}.pyramids.0.0.conv3d.weight"]), P[f"{Q}.pyramids.0.0.conv3d.bias"])
+        x0 = _rg(F.conv3d(_r(f4), _r(P[f"{Q}.pyramids.0.0.conv3d.weight"]), P[f"{Q}.pyramids.0.0.conv3d.bias"]))
         x0 = gn_relu(x0.squeeze(-1).squeeze(-1), P[f"{Q}.pyramids.0.1.weight"], P[f"{Q}.pyramids.0.1.bias"])
-        x1 = F.conv3d(_r(f5), _r(P[f"{Q}.pyramids.1.0.conv3d.weight"]), P[f"{Q}.pyramids.1.0.conv3d.bias"])
+        x1 = _rg(F.conv3d(_r(f5), _r(P[f"{Q}.pyramids.1.0.conv3d.weight"]), P[f"{Q}.pyramids.1.0.conv3d.bias"]))
         x1 = gn_relu(x1.squeeze(-1).squeeze(-1), P[f"{Q}.pyramids.1.1.weight"], P[f"{Q}.pyramids.1.1.bias"])
         x0 = x0 + F.interpolate(x1, x0.shape[2:], mode="nearest")   # BDNet.py:316-319
         feats = [x0, x1]
         x = x1
     else:
         # anet/BDNet.py:130-142,:284-290: one projection of Mixed_5c
-        x = F.conv3d(_r(f5), _r(P[f"{Q}.pyramids.0.0.conv3d.weight"]), P[f"{Q}.pyramids.0.0.conv3d.bias"])
+        x = _rg(F.conv3d(_r(f5), _r(P[f"{Q}.pyramids.0.0.conv3d.weight"]), P[f"{Q}.pyramids.0.0.conv3d.bias"]))
         x = gn_relu(x.squeeze(-1).squeeze(-1), P[f"{Q}.pyramids.0.1.weight"], P[f"{Q}.pyramids.0.1.bias"])
         feats = [x]
     for i in range(len(feats), cfg["layer_num"]):

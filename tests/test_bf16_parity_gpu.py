@@ -92,3 +92,107 @@ def test_bf16_path_matches_the_operand_rounding_oracle_layer_by_layer(batch):
         assert report[k][0] < 3.5e-2, (k, report[k])
     assert flips <= 0.3 * 2 * batch * 126, flips
     print("bf16 parity (max rel, rms rel):", {k: (round(v[0], 5), round(v[1], 5)) for k, v in report.items()}, "window flips", flips)
+
+
+def _grad_blocks(grads):
+    """Parameter gradients grouped into the blocks the bounds are stated for."""
+    blocks = {"Conv3d_1a": [], "Conv3d_2b": [], "Conv3d_2c": [], "Mixed_3b": [], "Mixed_3c": [], "Mixed_4b-4e": [], "Mixed_4f": [],
+              "Mixed_5b-5c": [], "pyramid": [], "towers+branches": [], "heads": []}
+    for k in sorted(grads):
+        if k.startswith("backbone."):
+            name = k.split(".")[2]
+            key = ("Conv3d_1a" if name.startswith("Conv3d_1a") else "Conv3d_2b" if name.startswith("Conv3d_2b") else
+                   "Conv3d_2c" if name.startswith("Conv3d_2c") else name if name in ("Mixed_3b", "Mixed_3c", "Mixed_4f") else
+                   "Mixed_4b-4e" if name.startswith("Mixed_4") else "Mixed_5b-5c")
+        elif ".pyramids." in k or ".deconv." in k:
+            key = "pyramid"
+        elif "tower" in k or "branch" in k:
+            key = "towers+branches"
+        else:
+            key = "heads"
+        blocks[key].append(k)
+    return blocks
+
+
+@pytest.mark.parametrize("batch", [8])
+def test_bf16_backward_matches_the_operand_rounding_oracle_block_by_block(batch):
+    """the BENCHMARKED backward (bf16 MFMA operands in the data- and weight-gradient GEMMs, bf16-STORED
+    activations and data gradients between Conv3d_1a and Mixed_4f) pinned end to end at the benchmark's batch.
+
+    Yardstick: the CPU oracle's training cost (AFSD/thumos14/train.py:164-235 restated: MultiSegmentLoss + boundary BCE, EDL
+    at epoch 0) differentiated by autograd under `operand_rounding("bf16", grads=True, stored_until="Mixed_4f")` -- the
+    reference's fp32 arithmetic with exactly the changes the bf16 mode makes: both operands of every MFMA convolution
+    rounded in the forward pass, the gradient operand dy of their backward GEMMs rounded as well, and the max-pools of the
+    bf16-stored region choosing their winners among rounded values.  What remains between the two: fp32 summation order,
+    activations on a rounding boundary (as in the forward test above), the proposal windows that flip with them (their
+    anchors pool other frames: a discrete change of a few head gradients), and one extra rounding where a stored gradient
+    has two producers.  Compared per block: the relative error of the block's gradient NORM, the cosine between the block's
+    concatenated gradients, and a 512-element probe of its largest tensor (max error relative to the tensor's scale).
+    Bounds = 2.5 x the figures measured on MI355X (printed by the test; listed in DESIGN.md 5).
+
+    The test is sensitive to a mis-routed gradient: with the temporal taps of pack_direct_kernel<MODE_DGRAD> left unflipped
+    (-DOTAL_BREAK_DGRAD_TAP; tools/break_dgrad_tap.sh builds that library next to the product one and runs this test
+    against it) the block norms move by 1 - 14 % only, but the cosines fall to Conv3d_1a 0.11, Conv3d_2b 0.897, Conv3d_2c
+    0.895, Mixed_3b 0.954, Mixed_3c 0.977 -- all outside the bounds below (measured on MI355X, round 4)."""
+    from opental_amd.common import ops
+    from opental_amd.thumos14.BDNet import BDNet
+    from opental_amd.thumos14.multisegment_loss import MultiSegmentLoss
+    from opental_amd.thumos14.train import forward_one_epoch, total_cost
+    torch.set_num_threads(min(32, os.cpu_count()))
+    params = arch.make_params(2020)
+    x = torch.from_numpy(arch.make_clip(31, batch))
+    targets = [torch.from_numpy(t) for t in arch.make_targets(77, batch)]
+    scores = torch.from_numpy(arch.make_scores(arch.make_targets(77, batch)))
+    # ---- oracle
+    P = O.to_torch(params, requires_grad=True)
+    with O.operand_rounding("bf16", grads=True, stored_until="Mixed_4f"):
+        out = O.bdnet_forward(P, x)
+        cost, _ = O.train_cost(out, targets, scores, state=O.EvidenceState())
+        cost.backward()
+    want = {k: v.grad.detach() for k, v in P.items() if v.grad is not None}
+    # ---- HIP path, as benchmarked
+    net = BDNet(training=False, use_edl=True)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    net = net.cuda().train()
+    edl = dict(evidence='exp', loss_type='log', iou_aware=True, with_ibm=True, ibm_start=10, momentum=0.99, num_bins=50)
+    crit = MultiSegmentLoss(15, 0.5, 1.0, cls_loss_type='edl', edl_config=edl, os_head=True, act_config=dict(margin=1.0, weight=0)).cuda()
+    old = (ops.CONV_PRECISION, ops.HALF_STORAGE, ops.HALF_CHAIN)
+    ops.CONV_PRECISION, ops.HALF_STORAGE, ops.HALF_CHAIN = 1, True, True
+    try:
+        losses = forward_one_epoch(net, crit, x.cuda(), [t.cuda() for t in targets], scores.cuda(), training=True, ssl=False)
+        got_cost = total_cost(losses, dict(lw=1.0, cw=10.0, ctw=1.0, actw=1.0))
+        got_cost.backward()
+    finally:
+        ops.CONV_PRECISION, ops.HALF_STORAGE, ops.HALF_CHAIN = old
+    got = {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    assert abs(float(got_cost) - float(cost)) < 2e-2 * abs(float(cost)), (float(got_cost), float(cost))
+    report = {}
+    for name, keys in _grad_blocks(want).items():
+        keys = [k for k in keys if k in got and float(want[k].norm()) > 0]
+        assert keys, name
+        a = torch.cat([got[k].flatten().double() for k in keys])
+        b = torch.cat([want[k].flatten().double() for k in keys])
+        big = max(keys, key=lambda k: float(want[k].norm()))
+        n = want[big].numel()
+        idx = torch.from_numpy(np.random.RandomState(5).randint(0, n, 512))
+        pa, pb = got[big].flatten()[idx].double(), want[big].flatten()[idx].double()
+        report[name] = (abs(float(a.norm()) / float(b.norm()) - 1.0), float(torch.nn.functional.cosine_similarity(a, b, dim=0)),
+                        float((pa - pb).abs().max() / want[big].abs().max()))
+    print("bf16 backward parity (norm error, cosine, probe error):", {k: tuple(round(v, 4) for v in r) for k, r in report.items()})
+    bounds = BACKWARD_BOUNDS
+    for name, (ne, cs, pe) in report.items():
+        bn, bc, bp = bounds[name]
+        assert ne < bn and cs > bc and pe < bp, (name, (ne, cs, pe), bounds[name])
+
+
+# (norm error <, cosine >, probe error <) per block: 2.5 x the errors measured on MI355X at b = 8 (1 - cosine scaled the same way;
+# norm bounds not below 2 %).  Measured: Conv3d_1a (0.005, 0.799, 0.349), Conv3d_2b (0.012, 0.973, 0.188), Conv3d_2c (0.030, 0.951,
+# 0.111), Mixed_3b (0.054, 0.986, 0.086), Mixed_3c (0.020, 0.989, 0.042), Mixed_4b-4e (0.019, 0.9955, 0.041), Mixed_4f (0.009,
+# 0.9974, 0.025), Mixed_5b-5c (0.008, 0.9965, 0.022), pyramid (0.009, 0.9981, 0.009), towers+branches (0.002, 0.9991, 0.013),
+# heads (0.0005, 1.0000, 0.0006).  The first layers' low cosines are the bf16 mode's own conditioning (a different fp32 summation
+# order moves activations across rounding boundaries and pool ties with them; the same oracle WITHOUT the stored-pool semantics
+# is at 0.92 from the one with it for Conv3d_1a), not a property of the kernels: see the broken-tap figures in the docstring.
+BACKWARD_BOUNDS = {"Conv3d_1a": (0.02, 0.50, 0.87), "Conv3d_2b": (0.031, 0.932, 0.47), "Conv3d_2c": (0.076, 0.878, 0.28),
+                   "Mixed_3b": (0.134, 0.965, 0.21), "Mixed_3c": (0.05, 0.973, 0.104), "Mixed_4b-4e": (0.048, 0.9887, 0.101),
+                   "Mixed_4f": (0.023, 0.9935, 0.062), "Mixed_5b-5c": (0.02, 0.9912, 0.054), "pyramid": (0.022, 0.9952, 0.023),
+                   "towers+branches": (0.02, 0.9977, 0.032), "heads": (0.02, 0.9999, 0.0015)}
