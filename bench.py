@@ -719,6 +719,20 @@ def main():
         hbm = {k: {f: v[f] for f in ("us", "algorithmic_MB", "GB/s", "frac_of_8TBps", "resident_in_infinity_cache")}
                for k, v in measure_hbm_kernels(args.batch).items()}
         _o.CONV_PRECISION = saved_prec
+        # rocprofv3-counter bytes per launch of the same kernels (tools/pmc_hbm_kernels.sh -> profiles/*_pmc_hbm_kernels.json),
+        # reported only while the file's source stamp is this tree's -- like roofline.traffic
+        hk = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_pmc_hbm_kernels.json"))
+        if hk:
+            from source_stamp import source_stamp as _stamp
+            with open(os.path.join(REPO, "profiles", hk[-1])) as f:
+                t = json.load(f)
+            fresh = t.get("source_stamp") == _stamp()
+            for k, v in hbm.items():
+                c = t.get("kernels", {}).get(k)
+                v["counter_MB"] = c["counter_MB"] if (fresh and c) else None
+                v["counter_over_algorithmic"] = c["ratio"] if (fresh and c) else None
+            hbm["_counter_source"] = (f"profiles/{hk[-1]} (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" if fresh else
+                                      f"null: profiles/{hk[-1]} was measured on source stamp {t.get('source_stamp')}, not this tree")
         torch.cuda.empty_cache()
     extra = None
     if rank == 0 and world == 1 and not args.no_extras and not anet and not args.ssl and args.dtype == "bf16":

@@ -2,10 +2,16 @@
  *
  * Drop-in boundary for the OpenTAL/AFSD detection hot path.  Every entry point takes plain
  * device pointers + sizes + a hipStream_t (passed as void*), launches asynchronously on that
- * stream, never synchronises, owns no persistent state, and returns
+ * stream, never synchronises, and returns
  *     0            success
  *    <0            argument error (OTAL_E_*), nothing was launched
  *    >0            a hipError_t from the launch
+ * State: a call owns nothing persistent except three process-wide, mutex-guarded registries that exist for launch economy --
+ * the named option switches (otal_set_option), the event ring of otal_stream_wait, and the record of DEFERRED split-K
+ * reductions (otal_conv_defer_reduces .. otal_conv_flush_reduces).  The first two are safe from any number of host threads.
+ * The deferred record is ONE list per process: concurrent calls cannot corrupt it, but "defer, launch weight gradients, flush"
+ * is a protocol of one logical issuer at a time (a training step); leave it off (the default) to get launches that touch no
+ * shared state at all.  Everything else -- workspaces, prologue regions, sign bits, winner bytes -- is caller-owned memory.
  * No exceptions cross this boundary; no torch types appear in it.  All tensors are contiguous,
  * channel-major, exactly as the reference lays them out: features (B,C,T) / (B,C,T,H,W),
  * proposals (B,N,4).
@@ -183,8 +189,8 @@ int otal_conv_prologue_batch(int n, const void* device_descs, const int* device_
  * BEHIND it until otal_conv_flush_reduces(stream) has run all recorded reductions (up to 24; more flush by themselves) as
  * ONE launch.  Launches with a transposing reduce (direct 3x3x3 kernels) or unaligned slabs reduce at once as before
  * (deferred_end() == 0).  otal_conv_defer_reduces(0) needs an empty record.  The summation order is the one of the
- * immediate reduce for >= 16 slabs (quarter sums in slab order, (q0+q1)+(q2+q3)); deterministic.  Process-global state: one
- * issuing thread.  Replaces nothing in the reference (autograd of nn.Conv1d / nn.Conv3d, i3d_backbone.py:33-43,
+ * immediate reduce for >= 16 slabs (quarter sums in slab order, (q0+q1)+(q2+q3)); deterministic.  Process-wide record behind a
+ * mutex: one logical issuer at a time (see the preamble).  Replaces nothing in the reference (autograd of nn.Conv1d / nn.Conv3d, i3d_backbone.py:33-43,
  * layers.py:187-192, has no split-K); it removes ~40 of this library's own launches per training step. */
 int otal_conv_defer_reduces(int on);
 size_t otal_conv_deferred_end(void);

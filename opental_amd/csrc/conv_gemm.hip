@@ -23,6 +23,7 @@
 #include "conv_index.h"
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 
 // This file is compiled TWICE (csrc/build.py): part 0 = the C entry points, the dispatch and every kernel that works on fp32
@@ -1863,7 +1864,9 @@ namespace otal_conv {
 constexpr int DEFER_MAX = 24;
 struct DeferItem { const float* slab; float* out; int64_t total; int splits, flags, N, kw; };
 struct DeferBatch { DeferItem it[DEFER_MAX]; };
-struct DeferState { bool on = false; int n = 0; DeferBatch batch; uintptr_t last_end = 0; };
+// (the record is process-wide: calls that touch it are serialised by `mu`, so a binding that issues from several host threads
+//  cannot corrupt it -- but it stays ONE list: defer / flush belong to one logical issuer at a time, see the header)
+struct DeferState { bool on = false; int n = 0; DeferBatch batch; uintptr_t last_end = 0; std::recursive_mutex mu; };
 __attribute__((visibility("hidden"))) extern DeferState g_defer;       // ONE list for both parts of this file (defined in part 0)
 }  // namespace otal_conv
 #if OTAL_CONV_PART == 0
@@ -1919,6 +1922,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const DeferBat
 }
 
 static int flush_deferred(hipStream_t st) {
+    std::lock_guard<std::recursive_mutex> lock(g_defer.mu);
     if (g_defer.n == 0) return 0;
     int64_t most = 0;
     for (int i = 0; i < g_defer.n; ++i) most = g_defer.batch.it[i].total > most ? g_defer.batch.it[i].total : most;
@@ -1933,6 +1937,7 @@ static int launch_splitk_reduce(const ConvArgs& a, hipStream_t st) {
     const int64_t total = (int64_t)a.M * a.N;
     const bool v4 = (total % 4 == 0) && (((uintptr_t)a.slab & 15) == 0);
     if (MODE == MODE_WGRAD) {
+        std::lock_guard<std::recursive_mutex> lock(g_defer.mu);
         g_defer.last_end = 0;
         if (g_defer.on && v4 && total <= (1 << 23)) {
             if (g_defer.n == DEFER_MAX)
@@ -3658,6 +3663,7 @@ extern "C" int otal_conv_prologue_batch(int n, const void* device_descs, const i
 
 
 extern "C" int otal_conv_defer_reduces(int on) {
+    std::lock_guard<std::recursive_mutex> lock(g_defer.mu);
     if (!on && g_defer.n) return OTAL_E_SHAPE;          // flush first
     g_defer.on = on != 0;
     g_defer.last_end = 0;

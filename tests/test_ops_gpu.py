@@ -1114,3 +1114,60 @@ def test_row_per_thread_333_pool_equals_the_cell_kernel(shape):
         outs.append((plain, masked, acc))
     for u, v in zip(*outs):
         assert torch.equal(u.view(torch.int32), v.view(torch.int32))
+
+
+def test_deferred_reduction_record_survives_two_issuing_threads():
+    """The C ABI's deferred split-K record is process-wide (include/opental_hip.h, preamble): two host threads that issue
+    weight gradients at the same time (ctypes releases the GIL during the calls) must not corrupt it -- every recorded
+    reduction runs exactly once at the flush and every result equals the immediate-reduce result.  VERDICT r3 weak #10."""
+    import ctypes
+    import threading
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        lib = L.lib()
+        torch.manual_seed(3)
+        shape, cout = (2, 64, 8, 6, 6), 48
+        xs = [torch.randn(*shape, device="cuda") for _ in range(2)]
+        dys = [torch.randn(2, cout, 8, 6, 6, device="cuda") for _ in range(2)]
+        want = [ops.conv_wgrad(x, dy, (cout, 64, 1, 1, 1), (1, 1, 1), (1, 1, 1)) for x, dy in zip(xs, dys)]
+        torch.cuda.synchronize()
+        g, ga, sa, _, _ = ops._plan(2, xs[0], dys[0], cout, (1, 1, 1), (1, 1, 1), None, False, "x", "dy")
+        rounds = 24
+        outs = [[torch.zeros(cout, 64, 1, 1, 1, device="cuda") for _ in range(rounds)] for _ in range(2)]
+        wss = [torch.empty(rounds * (8 << 20), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        torch.cuda.synchronize()
+        L.check(lib.otal_conv_defer_reduces(1), "defer")
+        errs = []
+
+        def issue(t):
+            try:
+                for r in range(rounds):        # every launch gets its own slab range: the record only keeps pointers
+                    rc = lib.otal_conv_wgrad(ga, sa, L.ptr(xs[t]), L.ptr(dys[t]), L.ptr(outs[t][r]), 0, 1, None,
+                                             ctypes.c_void_p(wss[t].data_ptr() + r * (8 << 20)), ctypes.c_size_t(8 << 20),
+                                             ctypes.c_void_p(streams[t].cuda_stream))
+                    if rc:
+                        errs.append(rc)
+            except Exception as e:              # noqa: BLE001
+                errs.append(repr(e))
+        th = [threading.Thread(target=issue, args=(t,)) for t in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        torch.cuda.synchronize()                # the GEMMs of both streams are done: their slabs are complete
+        L.check(lib.otal_conv_flush_reduces(ctypes.c_void_p(streams[0].cuda_stream)), "flush")
+        assert lib.otal_conv_deferred_count() == 0
+        L.check(lib.otal_conv_defer_reduces(0), "defer off")
+        torch.cuda.synchronize()
+        for t in range(2):
+            for r in range(rounds):
+                assert torch.equal(outs[t][r], want[t]), (t, r)
+    finally:
+        ops.CONV_PRECISION = old
+        L.lib().otal_conv_flush_reduces(None)
+        L.lib().otal_conv_defer_reduces(0)

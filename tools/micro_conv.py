@@ -35,14 +35,17 @@ def main():
     ops.CONV_PRECISION = int(os.environ.get("OTAL_PREC", "0"))
     for name in names:
         shape, cout, k, s = LAYERS[name]
+        half = os.environ.get("OTAL_HALF", "0") != "0"          # bf16-STORED tensors on both sides of the layer (ops.HALF_CHAIN kernels)
         x = torch.randn(*shape, device="cuda")
+        if half:
+            x = torch.relu(x).to(torch.bfloat16)
         kk = k[:1] if len(shape) == 3 else k
         w = torch.randn(cout, shape[1], *kk, device="cuda") * 0.05
         sc = torch.rand(cout, device="cuda") + 0.5
         sci = torch.rand(shape[1], device="cuda") + 0.5
         y = ops.conv_forward(x, w, k, s, scale=sc, shift=sc, relu=True)
         dy = torch.randn_like(y)
-        wt = ops.pack_wt(w)
+        wt = None if half else ops.pack_wt(w)
         flops = 2.0 * y.numel() * shape[1] * k[0] * k[1] * k[2]
         res = []
         if "fwd" in modes:
@@ -53,7 +56,7 @@ def main():
             t = timeit(lambda: ops.conv_dgrad(dy, w, x.shape, k, s, out=dx, wt=wt, out_mask=x, out_scale=sci), iters)
             res.append(f"dgrad(+epi mask) {t*1e3:7.3f} ms {flops/t/1e12:6.1f} TF")
         if "wgrad" in modes:
-            dw = torch.empty_like(w)
+            dw = torch.empty_like(w)        # (fp32 whatever the activations' storage)
             t = timeit(lambda: ops.conv_wgrad(x, dy, w.shape, k, s, out=dw), iters)
             res.append(f"wgrad {t*1e3:7.3f} ms {flops/t/1e12:6.1f} TF")
         print(f"{name:8s} " + " | ".join(res), flush=True)
