@@ -1004,6 +1004,127 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __r
     }
 }
 
+// ---- the (1,3,3)/(1,2,2) pools on bf16-STORED tensors, EIGHT input columns per thread.  With bf16 rows the two-output form above
+// moves half the bytes per thread for the same instruction count and stops being bandwidth-bound (MaxPool3d_2a: 135 us for
+// 434 MB where the fp32 form took 138 us for 793 MB); here a thread owns four neighbouring outputs and reads each of its three
+// input rows as ONE 16-byte load + the ninth column (forward), or owns a 2 x 8 input block and the <= 5 x 2 outputs that can
+// point into it (backward).  Same scan order, first-maximum rule, winner bytes, sign bits and -- backward -- the same
+// ascending-tap summation order per input element as the kernels above: results are bit-identical to them.  Wi % 8 == 0.
+__global__ __launch_bounds__(256) void maxpool133_s2_w8_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                   unsigned char* __restrict__ arg, PoolGeom g, FastDiv fW4,
+                                                                   unsigned char* __restrict__ signbits) {
+    const int W4 = g.Wo >> 2;
+    const int p4 = blockIdx.x * 256 + threadIdx.x;
+    if (p4 >= g.To * g.Ho * W4) return;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    const uint32_t q = fd_div(fW4, p4);
+    const int m = p4 - q * W4;
+    const uint32_t t = fd_div(g.fHo, q);
+    const int ho = q - t * g.Ho;
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(x) + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs +
+                               ((int64_t)t * g.Hi + 2 * ho) * g.Wi + 8 * m;
+    const bool cin = 8 * m + 8 < g.Wi;                 // the ninth column exists (else it is the zero pad)
+    float v[3][9];
+    bool rin[3];
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+        rin[dh] = 2 * ho + dh < g.Hi;
+        const unsigned short* r = xh + (int64_t)dh * g.Wi;
+        const uint4 w = rin[dh] ? *reinterpret_cast<const uint4*>(r) : make_uint4(0u, 0u, 0u, 0u);
+        v[dh][0] = h2f_lo(w.x); v[dh][1] = h2f_hi(w.x); v[dh][2] = h2f_lo(w.y); v[dh][3] = h2f_hi(w.y);
+        v[dh][4] = h2f_lo(w.z); v[dh][5] = h2f_hi(w.z); v[dh][6] = h2f_lo(w.w); v[dh][7] = h2f_hi(w.w);
+        v[dh][8] = (rin[dh] && cin) ? h2f_lo(r[8]) : 0.f;
+    }
+    float best[4];
+    int win[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        best[o] = 0.f; win[o] = 255;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int j = 2 * o + dw;
+                const bool in = rin[dh] && (j < 8 || cin);
+                scan_tap(v[dh][j], in, dh * 3 + dw, dh == 0 && dw == 0, best[o], win[o]);
+            }
+    }
+    const int p = ((int)t * g.Ho + ho) * g.Wo + 4 * m;
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(y) + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p) =
+        make_uint2(f2h_pair_exact(best[0], best[1]), f2h_pair_exact(best[2], best[3]));
+    *reinterpret_cast<unsigned*>(arg + (int64_t)bc * g.To * g.Ho * g.Wo + p) =
+        (unsigned)win[0] | ((unsigned)win[1] << 8) | ((unsigned)win[2] << 16) | ((unsigned)win[3] << 24);
+    if (signbits) {             // rows 2 ho, 2 ho + 1, columns 8m .. 8m+7: two of the 2 x 4 blocks, adjacent bytes
+        unsigned bits[2] = {0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bits[j >> 2] |= (unsigned)(v[i][j] > 0.f) << (i * 4 + (j & 3));
+        *reinterpret_cast<unsigned short*>(signbits + (((int64_t)bc * g.Ti + (int)t) * (g.Hi >> 1) + ho) * (g.Wi >> 2) + 2 * m) =
+            (unsigned short)(bits[0] | (bits[1] << 8));
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool133_s2_w8_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                                   float* __restrict__ dx, PoolGeom g, const float* __restrict__ escale,
+                                                                   FastDiv fW8, FastDiv fH2, const unsigned char* __restrict__ signbits) {
+    const int W8 = g.Wi >> 3, H2 = g.Hi >> 1;
+    const int p8 = blockIdx.x * 256 + threadIdx.x;
+    if (p8 >= g.Ti * H2 * W8) return;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    const uint32_t q = fd_div(fW8, p8);
+    const int m = p8 - q * W8;
+    const int t = (int)fd_div(fH2, q);
+    const int a = q - t * H2;
+    const int64_t xo = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)t * g.Hi + 2 * a) * g.Wi + 8 * m;
+    unsigned bits = 0xffffu;
+    if (signbits) bits = *reinterpret_cast<const unsigned short*>(signbits + (((int64_t)bc * g.Ti + t) * H2 + a) * (g.Wi >> 2) + 2 * m);
+    const unsigned short* dyh = reinterpret_cast<const unsigned short*>(dy) + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + (int64_t)t * g.Ho * g.Wo;
+    const unsigned char* ab = arg + ((int64_t)bc * g.To + t) * g.Ho * g.Wo;
+    // D[r][k], A[r][k]: output rows a-1 (r = 0) and a (r = 1), output columns 4m-1 (k = 0) .. 4m+3 (k = 4)
+    float D[2][5];
+    int A[2][5];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ho = a - 1 + r;
+        const bool rin = ho >= 0;
+        const int o = rin ? ho * g.Wo + 4 * m : 0;
+        const uint2 d4 = *reinterpret_cast<const uint2*>(dyh + o);
+        const unsigned t4 = *reinterpret_cast<const unsigned*>(ab + o);
+        const bool lin = rin && m > 0;
+        const float d0 = h2f_lo(dyh[lin ? o - 1 : o]);
+        const int t0 = ab[lin ? o - 1 : o];
+        D[r][0] = lin ? d0 : 0.f;          A[r][0] = lin ? t0 : 255;
+        D[r][1] = rin ? h2f_lo(d4.x) : 0.f; A[r][1] = rin ? (int)(t4 & 255u) : 255;
+        D[r][2] = rin ? h2f_hi(d4.x) : 0.f; A[r][2] = rin ? (int)((t4 >> 8) & 255u) : 255;
+        D[r][3] = rin ? h2f_lo(d4.y) : 0.f; A[r][3] = rin ? (int)((t4 >> 16) & 255u) : 255;
+        D[r][4] = rin ? h2f_hi(d4.y) : 0.f; A[r][4] = rin ? (int)(t4 >> 24) : 255;
+    }
+    auto hit = [&](int r, int k, int tap) { return A[r][k] == tap ? D[r][k] : 0.f; };
+    float s[2][8];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {        // ascending tap order per input element, as maxpoolk33_s2_bwd_kernel sums them
+        s[0][2 * qq] = ((hit(1, qq + 1, 0) + hit(1, qq, 2)) + hit(0, qq + 1, 6)) + hit(0, qq, 8);
+        s[0][2 * qq + 1] = hit(1, qq + 1, 1) + hit(0, qq + 1, 7);
+        s[1][2 * qq] = hit(1, qq + 1, 3) + hit(1, qq, 5);
+        s[1][2 * qq + 1] = hit(1, qq + 1, 4);
+    }
+    if (signbits) {
+        const float esc = escale[c];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[i][j] = ((bits >> ((j >> 2) * 8 + i * 4 + (j & 3))) & 1u) ? s[i][j] * esc : 0.f;
+    }
+    unsigned short* dh = reinterpret_cast<unsigned short*>(dx) + xo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<uint4*>(dh + (int64_t)i * g.Wi) = make_uint4(f2h_pair_rne(s[i][0], s[i][1]), f2h_pair_rne(s[i][2], s[i][3]),
+                                                                      f2h_pair_rne(s[i][4], s[i][5]), f2h_pair_rne(s[i][6], s[i][7]));
+}
+
 // 1: the (1,3,3)/(1,2,2) pools, 3: the (3,3,3)/(2,2,2) pool, 0: not one of them (or misaligned operands)
 static inline int strided_k33_kind(const PoolGeom& g, const void* x, const void* y) {
     if (!(g.kh == 3 && g.kw == 3 && g.sh == 2 && g.sw == 2 && g.pt == 0 && g.ph == 0 && g.pw == 0 && g.Hi % 2 == 0 &&
@@ -1074,7 +1195,13 @@ static int pool_fwd(const int* geom, const int64_t* strides, const float* x, flo
         const int n2 = g.To * g.Ho * (g.Wo / 2);
         const dim3 grid((n2 + 255) / 256, g.B * g.C);
         const FastDiv fW2 = make_fastdiv((uint32_t)(g.Wo / 2));
-        if (io == 3) {          // bf16 in, bf16 out
+        if (io == 3 && kind == 1 && g.Wi % 8 == 0 && g.x_bs % 8 == 0 && g.x_cs % 8 == 0 && g.y_bs % 4 == 0 && g.y_cs % 4 == 0 &&
+            (reinterpret_cast<uintptr_t>(argtap) & 3) == 0 && (!signbits || (reinterpret_cast<uintptr_t>(signbits) & 1) == 0) &&
+            !OTAL_OPT("OTAL_POOL_NOW8", 0)) {           // eight input columns per thread
+            const int n4 = g.To * g.Ho * (g.Wo / 4);
+            hipLaunchKernelGGL(maxpool133_s2_w8_fwd_kernel, dim3((n4 + 255) / 256, g.B * g.C), dim3(256), 0, st_, x, y, argtap, g,
+                               make_fastdiv((uint32_t)(g.Wo / 4)), signbits);
+        } else if (io == 3) {   // bf16 in, bf16 out
             if (kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_fwd_kernel<1, true, true>), grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
             else hipLaunchKernelGGL((maxpoolk33_s2_fwd_kernel<3, true, true>), grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
         } else if (io == 1) {   // bf16-stored input (8-byte rows), fp32 output: the (1,3,3)/(1,2,2) pools
@@ -1156,7 +1283,13 @@ static int pool_bwd(const int* geom, const int64_t* strides, const float* dy, co
         const int n4 = g.Ti * (g.Hi / 2) * (g.Wi / 4);
         const dim3 grid((n4 + 255) / 256, g.B * g.C);
         const FastDiv fW4 = make_fastdiv((uint32_t)(g.Wi / 4)), fH2 = make_fastdiv((uint32_t)(g.Hi / 2));
-        if (all_half && kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, true, true>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
+        if (all_half && kind == 1 && g.Wi % 8 == 0 && g.x_bs % 8 == 0 && g.x_cs % 8 == 0 && g.y_bs % 4 == 0 && g.y_cs % 4 == 0 &&
+            (reinterpret_cast<uintptr_t>(argtap) & 3) == 0 && (!signbits || (reinterpret_cast<uintptr_t>(signbits) & 1) == 0) &&
+            !OTAL_OPT("OTAL_POOL_NOW8", 0)) {
+            const int n8 = g.Ti * (g.Hi / 2) * (g.Wi / 8);
+            hipLaunchKernelGGL(maxpool133_s2_w8_bwd_kernel, dim3((n8 + 255) / 256, g.B * g.C), dim3(256), 0, st_, dy, argtap, dx, g, out_scale,
+                               make_fastdiv((uint32_t)(g.Wi / 8)), fH2, signbits);
+        } else if (all_half && kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, true, true>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
         else if (all_half) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<3, true, true>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
         else if (io == 1) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, true>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
         else if (kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, false>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);

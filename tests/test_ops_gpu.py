@@ -1135,7 +1135,7 @@ def test_deferred_reduction_record_survives_two_issuing_threads():
         want = [ops.conv_wgrad(x, dy, (cout, 64, 1, 1, 1), (1, 1, 1), (1, 1, 1)) for x, dy in zip(xs, dys)]
         torch.cuda.synchronize()
         g, ga, sa, _, _ = ops._plan(2, xs[0], dys[0], cout, (1, 1, 1), (1, 1, 1), None, False, "x", "dy")
-        rounds = 24
+        rounds = 10                 # 20 records in all: below the 24 at which a launch flushes by itself (on ITS stream)
         outs = [[torch.zeros(cout, 64, 1, 1, 1, device="cuda") for _ in range(rounds)] for _ in range(2)]
         wss = [torch.empty(rounds * (8 << 20), dtype=torch.uint8, device="cuda") for _ in range(2)]
         streams = [torch.cuda.Stream() for _ in range(2)]
