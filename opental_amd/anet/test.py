@@ -81,3 +81,89 @@ def detect_batch(net, videos, sample_fps, durations, idx_to_class=None, clip_len
     dec = decode_clips(merged, fps, clip_length, conf_thresh)
     rows, counts, _ = _t.softnms_classes(dec, list(range(len(videos) + 1)), top_k, nms_sigma)
     return {v: get_video_prediction(rows[v], counts[v], durations[v], idx_to_class) for v in range(len(videos))}
+
+
+# ----------------------------------------------------------------------------- the driver (anet/test.py:203-348)
+def prepare_data(npy_path, video_name, crop_size=96, device='cuda'):
+    """anet/test.py:71-80: <npy dir>/<name>.npy uint8 (T,H,W,3) -> centre-cropped planar (3,T,crop,crop) uint8 on the device."""
+    return _t.prepare_data(npy_path, video_name, crop_size, device)
+
+
+def get_class_names(class_info_path):
+    """anet/test.py:54-59: one class name per line -> {1..K: name}."""
+    with open(class_info_path) as f:
+        return {i + 1: line.strip() for i, line in enumerate(f.readlines())}
+
+
+def testing(net, video_list, video_infos, npy_path, idx_to_class=None, clip_length=CLIP_LENGTH, crop_size=96, conf_thresh=0.001,
+            top_k=5000, nms_sigma=0.85, batch_clips=4, rank=0, world=1, device='cuda'):
+    """anet/test.py:294-331 over this rank's share of the video list (every world-th video: the reference's
+    testing_multithread :248-273 splits the list over mp.Process workers; here the workers are the ranks of a torchrun
+    launch, one per GPU, and the per-rank dicts are gathered on rank 0).  Returns {name without "v_": proposal list}."""
+    mine = list(video_list)[rank::world]
+    out = {}
+    for i in range(0, len(mine), batch_clips):
+        part = mine[i:i + batch_clips]
+        vids = [prepare_data(npy_path, n, crop_size, device) for n in part]
+        fps = [float(video_infos[n]['fps']) for n in part]                # sample_fps = video_infos[name]['fps'] (:74)
+        res = detect_batch(net, vids, fps, [float(video_infos[n]['duration']) for n in part], idx_to_class, clip_length,
+                           conf_thresh, top_k, nms_sigma, batch_clips)
+        for v, n in enumerate(part):
+            out[n[2:]] = res[v]
+    return out
+
+
+def main(argv=None):
+    """python -m opental_amd.anet.test configs/anet_opental.yaml --open_set --split 0 [--random_init]
+
+    anet/test.py:334-348: the validation videos that exist on disk, a complete result file re-used, else the run; the file is
+    {"version": "ActivityNet-v1.3", "results": {...}, "external_data": {}} at <output_path>/<output_json>."""
+    import json
+    import os
+    import sys
+    from ..common import config as C
+    from ..common import ops
+    from .BDNet import BDNet, model_cfg_from
+    argv = list(sys.argv[1:] if argv is None else argv)
+    random_init = '--random_init' in argv
+    argv = [a for a in argv if a != '--random_init']
+    config = C.set_config(C.get_config(argv))
+    te, md, ds = config['testing'], config['model'], config['dataset']
+    t = ds['testing']
+    with open(t['video_info_path']) as f:
+        infos = {k: v for k, v in json.load(f).items() if v.get('subset', 'validation') == 'validation'}
+    on_disk = {f[:-4] for f in os.listdir(t['video_mp4_path']) if f.endswith('.npy')}
+    video_list = [n for n in infos if n in on_disk]
+    out_file = os.path.join(te['output_path'], te['output_json'])
+    if os.path.exists(out_file):
+        with open(out_file) as f:
+            if len(json.load(f)['results']) == len(video_list):
+                print(f'Result file exist and it is complete! \n{out_file}')
+                return out_file
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    torch.cuda.set_device(dev)
+    ops.CONV_PRECISION = 1 if os.environ.get('OTAL_DTYPE', 'bf16') == 'bf16' else 0
+    net = BDNet(in_channels=md['in_channels'], training=False, frame_num=t['clip_length'], use_edl=md.get('use_edl', False),
+                cfg=model_cfg_from(config))
+    if not random_init:
+        net.load_state_dict(torch.load(te['checkpoint_path'], map_location='cpu'))
+    net = net.to(dev).eval()
+    idx_to_class = None
+    if ds.get('class_info_path') and os.path.exists(ds['class_info_path']):
+        idx_to_class = get_class_names(ds['class_info_path'])
+    res = testing(net, video_list, infos, t['video_mp4_path'], idx_to_class, t['clip_length'], t['crop_size'], te['conf_thresh'],
+                  te['top_k'], te['nms_sigma'], rank=rank, world=world, device=dev)
+    res = _t.gather_results(res, [n[2:] for n in video_list], rank, world, dev)
+    if res is None:
+        return None
+    assert len(res) == len(video_list), "Incomplete testing results!"
+    os.makedirs(te['output_path'], exist_ok=True)
+    with open(out_file, 'w') as f:
+        json.dump(_t.results_json(res, version="ActivityNet-v1.3"), f)
+    print(f"{len(res)} videos, {sum(len(v) for v in res.values())} detections -> {out_file}")
+    return out_file
+
+
+if __name__ == '__main__':
+    main()

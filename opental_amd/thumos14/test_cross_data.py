@@ -58,3 +58,115 @@ def merge_results(thumos_out, anet_out):
     merged = dict(thumos_out['results'])
     merged.update(anet_out['results'])
     return T.results_json(merged)
+
+
+# ----------------------------------------------------------------------------- the driver (test_cross_data.py:219-262, :336-447)
+def load_anet_video(npy_path, name, crop_size=96, device='cuda'):
+    """<npy dir>/<name>.npy uint8 (T,H,W,3) -> centre-cropped planar (3,T,crop,crop) uint8 on the device (:244-250)."""
+    return T.prepare_data(npy_path, name, crop_size, device)
+
+
+def get_anet_video_info(video_info_path, subset='validation'):
+    """test_cross_data.py:381-391: the ActivityNet video_info_train_val.json rows of one subset."""
+    import json
+    with open(video_info_path) as f:
+        data = json.load(f)
+    return {k: v for k, v in data.items() if v['subset'] == subset}
+
+
+def main(argv=None):
+    """python -m opental_amd.thumos14.test_cross_data <yaml> --open_set --split 0 [--random_init]
+           [--anet_info datasets/activitynet/annotations/video_info_train_val.json]
+           [--anet_npy datasets/activitynet/train_val_npy_112]
+           [--anet_overlap datasets/activitynet/overlapping_classes_in_thumos.txt]
+
+    The reference's __main__ (test_cross_data.py:420-447): the THUMOS14 test detections (<output_path>/thumos14_open_rgb.json,
+    re-used when it exists), the detections of the same network on the ActivityNet1.3 validation videos
+    (<output_path>/anet_open_rgb.json, re-used likewise), the ActivityNet videos annotated with a class THUMOS14 has as well
+    dropped, and the two merged into <output_path>/<output_json>.  Under torchrun both video lists are sharded over the ranks
+    (no collective in the data path; results gathered on rank 0, which writes the files)."""
+    import json
+    import os
+    import sys
+    from ..common import config as C
+    from ..common import ops
+    from ..common.thumos_dataset import get_class_index_map, get_video_info
+    from .BDNet import BDNet, model_cfg_from
+    argv = list(sys.argv[1:] if argv is None else argv)
+    opts = {'--anet_info': 'datasets/activitynet/annotations/video_info_train_val.json',
+            '--anet_npy': 'datasets/activitynet/train_val_npy_112',
+            '--anet_overlap': 'datasets/activitynet/overlapping_classes_in_thumos.txt'}
+    random_init, rest, i = False, [], 0
+    while i < len(argv):
+        if argv[i] == '--random_init':
+            random_init = True
+        elif argv[i] in opts:
+            opts[argv[i]] = argv[i + 1]; i += 1
+        else:
+            rest.append(argv[i])
+        i += 1
+    config = C.set_config(C.get_config(rest))
+    te, md, ds = config['testing'], config['model'], config['dataset']
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    torch.cuda.set_device(dev)
+    ops.CONV_PRECISION = 1 if os.environ.get('OTAL_DTYPE', 'bf16') == 'bf16' else 0
+    net = BDNet(in_channels=md['in_channels'], training=False, use_edl=md.get('use_edl', False), cfg=model_cfg_from(config))
+    if not random_init:
+        net.load_state_dict(torch.load(te['checkpoint_path'], map_location='cpu'))
+    net = net.to(dev).eval()
+    _, idx_to_class = get_class_index_map(ds['class_info_path'])
+    t = ds['testing']
+    os.makedirs(te['output_path'], exist_ok=True)
+
+    def cached(path, run):
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f)
+        out = run()
+        if out is not None:
+            with open(path, 'w') as f:
+                json.dump(out, f)
+        return out
+
+    def run_thumos():
+        infos = get_video_info(t['video_info_path'])
+        res = T.test(net, infos, t['video_data_path'], idx_to_class, t['clip_length'], t['clip_stride'], t['crop_size'],
+                     te['conf_thresh'], te['top_k'], te['nms_sigma'], rank=rank, world=world, device=dev)
+        res = T.gather_results(res, list(infos.keys()), rank, world, dev)
+        return None if res is None else T.results_json(res)
+
+    anet_infos = get_anet_video_info(opts['--anet_info'], 'validation')
+    on_disk = {f[:-4] for f in os.listdir(opts['--anet_npy']) if f.endswith('.npy')}
+    anet_names = [n for n in anet_infos if n in on_disk]
+
+    def run_anet():
+        mine = anet_names[rank::world]
+        res = {}
+        for j in range(0, len(mine), 8):            # eight videos' windows per forward batch, loaded as they are needed
+            part = mine[j:j + 8]
+            vids = {n: load_anet_video(opts['--anet_npy'], n, t['crop_size'], dev) for n in part}
+            out = test_anet(net, vids, {n: anet_infos[n] for n in part}, idx_to_class, t['clip_length'], t['clip_stride'],
+                            te['conf_thresh'], te['top_k'], te['nms_sigma'])
+            res.update(out['results'])
+        res = T.gather_results(res, [n[2:] for n in anet_names], rank, world, dev)
+        return None if res is None else T.results_json(res)
+
+    thumos_out = cached(os.path.join(te['output_path'], 'thumos14_open_rgb.json'), run_thumos)
+    anet_out = cached(os.path.join(te['output_path'], 'anet_open_rgb.json'), run_anet)
+    if thumos_out is None or anet_out is None:
+        return None                                  # ranks > 0
+    print(f"Number of thumos videos: {len(thumos_out['results'])}; anet videos (before filtering): {len(anet_out['results'])}")
+    with open(opts['--anet_overlap']) as f:
+        anet_out = exclude_overlapping(anet_out, anet_infos, f.readlines())
+    print(f"Number of anet videos (after filtering): {len(anet_out['results'])}")
+    merged = merge_results(thumos_out, anet_out)
+    out_file = os.path.join(te['output_path'], te['output_json'])
+    with open(out_file, 'w') as f:
+        json.dump(merged, f)
+    print(f"Number of all merged videos: {len(merged['results'])} -> {out_file}")
+    return out_file
+
+
+if __name__ == '__main__':
+    main()
