@@ -974,6 +974,33 @@ class StepLog:
             self._free.append((buf, ev))
 
 
+class JsonlSink:
+    """A StepLog sink that appends one JSON object per logged step to <dir>/scalars.jsonl -- the scalars the reference hands
+    to tensorboardX (Total / loc / conf / prop_loc / prop_conf / IoU / start / end, AFSD/thumos14/train.py:249-268; the
+    package is not in this image, and a line-per-step file is what `pandas.read_json(..., lines=True)` or a TensorBoard
+    importer reads).  Call it as sink(step, values); the file is flushed per record (records arrive every N steps)."""
+    TAGS = ('Total', 'loc', 'conf', 'prop_loc', 'prop_conf', 'IoU', 'start', 'end')
+
+    def __init__(self, directory, filename='scalars.jsonl', echo=None):
+        import os
+        os.makedirs(directory, exist_ok=True)
+        self.path = os.path.join(directory, filename)
+        self._f = open(self.path, 'a')
+        self.echo = echo
+
+    def __call__(self, step, values):
+        import json
+        rec = {'step': int(step)}
+        rec.update({'Train/' + t: float(v) for t, v in zip(self.TAGS, values)})
+        self._f.write(json.dumps(rec) + '\n')
+        self._f.flush()
+        if self.echo is not None:
+            self.echo(step, values)
+
+    def close(self):
+        self._f.close()
+
+
 def run_one_epoch(epoch, trainer, dataset, stager, batch_size, rank=0, world=1, max_steps=None, log=print, step_log=None):
     """One pass over the shuffled sliding-window list (train.py:204-303).  Every rank draws the same permutation and
     the same per-sample decisions (shared seeds) and takes every world-th batch.  Nothing in the loop synchronises with
@@ -1068,8 +1095,9 @@ def main(argv=None):
     history = []
     step_log = None
     if extra['log_every'] > 0 and rank == 0:
-        step_log = StepLog(extra['log_every'], sink=lambda step, v: print(
-            'step {} '.format(step) + ', '.join('{} {:.5f}'.format(n, x) for n, x in zip(StepLog.NAMES, v))))
+        # per-step scalars: a console line AND <checkpoint_path>/training/scalars.jsonl (the reference's TensorBoard scalars)
+        step_log = StepLog(extra['log_every'], sink=JsonlSink(train_state_path, echo=lambda step, v: print(
+            'step {} '.format(step) + ', '.join('{} {:.5f}'.format(n, x) for n, x in zip(StepLog.NAMES, v)))))
     trainer.step_log = step_log
     for epoch in range(start_epoch, tr['max_epoch'] + 1):
         if crit.cls_loss_type == 'edl':
