@@ -2857,10 +2857,14 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const bool kwv = MODE == MODE_FWD && (C % 8) != 0;
     if (H && (kwv || (a.flags & EPI_ACCUM) || conv_in_positions(a.g) != conv_out_positions(a.g))) return OTAL_E_UNSUPPORTED;
     if (kwv) a.K = a.g.Cin * a.g.kt * a.g.kh * 8;          // kw padded to 8 taps per (ci, dt, dh) row
-    const int BMsel = choose_bm(a.M, kwv ? 0 : 1);
+    const int BMpack = choose_bm(a.M, kwv ? 0 : 1);           // the weight pack's row padding (persistent regions are sized by it)
+    int BMsel = BMpack;
+    // bf16 tensors: the 128-row variant needs 247 registers (two workgroups per CU), the 96-row one 105 (four); rows past the
+    // pack's padding read zeros through the buffer bounds check, so a different tile height may run on the same pack
+    if (H && BMsel == 128 && OTAL_OPT("OTAL_CHUNK_H_NO128", 1)) BMsel = 96;
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + 127) / 128;
     a.Kp = chunk_kp(a.K);
-    const size_t tb = chunk_tab_bytes(a.K), wb = chunk_wp_bytes(a.M, BMsel, a.K);
+    const size_t tb = chunk_tab_bytes(a.K), wb = chunk_wp_bytes(a.M, BMpack, a.K);
     int2* ctab;
     unsigned short* wp;
     if (a.pre) {            // tables + packed weights were prepared into a caller-owned region
