@@ -421,29 +421,33 @@ __device__ __forceinline__ void store_acc_h(const ConvArgs& a, const f32x16 (&ac
     const int64_t bs = MODE == MODE_FWD ? g.y_bs : g.x_bs, cs = MODE == MODE_FWD ? g.y_cs : g.x_cs;
     const FastDiv fP = a.fd.P;                                          // DGRAD: the host admits stride-1 SAME layers only (in = out positions)
     constexpr int PIECES = BM * (BN / 8);
-    for (int p0 = threadIdx.x; p0 < PIECES; p0 += 2 * nthreads) {     // two pieces per trip: both mask loads in flight together
-        int64_t off[2];
-        bool ok[2];
-        Words4 v[2], m4[2];
+    constexpr int U = BM >= 192 ? 3 : 6;                    // pieces per trip: all their mask loads are in flight together (one memory
+                                                            // round trip per trip -- the first version took two pieces per trip, three trips)
+    for (int p0 = threadIdx.x; p0 < PIECES; p0 += U * nthreads) {
+        int64_t off[U];
+        bool ok[U];
+        Words4 m4[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int p = p0 + u * nthreads;
             const int row = p / (BN / 8), q = p - row * (BN / 8);
             const int m = m0 + row, n = n0 + q * 8;
             ok[u] = p < PIECES && m < a.M && n < a.N;
             const uint32_t b = fd_div(fP, ok[u] ? (uint32_t)n : 0u);
             off[u] = ok[u] ? (int64_t)b * bs + (int64_t)m * cs + (int64_t)((uint32_t)n - b * fP.d) : 0;
-            v[u] = *reinterpret_cast<const Words4*>(lds + (ok[u] ? row : 0) * PT + (ok[u] ? q : 0) * 16);
             if (mk) m4[u] = *reinterpret_cast<const Words4*>(mk + off[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;
+            const int p = p0 + u * nthreads;
+            const int row = p / (BN / 8), q = p - row * (BN / 8);
+            Words4 v = *reinterpret_cast<const Words4*>(lds + row * PT + q * 16);
             if (mk) {
-                v[u].a &= bf16_relu_mask2(m4[u].a); v[u].b &= bf16_relu_mask2(m4[u].b);
-                v[u].c &= bf16_relu_mask2(m4[u].c); v[u].d &= bf16_relu_mask2(m4[u].d);
+                v.a &= bf16_relu_mask2(m4[u].a); v.b &= bf16_relu_mask2(m4[u].b);
+                v.c &= bf16_relu_mask2(m4[u].c); v.d &= bf16_relu_mask2(m4[u].d);
             }
-            *reinterpret_cast<Words4*>(out + off[u]) = v[u];
+            *reinterpret_cast<Words4*>(out + off[u]) = v;
         }
     }
 }
@@ -2383,16 +2387,31 @@ __global__ __launch_bounds__(BNP * 2 / WN, MINW) void conv3_direct_kernel(const 
         const unsigned short* mk = MODE == MODE_DGRAD ? reinterpret_cast<const unsigned short*>(a.emask) : nullptr;
         const int64_t ocs = MODE == MODE_FWD ? g.y_cs : g.x_cs;
         const int64_t ybase = (int64_t)bsm * (MODE == MODE_FWD ? g.y_bs : g.x_bs) + p0;
-        for (int p = tid; p < BM * (BNP / 8); p += DNT) {
-            const int row = p / (BNP / 8), q = p - row * (BNP / 8);
-            if (m0 + row >= a.M || n0 + q * 8 >= a.N) continue;
-            Words4 v = *reinterpret_cast<const Words4*>(tile + row * PT + q * 16);
-            const int64_t off = ybase + (int64_t)(m0 + row) * ocs + q * 8;
-            if (mk) {
-                const Words4 m4 = *reinterpret_cast<const Words4*>(mk + off);
-                v.a &= bf16_relu_mask2(m4.a); v.b &= bf16_relu_mask2(m4.b); v.c &= bf16_relu_mask2(m4.c); v.d &= bf16_relu_mask2(m4.d);
+        constexpr int U = 4;        // pieces per trip: their mask loads travel together (one memory round trip, not four)
+        for (int p0 = tid; p0 < BM * (BNP / 8); p0 += U * DNT) {
+            int64_t off[U];
+            bool ok[U];
+            Words4 m4[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * DNT;
+                const int row = p / (BNP / 8), q = p - row * (BNP / 8);
+                ok[u] = p < BM * (BNP / 8) && m0 + row < a.M && n0 + q * 8 < a.N;
+                off[u] = ok[u] ? ybase + (int64_t)(m0 + row) * ocs + q * 8 : 0;
+                if (mk) m4[u] = *reinterpret_cast<const Words4*>(mk + off[u]);
             }
-            *reinterpret_cast<Words4*>(yh + off) = v;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                const int p = p0 + u * DNT;
+                const int row = p / (BNP / 8), q = p - row * (BNP / 8);
+                Words4 v = *reinterpret_cast<const Words4*>(tile + row * PT + q * 16);
+                if (mk) {
+                    v.a &= bf16_relu_mask2(m4[u].a); v.b &= bf16_relu_mask2(m4[u].b);
+                    v.c &= bf16_relu_mask2(m4[u].c); v.d &= bf16_relu_mask2(m4[u].d);
+                }
+                *reinterpret_cast<Words4*>(yh + off[u]) = v;
+            }
         }
         return;
     }
