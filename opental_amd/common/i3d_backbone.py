@@ -439,7 +439,8 @@ class I3DFeaturesFunction(Function):
                 cur, cur_scale = Y, out_scale
             if name in endpoints:
                 if cur.dtype == BF and name not in raw_out:
-                    if need_grad or si + 1 == len(plan):
+                    ends = si + 1 == len(plan) or not _step_half_ok(plan[si + 1], cur.shape, weights)
+                    if need_grad or ends:
                         leave_half()                        # the region ends here: gradients from outside meet on the fp32 side
                         found[name] = (cur, len(tape))
                     else:                                   # no gradient will come back: a copy for the caller, the chain goes on
