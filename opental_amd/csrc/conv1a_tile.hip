@@ -1,0 +1,326 @@
+// opental_amd/csrc/conv1a_tile.hip -- Conv3d_1a_7x7 forward (7x7x7 taps, stride 2, THREE input channels, 96-wide planes;
+// reference AFSD/common/i3d_backbone.py:194-199, Unit3D :7-87), the 4 x 4 x 48 tile kernel.
+//
+// conv1a_direct_fwd_kernel (conv_gemm.hip) gave a workgroup a 2 (t) x 2 (h) x 48 (w) block of outputs: 12 288 workgroups
+// at b = 8, each staging 9 planes x 9 rows for 2 x 2 new ones (20x halo), two per CU, their phases (staging, 49 K steps,
+// epilogue) back to back -- tools/ablate_1a.sh: every phase switched off still left 0.24 of 0.74 ms (workgroup launches
+// and fixed per-workgroup work), the MFMA + LDS-read loop was 0.25, and the parts added up instead of overlapping.
+//
+// Here a workgroup of EIGHT waves owns 4 (t) x 4 (h) x 48 (w) = 768 output positions x 64 channels:
+//   * 768 workgroups at b = 8 (three per CU, one resident: 158 KB of LDS), 13 planes x 13 rows staged for 4 x 4 new ones;
+//   * the patch is the same channel-last bf16 {c0, c1, c2, 0} pixel layout -- a K step is one (dt, dh) kernel row, its
+//     8 dw x 4 ci are 64 contiguous bytes from pixel 2 wo on, every MFMA operand one aligned ds_read_b128 -- but only the
+//     planes the first kernel plane (dt = 0) reads are staged before the K loop starts (4 of 13); the other nine are
+//     loaded while the loop runs (plane p is first read at dt = p for odd p < 8, at dt = p - 6 for p >= 8), their global
+//     loads two K steps in front of the LDS stores;
+//   * a wave computes 64 channels x 96 positions (2 x 3 MFMA tiles): 10 operand reads per 12 MFMAs instead of 6 per 4;
+//   * bf16 output: each wave transposes 8 channels x 96 positions at a time through its own 1.6 KB of LDS (no workgroup
+//     barrier) and stores 16-byte pieces, 192 contiguous bytes per channel row.
+// The accumulation order of an output is that of conv1a_direct_fwd_kernel (K steps in (dt, dh) order, two MFMAs per step),
+// so the two kernels agree bit for bit.
+#include "common.h"
+#include "conv1a_tile.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+struct Words4 { unsigned a, b, c, d; };
+struct Words2 { unsigned a, b; };
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {     // v_cvt_pk_bf16_f32: RNE, lo in bits 0..15
+    const hw_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, hw_bf16x2));
+}
+
+// compile-time loop: the K steps index register arrays and carry a static staging schedule (a `#pragma unroll` of this body
+// is refused by the optimizer)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+constexpr int TT = 4, TR = 4, WO = 48;                      // output tile: planes x rows x columns
+constexpr int NPL = 2 * TT + 5, NR = 2 * TR + 5;            // input planes / rows under it
+constexpr int NC = 102, PITCH = NC * 8, PLANE = NR * PITCH; // pixels per patch row (w = -2 .. 99), bytes
+constexpr int NT = 512, NWAVE = NT / 64, WPOS = TT * TR * WO / NWAVE;      // 96 positions per wave
+constexpr int BM = 64, WM = 2, WN = WPOS / 32;
+constexpr int STEPS = 49;
+constexpr int EPI_ROWS = 8, EPI_PITCH = WPOS * 2 + 16, EPI_BYTES = EPI_ROWS * EPI_PITCH;
+constexpr int QPR = 24, IPP = NR * QPR;                     // 4-pixel quads per row; staging items per plane
+static_assert(TT * TR * WO == NWAVE * WPOS && WPOS % 32 == 0 && (TR * WO) % WPOS == 0, "a wave's positions lie in one output plane");
+static_assert(NPL * PLANE + NWAVE * EPI_BYTES + 2 * BM * 4 <= 160 * 1024, "LDS");
+
+__global__ __launch_bounds__(NT) void conv1a_tile_fwd_kernel(const otal_conv::Conv1aTileArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char patch[NPL * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char epi[NWAVE][EPI_BYTES];
+    __shared__ float rows[2 * BM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_h = a.Ho / TR, tiles_t = a.To / TT;
+    // workgroups are dealt round-robin to the 8 XCDs, each with its own L2: a CONTIGUOUS range of tiles per XCD, so that
+    // the tiles resident on it are neighbours in (t, h) and share their halo rows / planes in that L2
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int th = bid % tiles_h; bid /= tiles_h;
+    const int tt0 = bid % tiles_t;
+    const int b = bid / tiles_t;
+    const int to0 = tt0 * TT, ho0 = th * TR;
+    const int m0 = blockIdx.y * BM;
+    const int ti0 = 2 * to0 - 2, hi0 = 2 * ho0 - 2;         // input plane / row of patch plane 0 / row 0 (front pad 2)
+    // one sample's three channels behind a buffer descriptor: a plane / row outside the input reads zeros through the
+    // bounds check (offset 0xffffffff), no branch around the load
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)b * a.x_bs), 0,
+                                                      (int)((2 * a.x_cs + (int64_t)a.Ti * a.Hi * 96) * 4), 0x00020000);
+    const unsigned cs_bytes = (unsigned)(a.x_cs * 4);
+
+    // ---- staging item e of a plane group {pl0, pl0 + plstep, ...}: (plane, row, quad of 4 pixels) x 3 channels
+    auto item_issue = [&](int e, int pl0, int plstep, int nitems, f32x4 (&v)[3], int& off) {
+        const bool live = e < nitems;
+        const int gi = e / IPP, rem = e - gi * IPP, rr = rem / QPR, q = rem - rr * QPR;
+        const int pl = pl0 + plstep * gi;
+        const int ti = ti0 + pl, hi = hi0 + rr;
+        const bool ok = live && (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi;
+#ifdef OTAL_DIRECT_ABLATE
+        const bool ld = ok && !(a.flags & 4);
+#else
+        const bool ld = ok;
+#endif
+        off = live ? pl * PLANE + rr * PITCH + (4 * q + 2) * 8 : -1;
+        const unsigned vo = ld ? (unsigned)((((int64_t)ti * a.Hi + hi) * 96 + 4 * q) * 4) : 0xffffffffu;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+            v[ci] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, ci * cs_bytes, 0));
+    };
+    auto item_commit = [&](const f32x4 (&v)[3], int off) {
+        if (off < 0) return;
+        u32x4 lo, hi;
+        lo[0] = cvt_pk_bf16(v[0][0], v[1][0]); lo[1] = cvt_pk_bf16(v[2][0], 0.f);
+        lo[2] = cvt_pk_bf16(v[0][1], v[1][1]); lo[3] = cvt_pk_bf16(v[2][1], 0.f);
+        hi[0] = cvt_pk_bf16(v[0][2], v[1][2]); hi[1] = cvt_pk_bf16(v[2][2], 0.f);
+        hi[2] = cvt_pk_bf16(v[0][3], v[1][3]); hi[3] = cvt_pk_bf16(v[2][3], 0.f);
+        *reinterpret_cast<u32x4*>(patch + off) = lo;
+        *reinterpret_cast<u32x4*>(patch + off + 16) = hi;
+    };
+
+    // ---- before the loop: scale / shift rows, the zero columns of every patch row, planes 0, 2, 4, 6
+    if (tid < BM) {
+        const int m = m0 + tid;
+        rows[2 * tid] = (m < a.M && a.scale) ? a.scale[m] : 1.f;
+        rows[2 * tid + 1] = (m < a.M && a.shift) ? a.shift[m] : 0.f;
+    }
+    for (int i = tid; i < NPL * NR * 6; i += NT) {          // pixels 0, 1 (w = -2, -1) and 98 .. 101 (w = 96 .. 99)
+        const int row = i / 6, e = i - row * 6;
+        *reinterpret_cast<Words2*>(patch + row * PITCH + (e < 2 ? e : 96 + e) * 8) = Words2{0u, 0u};
+    }
+    {
+        f32x4 v[3][3];
+        int off[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) item_issue(tid + NT * u, 0, 2, 4 * IPP, v[u], off[u]);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) item_commit(v[u], off[u]);
+    }
+    // ---- weights: NO LDS.  pack_conv1a_tile_kernel lays them out in MFMA-operand order -- [64-row block][K step][kk][i]
+    // [lane][8 bf16] -- so an A operand is ONE 16-byte load per lane, 1 KB contiguous per wave, the same for all eight
+    // waves (L1 hits).  A FIFO of WD K steps (4 operands each) in registers; with the weight ring gone the K loop needs
+    // no per-step barrier and the waves drift apart instead of draining the MFMA pipe 49 times in lockstep.
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0,
+                                                      (int)((int64_t)gridDim.y * BM * STEPS * 64), 0x00020000);
+#ifdef OTAL_DIRECT_ABLATE
+    const unsigned wvo = (a.flags & 128) ? 0xffffffffu : (unsigned)(blockIdx.y * (BM * STEPS * 64) + lane * 16);
+#else
+    const unsigned wvo = (unsigned)(blockIdx.y * (BM * STEPS * 64) + lane * 16);
+#endif
+    constexpr int WD = 3;
+    bf16x8 aw[WD][2][WM];
+    auto load_w = [&](int s) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                aw[s % WD][kk][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wvo, ((s * 2 + kk) * WM + i) * 1024, 0));
+    };
+#pragma unroll
+    for (int s = 0; s < WD; ++s) load_w(s);
+    // planes 1, 3, 5, 7 (first read at dt = 1): three items per thread, one in flight at a time
+    f32x4 sv[3];
+    int soff;
+    item_issue(tid, 1, 2, 4 * IPP, sv, soff);
+    __syncthreads();
+
+    // this lane's output positions (one per 32-column MFMA tile j) and the byte offset of pixel 2 wo in patch row (dt = 0, dh = 0)
+    const int lt = wave >> 1;                               // output plane of the tile: a wave's 96 positions lie in one
+    int xbase[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int o = (wave & 1) * WPOS + j * 32 + (lane & 31);
+        const int lr = o / WO, wo = o - lr * WO;
+        xbase[j] = ((2 * lt) * NR + 2 * lr) * PITCH + (2 * wo) * 8 + (lane >> 5) * 16;
+    }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // Software pipeline: the patch operands of step s+1 are read from LDS while the MFMAs of step s run.
+    bf16x8 bv[2][2][WN];
+    auto read_ops = [&](int set, int s) {
+        const int dt = s / 7, dh = s - dt * 7;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                bv[set][kk][j] = *reinterpret_cast<const bf16x8*>(patch + xbase[j] + (dt * NR + dh) * PITCH + kk * 32);
+    };
+    read_ops(0, 0);
+    static_for<0, STEPS>([&](auto step) {       // `set`, the FIFO slot and the staging schedule are compile-time
+        constexpr int s = decltype(step)::value;
+        constexpr int set = s & 1;
+#ifdef OTAL_DIRECT_ABLATE
+        if (s + 1 < STEPS && !(a.flags & 256)) read_ops(set ^ 1, s + 1);
+        if (!(a.flags & 512))
+#else
+        if (s + 1 < STEPS) read_ops(set ^ 1, s + 1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);      // the LDS reads of the next step first: their latency runs under these MFMAs
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[s % WD][kk][i], bv[set][kk][j], acc[i][j], 0, 0, 0);
+        if (s + WD < STEPS) load_w(s + WD);
+        __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks these loads to just in front of their use)
+        // The planes read from dt = 1 on: 1, 3, 5, 7 (first read during step 6, for step 7), then 8 .. 12 (plane 8 + k first
+        // read during step 13 + 7 k).  One item per thread in flight, its loads two steps in front of its LDS stores; a
+        // workgroup barrier after the stores of steps 4, 8 and 12 -- the only three of the K loop.
+        if (s == 0) { item_commit(sv, soff); item_issue(tid + NT, 1, 2, 4 * IPP, sv, soff); }
+        if (s == 2) { item_commit(sv, soff); item_issue(tid + 2 * NT, 1, 2, 4 * IPP, sv, soff); }
+        if (s == 4) { item_commit(sv, soff); item_issue(tid, 8, 1, 5 * IPP, sv, soff); }
+        if (s == 6) { item_commit(sv, soff); item_issue(tid + NT, 8, 1, 5 * IPP, sv, soff); }
+        if (s == 8) { item_commit(sv, soff); item_issue(tid + 2 * NT, 8, 1, 5 * IPP, sv, soff); }
+        if (s == 10) { item_commit(sv, soff); item_issue(tid + 3 * NT, 8, 1, 5 * IPP, sv, soff); }
+        if (s == 12) item_commit(sv, soff);
+        if (s == 4 || s == 8 || s == 12) {
+#ifdef OTAL_DIRECT_ABLATE
+            if (!(a.flags & 16))
+#endif
+            __syncthreads();
+        }
+    });
+#ifdef OTAL_DIRECT_ABLATE
+    if (a.flags & 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 1.2345678e30f) reinterpret_cast<float*>(a.out)[0] = t;
+        return;
+    }
+#endif
+    // ---- epilogue.  The wave's 96 positions are CONTIGUOUS in the output: rows ho0 .. ho0+3 of plane to0 + lt are whole
+    // 48-wide rows, the wave holds the first or second 96 of those 192 elements.
+    const int64_t pbase = ((int64_t)(to0 + lt) * a.Ho + ho0) * WO + (wave & 1) * WPOS;
+    const bool relu = a.relu != 0;
+    if (a.half) {
+        unsigned short* yh = reinterpret_cast<unsigned short*>(a.out) + (int64_t)b * a.y_bs + pbase;
+        unsigned char* tile = epi[wave];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                   // channels 32 i + 8 q .. + 7: accumulator rows 4 q .. 4 q + 3 of both half waves
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int lr = i * 32 + 8 * q + 4 * (lane >> 5) + rr;
+                    const float sc = rows[2 * lr], sh = rows[2 * lr + 1];
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        float v = acc[i][j][4 * q + rr] * sc + sh;
+                        if (relu) v = fmaxf(v, 0.f);
+                        *reinterpret_cast<unsigned short*>(tile + (4 * (lane >> 5) + rr) * EPI_PITCH + (j * 32 + (lane & 31)) * 2) =
+                            (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {               // 8 rows x 12 sixteen-byte pieces = 96 pieces
+                    const int p = lane + 64 * u;
+                    const int row = p / 12, c = p - row * 12;
+                    const int m = m0 + i * 32 + 8 * q + row;
+                    if (p < 96 && m < a.M) {
+                        const Words4 v = *reinterpret_cast<const Words4*>(tile + row * EPI_PITCH + c * 16);
+                        *reinterpret_cast<Words4*>(yh + (int64_t)m * a.y_cs + c * 8) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        return;
+    }
+    float* yf = reinterpret_cast<float*>(a.out) + (int64_t)b * a.y_bs + pbase;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float sc = rows[2 * lr], sh = rows[2 * lr + 1];
+            if (m0 + lr >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                float v = acc[i][j][r] * sc + sh;
+                if (relu) v = fmaxf(v, 0.f);
+                yf[(int64_t)(m0 + lr) * a.y_cs + j * 32 + (lane & 31)] = v;
+            }
+        }
+}
+
+// weights (M, 3, 7, 7, 7) fp32 -> bf16 in MFMA-operand order: [64-row block][s = dt * 7 + dh][kk][i][lane = h * 32 + n][e],
+// row = 64 block + 32 i + n, k = 16 kk + 8 h + e = 4 dw + ci; zero where ci = 3, dw = 7 or row >= M
+__global__ __launch_bounds__(256) void pack_conv1a_tile_kernel(unsigned* __restrict__ wp, const float* __restrict__ w, int M, int pairs) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < pairs; p += gridDim.x * 256) {
+        const int e2 = p & 3, ln = (p >> 2) & 63, i = (p >> 8) & 1, kk = (p >> 9) & 1, rest = p >> 10;
+        const int s = rest % STEPS, blk = rest / STEPS;
+        const int m = blk * BM + i * 32 + (ln & 31);
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = kk * 16 + (ln >> 5) * 8 + e2 * 2 + u, dw = k >> 2, ci = k & 3;
+            v[u] = (m < M && dw < 7 && ci < 3) ? w[((int64_t)m * 3 + ci) * 343 + s * 7 + dw] : 0.f;
+        }
+        wp[p] = cvt_pk_bf16(v[0], v[1]);
+    }
+}
+
+}  // namespace
+
+int otal_conv::conv1a_tile_eligible(int To, int Ho) {
+    return To % TT == 0 && Ho % TR == 0 && !OTAL_OPT("OTAL_CONV_1A_NOTILE", 0);
+}
+
+int otal_conv::launch_conv1a_tile(const Conv1aTileArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    if ((2 * a.x_cs + (int64_t)a.Ti * a.Hi * 96) * 4 >= (1LL << 31)) return OTAL_E_UNSUPPORTED;
+    const int tm = (a.M + BM - 1) / BM;
+    const size_t wb = (size_t)tm * BM * STEPS * 64;
+    if (!ws || ws_bytes < wb) return OTAL_E_UNSUPPORTED;
+    const int pairs = tm * BM * STEPS * 16;
+    hipLaunchKernelGGL(pack_conv1a_tile_kernel, dim3((pairs + 255) / 256), dim3(256), 0, st, reinterpret_cast<unsigned*>(ws), a.w, a.M, pairs);
+    if (int e = otal_launch_status()) return e;
+    Conv1aTileArgs t = a;
+    t.wp = reinterpret_cast<const unsigned short*>(ws);
+    const dim3 grid(a.B * (a.To / TT) * (a.Ho / TR), tm, 1);
+    hipLaunchKernelGGL(conv1a_tile_fwd_kernel, grid, dim3(NT), 0, st, t);
+    return otal_launch_status();
+}

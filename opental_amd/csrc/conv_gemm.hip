@@ -34,6 +34,7 @@
 #define OTAL_CONV_PART 0
 #endif
 
+#include "conv1a_tile.h"
 namespace otal_conv {
 struct ConvArgs;
 // part 1's dispatcher: the launch for bf16-stored tensors (a.half / a.xhalf set), or OTAL_E_UNSUPPORTED
@@ -2505,8 +2506,13 @@ __global__ __launch_bounds__(C1_NT) void conv1a_direct_fwd_kernel(const Conv1aAr
             const int item = tid + C1_NT * (it0 + u);
             const int pl = item / (C1_NR * 24), rem = item - pl * (C1_NR * 24), rr = rem / 24, q = rem - rr * 24;
             const int ti = 2 * to0 - g.pt + pl, hi = 2 * ho0 - g.ph + rr;
+#ifdef OTAL_DIRECT_ABLATE
+            const bool ok = !(a.flags & 4) && it0 + u < ITERS && item < ITEMS && (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)g.Hi;
+            lds_off[u] = !(a.flags & 8) && item < ITEMS && it0 + u < ITERS ? (pl * C1_NR + rr) * C1_PITCH + (4 * q + 2) * 8 : -1;
+#else
             const bool ok = it0 + u < ITERS && item < ITEMS && (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)g.Hi;
             lds_off[u] = item < ITEMS && it0 + u < ITERS ? (pl * C1_NR + rr) * C1_PITCH + (4 * q + 2) * 8 : -1;
+#endif
             const float* src = xb + ((int64_t)(ok ? ti : 0) * g.Hi + (ok ? hi : 0)) * g.Wi + 4 * q;
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci)
@@ -2535,8 +2541,14 @@ __global__ __launch_bounds__(C1_NT) void conv1a_direct_fwd_kernel(const Conv1aAr
     // only ~130 MFMA cycles long, so a load issued two steps ahead (first version) stalled EVERY step on the L2 latency:
     // the registers form a FIFO of seven slices (slice s lives in rq[s % 7]) -- loads run nine steps ahead of their use.
     Words4 rq[7];
+#ifdef OTAL_DIRECT_ABLATE
+    const bool abl_w = (a.flags & 128) != 0;
+    auto load_a = [&](int s) { if (tid < 256 && !abl_w) rq[s % 7] = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rw, avo, s * 64, 0)); };
+    auto store_a = [&](int s) { if (tid < 256 && !abl_w) *reinterpret_cast<Words4*>(smA[s & 1] + (tid >> 2) * C1_PA + (tid & 3) * 16) = rq[s % 7]; };
+#else
     auto load_a = [&](int s) { if (tid < 256) rq[s % 7] = __builtin_bit_cast(Words4, __builtin_amdgcn_raw_buffer_load_b128(rw, avo, s * 64, 0)); };
     auto store_a = [&](int s) { if (tid < 256) *reinterpret_cast<Words4*>(smA[s & 1] + (tid >> 2) * C1_PA + (tid & 3) * 16) = rq[s % 7]; };
+#endif
     load_a(0);
     load_a(1);
 #pragma unroll
@@ -2578,7 +2590,12 @@ __global__ __launch_bounds__(C1_NT) void conv1a_direct_fwd_kernel(const Conv1aAr
 #pragma unroll
     for (int s = 0; s < C1_STEPS; ++s) {    // fully unrolled: `set` and the FIFO slot index register arrays
         const int set = s & 1;
+#ifdef OTAL_DIRECT_ABLATE       // timing experiments only (tools/ablate_direct.sh): results are wrong under these flags
+        if (s + 1 < C1_STEPS && !(a.flags & 256)) read_ops(set ^ 1, s + 1);
+        if (!(a.flags & 512))
+#else
         if (s + 1 < C1_STEPS) read_ops(set ^ 1, s + 1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -2586,8 +2603,22 @@ __global__ __launch_bounds__(C1_NT) void conv1a_direct_fwd_kernel(const Conv1aAr
                 acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[set][kk][i], bv[set][kk], acc[i][0], 0, 0, 0);
         if (s + 2 < C1_STEPS) store_a(s + 2);              // into the slot of slice s (its operands were read during step s-1)
         if (s + 9 < C1_STEPS) load_a(s + 9);                // refills the register just stored
+#ifdef OTAL_DIRECT_ABLATE
+        if (!(a.flags & DBG_NOBARRIER))
+#endif
         __syncthreads();
     }
+#ifdef OTAL_DIRECT_ABLATE
+    if (a.flags & 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[i][0][r];
+        if (t == 1.2345678e30f) a.out[0] = t;
+        return;
+    }
+#endif
     if (a.half) {
         // bf16 output (the layer's 604 MB of fp32 activations are only ever read back through bf16 roundings: MaxPool3d_2a
         // commutes with the monotonic rounding and Conv3d_2b rounds its operand anyway -- the forward values are unchanged):
@@ -2638,6 +2669,18 @@ static inline bool conv1a_direct_eligible(const ConvGeom& g, int mode, int prec,
 static inline size_t conv1a_wp_bytes(int M) { return (((size_t)((M + 63) / 64 * 64) * C1_STEPS * 64) + 255) & ~(size_t)255; }
 
 int launch_conv1a_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+#ifdef OTAL_DIRECT_ABLATE
+    a.flags |= (OTAL_OPT("OTAL_CONV_DEBUG", 0) & (4 | 8 | 16 | 64 | 128 | 256 | 512));
+#endif
+    if (otal_conv::conv1a_tile_eligible(a.g.To, a.g.Ho) && !(a.flags & EPI_ACCUM)) {      // 4 x 4 x 48 tiles (conv1a_tile.hip)
+        otal_conv::Conv1aTileArgs t;
+        t.x = a.x; t.w = a.w; t.wp = nullptr; t.out = a.out; t.scale = a.scale; t.shift = a.shift;
+        t.x_bs = a.g.x_bs; t.x_cs = a.g.x_cs; t.y_bs = a.g.y_bs; t.y_cs = a.g.y_cs;
+        t.B = a.g.B; t.Ti = a.g.Ti; t.Hi = a.g.Hi; t.To = a.g.To; t.Ho = a.g.Ho; t.M = a.M;
+        t.relu = (a.flags & EPI_RELU) ? 1 : 0; t.half = a.half; t.flags = a.flags;
+        const int e = otal_conv::launch_conv1a_tile(t, ws, ws_bytes, st);
+        if (e != OTAL_E_UNSUPPORTED) return e;
+    }
     const int tm = (a.M + 63) / 64, Mpad = tm * 64;
     const size_t wb = conv1a_wp_bytes(a.M);
     if (!ws || ws_bytes < wb) return OTAL_E_UNSUPPORTED;

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 
-_SWITCHES = ("OTAL_POOL_NO133", "OTAL_CONV_NO1A", "OTAL_CONV_NOW1D")
+_SWITCHES = ("OTAL_POOL_NO133", "OTAL_CONV_NO1A", "OTAL_CONV_NOW1D", "OTAL_CONV_1A_NOTILE")
 
 
 def _switch(monkeypatch, name, value):
@@ -431,7 +431,8 @@ def test_strided_pool_fast_path_equals_generic_kernels(shape, k, s, monkeypatch)
         assert torch.equal(d_bits, d_mask)
 
 
-@pytest.mark.parametrize("shape,cout", [((2, 3, 8, 96, 96), 64), ((1, 3, 12, 20, 96), 64), ((1, 3, 4, 8, 96), 96)])
+@pytest.mark.parametrize("shape,cout", [((2, 3, 8, 96, 96), 64), ((1, 3, 12, 20, 96), 64), ((1, 3, 4, 8, 96), 96),
+                                        ((1, 3, 16, 24, 96), 64), ((2, 3, 8, 8, 96), 96)])
 def test_conv1a_direct_kernel_matches_the_gather_kernel(shape, cout, monkeypatch):
     """Conv3d_1a_7x7 (7x7x7, stride 2, 3 channels, 96-wide planes): the LDS-patch kernel against the kw-vector gather
     kernel (same bf16-rounded operands, fp32 accumulation in a different order) and against torch on the rounded
@@ -452,6 +453,29 @@ def test_conv1a_direct_kernel_matches_the_gather_kernel(shape, cout, monkeypatch
     xr, wr = x.to(torch.bfloat16).float().cpu(), w.to(torch.bfloat16).float().cpu()
     ref = F.conv3d(F.pad(xr, [2, 3, 2, 3, 2, 3]), wr, stride=2) * sc.cpu().view(1, -1, 1, 1, 1) + sh.cpu().view(1, -1, 1, 1, 1)
     close(y1, ref.clamp(min=0))
+
+
+@pytest.mark.parametrize("shape,cout", [((2, 3, 8, 96, 96), 64), ((1, 3, 16, 24, 96), 64), ((2, 3, 8, 8, 96), 96), ((1, 3, 24, 16, 96), 40)])
+def test_conv1a_tile_kernel_matches_the_2x2_tile_kernel_bit_for_bit(shape, cout, monkeypatch):
+    """conv1a_tile_fwd_kernel (csrc/conv1a_tile.hip: 4 x 4 x 48 output tiles, planes staged while the K loop runs) against
+    conv1a_direct_fwd_kernel (2 x 2 x 48 tiles): same operand roundings and the same accumulation order per output, so
+    fp32 and bf16-stored outputs are equal bit for bit; the bf16 output is the rounding of the fp32 one."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(43)
+    k, s = (7, 7, 7), (2, 2, 2)
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    w = torch.from_numpy((rs.randn(cout, 3, 7, 7, 7) / 30).astype(np.float32)).cuda()
+    sc = torch.from_numpy(rs.uniform(0.5, 1.5, cout).astype(np.float32)).cuda()
+    sh = torch.from_numpy(rs.uniform(-0.3, 0.3, cout).astype(np.float32)).cuda()
+    monkeypatch.setattr(ops, "CONV_PRECISION", 1)
+    got = [ops.conv_forward(x, w, k, s, scale=sc, shift=sh, relu=relu, half_out=h) for relu in (True, False) for h in (False, True)]
+    _switch(monkeypatch, "OTAL_CONV_1A_NOTILE", 1)
+    want = [ops.conv_forward(x, w, k, s, scale=sc, shift=sh, relu=relu, half_out=h) for relu in (True, False) for h in (False, True)]
+    _switch(monkeypatch, "OTAL_CONV_1A_NOTILE", 0)
+    for g, t in zip(got, want):
+        assert g.dtype == t.dtype and torch.equal(g, t)
+    assert torch.equal(got[1], got[0].to(torch.bfloat16)) and torch.equal(got[3], got[2].to(torch.bfloat16))
+    assert float(got[2].abs().max()) > 0.1 and bool((got[2] < 0).any())
 
 
 @pytest.mark.parametrize("lev,strides,K", [((0, 64, 96, 112, 120, 124, 126), None, 15), ((0, 96, 144, 168, 180, 186, 189), (4, 8, 16, 32, 64, 128), 150)])

@@ -17,7 +17,7 @@ if [ "$1" = "build" ]; then
   objs=""
   for f in opental_amd/csrc/*.hip; do
     o=$L/obj/$(basename ${f%.hip}).o
-    if [ "$(basename $f)" = "conv_gemm.hip" ] || [ "$(basename $f)" = "conv_gemm_half.hip" ]; then
+    if [ "$(basename $f)" = "conv_gemm.hip" ] || [ "$(basename $f)" = "conv_gemm_half.hip" ] || [ "$(basename $f)" = "conv1a_tile.hip" ]; then
       o=$L/obj/$(basename ${f%.hip})_ablate.o
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Iopental_amd/csrc -DOTAL_DIRECT_ABLATE -c $f -o $o || exit 1
     fi

@@ -43,13 +43,14 @@ def main():
         w = torch.randn(cout, shape[1], *kk, device="cuda") * 0.05
         sc = torch.rand(cout, device="cuda") + 0.5
         sci = torch.rand(shape[1], device="cuda") + 0.5
-        y = ops.conv_forward(x, w, k, s, scale=sc, shift=sc, relu=True)
+        yh = os.environ.get("OTAL_HALF_OUT", "0") != "0"        # fp32 x, bf16-stored y / dy (the model's Conv3d_1a)
+        y = ops.conv_forward(x, w, k, s, scale=sc, shift=sc, relu=True, half_out=yh)
         dy = torch.randn_like(y)
         wt = None if half else ops.pack_wt(w)
         flops = 2.0 * y.numel() * shape[1] * k[0] * k[1] * k[2]
         res = []
         if "fwd" in modes:
-            t = timeit(lambda: ops.conv_forward(x, w, k, s, scale=sc, shift=sc, relu=True, out=y), iters)
+            t = timeit(lambda: ops.conv_forward(x, w, k, s, scale=sc, shift=sc, relu=True, out=y, half_out=yh), iters)
             res.append(f"fwd {t*1e3:7.3f} ms {flops/t/1e12:6.1f} TF")
         if "dgrad" in modes:
             dx = torch.empty_like(x)
