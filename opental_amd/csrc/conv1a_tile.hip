@@ -53,40 +53,53 @@ constexpr int NC = 102, PITCH = NC * 8, PLANE = NR * PITCH; // pixels per patch 
 constexpr int NT = 512, NWAVE = NT / 64, WPOS = TT * TR * WO / NWAVE;      // 96 positions per wave
 constexpr int BM = 64, WM = 2, WN = WPOS / 32;
 constexpr int STEPS = 49;
-constexpr int EPI_ROWS = 8, EPI_PITCH = WPOS * 2 + 16, EPI_BYTES = EPI_ROWS * EPI_PITCH;
+constexpr int EPI_PITCH = WPOS * 2 + 16;                  // bytes per channel row of a wave's transposition tile (in the dead patch)
 constexpr int QPR = 24, IPP = NR * QPR;                     // 4-pixel quads per row; staging items per plane
 static_assert(TT * TR * WO == NWAVE * WPOS && WPOS % 32 == 0 && (TR * WO) % WPOS == 0, "a wave's positions lie in one output plane");
-static_assert(NPL * PLANE + NWAVE * EPI_BYTES + 2 * BM * 4 <= 160 * 1024, "LDS");
+static_assert(NPL * PLANE + 2 * BM * 4 <= 160 * 1024 && NWAVE * BM * EPI_PITCH <= NPL * PLANE, "LDS");
 
-__global__ __launch_bounds__(NT) void conv1a_tile_fwd_kernel(const otal_conv::Conv1aTileArgs a) {
+struct TileAt {                 // one work item: a 4 x 4 x 48 output tile of one sample and one 64-channel block
+    int b, to0, ho0, mblk;
+};
+
+__global__ __launch_bounds__(NT) void conv1a_tile_fwd_kernel(const otal_conv::Conv1aTileArgs a, int nwork, int per_wg, int tm) {
     __shared__ __attribute__((aligned(16))) unsigned char patch[NPL * PLANE];
-    __shared__ __attribute__((aligned(16))) unsigned char epi[NWAVE][EPI_BYTES];
-    __shared__ float rows[2 * BM];
+    __shared__ __attribute__((aligned(16))) float rows[2 * BM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_h = a.Ho / TR, tiles_t = a.To / TT;
-    // workgroups are dealt round-robin to the 8 XCDs, each with its own L2: a CONTIGUOUS range of tiles per XCD, so that
-    // the tiles resident on it are neighbours in (t, h) and share their halo rows / planes in that L2
-    int bid = blockIdx.x;
-    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-    const int th = bid % tiles_h; bid /= tiles_h;
-    const int tt0 = bid % tiles_t;
-    const int b = bid / tiles_t;
-    const int to0 = tt0 * TT, ho0 = th * TR;
-    const int m0 = blockIdx.y * BM;
-    const int ti0 = 2 * to0 - 2, hi0 = 2 * ho0 - 2;         // input plane / row of patch plane 0 / row 0 (front pad 2)
-    // one sample's three channels behind a buffer descriptor: a plane / row outside the input reads zeros through the
-    // bounds check (offset 0xffffffff), no branch around the load
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)b * a.x_bs), 0,
-                                                      (int)((2 * a.x_cs + (int64_t)a.Ti * a.Hi * 96) * 4), 0x00020000);
+    // PERSISTENT workgroups (one per CU: 135 KB of LDS), each with a contiguous range of tiles -- neighbours in (h, t), so
+    // a workgroup's consecutive tiles share halo rows / planes in its XCD's L2.  Between two tiles nothing drains: the
+    // output stores of tile i retire while tile i + 1 is staged and multiplied, and the loads of the first four planes of
+    // tile i + 1 are issued BEFORE the epilogue of tile i (one workgroup per tile, first version: the store acknowledgements
+    // and the first staging round trip were exposed twelve times per CU, ~0.1 of 0.45 ms).
+    // (workgroups are dealt round-robin to the 8 XCDs, each with its own L2: XCD x gets a CONTIGUOUS run of tile ranges, so the
+    //  t-neighbours that share 9 of their 13 input planes run on one XCD at the same time)
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
+    const int w_begin = wg * per_wg, w_end = min(nwork, w_begin + per_wg);
+    if (w_begin >= w_end) return;
+    auto tile_at = [&](int w) {
+        TileAt t;
+        t.mblk = w % tm; w /= tm;
+        const int th = w % tiles_h; w /= tiles_h;
+        t.to0 = (w % tiles_t) * TT;
+        t.b = w / tiles_t;
+        t.ho0 = th * TR;
+        return t;
+    };
     const unsigned cs_bytes = (unsigned)(a.x_cs * 4);
+    const int x_extent = (int)((2 * a.x_cs + (int64_t)a.Ti * a.Hi * 96) * 4);
 
-    // ---- staging item e of a plane group {pl0, pl0 + plstep, ...}: (plane, row, quad of 4 pixels) x 3 channels
-    auto item_issue = [&](int e, int pl0, int plstep, int nitems, f32x4 (&v)[3], int& off) {
+    // ---- staging item e of a plane group {pl0, pl0 + plstep, ...} of tile t: (plane, row, quad of 4 pixels) x 3 channels.
+    // One sample's three channels sit behind a buffer descriptor: a plane / row outside the input reads zeros through the
+    // bounds check (offset 0xffffffff), no branch around the load.
+    auto item_issue = [&](const TileAt& t, int e, int pl0, int plstep, int nitems, f32x4 (&v)[3], int& off) {
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)t.b * a.x_bs), 0, x_extent, 0x00020000);
         const bool live = e < nitems;
         const int gi = e / IPP, rem = e - gi * IPP, rr = rem / QPR, q = rem - rr * QPR;
         const int pl = pl0 + plstep * gi;
-        const int ti = ti0 + pl, hi = hi0 + rr;
+        const int ti = 2 * t.to0 - 2 + pl, hi = 2 * t.ho0 - 2 + rr;     // front pad 2
         const bool ok = live && (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi;
 #ifdef OTAL_DIRECT_ABLATE
         const bool ld = ok && !(a.flags & 4);
@@ -110,51 +123,12 @@ __global__ __launch_bounds__(NT) void conv1a_tile_fwd_kernel(const otal_conv::Co
         *reinterpret_cast<u32x4*>(patch + off + 16) = hi;
     };
 
-    // ---- before the loop: scale / shift rows, the zero columns of every patch row, planes 0, 2, 4, 6
-    if (tid < BM) {
-        const int m = m0 + tid;
-        rows[2 * tid] = (m < a.M && a.scale) ? a.scale[m] : 1.f;
-        rows[2 * tid + 1] = (m < a.M && a.shift) ? a.shift[m] : 0.f;
-    }
-    for (int i = tid; i < NPL * NR * 6; i += NT) {          // pixels 0, 1 (w = -2, -1) and 98 .. 101 (w = 96 .. 99)
-        const int row = i / 6, e = i - row * 6;
-        *reinterpret_cast<Words2*>(patch + row * PITCH + (e < 2 ? e : 96 + e) * 8) = Words2{0u, 0u};
-    }
-    {
-        f32x4 v[3][3];
-        int off[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) item_issue(tid + NT * u, 0, 2, 4 * IPP, v[u], off[u]);
-#pragma unroll
-        for (int u = 0; u < 3; ++u) item_commit(v[u], off[u]);
-    }
     // ---- weights: NO LDS.  pack_conv1a_tile_kernel lays them out in MFMA-operand order -- [64-row block][K step][kk][i]
     // [lane][8 bf16] -- so an A operand is ONE 16-byte load per lane, 1 KB contiguous per wave, the same for all eight
-    // waves (L1 hits).  A FIFO of WD K steps (4 operands each) in registers; with the weight ring gone the K loop needs
+    // waves (L1 hits).  A FIFO of WD K steps (4 operands each) in registers; with no weight ring in LDS the K loop needs
     // no per-step barrier and the waves drift apart instead of draining the MFMA pipe 49 times in lockstep.
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0,
-                                                      (int)((int64_t)gridDim.y * BM * STEPS * 64), 0x00020000);
-#ifdef OTAL_DIRECT_ABLATE
-    const unsigned wvo = (a.flags & 128) ? 0xffffffffu : (unsigned)(blockIdx.y * (BM * STEPS * 64) + lane * 16);
-#else
-    const unsigned wvo = (unsigned)(blockIdx.y * (BM * STEPS * 64) + lane * 16);
-#endif
-    constexpr int WD = 3;
-    bf16x8 aw[WD][2][WM];
-    auto load_w = [&](int s) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-                aw[s % WD][kk][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wvo, ((s * 2 + kk) * WM + i) * 1024, 0));
-    };
-#pragma unroll
-    for (int s = 0; s < WD; ++s) load_w(s);
-    // planes 1, 3, 5, 7 (first read at dt = 1): three items per thread, one in flight at a time
-    f32x4 sv[3];
-    int soff;
-    item_issue(tid, 1, 2, 4 * IPP, sv, soff);
-    __syncthreads();
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, (int)((int64_t)tm * BM * STEPS * 64), 0x00020000);
+    constexpr int WD = 2;
 
     // this lane's output positions (one per 32-column MFMA tile j) and the byte offset of pixel 2 wo in patch row (dt = 0, dh = 0)
     const int lt = wave >> 1;                               // output plane of the tile: a wave's 96 positions lie in one
@@ -165,126 +139,206 @@ __global__ __launch_bounds__(NT) void conv1a_tile_fwd_kernel(const otal_conv::Co
         const int lr = o / WO, wo = o - lr * WO;
         xbase[j] = ((2 * lt) * NR + 2 * lr) * PITCH + (2 * wo) * 8 + (lane >> 5) * 16;
     }
-    f32x16 acc[WM][WN];
+
+    // planes 0, 2, 4, 6 (read by dt = 0) of the first tile: three items per thread
+    f32x4 pv[3][3];
+    int poff[3];
+    TileAt cur = tile_at(w_begin);
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int u = 0; u < 3; ++u) item_issue(cur, tid + NT * u, 0, 2, 4 * IPP, pv[u], poff[u]);
+
+    // ---- start of a tile: scale / shift rows, the zero columns of every patch row (the last epilogue wrote over them) and the
+    // stores of planes 0, 2, 4, 6, whose loads were issued under the previous tile's epilogue
+    auto begin_tile = [&](const TileAt& t, int tid_l) {
+        if (tid_l < BM) {
+            const int m = t.mblk * BM + tid_l;
+            rows[2 * tid_l] = (m < a.M && a.scale) ? a.scale[m] : 1.f;
+            rows[2 * tid_l + 1] = (m < a.M && a.shift) ? a.shift[m] : 0.f;
+        }
+        for (int i = tid_l; i < NPL * NR * 6; i += NT) {    // pixels 0, 1 (w = -2, -1) and 98 .. 101 (w = 96 .. 99)
+            const int row = i / 6, e = i - row * 6;
+            *reinterpret_cast<Words2*>(patch + row * PITCH + (e < 2 ? e : 96 + e) * 8) = Words2{0u, 0u};
+        }
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int u = 0; u < 3; ++u) item_commit(pv[u], poff[u]);
+    };
+    begin_tile(cur, tid);
+
+    for (int work = w_begin; work < w_end; ++work) {
+        const int m0 = cur.mblk * BM;
+        // (per-lane addresses of the staging items and of the epilogue are re-derived per tile from an opaque copy of the
+        //  thread index: hoisted out of this loop they are ~100 live registers across the K loop, i.e. spills)
+        int tid_l = tid;
+        asm volatile("" : "+v"(tid_l));
+        const int lane_l = tid_l & 63;
+#ifdef OTAL_DIRECT_ABLATE
+        const unsigned wvo = (a.flags & 128) ? 0xffffffffu : (unsigned)(cur.mblk * (BM * STEPS * 64) + lane * 16);
+#else
+        const unsigned wvo = (unsigned)(cur.mblk * (BM * STEPS * 64) + lane * 16);
+#endif
+        bf16x8 aw[WD][2][WM];
+        auto load_w = [&](int s) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // Software pipeline: the patch operands of step s+1 are read from LDS while the MFMAs of step s run.
-    bf16x8 bv[2][2][WN];
-    auto read_ops = [&](int set, int s) {
-        const int dt = s / 7, dh = s - dt * 7;
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+                for (int i = 0; i < WM; ++i)
+                    aw[s % WD][kk][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wvo, ((s * 2 + kk) * WM + i) * 1024, 0));
+        };
+#pragma unroll
+        for (int s = 0; s < WD; ++s) load_w(s);
+        // planes 1, 3, 5, 7 (first read at dt = 1) and 8 .. 12 travel under the K loop: two items per thread in flight
+        f32x4 sva[3], svb[3];
+        int soffa, soffb;
+        item_issue(cur, tid_l, 1, 2, 4 * IPP, sva, soffa);
+        item_issue(cur, tid_l + NT, 1, 2, 4 * IPP, svb, soffb);
+        __syncthreads();
+
+        f32x16 acc[WM][WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j)
-                bv[set][kk][j] = *reinterpret_cast<const bf16x8*>(patch + xbase[j] + (dt * NR + dh) * PITCH + kk * 32);
-    };
-    read_ops(0, 0);
-    static_for<0, STEPS>([&](auto step) {       // `set`, the FIFO slot and the staging schedule are compile-time
-        constexpr int s = decltype(step)::value;
-        constexpr int set = s & 1;
-#ifdef OTAL_DIRECT_ABLATE
-        if (s + 1 < STEPS && !(a.flags & 256)) read_ops(set ^ 1, s + 1);
-        if (!(a.flags & 512))
-#else
-        if (s + 1 < STEPS) read_ops(set ^ 1, s + 1);
-#endif
-        __builtin_amdgcn_sched_barrier(0);      // the LDS reads of the next step first: their latency runs under these MFMAs
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // Software pipeline: the patch operands of step s+1 are read from LDS while the MFMAs of step s run.
+        bf16x8 bv[2][2][WN];
+        auto read_ops = [&](int set, int s) {
+            const int dt = s / 7, dh = s - dt * 7;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    bv[set][kk][j] = *reinterpret_cast<const bf16x8*>(patch + xbase[j] + (dt * NR + dh) * PITCH + kk * 32);
+        };
+        read_ops(0, 0);
+        static_for<0, STEPS>([&](auto step) {   // `set`, the FIFO slot and the staging schedule are compile-time
+            constexpr int s = decltype(step)::value;
+            constexpr int set = s & 1;
+#ifdef OTAL_DIRECT_ABLATE
+            if (s + 1 < STEPS && !(a.flags & 256)) read_ops(set ^ 1, s + 1);
+            if (!(a.flags & 512))
+#else
+            if (s + 1 < STEPS) read_ops(set ^ 1, s + 1);
+#endif
+            __builtin_amdgcn_sched_barrier(0);  // the LDS reads of the next step first: their latency runs under these MFMAs
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[s % WD][kk][i], bv[set][kk][j], acc[i][j], 0, 0, 0);
+            if (s + WD < STEPS) load_w(s + WD);
+            __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks these loads to just in front of their use)
+            // The planes read from dt = 1 on: 1, 3, 5, 7 (first read during step 6, for step 7), then 8 .. 12 (plane 8 + k
+            // first read during step 13 + 7 k).  An item's loads are FOUR steps in front of its LDS stores (HBM / L2; vmcnt
+            // retires in order, so a late one also holds up the weight loads queued behind it).  A workgroup barrier after
+            // the stores of steps 5, 9 and 13: the only three of the K loop.
+            if (s == 1) { item_commit(sva, soffa); item_issue(cur, tid_l + 2 * NT, 1, 2, 4 * IPP, sva, soffa); }
+            if (s == 3) { item_commit(svb, soffb); item_issue(cur, tid_l, 8, 1, 5 * IPP, svb, soffb); }
+            if (s == 5) { item_commit(sva, soffa); item_issue(cur, tid_l + NT, 8, 1, 5 * IPP, sva, soffa); }
+            if (s == 7) { item_commit(svb, soffb); item_issue(cur, tid_l + 2 * NT, 8, 1, 5 * IPP, svb, soffb); }
+            if (s == 9) { item_commit(sva, soffa); item_issue(cur, tid_l + 3 * NT, 8, 1, 5 * IPP, sva, soffa); }
+            if (s == 11) item_commit(svb, soffb);
+            if (s == 13) item_commit(sva, soffa);
+            if (s == 5 || s == 9 || s == 13) {
+#ifdef OTAL_DIRECT_ABLATE
+                if (!(a.flags & 16))
+#endif
+                __syncthreads();
+            }
+        });
+        const TileAt done = cur;
+        // the first four planes of the NEXT tile: issued as soon as the accumulators have left their registers, in flight
+        // under the rest of this tile's epilogue
+        auto prefetch_next = [&]() {    // (unconditional: behind the last tile it re-reads that tile's planes and drops them)
+            cur = tile_at(min(work + 1, w_end - 1));
+#pragma unroll
+            for (int u = 0; u < 3; ++u) item_issue(cur, tid_l + NT * u, 0, 2, 4 * IPP, pv[u], poff[u]);
+        };
+        __syncthreads();        // every wave has left the K loop: the patch is dead
+#ifdef OTAL_DIRECT_ABLATE
+        if (a.flags & 64) {
+            float t = 0.f;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[s % WD][kk][i], bv[set][kk][j], acc[i][j], 0, 0, 0);
-        if (s + WD < STEPS) load_w(s + WD);
-        __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks these loads to just in front of their use)
-        // The planes read from dt = 1 on: 1, 3, 5, 7 (first read during step 6, for step 7), then 8 .. 12 (plane 8 + k first
-        // read during step 13 + 7 k).  One item per thread in flight, its loads two steps in front of its LDS stores; a
-        // workgroup barrier after the stores of steps 4, 8 and 12 -- the only three of the K loop.
-        if (s == 0) { item_commit(sv, soff); item_issue(tid + NT, 1, 2, 4 * IPP, sv, soff); }
-        if (s == 2) { item_commit(sv, soff); item_issue(tid + 2 * NT, 1, 2, 4 * IPP, sv, soff); }
-        if (s == 4) { item_commit(sv, soff); item_issue(tid, 8, 1, 5 * IPP, sv, soff); }
-        if (s == 6) { item_commit(sv, soff); item_issue(tid + NT, 8, 1, 5 * IPP, sv, soff); }
-        if (s == 8) { item_commit(sv, soff); item_issue(tid + 2 * NT, 8, 1, 5 * IPP, sv, soff); }
-        if (s == 10) { item_commit(sv, soff); item_issue(tid + 3 * NT, 8, 1, 5 * IPP, sv, soff); }
-        if (s == 12) item_commit(sv, soff);
-        if (s == 4 || s == 8 || s == 12) {
-#ifdef OTAL_DIRECT_ABLATE
-            if (!(a.flags & 16))
-#endif
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+            if (t == 1.2345678e30f) reinterpret_cast<float*>(a.out)[0] = t;
+            prefetch_next();
             __syncthreads();
+            if (work + 1 < w_end) begin_tile(cur, tid_l);
+            continue;
         }
-    });
-#ifdef OTAL_DIRECT_ABLATE
-    if (a.flags & 64) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-        if (t == 1.2345678e30f) reinterpret_cast<float*>(a.out)[0] = t;
-        return;
-    }
 #endif
-    // ---- epilogue.  The wave's 96 positions are CONTIGUOUS in the output: rows ho0 .. ho0+3 of plane to0 + lt are whole
-    // 48-wide rows, the wave holds the first or second 96 of those 192 elements.
-    const int64_t pbase = ((int64_t)(to0 + lt) * a.Ho + ho0) * WO + (wave & 1) * WPOS;
-    const bool relu = a.relu != 0;
-    if (a.half) {
-        unsigned short* yh = reinterpret_cast<unsigned short*>(a.out) + (int64_t)b * a.y_bs + pbase;
-        unsigned char* tile = epi[wave];
+        // ---- epilogue.  The wave's 96 positions are CONTIGUOUS in the output: rows ho0 .. ho0+3 of plane to0 + lt are
+        // whole 48-wide rows, the wave holds the first or second 96 of those 192 elements.
+        const int64_t pbase = (int64_t)done.b * a.y_bs + ((int64_t)(done.to0 + lt) * a.Ho + done.ho0) * WO + (wave & 1) * WPOS;
+        const bool relu = a.relu != 0;
+        if (a.half) {
+            // bf16 output through ONE transposition per wave: each wave owns 64 channel rows x 96 positions of the dead
+            // patch.  All 96 values of a lane go to LDS, then 12 sixteen-byte pieces per lane come back and leave as 192
+            // contiguous bytes per channel row.
+            unsigned short* yh = reinterpret_cast<unsigned short*>(a.out) + pbase;
+            unsigned char* tile = patch + wave * (BM * EPI_PITCH);
+            f32x4 ss[WM][4][2];                             // {scale, shift} x 4 rows of this lane's half wave, per (i, q)
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+            for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                   // channels 32 i + 8 q .. + 7: accumulator rows 4 q .. 4 q + 3 of both half waves
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int lr = i * 32 + 8 * q + 4 * (lane >> 5) + rr;
+                    for (int u = 0; u < 2; ++u)
+                        ss[i][q][u] = *reinterpret_cast<const f32x4*>(rows + 2 * (i * 32 + 8 * q + 4 * (lane_l >> 5)) + 4 * u);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const float sc = ss[i][q][rr >> 1][2 * (rr & 1)], sh = ss[i][q][rr >> 1][2 * (rr & 1) + 1];
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) {
+                            float v = acc[i][j][4 * q + rr] * sc + sh;
+                            if (relu) v = fmaxf(v, 0.f);
+                            *reinterpret_cast<unsigned short*>(tile + (i * 32 + 8 * q + 4 * (lane_l >> 5) + rr) * EPI_PITCH + (j * 32 + (lane_l & 31)) * 2) =
+                                (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);
+                        }
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch_next();
+            __builtin_amdgcn_sched_barrier(0);              // (LDS executes a wave's instructions in order: no wait needed)
+#pragma unroll
+            for (int u = 0; u < BM * 12 / 64; ++u) {        // 64 rows x 12 sixteen-byte pieces
+                const int p = lane_l + 64 * u;
+                const int row = p / 12, c = p - row * 12;
+                if (m0 + row < a.M) {
+                    const Words4 v = *reinterpret_cast<const Words4*>(tile + row * EPI_PITCH + c * 16);
+                    *reinterpret_cast<Words4*>(yh + (int64_t)(m0 + row) * a.y_cs + c * 8) = v;
+                }
+            }
+        } else {
+            float* yf = reinterpret_cast<float*>(a.out) + pbase;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane_l >> 5);
                     const float sc = rows[2 * lr], sh = rows[2 * lr + 1];
+                    if (m0 + lr >= a.M) continue;
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
-                        float v = acc[i][j][4 * q + rr] * sc + sh;
+                        float v = acc[i][j][r] * sc + sh;
                         if (relu) v = fmaxf(v, 0.f);
-                        *reinterpret_cast<unsigned short*>(tile + (4 * (lane >> 5) + rr) * EPI_PITCH + (j * 32 + (lane & 31)) * 2) =
-                            (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);
+                        yf[(int64_t)(m0 + lr) * a.y_cs + j * 32 + (lane_l & 31)] = v;
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {               // 8 rows x 12 sixteen-byte pieces = 96 pieces
-                    const int p = lane + 64 * u;
-                    const int row = p / 12, c = p - row * 12;
-                    const int m = m0 + i * 32 + 8 * q + row;
-                    if (p < 96 && m < a.M) {
-                        const Words4 v = *reinterpret_cast<const Words4*>(tile + row * EPI_PITCH + c * 16);
-                        *reinterpret_cast<Words4*>(yh + (int64_t)m * a.y_cs + c * 8) = v;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        return;
-    }
-    float* yf = reinterpret_cast<float*>(a.out) + (int64_t)b * a.y_bs + pbase;
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const float sc = rows[2 * lr], sh = rows[2 * lr + 1];
-            if (m0 + lr >= a.M) continue;
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                float v = acc[i][j][r] * sc + sh;
-                if (relu) v = fmaxf(v, 0.f);
-                yf[(int64_t)(m0 + lr) * a.y_cs + j * 32 + (lane & 31)] = v;
-            }
+            prefetch_next();
         }
+        __syncthreads();        // the transposition tiles and `rows` have been read: the next tile may overwrite them
+        if (work + 1 < w_end) begin_tile(cur, tid_l);
+    }
 }
 
 // weights (M, 3, 7, 7, 7) fp32 -> bf16 in MFMA-operand order: [64-row block][s = dt * 7 + dh][kk][i][lane = h * 32 + n][e],
@@ -320,7 +374,12 @@ int otal_conv::launch_conv1a_tile(const Conv1aTileArgs& a, void* ws, size_t ws_b
     if (int e = otal_launch_status()) return e;
     Conv1aTileArgs t = a;
     t.wp = reinterpret_cast<const unsigned short*>(ws);
-    const dim3 grid(a.B * (a.To / TT) * (a.Ho / TR), tm, 1);
-    hipLaunchKernelGGL(conv1a_tile_fwd_kernel, grid, dim3(NT), 0, st, t);
+    // persistent workgroups, one per CU; every workgroup gets the same number of tiles where that is possible
+    const int nwork = a.B * (a.To / TT) * (a.Ho / TR) * tm;
+    int ncu = OTAL_OPT("OTAL_CONV_1A_WGS", 0);
+    if (ncu <= 0) ncu = 256;
+    const int per_wg = (nwork + ncu - 1) / ncu;
+    const int nwg = (nwork + per_wg - 1) / per_wg;
+    hipLaunchKernelGGL(conv1a_tile_fwd_kernel, dim3(nwg), dim3(NT), 0, st, t, nwork, per_wg, tm);
     return otal_launch_status();
 }
