@@ -682,7 +682,7 @@ def main():
         tot_f = sum(e[0] for e in by.values()); tot_t = sum(e[1] for e in by.values()); tot_n = sum(e[2] for e in by.values())
         ach = tot_f / tot_t / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        roofline = {"bound": "mfma", "kernel": ("implicit-GEMM convolution family: conv3_direct / conv_gemm_bf16c / conv1a_direct / conv1d_tile (fwd, dgrad), "
+        roofline = {"bound": "mfma", "kernel": ("implicit-GEMM convolution family: conv3_direct / conv_gemm_bf16c / conv1a_tile / conv1d_tile (fwd, dgrad), "
                                           "conv3_wgrad_direct / conv1a_wgrad_direct / conv_wgrad_bf16v / conv_wgrad1d (wgrad), conv_gemm_kernel (irregular geometries)"
                                if args.dtype == "bf16" else "conv_gemm_kernel") +
                               f": implicit-GEMM convolution, {args.dtype} MFMA operands, fp32 accumulate; per-op time incl. prologue and split-K reduce",

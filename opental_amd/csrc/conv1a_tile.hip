@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NT) void conv1a_tile_fwd_kernel(const otal_conv::Co
         *reinterpret_cast<u32x4*>(patch + off + 16) = hi;
     };
 
-    // ---- weights: NO LDS.  pack_conv1a_tile_kernel lays them out in MFMA-operand order -- [64-row block][K step][kk][i]
+    // ---- weights: NO LDS.  pack_conv1a_operand_order_kernel lays them out in MFMA-operand order -- [64-row block][K step][kk][i]
     // [lane][8 bf16] -- so an A operand is ONE 16-byte load per lane, 1 KB contiguous per wave, the same for all eight
     // waves (L1 hits).  A FIFO of WD K steps (4 operands each) in registers; with no weight ring in LDS the K loop needs
     // no per-step barrier and the waves drift apart instead of draining the MFMA pipe 49 times in lockstep.
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(NT) void conv1a_tile_fwd_kernel(const otal_conv::Co
 
 // weights (M, 3, 7, 7, 7) fp32 -> bf16 in MFMA-operand order: [64-row block][s = dt * 7 + dh][kk][i][lane = h * 32 + n][e],
 // row = 64 block + 32 i + n, k = 16 kk + 8 h + e = 4 dw + ci; zero where ci = 3, dw = 7 or row >= M
-__global__ __launch_bounds__(256) void pack_conv1a_tile_kernel(unsigned* __restrict__ wp, const float* __restrict__ w, int M, int pairs) {
+__global__ __launch_bounds__(256) void pack_conv1a_operand_order_kernel(unsigned* __restrict__ wp, const float* __restrict__ w, int M, int pairs) {
     for (int p = blockIdx.x * 256 + threadIdx.x; p < pairs; p += gridDim.x * 256) {
         const int e2 = p & 3, ln = (p >> 2) & 63, i = (p >> 8) & 1, kk = (p >> 9) & 1, rest = p >> 10;
         const int s = rest % STEPS, blk = rest / STEPS;
@@ -370,7 +370,7 @@ int otal_conv::launch_conv1a_tile(const Conv1aTileArgs& a, void* ws, size_t ws_b
     const size_t wb = (size_t)tm * BM * STEPS * 64;
     if (!ws || ws_bytes < wb) return OTAL_E_UNSUPPORTED;
     const int pairs = tm * BM * STEPS * 16;
-    hipLaunchKernelGGL(pack_conv1a_tile_kernel, dim3((pairs + 255) / 256), dim3(256), 0, st, reinterpret_cast<unsigned*>(ws), a.w, a.M, pairs);
+    hipLaunchKernelGGL(pack_conv1a_operand_order_kernel, dim3((pairs + 255) / 256), dim3(256), 0, st, reinterpret_cast<unsigned*>(ws), a.w, a.M, pairs);
     if (int e = otal_launch_status()) return e;
     Conv1aTileArgs t = a;
     t.wp = reinterpret_cast<const unsigned short*>(ws);

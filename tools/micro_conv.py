@@ -14,6 +14,14 @@ LAYERS = {
     "3c_1x1": ((8, 256, 128, 12, 12), 288, (1, 1, 1), (1, 1, 1)),     # Mixed_3c: the fused [b1a | b2a | b0] launch
     "4e_1x1": ((8, 512, 64, 6, 6), 288, (1, 1, 1), (1, 1, 1)),
     "tower": ((8, 512, 126), 512, (3, 1, 1), (1, 1, 1)),
+    "3c_b2b": ((8, 32, 128, 12, 12), 96, (3, 3, 3), (1, 1, 1)),
+    "3b_b2b": ((8, 16, 128, 12, 12), 32, (3, 3, 3), (1, 1, 1)),
+    "4b_b2b": ((8, 16, 64, 6, 6), 48, (3, 3, 3), (1, 1, 1)),
+    "4c_b2b": ((8, 24, 64, 6, 6), 64, (3, 3, 3), (1, 1, 1)),
+    "4f_b2b": ((8, 32, 64, 6, 6), 128, (3, 3, 3), (1, 1, 1)),
+    "5b_b1b": ((8, 160, 32, 3, 3), 320, (3, 3, 3), (1, 1, 1)),
+    "5c_b1b": ((8, 192, 32, 3, 3), 384, (3, 3, 3), (1, 1, 1)),
+    "5c_b2b": ((8, 48, 32, 3, 3), 128, (3, 3, 3), (1, 1, 1)),
 }
 
 

@@ -24,7 +24,7 @@ for r in csv.DictReader(open(f)):
     calls[n].add(r["Dispatch_Id"])
     if "detection_loss_kernel" in n and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
         steps += 1
-CONV = ("conv_gemm", "conv_wgrad", "conv3_direct", "conv1a_direct", "conv3_wgrad", "conv1a_wgrad", "wgrad1x1_wide", "conv1d_tile", "proj_fwd")
+CONV = ("conv_gemm", "conv_wgrad", "conv3_direct", "conv1a_direct", "conv1a_tile", "conv3_wgrad", "conv1a_wgrad", "wgrad1x1_wide", "conv1d_tile", "proj_fwd")
 rows = [(n, c) for n, c in per.items() if any(p in n for p in CONV)]
 rows.sort(key=lambda nc: -nc[1]["GRBM_GUI_ACTIVE"])
 lines = [f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA over `bench.py --graph off --steps 4 --warmup 2`: {steps} training steps, b=8, bf16 operands.",
