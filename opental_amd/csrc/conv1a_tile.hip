@@ -377,7 +377,15 @@ int otal_conv::launch_conv1a_tile(const Conv1aTileArgs& a, void* ws, size_t ws_b
     // persistent workgroups, one per CU; every workgroup gets the same number of tiles where that is possible
     const int nwork = a.B * (a.To / TT) * (a.Ho / TR) * tm;
     int ncu = OTAL_OPT("OTAL_CONV_1A_WGS", 0);
-    if (ncu <= 0) ncu = 256;
+    if (ncu <= 0) {
+        static int cus = 0;                 // compute units of the current device (256 on MI355X), asked once
+        if (!cus) {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            cus = n;
+        }
+        ncu = cus;
+    }
     const int per_wg = (nwork + ncu - 1) / ncu;
     const int nwg = (nwork + per_wg - 1) / per_wg;
     hipLaunchKernelGGL(conv1a_tile_fwd_kernel, dim3(nwg), dim3(NT), 0, st, t, nwork, per_wg, tm);
