@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 
-_SWITCHES = ("OTAL_POOL_NO133", "OTAL_CONV_NO1A", "OTAL_CONV_NOW1D", "OTAL_CONV_1A_NOTILE")
+_SWITCHES = ("OTAL_POOL_NO133", "OTAL_CONV_NO1A", "OTAL_CONV_NOW1D", "OTAL_CONV_1A_NOTILE", "OTAL_CONV_1A_WGS")
 
 
 def _switch(monkeypatch, name, value):
@@ -474,6 +474,14 @@ def test_conv1a_tile_kernel_matches_the_2x2_tile_kernel_bit_for_bit(shape, cout,
     _switch(monkeypatch, "OTAL_CONV_1A_NOTILE", 0)
     for g, t in zip(got, want):
         assert g.dtype == t.dtype and torch.equal(g, t)
+    # few persistent workgroups: every workgroup walks SEVERAL tiles (the next tile's planes prefetched under the epilogue,
+    # the patch re-zeroed and re-filled, the last range shorter than the others)
+    for wgs in (1, 4):
+        _switch(monkeypatch, "OTAL_CONV_1A_WGS", wgs)
+        again = [ops.conv_forward(x, w, k, s, scale=sc, shift=sh, relu=relu, half_out=h) for relu in (True, False) for h in (False, True)]
+        for g, t in zip(again, want):
+            assert torch.equal(g, t)
+    _switch(monkeypatch, "OTAL_CONV_1A_WGS", 0)
     assert torch.equal(got[1], got[0].to(torch.bfloat16)) and torch.equal(got[3], got[2].to(torch.bfloat16))
     assert float(got[2].abs().max()) > 0.1 and bool((got[2] < 0).any())
 
