@@ -2450,7 +2450,9 @@ __global__ __launch_bounds__(256) void pack_direct_kernel(unsigned* __restrict__
 // Measured (b = 8, 310 GFLOP): 0.84 ms against 0.95 ms of the gather kernel (tools/micro_conv.py 1a fwd).  Ablation: the
 // epilogue + 49 barriers alone 0.29 ms (604 MB of output in 384-byte runs), staging 0.13, weight ring 0.07, LDS operand
 // reads + MFMA 0.12 -- the phases of a workgroup run back to back and only two workgroups fit a CU (77 KB of LDS), so they
-// add up instead of overlapping.  Next: stage tile i+1 while tile i drains (persistent workgroups), longer output runs.
+// add up instead of overlapping.  Round 4: geometries with To % 4 == 0 and Ho % 4 == 0 (the training shapes) run on
+// conv1a_tile_fwd_kernel (conv1a_tile.hip: 4 x 4 x 48 tiles, persistent workgroups, weights in registers); this kernel
+// serves the rest and is the bit-exact reference of that one (tests/test_ops_gpu.py).
 constexpr int C1_TT = 2, C1_TR = 2, C1_WO = 48, C1_NPL = 9, C1_NR = 9, C1_NC = 104, C1_PITCH = C1_NC * 8;   // bytes per patch row
 constexpr int C1_BNP = C1_TT * C1_TR * C1_WO, C1_NT = C1_BNP * 2, C1_PA = 80, C1_STEPS = 49;
 
