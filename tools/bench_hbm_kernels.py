@@ -76,7 +76,7 @@ def measure(batch=8):
     out = {}
 
     def add(name, seconds, nbytes, resident, note, kernel=None):
-        # kernel: substring of the device kernel's name (the counter passes attribute FETCH_SIZE / WRITE_SIZE rows by it)
+        # kernel: substring(s, '|'-separated alternatives) of the device kernel's name (the counter passes attribute FETCH_SIZE / WRITE_SIZE rows by it)
         out[name] = {"us": round(seconds * 1e6, 2), "algorithmic_MB": round(nbytes / 1e6, 3),
                      "GB/s": round(nbytes / seconds / 1e9, 1), "frac_of_8TBps": round(nbytes / seconds / 1e9 / PEAK_GBS, 4),
                      "resident_in_infinity_cache": resident, "what": note, "kernel": kernel}
@@ -137,12 +137,12 @@ def measure(batch=8):
     n_in, n_out = xp.numel(), xp.numel() // 4
     yp, arg, bits = ops.maxpool3d_forward(xp, (1, 3, 3), (1, 2, 2), signbits=True, half_out=True)
     add("maxpool_2a_fwd", timed(lambda: ops.maxpool3d_forward(xp, (1, 3, 3), (1, 2, 2), out=yp, signbits=True, half_out=True), reps=20),
-        2 * n_in + 3 * n_out + n_in // 8, False, "otal_maxpool3d_fwd_io on Conv3d_1a's bf16-stored output (302 MB in)", "maxpoolk33_s2_fwd_kernel")
+        2 * n_in + 3 * n_out + n_in // 8, False, "otal_maxpool3d_fwd_io on Conv3d_1a's bf16-stored output (302 MB in)", "maxpool133_s2_w8_fwd_kernel|maxpoolk33_s2_fwd_kernel")
     dxp = torch.empty_like(xp)
     sc = torch.ones(64, device=dev)
     add("maxpool_2a_bwd", timed(lambda: ops.maxpool3d_backward(yp, arg, xp.shape, (1, 3, 3), (1, 2, 2), out=dxp, out_scale=sc, out_signbits=bits), reps=20),
         3 * n_out + n_in // 8 + 2 * n_in, False, "otal_maxpool3d_bwd_io with the producer's ReLU mask (sign bits) and BN scale fused into the store",
-        "maxpoolk33_s2_bwd_kernel")
+        "maxpool133_s2_w8_bwd_kernel|maxpoolk33_s2_bwd_kernel")
     del xp, yp, arg, dxp, bits
     # the fused 1x1x1 launch of Mixed_3c on bf16-stored tensors (256 -> 288 channels on 8 x 128 x 12 x 12 positions): the HBM-bound
     # convolution class of the backbone.  Bytes: x + y (2 B each) + the packed bf16 weights; the data gradient also reads the mask

@@ -26,12 +26,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     pos = 0
     for name, e in entries.items():         # dict order = launch order
-        pat = e["kernel"]
-        got = []
+        pats = e["kernel"].split("|")
+        got, start = [], pos
         while pos < len(rows) and len(got) < N:
-            if pat in rows[pos]["Kernel_Name"]:
+            if any(p in rows[pos]["Kernel_Name"] for p in pats):
                 got.append(float(rows[pos]["Counter_Value"]))
             pos += 1
+        if not got:
+            pos = start                     # (a renamed kernel must not swallow the rows of the entries behind it)
         tail = got[len(got) // 2:] or [float("nan")]
         per.setdefault(name, {})[c] = sum(tail) / len(tail)        # KB per launch (rocprofv3 unit), warm launches only
 res = {"source_stamp": source_stamp(), "unit": "MB per launch", "kernels": {}}
