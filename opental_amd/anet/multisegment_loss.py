@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..thumos14.multisegment_loss import _tiou, iou_loss, pad_targets  # noqa: F401  (iou_loss: reference name)
+from ..thumos14.multisegment_loss import _tiou, as_padded, iou_loss, pad_targets  # noqa: F401  (iou_loss: reference name)
 from .cls_loss import ActionnessLoss, EvidenceLoss, FocalLoss_Ori
 
 bounds = [[0, 30], [15, 60], [30, 120], [60, 240], [96, 768], [256, 768]]
@@ -49,7 +49,8 @@ class MultiSegmentLoss(nn.Module):
     def match(self, loc, priors, targets):
         """Anchor <-> GT assignment for the whole batch (anet/multisegment_loss.py:144-188)."""
         clip = float(self.clip_length)
-        gt, valid = pad_targets(targets, loc.device) if isinstance(targets, (list, tuple)) else targets
+        gt, valid = as_padded(targets, loc.device)
+        valid = valid.bool()
         lvl = priors[:, 1].long()
         lb = self.level_bounds.to(loc.device)[lvl, 0].view(1, -1, 1)
         rb = self.level_bounds.to(loc.device)[lvl, 1].view(1, -1, 1)
@@ -108,7 +109,7 @@ class MultiSegmentLoss(nn.Module):
         B, K = loc.shape[0], priors.shape[0]
         if self._fused_ok(loc, conf, priors):
             from ..common.ops import AnetDetectionLossFunction
-            gt, valid = pad_targets(targets, loc.device) if isinstance(targets, (list, tuple)) else targets
+            gt, valid = as_padded(targets, loc.device)
             cl = self.cls_loss
             return AnetDetectionLossFunction.apply(
                 loc, conf, prop_loc, prop_conf, center.reshape(B, K), act.reshape(B, K), prop_act.reshape(B, K), priors, gt, valid,

@@ -91,7 +91,7 @@ def main(argv=None):
     """python -m opental_amd.anet.train configs/anet_opental.yaml --open_set --split 0 --lw 1 --cw 1 --piou 0.6 [--resume N]
 
     The reference's command line (AFSD/anet/README.md:61; AFSD/common/config.py:10-37) plus --random_init, --save_after N,
-    --max_steps N as in opental_amd.thumos14.train.  One process per GPU; under torchrun the ranks all-reduce gradients
+    --max_steps N, --launch lanes|eager as in opental_amd.thumos14.train.  One process per GPU; under torchrun the ranks all-reduce gradients
     over RCCL (DetectorTrainer).  The epoch loop is thumos14.train.run_one_epoch: same batches-by-permutation sampler,
     ssl branch when the first sample's splice succeeded (`if flags[0]`, anet/train.py:223), device-side loss sums."""
     import os
@@ -100,10 +100,10 @@ def main(argv=None):
     from ..common import anet_dataset as D
     from ..common import config as C
     from ..common import ops
-    from ..common.thumos_dataset import ClipStager
+    from ..common.thumos_dataset import ClipStager, max_target_count
     from ..thumos14.train import run_one_epoch, set_seed
     argv = list(sys.argv[1:] if argv is None else argv)
-    extra = {'random_init': False, 'save_after': 10, 'max_steps': None}
+    extra = {'random_init': False, 'save_after': 10, 'max_steps': None, 'launch': 'lanes'}
     rest, i = [], 0
     while i < len(argv):
         a = argv[i]
@@ -111,6 +111,8 @@ def main(argv=None):
             extra['random_init'] = True
         elif a in ('--save_after', '--max_steps'):
             extra[a[2:]] = int(argv[i + 1]); i += 1
+        elif a == '--launch':
+            extra['launch'] = argv[i + 1]; i += 1
         else:
             rest.append(a)
         i += 1
@@ -135,7 +137,10 @@ def main(argv=None):
         raise SystemExit("no training videos found under " + str(ds['video_mp4_path']))
     any_shape = dataset.video_shape(dataset.training_list[0]['video_name'])
     stager = ClipStager(tr['batch_size'], ds['clip_length'], int(any_shape[1]), int(any_shape[2]), ds['crop_size'],
-                        device=dev)
+                        device=dev, max_targets=max_target_count(dataset), score_rows=3)
+    if extra['launch'] not in ('lanes', 'eager'):
+        raise SystemExit("--launch takes lanes or eager")
+    trainer.launch = extra['launch']
     checkpoint_path = tr['checkpoint_path']
     train_state_path = os.path.join(checkpoint_path, 'training')
     start_epoch = trainer.resume_training(tr['resume'], checkpoint_path, train_state_path)

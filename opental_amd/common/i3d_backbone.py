@@ -280,6 +280,11 @@ def _pool_half_ok(shape, k, s):
     """A max-pool that has bf16-tensor kernels (csrc/pool3d.hip): the strided 3x3 pools and the 12x12 / 6x6 branch pools."""
     _, _, T, H, W = shape
     k, s = tuple(k), tuple(s)
+    # ... whose OUTPUT map the next bf16-tensor kernel can take: the convolutions and otal_convert_storage move eight
+    # positions per lane, so To * Ho * Wo must be a multiple of eight (SAME padding: ceil(in / stride))
+    out_positions = -(-T // s[0]) * -(-H // s[1]) * -(-W // s[2])
+    if out_positions % 8:
+        return False
     if k[1:] == (3, 3) and s[1:] == (2, 2) and H % 2 == 0 and W % 4 == 0:
         return (k[0], s[0]) == (1, 1) or ((k[0], s[0]) == (3, 2) and T % 2 == 0)
     return k == THREE and s == ONE and H == W and H in (12, 6)
@@ -358,9 +363,15 @@ class I3DFeaturesFunction(Function):
 
         for si, step in enumerate(plan):
             kind, name = step[0], step[-1]
-            if cur.dtype == BF and not _step_half_ok(step, cur.shape, weights):
+            chain = cur.dtype == BF and _step_half_ok(step, cur.shape, weights)
+            # a bf16-stored conv output straight in front of its (1,3,3)/(1,2,2) pool WITHOUT the chain (ops.HALF_CHAIN off,
+            # or a geometry the chain's kernels do not cover): the pool's bf16-in / fp32-out kernel reads it as it is
+            # (ops.maxpool3d_forward on a bfloat16 input) -- no conversion pass, no "cvt" seam, the gradient convention of
+            # the tape entry below (half_grads) decides how the pool's backward stores dx
+            pool_io1 = (cur.dtype == BF and not chain and kind == "pool" and cur_scale is not None
+                        and tuple(step[1]) == (1, 3, 3) and tuple(step[2]) == (1, 2, 2))
+            if cur.dtype == BF and not chain and not pool_io1:
                 leave_half()
-            chain = cur.dtype == BF
             if kind == "conv" and chain:
                 _, wi, k, s, _ = step
                 y = ops.conv_forward(cur, weights[wi], k, s, scale=sc(wi), shift=sh(wi), relu=True)
@@ -394,8 +405,10 @@ class I3DFeaturesFunction(Function):
                 # backward pass does not re-read the 4-byte activations only for their sign
                 if chain:
                     y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=True, half_out=True)
-                else:
-                    y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=cur_scale is not None)
+                elif cur_scale is not None:
+                    y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=True)
+                else:                                       # (a pool that is not behind a conv + ReLU: nothing to mask)
+                    (y, arg), bits = ops.maxpool3d_forward(cur, k, s), None
                 tape.append(("pool", k, s, cur, (arg, bits, half_grads.get(si, False)), cur_scale, None))
                 cur, cur_scale = y, None
             else:
@@ -541,7 +554,8 @@ class I3DFeaturesFunction(Function):
                 elif grad_half:                             # Conv3d_1a's bf16-stored output: its gradient is stored the same way
                     dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out_scale=in_scale, out_signbits=bits, half_out=True)
                 else:
-                    dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, xin),
+                    # (a bf16-stored xin behind an fp32 gradient -- ops.HALF_ACT_DIRECT without the chain -- keeps an fp32 dx)
+                    dcur = ops.maxpool3d_backward(dcur, arg, xin.shape, k, s, out=out_grad_buffer(pos - 1, xin.shape, dcur),
                                                   out_mask=xin if (in_scale is not None and bits is None) else None,
                                                   out_scale=in_scale, out_signbits=bits)
             else:

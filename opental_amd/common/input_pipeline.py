@@ -55,3 +55,81 @@ def prepare_clips(videos, offsets, clip_length=256, crop=96, training=True, devi
     L.check(L.lib().otal_prepare_clips(L.ptr(frames), L.ptr(params), L.ptr(out), B, clip_length, H, W, crop, crop,
                                        L.stream()), "otal_prepare_clips")
     return out, used
+
+
+class PaddedTargets:
+    """Fixed-shape form of a batch's targets: rows (B,G,3) float32 [start, end, label] zero padded, validity (B,G) uint8.
+    MultiSegmentLoss (both recipes) takes it wherever the reference takes the list of ragged (n_i,3) arrays."""
+    __slots__ = ('gt', 'valid')
+
+    def __init__(self, gt, valid):
+        self.gt, self.valid = gt, valid
+
+    def __iter__(self):
+        yield self.gt
+        yield self.valid
+
+
+class LabelRecord:
+    """The labels of ONE batch in ONE flat buffer of fixed shape -- what the captured training step replays from.
+
+    The reference hands `run_one_epoch` a list of per-sample (n_i,3) target arrays of any length plus the (B,2,T) boundary
+    masks (AFSD/thumos14/train.py:204-252, AFSD/common/thumos_dataset.py:278-300 `detection_collate`).  Here they travel as
+    ONE record whose layout does not depend on the n_i:
+
+        gt      float32 (B, G, 3)   [start, end, label] rows, zero padded to G = `max_targets`
+        scores  float32 (B, R, T)   boundary masks (R = 2: [start, end]; 3 for ActivityNet: [action, start, end])
+        ssl     float32 (B, 3, 2)   anchor / positive / negative segments of the self-supervised branch (frames)
+        valid   uint8   (B, G)      1 for the first n_i rows of a sample
+
+    so a batch is one pinned host buffer, one asynchronous H2D copy and -- into the captured step's input record -- one
+    device-to-device copy; the loss kernels read `valid` as their row mask (otal_detection_loss, `gvalid`), which makes the
+    padded rows inert: results are bit-identical to the ragged form."""
+
+    def __init__(self, batch, max_targets, score_rows, clip_length, device="cpu", pin=False):
+        self.B, self.G, self.R, self.T = int(batch), int(max_targets), int(score_rows), int(clip_length)
+        n_gt, n_sc, n_ssl = self.B * self.G * 3, self.B * self.R * self.T, self.B * 6
+        self._float_count = n_gt + n_sc + n_ssl
+        nbytes = 4 * self._float_count + (self.B * self.G + 15) // 16 * 16
+        self.flat = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        if pin:
+            self.flat = self.flat.pin_memory()
+        f = self.flat[:4 * self._float_count].view(torch.float32)
+        self.gt = f[:n_gt].view(self.B, self.G, 3)
+        self.scores = f[n_gt:n_gt + n_sc].view(self.B, self.R, self.T)
+        self.ssl = f[n_gt + n_sc:].view(self.B, 3, 2)
+        self.valid = self.flat[4 * self._float_count: 4 * self._float_count + self.B * self.G].view(self.B, self.G)
+
+    @property
+    def targets(self):
+        """What MultiSegmentLoss takes in place of the list of ragged arrays."""
+        return PaddedTargets(self.gt, self.valid)
+
+    def ssl_targets(self):
+        return [self.ssl[b] for b in range(self.B)]
+
+    def fill(self, samples):
+        """Host side: write the batch's labels (numpy) into this (CPU) record."""
+        gt, valid, sc, ssl = self.gt.numpy(), self.valid.numpy(), self.scores.numpy(), self.ssl.numpy()
+        gt[:] = 0.0
+        valid[:] = 0
+        for b, s in enumerate(samples):
+            t = np.asarray(s['target'], np.float32).reshape(-1, 3)
+            if t.shape[0] > self.G:
+                raise RuntimeError(f"LabelRecord: a sample has {t.shape[0]} targets, the record holds {self.G} "
+                                   "(max_targets must cover the dataset's longest target list)")
+            gt[b, :t.shape[0]] = t
+            valid[b, :t.shape[0]] = 1
+            sc[b] = s['scores']
+            # (anchor / positive / negative rows exist only where the splice succeeded; otherwise the datasets hand the
+            # plain annotations through, thumos_dataset.py:264-270)
+            st = s.get('ssl_target') if s.get('flag', True) else None
+            st = None if st is None else np.asarray(st, np.float32)
+            ssl[b] = st[:, :2] if (st is not None and st.shape[0] == 3) else 0.0
+
+
+def max_target_count(dataset, multiple=4):
+    """The longest target list any window of `dataset` carries (its `training_list[i]['annos']`), rounded up: the G of the
+    label records of a run."""
+    n = max((len(info['annos']) for info in dataset.training_list), default=1)
+    return max(multiple, (n + multiple - 1) // multiple * multiple)

@@ -1186,6 +1186,11 @@ def convert_storage(src, dtype, out=None):
         raise RuntimeError("convert_storage: float32 <-> bfloat16, same shape")
     _check(s5, "src", s5.dtype); _check(o5, "dst", o5.dtype)
     B, C, T, H, W = s5.shape
+    if (T * H * W) % 8:
+        # the kernel moves eight positions per lane; a map whose position count is not a multiple of eight (short clips, odd
+        # T behind a strided pool) takes the elementwise conversion of the tensor library -- the same round-to-nearest-even
+        out.copy_(src)
+        return out
     (sb, sc), (db, dc) = _bs(s5), _bs(o5)
     L.check(L.lib().otal_convert_storage(L.ptr(s5), ctypes.c_int64(sb), ctypes.c_int64(sc), L.ptr(o5), ctypes.c_int64(db),
                                          ctypes.c_int64(dc), int(out.dtype == torch.bfloat16), B, C, T * H * W, L.stream()),

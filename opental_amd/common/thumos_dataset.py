@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
-from .input_pipeline import _PARAM_DTYPE, sample_crop_flip
+from .input_pipeline import _PARAM_DTYPE, LabelRecord, max_target_count, sample_crop_flip  # noqa: F401
 
 
 def get_class_index_map(class_info_path='datasets/thumos14/annotations/Class_Index_Detection.txt'):
@@ -206,9 +206,17 @@ class ClipStager:
     otherwise pair batch k's frames with batch k+2's decisions.  That wait is over long before it is reached unless
     the host really is that far ahead."""
 
-    def __init__(self, batch, clip_length, H, W, crop, device="cuda"):
+    def __init__(self, batch, clip_length, H, W, crop, device="cuda", max_targets=None, score_rows=2):
+        """`max_targets` (input_pipeline.max_target_count(dataset)): the batch's labels -- targets padded to that row count,
+        boundary masks, ssl segments -- travel with the frames as ONE fixed-shape record per slot (LabelRecord): one pinned
+        buffer, one asynchronous copy; `labels()` hands out the device record of the batch collected last."""
         self.B, self.T, self.H, self.W, self.crop = batch, clip_length, H, W, crop
         self.device = torch.device(device)
+        self.labels_host = self.labels_dev = None
+        if max_targets is not None:
+            self.labels_host = [LabelRecord(batch, max_targets, score_rows, clip_length, pin=True) for _ in range(2)]
+            self.labels_dev = [LabelRecord(batch, max_targets, score_rows, clip_length, device=self.device) for _ in range(2)]
+        self._last = None
         self.frame_bytes = H * W * 3
         self.stage = [torch.empty(batch * clip_length * self.frame_bytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.params_host = [torch.empty(batch * _PARAM_DTYPE.itemsize, dtype=torch.uint8).pin_memory() for _ in range(2)]
@@ -250,13 +258,18 @@ class ClipStager:
             self.params_host[s].numpy()[:] = recs.view(np.uint8)
             self.params_dev[s].copy_(self.params_host[s], non_blocking=True)
             self.maps_dev[s].copy_(self.maps_host[s], non_blocking=True)     # 1 KB per clip: always (collect may ask for ssl)
+            if self.labels_host is not None and 'target' in samples[0]:
+                self.labels_host[s].fill(samples)
+                self.labels_dev[s].flat.copy_(self.labels_host[s].flat, non_blocking=True)
             self.ready[s].record(self.copy_stream)
         self._copied[s] = True
         self.pending = (s, any_ssl)
         self.slot ^= 1
 
-    def collect(self, want_ssl=None):
-        """-> (clips, ssl_clips or None), fp32 (B,3,T,crop,crop) on the device, produced on the CURRENT stream."""
+    def collect(self, want_ssl=None, out=None):
+        """-> (clips, ssl_clips or None), fp32 (B,3,T,crop,crop) on the device, produced on the CURRENT stream.
+        `out`: write the clips THERE (the input buffer a captured step replays from, DetectorTrainer.static_inputs():
+        the batch then needs no device-to-device copy)."""
         if self.pending is None:
             raise RuntimeError("ClipStager.collect without submit")
         s, any_ssl = self.pending
@@ -264,14 +277,28 @@ class ClipStager:
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(self.ready[s])
         shape = (self.B, 3, self.T, self.crop, self.crop)
-        clips = torch.empty(shape, dtype=torch.float32, device=self.device)
+        if out is not None and (tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous()):
+            raise RuntimeError("ClipStager.collect: `out` must be a contiguous fp32 (B,3,T,crop,crop) tensor")
+        clips = torch.empty(shape, dtype=torch.float32, device=self.device) if out is None else out
         ssl = torch.empty(shape, dtype=torch.float32, device=self.device) if (any_ssl if want_ssl is None else want_ssl) else None
         L.check(L.lib().otal_prepare_clips_map(L.ptr(self.stage[s]), L.ptr(self.params_dev[s]),
                                                L.ptr(self.maps_dev[s]) if ssl is not None else None, L.ptr(clips),
                                                L.ptr(ssl) if ssl is not None else None, self.B, self.T, self.H, self.W,
                                                self.crop, self.crop, L.stream()), "otal_prepare_clips_map")
         self.consumed[s].record(cur)
+        self._last = s
         return clips, ssl
+
+    def labels(self):
+        """The device LabelRecord of the batch collected last (None without `max_targets`).  It is a slot of the double
+        buffer: call `release()` once the step that reads it has been issued."""
+        return None if self.labels_dev is None or self._last is None else self.labels_dev[self._last]
+
+    def release(self):
+        """The consumer of the last collected slot (frames AND labels) has been issued on the current stream: the slot may
+        be refilled once that work has run.  (collect() marks the frames consumed; a step reads the label record later.)"""
+        if self._last is not None:
+            self.consumed[self._last].record(torch.cuda.current_stream(self.device))
 
 
 def batches(dataset, batch_size, shuffle=True, drop_last=True, generator=None, rng=random):

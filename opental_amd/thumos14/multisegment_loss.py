@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..common.input_pipeline import PaddedTargets
 from .cls_loss import ActionnessLoss, EvidenceLoss, FocalLoss_Ori
 
 _EPS = torch.finfo(torch.float32).eps
@@ -76,6 +77,16 @@ def pad_targets(targets, device):
     return out, valid
 
 
+def as_padded(targets, device):
+    """(rows (B,G,3), validity (B,G)) of either form of a batch's targets: the reference's list of ragged (n_i,3) arrays
+    (padded here to the batch's longest list) or an input_pipeline.PaddedTargets (fixed G, used as it is)."""
+    if isinstance(targets, PaddedTargets):
+        return targets.gt, targets.valid
+    if isinstance(targets, (list, tuple)):
+        return pad_targets(targets, device)
+    return targets
+
+
 class MultiSegmentLoss(nn.Module):
     def __init__(self, num_classes, overlap_thresh, negpos_ratio, use_gpu=True, cls_loss_type='focal',
                  edl_config=None, rpl_config=None, os_head=False, act_config=None, size_average=False,
@@ -109,7 +120,8 @@ class MultiSegmentLoss(nn.Module):
     def match(self, loc, priors, targets):
         """Anchor <-> GT assignment for the whole batch (multisegment_loss.py:120-153)."""
         clip = float(self.clip_length)
-        gt, valid = pad_targets(targets, loc.device) if isinstance(targets, (list, tuple)) else targets
+        gt, valid = as_padded(targets, loc.device)
+        valid = valid.bool()
         c = priors[:, 0].view(1, -1, 1)                                     # (1,K,1)
         left = (c - gt[:, None, :, 0]) * clip                               # (B,K,G)
         right = (gt[:, None, :, 1] - c) * clip
@@ -148,7 +160,7 @@ class MultiSegmentLoss(nn.Module):
         C = self.num_classes
         if self._fused_ok(loc):
             from ..common.ops import DetectionLossFunction
-            gt, valid = pad_targets(targets, loc.device) if isinstance(targets, (list, tuple)) else targets
+            gt, valid = as_padded(targets, loc.device)
             cl = self.cls_loss
             if self.cls_loss_type == 'focal':
                 if getattr(self, '_no_ibm', None) is None or self._no_ibm.device != loc.device:

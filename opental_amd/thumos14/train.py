@@ -24,6 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..common import ops
+from ..common.input_pipeline import PaddedTargets
 
 
 def calc_bce_loss(start, end, scores):
@@ -82,6 +83,62 @@ def total_cost(losses, w):
     if wv is None:
         wv = _COST_WEIGHTS[key] = torch.tensor(weights, dtype=torch.float32, device=parts[0].device)
     return torch.dot(torch.stack([p.reshape(()) for p in parts]), wv)
+
+
+def _detached(losses):
+    """The loss terms a step hands back, without their autograd graph.  A caller that keeps the tuple (an epoch loop's
+    `cost, losses = trainer.step(...)`) would otherwise keep the step's graph alive, and with it the parameters'
+    AccumulateGrad nodes -- which remember the stream they were created on.  A later step captured on another stream then
+    re-uses them, autograd makes THAT stream (the default stream of an eager step) wait for events recorded inside the
+    capture, the default stream joins the capture and hipStreamEndCapture dies (found with AMD_LOG_LEVEL=3, round 5)."""
+    if isinstance(losses, (list, tuple)):
+        return tuple(None if l is None else l.detach() for l in losses)
+    return None if losses is None else losses.detach()
+
+
+def _flatten_inputs(clips, targets, scores):
+    """The device tensors of a step's inputs, in a fixed order (targets: a list of ragged arrays, or the padded
+    (rows, validity) pair of an input_pipeline.LabelRecord)."""
+    out = [clips]
+    if isinstance(targets, (list, tuple, PaddedTargets)):
+        out += list(targets)
+    elif targets is not None:
+        out.append(targets)
+    if scores is not None:
+        out.append(scores)
+    return out
+
+
+def _bytes_of(t):
+    """uint8 view of the whole storage `t` lives in."""
+    return torch.empty(0, dtype=torch.uint8, device=t.device).set_(t.untyped_storage())
+
+
+def _clone_inputs(clips, targets, scores):
+    """Clones of a step's inputs for a captured step to replay from.  Tensors that are views of ONE storage (the fields of
+    a LabelRecord) stay views of one cloned storage, so a replay refreshes them with a single copy."""
+    leaves = _flatten_inputs(clips, targets, scores)
+    by_storage = {}
+    for t in leaves:
+        by_storage.setdefault(t.untyped_storage().data_ptr(), []).append(t)
+    fresh = {}
+    for ptr, ts in by_storage.items():
+        if len(ts) > 1:
+            fresh[ptr] = _bytes_of(ts[0]).clone()
+
+    def one(t):
+        flat = fresh.get(t.untyped_storage().data_ptr())
+        if flat is None:
+            return t.clone()
+        return torch.empty(0, dtype=t.dtype, device=t.device).set_(flat.untyped_storage(), t.storage_offset(), t.shape, t.stride())
+    c = one(clips)
+    if isinstance(targets, PaddedTargets):
+        tg = PaddedTargets(one(targets.gt), one(targets.valid))
+    elif isinstance(targets, (list, tuple)):
+        tg = [one(u) for u in targets]
+    else:
+        tg = None if targets is None else one(targets)
+    return c, tg, (None if scores is None else one(scores))
 
 
 class FlatArena:
@@ -189,6 +246,10 @@ class DetectorTrainer:
         self._graph = None          # (CUDAGraph, static inputs, static outputs) once capture_step() succeeded
         self._graph_key = None      # the host scalars baked into the capture
         self._graph_keepalive = None
+        self._copy_plans = {}       # (static, given) addresses -> the copies a replay needs
+        self.launch = 'eager'       # 'lanes': step() captures fixed-shape plain steps as lane graphs by itself (the drivers)
+        self._eager_shapes = None   # input shapes of the last plain eager step
+        self.replayed_steps = 0     # steps that ran as replayed lane graphs
         self._bias_corr = None      # 2-float device tensor: Adam bias corrections of the step being run
         self.collectives = self.distributed and (self.world > 1 or force_collectives)   # force: 1-rank RCCL smoke test
         self._flushed = None
@@ -420,6 +481,15 @@ class DetectorTrainer:
             stale = True            # a baked-in host scalar changed (learning rate, IBM switch): eager now, capture again
             was_split, was_lanes = self._graph[0] == "split", self._graph[0] == "lanes"
             self._graph = None
+        elif self.launch == 'lanes' and ssl_clips is None and isinstance(targets, PaddedTargets):
+            # The drivers' launch mode (run_one_epoch): fixed-shape inputs (a LabelRecord's padded targets) replay as lane
+            # graphs.  The first plain step of a shape runs eagerly -- a real step, after which every region, workspace and
+            # launch plan exists -- the second one is captured (a capture executes nothing) and replayed.
+            shapes = tuple(tuple(t.shape) for t in _flatten_inputs(clips, targets, scores))
+            if self._eager_shapes == shapes:
+                self.capture_step(clips, targets, scores, warmup=0, lanes=True)
+                return self._replay(clips, targets, scores)
+            self._eager_shapes = shapes
         # an eager step next to a captured graph (ssl branch) must not touch the descriptor buffers the graph replays
         # from: it works on its own prologue cache
         cache = self._prologues if self._graph is None else self._eager_prologues()
@@ -440,7 +510,7 @@ class DetectorTrainer:
         self.optimizer_update()
         if stale:
             self.capture_step(clips, targets, scores, warmup=0, split=was_split, lanes=was_lanes)
-        return cost.detach(), losses
+        return cost.detach(), _detached(losses)
 
     def _eager_prologues(self):
         c = getattr(self, '_prologues_eager', None)
@@ -514,7 +584,7 @@ class DetectorTrainer:
             ops.adam_flat_dev(a.flat[lo:hi], a.grad[lo:hi], a.m[lo:hi], a.v[lo:hi], self._bias_corr, g_lr,
                               self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
         self._restore_skipped(keep)
-        return cost.detach(), losses
+        return cost.detach(), _detached(losses)
 
     def capture_step(self, clips, targets, scores, warmup=2, split=False, lanes=False):
         """Capture forward + losses + backward (+ gradient all-reduce) + Adam for inputs of these shapes.
@@ -536,8 +606,7 @@ class DetectorTrainer:
                                "query inside stream capture); use split=True (two graphs, collectives between them) or "
                                "eager launches")
         self._bias_corr = torch.zeros(2, dtype=torch.float32, device=dev)
-        clone = lambda t: None if t is None else ([u.clone() for u in t] if isinstance(t, (list, tuple)) else t.clone())
-        static = tuple(clone(t) for t in (clips, targets, scores))
+        static = _clone_inputs(clips, targets, scores)
         # (the warm-up steps run on a side stream on purpose: the AccumulateGrad stream-mismatch warning is noise here)
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         side = torch.cuda.Stream(device=dev)
@@ -573,8 +642,7 @@ class DetectorTrainer:
         import gc
         dev = clips.device
         self._bias_corr = torch.zeros(2, dtype=torch.float32, device=dev)
-        clone = lambda t: None if t is None else ([u.clone() for u in t] if isinstance(t, (list, tuple)) else t.clone())
-        static = tuple(clone(t) for t in (clips, targets, scores))
+        static = _clone_inputs(clips, targets, scores)
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         cap = torch.cuda.Stream(device=dev)
         cap.wait_stream(torch.cuda.current_stream(dev))
@@ -616,6 +684,7 @@ class DetectorTrainer:
         self._copy_inputs(static, (clips, targets, scores))
         self._skipped = []
         self.step_count += 1
+        self.replayed_steps += 1
         self._set_bias(self.step_count)
         plan.replay()
         return out
@@ -639,8 +708,7 @@ class DetectorTrainer:
         already_split = bool(getattr(model, 'split_backward', False))
         model.split_backward = True
         self._bias_corr = torch.zeros(2, dtype=torch.float32, device=dev)
-        clone = lambda t: None if t is None else ([u.clone() for u in t] if isinstance(t, (list, tuple)) else t.clone())
-        static = tuple(clone(t) for t in (clips, targets, scores))
+        static = _clone_inputs(clips, targets, scores)
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -690,7 +758,7 @@ class DetectorTrainer:
             self._pending = None
         if self._skipped:
             raise RuntimeError("capture_step(split=True): a parameter received no gradient; use eager launches")
-        out = (cost.detach(), losses)
+        out = (cost.detach(), _detached(losses))
         self._graph = ("split", g1, g2, static, out)
         self._graph_key = self._capture_key()
         self._graph_keepalive = (self._prologues.dev_descs, self._prologues.dev_starts, stem_out, gcut)
@@ -723,19 +791,39 @@ class DetectorTrainer:
         return out
 
     def _copy_inputs(self, static, given):
-        pairs = []
-        for dst, src in zip(static, given):
-            if isinstance(dst, list):
-                if len(dst) != len(src):
-                    raise RuntimeError("captured step replayed with a different batch; call capture_step again")
-                pairs += list(zip(dst, src))
-            elif dst is not None:
-                pairs.append((dst, src))
-        for dst, src in pairs:
-            if dst.data_ptr() != src.data_ptr():
-                if dst.shape != src.shape:      # ragged targets: the per-sample row counts are baked into the capture
+        """Refresh the captured step's input buffers from `given`.  What already lives there is left alone; tensors that are
+        views of one storage on both sides with the same layout (a LabelRecord) travel as ONE copy of that storage."""
+        dsts, srcs = _flatten_inputs(*static), _flatten_inputs(*given)
+        if len(dsts) != len(srcs):
+            raise RuntimeError("captured step replayed with a different batch; call capture_step again")
+        key = tuple((d.data_ptr(), g.data_ptr()) for d, g in zip(dsts, srcs))
+        plan = self._copy_plans.get(key)
+        if plan is None:
+            todo = []
+            for dst, src in zip(dsts, srcs):
+                if dst.data_ptr() == src.data_ptr():
+                    continue
+                if dst.shape != src.shape or dst.dtype != src.dtype:
+                    # ragged targets: the per-sample row counts are baked into the capture (padded records never get here)
                     raise RuntimeError("captured step replayed with different input shapes; call capture_step again")
-                dst.copy_(src, non_blocking=True)
+                todo.append((dst, src))
+            groups = {}
+            for dst, src in todo:
+                groups.setdefault((dst.untyped_storage().data_ptr(), src.untyped_storage().data_ptr()), []).append((dst, src))
+            plan = []
+            for pairs in groups.values():
+                d0, s0 = pairs[0]
+                whole = (len(pairs) > 1 and d0.untyped_storage().nbytes() == s0.untyped_storage().nbytes()
+                         and all(d.storage_offset() == g.storage_offset() and d.stride() == g.stride() for d, g in pairs))
+                plan += [(_bytes_of(d0), _bytes_of(s0))] if whole else pairs
+            # (a cached plan keeps its source tensors alive, which is what makes the address key safe -- so only plans over
+            # small, persistent sources are kept: label records; a freshly allocated 226 MB clip batch is not)
+            if all(src.numel() * src.element_size() <= (1 << 20) for _, src in plan):
+                if len(self._copy_plans) > 64:
+                    self._copy_plans.clear()
+                self._copy_plans[key] = plan
+        for dst, src in plan:
+            dst.copy_(src, non_blocking=True)
 
     def static_inputs(self):
         """The (clips, targets, scores) buffers a captured step replays from, or None.  A producer that writes its batch
@@ -932,7 +1020,7 @@ def rank_batches(every, rank, world):
     watchdog aborts the job at the end of the first epoch).  The truncation comes BEFORE a caller's max_steps cut, and every
     rank materialises the whole list (the sampling decisions draw from one shared random stream, so all ranks must draw all of
     them to stay aligned; decisions are host-only records -- no pixels, see anet_dataset.LazyVideo).  The per-epoch means a
-    driver prints are this rank's means over its own steps, not global ones."""
+    driver prints are averaged over the ranks (one 8-float all-reduce per epoch, run_one_epoch)."""
     every = list(every)
     every = every[:len(every) // world * world]
     return every[rank::world]
@@ -1005,7 +1093,12 @@ def run_one_epoch(epoch, trainer, dataset, stager, batch_size, rank=0, world=1, 
     """One pass over the shuffled sliding-window list (train.py:204-303).  Every rank draws the same permutation and
     the same per-sample decisions (shared seeds) and takes every world-th batch.  Nothing in the loop synchronises with
     the host: the loss sums stay on the device until the epoch's log line; `step_log` (StepLog) receives the per-step
-    scalars through asynchronous copies."""
+    scalars through asynchronous copies.
+
+    Labels: with a stager built with `max_targets` the batch's targets (any number per sample, train.py:221-224), boundary
+    masks and ssl segments cross PCIe as ONE fixed-shape pinned record next to the frames (input_pipeline.LabelRecord), so
+    every plain step has the same input shapes and -- `trainer.launch == 'lanes'` -- replays the captured lane graphs, the
+    clip kernel writing straight into the captured step's clip buffer; ssl steps (`flags[0]`) run eagerly beside it."""
     from ..common import thumos_dataset as D
     dev = trainer.arena.flat.device
     sums, n_iter = None, 0
@@ -1017,13 +1110,19 @@ def run_one_epoch(epoch, trainer, dataset, stager, batch_size, rank=0, world=1, 
     stager.submit(mine[0])
     for k, samples in enumerate(mine):
         use_ssl = bool(samples[0]['flag'])                 # `if flags[0]` (train.py:237)
-        clips, ssl_clips = stager.collect(want_ssl=use_ssl)
+        static = trainer.static_inputs()
+        clips, ssl_clips = stager.collect(want_ssl=use_ssl, out=None if static is None else static[0])
+        rec = stager.labels()
         if k + 1 < len(mine):
             stager.submit(mine[k + 1])                     # next batch crosses PCIe while this step runs
-        targets = [torch.from_numpy(s['target']).to(dev, non_blocking=True) for s in samples]
-        scores = torch.from_numpy(np.stack([s['scores'] for s in samples], 0)).to(dev, non_blocking=True)
-        ssl_targets = [torch.from_numpy(s['ssl_target'][:, :2].copy()).to(dev) for s in samples] if use_ssl else None
+        if rec is not None:
+            targets, scores, ssl_targets = rec.targets, rec.scores, rec.ssl_targets() if use_ssl else None
+        else:                                              # a stager without label records: ragged lists, eager steps
+            targets = [torch.from_numpy(s['target']).to(dev, non_blocking=True) for s in samples]
+            scores = torch.from_numpy(np.stack([s['scores'] for s in samples], 0)).to(dev, non_blocking=True)
+            ssl_targets = [torch.from_numpy(s['ssl_target'][:, :2].copy()).to(dev) for s in samples] if use_ssl else None
         cost, losses = trainer.step(clips, targets, scores, ssl_clips if use_ssl else None, ssl_targets)
+        stager.release()                                   # the slot's labels have been read by everything issued so far
         vec = torch.stack([cost.reshape(())] + [l.detach().reshape(()) for l in losses[:7]])
         sums = vec if sums is None else sums + vec
         n_iter += 1
@@ -1031,7 +1130,11 @@ def run_one_epoch(epoch, trainer, dataset, stager, batch_size, rank=0, world=1, 
             step_log.push(trainer.step_count, vec)
     if step_log is not None:
         step_log.poll(wait=True)
-    v = (sums / n_iter).tolist()                           # the epoch's only host synchronisation
+    mean = sums / n_iter
+    if world > 1 and dist.is_available() and dist.is_initialized():
+        dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=trainer.group)   # every rank ran n_iter steps (rank_batches):
+        mean = mean / world                                                # the line below is the epoch's GLOBAL mean
+    v = mean.tolist()                                      # the epoch's only host synchronisation
     log('Epoch-{} Train Loss: Total - {:.5f}, loc - {:.5f}, conf - {:.5f}, prop_loc - {:.5f}, prop_conf - {:.5f}, '
         'IoU - {:.5f}, start - {:.5f}, end - {:.5f}'.format(epoch, *v))
     return v
@@ -1046,13 +1149,16 @@ def main(argv=None):
       --save_after N          save checkpoints for epochs > N (reference: 10, train.py:289)
       --max_steps N           cap the steps per epoch (smoke runs)
       --log_every N           per-step loss line every N steps through asynchronous D2H copies (StepLog; 0 = epoch lines only)
+      --launch lanes|eager    lanes (default): plain steps replay captured HIP graphs on two streams (DetectorTrainer.
+                              capture_step(lanes=True)) from fixed-shape label records; eager: one launch at a time
     One process per GPU; under torchrun the ranks all-reduce gradients over RCCL (DetectorTrainer)."""
     import os
     import sys
     from ..common import config as C
     from ..common import thumos_dataset as D
     argv = list(sys.argv[1:] if argv is None else argv)
-    extra = {'as_shipped_dispatch': False, 'random_init': False, 'save_after': 10, 'max_steps': None, 'log_every': 0}
+    extra = {'as_shipped_dispatch': False, 'random_init': False, 'save_after': 10, 'max_steps': None, 'log_every': 0,
+             'launch': 'lanes'}
     rest, i = [], 0
     while i < len(argv):
         a = argv[i]
@@ -1060,9 +1166,13 @@ def main(argv=None):
             extra[a[2:]] = True
         elif a in ('--save_after', '--max_steps', '--log_every'):
             extra[a[2:]] = int(argv[i + 1]); i += 1
+        elif a == '--launch':
+            extra['launch'] = argv[i + 1]; i += 1
         else:
             rest.append(a)
         i += 1
+    if extra['launch'] not in ('lanes', 'eager'):
+        raise SystemExit("--launch takes lanes or eager")
     config = C.set_config(C.get_config(rest))
     tr = config['training']
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -1085,7 +1195,8 @@ def main(argv=None):
                                stride=ds_cfg['clip_stride'])
     any_video = next(iter(data.values()))
     stager = D.ClipStager(tr['batch_size'], ds_cfg['clip_length'], int(any_video.shape[1]), int(any_video.shape[2]),
-                          ds_cfg['crop_size'], device=dev)
+                          ds_cfg['crop_size'], device=dev, max_targets=D.max_target_count(dataset), score_rows=2)
+    trainer.launch = extra['launch']
     checkpoint_path = tr['checkpoint_path']
     train_state_path = os.path.join(checkpoint_path, 'training')
     start_epoch = trainer.resume_training(tr['resume'], checkpoint_path, train_state_path)

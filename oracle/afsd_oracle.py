@@ -150,8 +150,24 @@ class operand_rounding:
         _ROUND, _ROUND_GRADS, _STORED_UNTIL = self.old
 
 
+class _RoundOperand(torch.autograd.Function):
+    """Round-to-nearest-even to bfloat16 and back, with a pass-through gradient.  (A plain `.to(bfloat16).to(float32)`
+    makes autograd cast the GRADIENT through bfloat16 as well: every weight gradient and every convolution's data-gradient
+    contribution would come out rounded to 8 bits -- an artefact of the restatement, not something the HIP path does: its
+    weight gradients are fp32 sums and a stored data gradient is rounded once, where `_rg` rounds it here.)"""
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 def _r(t):
-    return t.to(torch.bfloat16).to(t.dtype) if _ROUND == "bf16" and t.dtype == torch.float32 else t
+    if _ROUND == "bf16" and t.dtype == torch.float32:
+        return _RoundOperand.apply(t) if t.requires_grad else t.to(torch.bfloat16).to(t.dtype)
+    return t
 
 
 class _RoundGrad(torch.autograd.Function):

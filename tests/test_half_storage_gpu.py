@@ -144,3 +144,46 @@ def test_model_forward_is_unchanged_and_only_backbone_gradients_move(golden_dir)
         bound = 0.8 if "Conv3d_" in k else (0.94 if "Mixed_3" in k else 0.97)
         assert cos > bound, (k, cos)
     print("bf16-stored vs fp32-stored gradients, lowest cosines:", sorted(worst.items(), key=lambda kv: kv[1])[:4])
+
+
+@pytest.mark.parametrize("act_direct", [False, True])
+def test_half_storage_without_the_chain_runs_forward_and_backward(golden_dir, act_direct):
+    """ops.HALF_CHAIN = False is the documented off-switch of the bf16 chain.  Conv3d_1a then still stores
+    its output as bf16 for MaxPool3d_2a (round 2's HALF_STORAGE; with ops.HALF_ACT_DIRECT also Conv3d_2c for MaxPool3d_3a): the
+    pool's bf16-in / fp32-out kernel must consume it WITHOUT a conversion seam, and the backward pass must come out with the
+    dtypes every consumer expects.  Forward values equal the fp32-stored run bit for bit; only Conv3d_1a's (and, with
+    HALF_ACT_DIRECT, nothing else's: fp32 gradients there) weight gradient moves, by the pool's tie re-routing (cosine 0.997 at
+    round 2; bound 0.99)."""
+    from oracle import arch
+    from test_model_gpu import build, _criterion, W
+    from opental_amd.common import ops
+    from opental_amd.thumos14.train import forward_one_epoch, total_cost
+    fx = np.load(os.path.join(golden_dir, "thumos_b1.npz"))
+    net = build(fx)
+    x = torch.from_numpy(arch.make_clip(int(fx["clip_seed"]), 1)).cuda()
+    targets = [torch.from_numpy(fx["target_0"]).cuda()]
+    scores = torch.from_numpy(fx["scores"]).cuda()
+    saved = (ops.HALF_CHAIN, ops.HALF_ACT_DIRECT)
+
+    def run(half, chain, direct):
+        ops.HALF_STORAGE, ops.HALF_CHAIN, ops.HALF_ACT_DIRECT = half, chain, direct
+        net.zero_grad(set_to_none=True)
+        losses = forward_one_epoch(net, _criterion("edl", 0), x, targets, scores, training=True, ssl=False)
+        cost = total_cost(losses, W)
+        cost.backward()
+        return float(cost.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    try:
+        c0, g0 = run(False, False, False)
+        c1, g1 = run(True, False, act_direct)
+    finally:
+        ops.HALF_CHAIN, ops.HALF_ACT_DIRECT = saved
+    assert c0 == c1
+    moved = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    # MaxPool3d_2a routes a tied window differently on rounded inputs: Conv3d_1a's gradient moves; with HALF_ACT_DIRECT
+    # MaxPool3d_3a does the same to everything in front of it (Conv3d_2c, 2b, 1a)
+    stem = ["backbone._model.Conv3d_1a_7x7.conv3d.weight"] + (
+        ["backbone._model.Conv3d_2b_1x1.conv3d.weight", "backbone._model.Conv3d_2c_3x3.conv3d.weight"] if act_direct else [])
+    assert moved and set(moved) <= set(stem), moved
+    for k in moved:
+        cos = float(torch.nn.functional.cosine_similarity(g0[k].flatten().double(), g1[k].flatten().double(), dim=0))
+        assert cos > (0.95 if act_direct else 0.99), (k, cos)

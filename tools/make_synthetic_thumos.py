@@ -17,7 +17,9 @@ CLASSES = [(7, "BaseballPitch"), (9, "BasketballDunk"), (12, "Billiards"), (21, 
            (36, "HammerThrow"), (40, "HighJump"), (45, "JavelinThrow"), (51, "LongJump"), (68, "PoleVault")]
 
 
-def make(out, videos=2, frames=400, size=100, seed=0, test_videos=2):
+def make(out, videos=2, frames=400, size=100, seed=0, test_videos=2, uniform=0):
+    """`uniform`: the last so many training videos carry actions of ONE length (~32 frames) at irregular distances: no action is
+    twice as long as the shortest, so the ssl splice never applies to their windows (flag False: plain steps)."""
     rs = np.random.RandomState(seed)
     os.makedirs(os.path.join(out, "train_npy"), exist_ok=True)
     os.makedirs(os.path.join(out, "test_npy"), exist_ok=True)
@@ -32,10 +34,15 @@ def make(out, videos=2, frames=400, size=100, seed=0, test_videos=2):
         t, k = 20, 0
         while t + 80 < frames:                              # short (~14) and long (~64 frame) actions between long backgrounds:
             cid, cname = CLASSES[rs.randint(len(CLASSES))]  # the ssl splice needs an action longer than twice the shortest one
-            ln = int(rs.randint(12, 16)) if k % 2 == 0 else int(rs.randint(58, 70))
+            if v >= videos - uniform:
+                ln = int(rs.randint(30, 35))
+                gap = int(rs.randint(20, 110))
+            else:
+                ln = int(rs.randint(12, 16)) if k % 2 == 0 else int(rs.randint(58, 70))
+                gap = int(rs.randint(60, 90))
             k += 1
             anno.append(f"{name},{cname},{cid},{t / 10:.1f},{(t + ln) / 10:.1f},{t * 3},{(t + ln) * 3}")
-            t += ln + int(rs.randint(60, 90))
+            t += ln + gap
     tinfo = ["video,fps,sample_fps,count,sample_count"]
     gt = {"database": {}}
     for v in range(test_videos):
