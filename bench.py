@@ -699,13 +699,29 @@ def main():
     exposed_ms = None
     if trainer.exposed_events:
         exposed_ms = sum(a.elapsed_time(b) for a, b in trainer.exposed_events) / len(trainer.exposed_events)
+    per_rank_ms = None
     if multi:
+        mine = torch.tensor([dt / args.steps * 1e3], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [round(float(v), 3) for v in allr]        # every rank's own clock around the same K steps
         t = torch.tensor([dt, exposed_ms if exposed_ms is not None else -1.0], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
         exposed_ms = float(t[1]) if float(t[1]) >= 0 else None
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
+    # A data-parallel step whose gradient all-reduce is not hidden under the backward pass is a scaling bug, not a number to
+    # report quietly: more than 10 % of the step spent waiting for the collectives is flagged in the line AND shouted on
+    # stderr (OTAL_BENCH_STRICT=1: the run fails with exit code 4 after printing the line).
+    allreduce_check = None
+    if multi and exposed_ms is not None:
+        frac = exposed_ms / ms_per_step
+        allreduce_check = {"exposed_frac_of_step": round(frac, 4), "ok": bool(frac <= 0.10)}
+        if frac > 0.10 and rank == 0:
+            print("\n" + "!" * 100 + f"\n[bench] GRADIENT ALL-REDUCE EXPOSED: {exposed_ms:.3f} ms of a {ms_per_step:.3f} ms step "
+                  f"({100 * frac:.1f} % > 10 %) -- the collectives are NOT hidden under the backward pass at N = {world}\n" + "!" * 100,
+                  file=sys.stderr, flush=True)
     replicas_ok = replica_check("after the timed steps") and replicas_ok
 
     nbuckets = len(trainer.arena.buckets)
@@ -835,6 +851,9 @@ def main():
                                          "the backward pass (the backbone hands its finished layers over while it runs); "
                                          "exposed = compute-stream wait for the collectives after backward" % nbuckets,
                        "allreduce_exposed_ms": None if exposed_ms is None else round(exposed_ms, 3),
+                       "allreduce_check": allreduce_check,
+                       "ms_per_step_per_rank": per_rank_ms,
+                       "rank_spread_ms": None if not per_rank_ms else round(max(per_rank_ms) - min(per_rank_ms), 3),
                        "ssl_branch": bool(args.ssl), "inputs": inputs_note, "launch_probe": launch_probe,
                        "launch": (lanes_note if lanes else
                                   "two captured HIP graphs per step, the gradient all-reduces issued between them" if multi else
@@ -846,6 +865,8 @@ def main():
     if world > 1 or force_dist:
         dist.barrier()              # every rank leaves together (rank 0 was busy with the roofline steps)
         dist.destroy_process_group()
+    if allreduce_check is not None and not allreduce_check["ok"] and os.environ.get("OTAL_BENCH_STRICT"):
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -26,10 +26,13 @@ RANK_CODE = textwrap.dedent('''
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    tr = bench.build_trainer(dev, seed=5)
+    anet = mode.startswith("anet")
+    tr = bench.build_anet_trainer(dev, seed=5) if anet else bench.build_trainer(dev, seed=5)
     assert tr.collectives and tr.world == world
     tr.lr = 1e-4
-    clips, targets, scores = bench.synth_batch(2, 1000 + rank, dev)
+    kw = dict(frames=768, classes=150, score_rows=3) if anet else {}
+    clips, targets, scores = bench.synth_batch(2, 1000 + rank, dev, **kw)
+    ring = bench.synth_label_ring(2, 1000 + rank, dev, n=3, **kw)      # mode "driver*": other labels (other counts) every step
     steps = 3
     ssl_args = ()
     if mode.startswith("mixed") and rank == 0:
@@ -46,14 +49,27 @@ RANK_CODE = textwrap.dedent('''
         tr.capture_step(clips, targets, scores, warmup=1, split=True)       # one real (eager) step, then the capture
         assert tr._graph[0] == "split"
         done = 1
+    elif mode in ("lanes", "anet_lanes"):
+        tr.capture_step(clips, targets, scores, warmup=1, lanes=True)       # the lane graphs: collectives issued between them
+        assert tr._graph[0] == "lanes"
+        done = 1
     else:
         done = 0
     costs = []
-    for _ in range(steps - done):
-        costs.append(float(tr.step(clips, targets, scores, *ssl_args)[0]))
+    if mode == "driver":
+        # what run_one_epoch does: fixed-shape label records, trainer.launch = 'lanes' -- step 1 eager, step 2 captured and
+        # replayed, step 3 replayed, each with other labels
+        tr.launch = "lanes"
+        for k in range(steps):
+            costs.append(float(tr.step(clips, ring[k].targets, ring[k].scores)[0]))
+        assert tr._graph is not None and tr._graph[0] == "lanes" and tr.replayed_steps == steps - 1, tr.replayed_steps
+    else:
+        for _ in range(steps - done):
+            costs.append(float(tr.step(clips, targets, scores, *ssl_args)[0]))
     torch.cuda.synchronize()
     assert tr.step_count == steps
-    torch.save({"flat": tr.arena.flat.cpu(), "m": tr.arena.m.cpu(), "ibm": tr.criterion.cls_loss.weight_accum.cpu(),
+    wa = getattr(tr.criterion.cls_loss, "weight_accum", None)
+    torch.save({"flat": tr.arena.flat.cpu(), "m": tr.arena.m.cpu(), "ibm": wa.cpu() if wa is not None else torch.zeros(1),
                 "costs": costs, "order": list(tr._flush_order), "buckets": list(tr.arena.buckets)}, out + f".{rank}")
     dist.barrier()
     dist.destroy_process_group()
@@ -82,9 +98,10 @@ def _run(mode, tmp_path, port):
     return [torch.load(out + f".{r}") for r in range(2)]
 
 
-def _reference(steps=3, ssl_rank0_from=None):
+def _reference(steps=3, ssl_rank0_from=None, anet=False, label_ring=False):
     """What two data-parallel ranks must compute, in ONE process without collectives.  `ssl_rank0_from`: first step
-    (0-based) from which rank 0's cost includes the triplet branch."""
+    (0-based) from which rank 0's cost includes the triplet branch.  `label_ring`: step k uses record k of each rank's
+    label ring (the drivers' mode) instead of the rank's fixed labels."""
     import torch
     import bench
     from opental_amd.common import ops
@@ -92,17 +109,23 @@ def _reference(steps=3, ssl_rank0_from=None):
     old = ops.CONV_PRECISION
     ops.CONV_PRECISION = 1
     try:
-        tr = bench.build_trainer(dev, seed=5)
+        tr = bench.build_anet_trainer(dev, seed=5) if anet else bench.build_trainer(dev, seed=5)
         tr.lr = 1e-4
         tr.world = 2                                    # Adam's grad_scale = 1 / world
-        batches = [bench.synth_batch(2, 1000 + r, dev) for r in range(2)]
+        kw = dict(frames=768, classes=150, score_rows=3) if anet else {}
+        batches = [bench.synth_batch(2, 1000 + r, dev, **kw) for r in range(2)]
+        rings = [bench.synth_label_ring(2, 1000 + r, dev, n=3, **kw) for r in range(2)] if label_ring else None
         ssl_clips, _, _ = bench.synth_batch(2, 2000, dev)
         ssl_targets = [torch.tensor([[0.30, 0.55], [0.32, 0.52], [0.70, 0.90]], device=dev) * 256 for _ in range(2)]
-        ibm = tr.criterion.cls_loss.weight_accum
+        ibm = getattr(tr.criterion.cls_loss, "weight_accum", None)
+        if ibm is None or tr._ibm_state() is None:      # (the ActivityNet recipe's closed-form IBM weight has no state)
+            ibm = torch.zeros(1, device=dev)
         for k in range(steps):
             state = ibm.detach().clone()
             total, states = torch.zeros_like(tr.arena.grad), []
             for r, b in enumerate(batches):
+                if rings is not None:
+                    b = (b[0], rings[r][k].targets, rings[r][k].scores)
                 ibm.copy_(state)
                 ops.activate_prologues(tr._prologues)
                 with_ssl = r == 0 and ssl_rank0_from is not None and k >= ssl_rank0_from
@@ -125,14 +148,18 @@ def _reference(steps=3, ssl_rank0_from=None):
         ops.CONV_PRECISION = old
 
 
-@pytest.mark.parametrize("mode", ["eager", "split"])
+@pytest.mark.parametrize("mode", ["eager", "split", "lanes", "driver", "anet", "anet_lanes"])
 def test_two_ranks_on_one_gpu_match_the_single_process_restatement(mode, tmp_path):
+    """eager / split: round 2.  lanes: the LANE-graph data-parallel step -- the form bench.py and the
+    drivers run -- with the bucket all-reduces issued between the graphs; driver: trainer.launch = 'lanes' fed other
+    fixed-shape label records every step (eager step, capture, replays) as run_one_epoch feeds it; anet / anet_lanes: the
+    ActivityNet recipe's criterion (per-sample normalisation, no IBM state) and its two optimizer groups on real kernels."""
     import torch
-    res = _run(mode, tmp_path, 29551 if mode == "eager" else 29552)
+    res = _run(mode, tmp_path, 29551 + ["eager", "split", "lanes", "driver", "anet", "anet_lanes"].index(mode) * 7)
     # both ranks hold the same parameters, moments and IBM state, and issued their collectives in the same order
     assert torch.equal(res[0]["flat"], res[1]["flat"]) and torch.equal(res[0]["m"], res[1]["m"])
     assert torch.equal(res[0]["ibm"], res[1]["ibm"]) and res[0]["order"] == res[1]["order"] and res[0]["buckets"] == res[1]["buckets"]
-    flat, m, ibm = _reference()
+    flat, m, ibm = _reference(anet=mode.startswith("anet"), label_ring=mode == "driver")
     scale = float(flat.abs().max())
     # the sum over ranks is one fp32 add per element either way; what may differ is the order of the two addends (none:
     # a + b) and the reference's extra accumulate through a zero tensor (0 + a + b): exact
@@ -148,7 +175,7 @@ def test_mixed_ssl_and_plain_ranks_stay_in_step(mode, tmp_path):
     The fixed collective order (IBM state, buckets in _flush_order, used-parameter flags) must keep them aligned, and
     the result must equal the single-process restatement: rank 0's gradient of (cost + ssl * triplet) plus rank 1's."""
     import torch
-    res = _run(mode, tmp_path, 29553 if mode == "mixed" else 29554)
+    res = _run(mode, tmp_path, 29653 if mode == "mixed" else 29654)
     assert torch.equal(res[0]["flat"], res[1]["flat"]) and torch.equal(res[0]["m"], res[1]["m"])
     assert torch.equal(res[0]["ibm"], res[1]["ibm"])
     # mixed_split: the warm-up step of the capture is a plain step on both ranks, the ssl steps follow
