@@ -119,14 +119,25 @@ def main(argv=None):
     t = ds['testing']
     os.makedirs(te['output_path'], exist_ok=True)
 
-    def cached(path, run):
+    def cached(path, run, expected):
+        """A result file of an earlier run is re-used only when it parses AND holds exactly the videos this run would
+        produce (a killed run leaves truncated or partial files; anet/test.py checks its file the same way); new files are
+        written next to their place and moved in (os.replace is atomic)."""
         if os.path.exists(path):
-            with open(path) as f:
-                return json.load(f)
+            try:
+                with open(path) as f:
+                    old = json.load(f)
+                if sorted(old.get('results', {})) == sorted(expected):
+                    return old
+                print(f"{path}: holds {len(old.get('results', {}))} of {len(expected)} videos -- recomputed")
+            except (ValueError, OSError):
+                print(f"{path}: unreadable -- recomputed")
         out = run()
         if out is not None:
-            with open(path, 'w') as f:
+            tmp = path + '.tmp'
+            with open(tmp, 'w') as f:
                 json.dump(out, f)
+            os.replace(tmp, path)
         return out
 
     def run_thumos():
@@ -152,8 +163,9 @@ def main(argv=None):
         res = T.gather_results(res, [n[2:] for n in anet_names], rank, world, dev)
         return None if res is None else T.results_json(res)
 
-    thumos_out = cached(os.path.join(te['output_path'], 'thumos14_open_rgb.json'), run_thumos)
-    anet_out = cached(os.path.join(te['output_path'], 'anet_open_rgb.json'), run_anet)
+    thumos_out = cached(os.path.join(te['output_path'], 'thumos14_open_rgb.json'), run_thumos,
+                        list(get_video_info(t['video_info_path']).keys()))
+    anet_out = cached(os.path.join(te['output_path'], 'anet_open_rgb.json'), run_anet, [n[2:] for n in anet_names])
     if thumos_out is None or anet_out is None:
         return None                                  # ranks > 0
     print(f"Number of thumos videos: {len(thumos_out['results'])}; anet videos (before filtering): {len(anet_out['results'])}")
