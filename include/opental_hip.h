@@ -262,6 +262,10 @@ int otal_maxpool3d_bwd_signbits_h(const int* geom, const int64_t* strides, const
  *   _fwd_io  io: bit 0 x, bit 1 y.  1 = _fwd_signbits_h; 3 = both: the strided 3x3 pools ((1,3,3)/(1,2,2), (3,3,3)/(2,2,2)) and
  *            the 3x3x3 / stride-1 branch pools on 12 x 12 and 6 x 6 planes.  A max-pool commutes with the monotonic bf16
  *            rounding and its winners are copied, not rounded: the output equals the fp32 pool's output rounded once.
+ *            bit 2 (value 4, with 3; round 5): the caller guarantees x >= +0 everywhere -- the output of a conv + ReLU, which
+ *            is what MaxPool3d_2a / 3a / 4a read (AFSD/common/i3d_backbone.py:194-244) -- and the (1,3,3)/(1,2,2) pools then
+ *            run on ordered integer keys (the bf16 bit patterns themselves; v_max3_u32 over bits << 16 | tap priority):
+ *            same winners, values and sign bits on such inputs; a -0.0 is read as +0.0, a NaN is not ordered.
  *   _bwd_io  io: bit 0 dx, bit 1 dy, bit 2 out_mask.  1 = _bwd_signbits_h; 3 / 7 = all of them: strided pools with the sign-bit
  *            mask and a plain store; branch pools with a bf16 out_mask tensor, `accumulate` = read the bf16 dx, add this
  *            pool's contribution in fp32, round to nearest even once (the second producer of an Inception module's input

@@ -404,7 +404,8 @@ class I3DFeaturesFunction(Function):
                 # a pool behind a conv + ReLU: let the forward kernel keep that layer's ReLU mask as sign bits, so that the
                 # backward pass does not re-read the 4-byte activations only for their sign
                 if chain:
-                    y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=True, half_out=True)
+                    # (cur_scale is not None: `cur` is a conv / Inception output behind its ReLU, so >= +0 everywhere)
+                    y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=True, half_out=True, nonneg=cur_scale is not None)
                 elif cur_scale is not None:
                     y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=True)
                 else:                                       # (a pool that is not behind a conv + ReLU: nothing to mask)

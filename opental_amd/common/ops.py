@@ -1064,10 +1064,11 @@ def _pool_geom(x5, k, s):
     return [B, C, Ti, Hi, Wi, *outs, *k, *s, *pads], tuple(outs)
 
 
-def maxpool3d_forward(x, k, s, out=None, signbits=False, half_out=False):
+def maxpool3d_forward(x, k, s, out=None, signbits=False, half_out=False, nonneg=False):
     """(y, winner bytes) -- with signbits=True (y, winner bytes, sign bits of x or None): the strided 3x3 pools can hand
     the ReLU mask of their input to the backward pass as one bit per element (maxpool3d_backward(out_signbits=...)).
-    half_out (bfloat16 x only): y is STORED as bf16 too (otal_maxpool3d_fwd_io, io = 3)."""
+    half_out (bfloat16 x only): y is STORED as bf16 too (otal_maxpool3d_fwd_io, io = 3).
+    nonneg (with half_out): x is the output of a conv + ReLU, i.e. >= +0 everywhere (io bit 2: the ordered-key kernels)."""
     x5 = _as5(x)
     g, outn = _pool_geom(x5, k, s)
     B, C = x5.shape[:2]
@@ -1086,7 +1087,8 @@ def maxpool3d_forward(x, k, s, out=None, signbits=False, half_out=False):
             nbytes = int(lib.otal_maxpool3d_signbits_bytes(ga, sa))
             if nbytes:
                 bits = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        L.check(lib.otal_maxpool3d_fwd_io(ga, sa, L.ptr(x5), L.ptr(out), L.ptr(arg), _opt(bits), 3, L.stream()), "otal_maxpool3d_fwd_io")
+        L.check(lib.otal_maxpool3d_fwd_io(ga, sa, L.ptr(x5), L.ptr(out), L.ptr(arg), _opt(bits), 7 if nonneg else 3, L.stream()),
+                "otal_maxpool3d_fwd_io")
         return (out, arg, bits) if signbits else (out, arg)
     if out is None:
         out = torch.empty((B, C) + outn, dtype=x.dtype, device=x.device)

@@ -849,16 +849,24 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_fwd_kernel(const float* __r
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh) {
             rin[dt][dh] = (int)t * ST + dt < g.Ti && 2 * ho + dh < g.Hi;
+            // branch-free: rows / columns outside the tensor are read from a clamped address and masked to the zero pad, so all
+            // 2 KT x 3 loads of a thread are in flight together (a conditional load costs one exposed round trip EACH: 18 for KT = 3)
+            const int roff = (min(dt, g.Ti - 1 - (int)t * ST) * g.Hi + min(dh, g.Hi - 1 - 2 * ho)) * g.Wi;
             if constexpr (XH) {
-                const unsigned short* r = xh + ((int64_t)dt * g.Hi + dh) * g.Wi;
-                const uint2 w = rin[dt][dh] ? *reinterpret_cast<const uint2*>(r) : make_uint2(0u, 0u);
+                const unsigned short* r = xh + roff;
+                uint2 w = *reinterpret_cast<const uint2*>(r);
+                const unsigned keep = rin[dt][dh] ? ~0u : 0u;
+                w.x &= keep; w.y &= keep;
                 v[dt][dh] = make_float4(bf16_bits_to_float(w.x & 0xffffu), bf16_bits_to_float(w.x >> 16),
                                         bf16_bits_to_float(w.y & 0xffffu), bf16_bits_to_float(w.y >> 16));
-                e[dt][dh] = (rin[dt][dh] && cin) ? bf16_bits_to_float(r[4]) : 0.f;
+                e[dt][dh] = bf16_bits_to_float((unsigned)r[cin ? 4 : 0] & ((rin[dt][dh] && cin) ? 0xffffu : 0u));
             } else {
-                const float* r = xr + ((int64_t)dt * g.Hi + dh) * g.Wi;
-                v[dt][dh] = rin[dt][dh] ? *reinterpret_cast<const float4*>(r) : make_float4(0.f, 0.f, 0.f, 0.f);
-                e[dt][dh] = (rin[dt][dh] && cin) ? r[4] : 0.f;
+                const float* r = xr + roff;
+                const float4 w = *reinterpret_cast<const float4*>(r);
+                const unsigned keep = rin[dt][dh] ? ~0u : 0u, keep5 = (rin[dt][dh] && cin) ? ~0u : 0u;
+                v[dt][dh] = make_float4(__uint_as_float(__float_as_uint(w.x) & keep), __uint_as_float(__float_as_uint(w.y) & keep),
+                                        __uint_as_float(__float_as_uint(w.z) & keep), __uint_as_float(__float_as_uint(w.w) & keep));
+                e[dt][dh] = __uint_as_float(__float_as_uint(r[cin ? 4 : 0]) & keep5);
             }
         }
     float b0 = 0.f, b1 = 0.f;
@@ -918,13 +926,10 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __r
     const int a = q - t * H2;
     const int64_t xo = (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)t * g.Hi + 2 * a) * g.Wi + 4 * m;
     float4 mk[2], old[2];
-    if (signbits) {             // the producer's ReLU mask as one byte per thread (written by the forward kernel)
-        const unsigned bits = signbits[(((int64_t)bc * g.Ti + t) * H2 + a) * W4 + m];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            mk[i] = make_float4((float)((bits >> (i * 4)) & 1u), (float)((bits >> (i * 4 + 1)) & 1u), (float)((bits >> (i * 4 + 2)) & 1u),
-                                (float)((bits >> (i * 4 + 3)) & 1u));
-    }
+    // the producer's ReLU mask as one byte per thread (written by the forward kernel): loaded here, expanded only after the
+    // gradient loads below have been issued (expanding it here put a full s_waitcnt in front of them)
+    unsigned signbyte = 0u;
+    if (signbits) signbyte = signbits[(((int64_t)bc * g.Ti + t) * H2 + a) * W4 + m];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         if (!signbits) mk[i] = (!XH && emask) ? *reinterpret_cast<const float4*>(emask + xo + i * g.Wi) : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -984,6 +989,12 @@ __global__ __launch_bounds__(256) void maxpoolk33_s2_bwd_kernel(const float* __r
         s1.z += hit(1, 2, 3) + hit(1, 1, 5);
         s1.w += hit(1, 2, 4);
     }
+    if (signbits) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            mk[i] = make_float4((float)((signbyte >> (i * 4)) & 1u), (float)((signbyte >> (i * 4 + 1)) & 1u),
+                                (float)((signbyte >> (i * 4 + 2)) & 1u), (float)((signbyte >> (i * 4 + 3)) & 1u));
+    }
     if (emask || signbits) {
         const float esc = escale[c];
         s0.x = mk[0].x > 0.f ? s0.x * esc : 0.f; s0.y = mk[0].y > 0.f ? s0.y * esc : 0.f;
@@ -1029,12 +1040,14 @@ __global__ __launch_bounds__(256) void maxpool133_s2_w8_fwd_kernel(const float* 
     bool rin[3];
 #pragma unroll
     for (int dh = 0; dh < 3; ++dh) {
-        rin[dh] = 2 * ho + dh < g.Hi;
-        const unsigned short* r = xh + (int64_t)dh * g.Wi;
-        const uint4 w = rin[dh] ? *reinterpret_cast<const uint4*>(r) : make_uint4(0u, 0u, 0u, 0u);
+        rin[dh] = 2 * ho + dh < g.Hi;          // loads from clamped addresses, masked afterwards: all six in flight together
+        const unsigned short* r = xh + (rin[dh] ? dh * g.Wi : 0);
+        uint4 w = *reinterpret_cast<const uint4*>(r);
+        const unsigned keep = rin[dh] ? ~0u : 0u;
+        w.x &= keep; w.y &= keep; w.z &= keep; w.w &= keep;
         v[dh][0] = h2f_lo(w.x); v[dh][1] = h2f_hi(w.x); v[dh][2] = h2f_lo(w.y); v[dh][3] = h2f_hi(w.y);
         v[dh][4] = h2f_lo(w.z); v[dh][5] = h2f_hi(w.z); v[dh][6] = h2f_lo(w.w); v[dh][7] = h2f_hi(w.w);
-        v[dh][8] = (rin[dh] && cin) ? h2f_lo(r[8]) : 0.f;
+        v[dh][8] = h2f_lo((unsigned)r[cin ? 8 : 0] & ((rin[dh] && cin) ? 0xffffu : 0u));
     }
     float best[4];
     int win[4];
@@ -1066,6 +1079,80 @@ __global__ __launch_bounds__(256) void maxpool133_s2_w8_fwd_kernel(const float* 
     }
 }
 
+// The same forward for inputs that are NON-NEGATIVE (the output of a conv + ReLU: what all three strided pools of the
+// backbone read; the caller says so, io bit 2).  For non-negative bf16 values the BIT PATTERNS are ordered keys, so a window's
+// scan collapses into unsigned maxima of composites (bits << 16 | 15 - tap): the larger value wins, equal values keep the
+// EARLIER tap (the larger low field) -- exactly the first-maximum rule of scan_tap -- and the padding (zeros that are never
+// larger than tap 0, which is always inside) can never win, so no winner is 255.  Per output 9 v_lshl_or / v_and_or + 4
+// v_max3_u32 instead of 9 x (compare, NaN compare, two selects): 298 -> ~150 VALU instructions per thread, same bytes.
+// A -0.0 (which a ReLU does not produce) is read as +0.0; NaN cannot occur behind fmaxf(x, 0).  Winners, values and sign bits
+// are bit-identical to maxpool133_s2_w8_fwd_kernel on such inputs (tests/test_half_chain_gpu.py).
+typedef unsigned short pool_u16x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void maxpool133_s2_w8_nn_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                      unsigned char* __restrict__ arg, PoolGeom g, FastDiv fW4,
+                                                                      unsigned char* __restrict__ signbits) {
+    const int W4 = g.Wo >> 2;
+    const int p4 = blockIdx.x * 256 + threadIdx.x;
+    if (p4 >= g.To * g.Ho * W4) return;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    const uint32_t q = fd_div(fW4, p4);
+    const int m = p4 - q * W4;
+    const uint32_t t = fd_div(g.fHo, q);
+    const int ho = q - t * g.Ho;
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(x) + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs +
+                               ((int64_t)t * g.Hi + 2 * ho) * g.Wi + 8 * m;
+    const bool cin = 8 * m + 8 < g.Wi;                 // the ninth column exists (else it is the zero pad)
+    unsigned W[3][5];                                   // four words of two columns each + the ninth column (low half)
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+        // branch-free: a row / column outside the tensor is read from a clamped address and masked to the zero pad, so the six
+        // loads of a thread are all in flight together (a conditional load costs one exposed memory round trip EACH)
+        const bool rin = 2 * ho + dh < g.Hi;
+        const unsigned short* r = xh + (rin ? dh * g.Wi : 0);
+        const uint4 w = *reinterpret_cast<const uint4*>(r);
+        const unsigned keep = rin ? 0x7fff7fffu : 0u;
+        W[dh][0] = w.x & keep; W[dh][1] = w.y & keep; W[dh][2] = w.z & keep; W[dh][3] = w.w & keep;
+        W[dh][4] = (unsigned)r[cin ? 8 : 0] & ((rin && cin) ? 0x7fffu : 0u);
+    }
+    unsigned best[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        unsigned rowmax[3];
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const unsigned c0 = (W[dh][o] << 16) | (unsigned)(15 - (dh * 3 + 0));
+            const unsigned c1 = (W[dh][o] & 0xffff0000u) | (unsigned)(15 - (dh * 3 + 1));
+            const unsigned c2 = (W[dh][o + 1] << 16) | (unsigned)(15 - (dh * 3 + 2));
+            rowmax[dh] = max(max(c0, c1), c2);
+        }
+        best[o] = max(max(rowmax[0], rowmax[1]), rowmax[2]);
+    }
+    const int p = ((int)t * g.Ho + ho) * g.Wo + 4 * m;
+    // values: the high halves of the composites; winners: 15 - low nibble (no byte exceeds 15: no borrow between bytes)
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(y) + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs + p) =
+        make_uint2(__builtin_amdgcn_perm(best[1], best[0], 0x07060302u), __builtin_amdgcn_perm(best[3], best[2], 0x07060302u));
+    const unsigned lows = __builtin_amdgcn_perm(best[1], best[0], 0x0c0c0400u) | __builtin_amdgcn_perm(best[3], best[2], 0x04000c0cu);
+    *reinterpret_cast<unsigned*>(arg + (int64_t)bc * g.To * g.Ho * g.Wo + p) = 0x0f0f0f0fu - lows;
+    if (signbits) {             // rows 2 ho, 2 ho + 1, columns 8m .. 8m+7: two of the 2 x 4 blocks, adjacent bytes
+        unsigned rowbits[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned acc = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const pool_u16x2 one = {1, 1};
+                const unsigned f = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(pool_u16x2, W[i][k]), one));
+                acc |= ((f | (f >> 15)) & 3u) << (2 * k);       // bit 2k: column 2k > 0, bit 2k+1: column 2k+1 > 0
+            }
+            rowbits[i] = acc;
+        }
+        const unsigned b0 = (rowbits[0] & 15u) | ((rowbits[1] & 15u) << 4), b1 = (rowbits[0] >> 4) | (rowbits[1] & 0xf0u);
+        *reinterpret_cast<unsigned short*>(signbits + (((int64_t)bc * g.Ti + (int)t) * (g.Hi >> 1) + ho) * (g.Wi >> 2) + 2 * m) =
+            (unsigned short)(b0 | (b1 << 8));
+    }
+}
+
 __global__ __launch_bounds__(256) void maxpool133_s2_w8_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
                                                                    float* __restrict__ dx, PoolGeom g, const float* __restrict__ escale,
                                                                    FastDiv fW8, FastDiv fH2, const unsigned char* __restrict__ signbits) {
@@ -1088,19 +1175,22 @@ __global__ __launch_bounds__(256) void maxpool133_s2_w8_bwd_kernel(const float* 
     int A[2][5];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
+        // clamped addresses + bit masks (not selects, which the compiler turns into a branch around the load with a full wait
+        // behind it): the eight loads of a thread are in flight together
         const int ho = a - 1 + r;
         const bool rin = ho >= 0;
-        const int o = rin ? ho * g.Wo + 4 * m : 0;
-        const uint2 d4 = *reinterpret_cast<const uint2*>(dyh + o);
-        const unsigned t4 = *reinterpret_cast<const unsigned*>(ab + o);
+        const int o = max(ho, 0) * g.Wo + 4 * m;
+        const unsigned keep = rin ? ~0u : 0u;
+        uint2 d4 = *reinterpret_cast<const uint2*>(dyh + o);
+        d4.x &= keep; d4.y &= keep;
+        const unsigned t4 = *reinterpret_cast<const unsigned*>(ab + o) | ~keep;
         const bool lin = rin && m > 0;
-        const float d0 = h2f_lo(dyh[lin ? o - 1 : o]);
-        const int t0 = ab[lin ? o - 1 : o];
-        D[r][0] = lin ? d0 : 0.f;          A[r][0] = lin ? t0 : 255;
-        D[r][1] = rin ? h2f_lo(d4.x) : 0.f; A[r][1] = rin ? (int)(t4 & 255u) : 255;
-        D[r][2] = rin ? h2f_hi(d4.x) : 0.f; A[r][2] = rin ? (int)((t4 >> 8) & 255u) : 255;
-        D[r][3] = rin ? h2f_lo(d4.y) : 0.f; A[r][3] = rin ? (int)((t4 >> 16) & 255u) : 255;
-        D[r][4] = rin ? h2f_hi(d4.y) : 0.f; A[r][4] = rin ? (int)(t4 >> 24) : 255;
+        const int ol = o - (m > 0 ? 1 : 0);
+        D[r][0] = h2f_lo((unsigned)dyh[ol] & (lin ? 0xffffu : 0u)); A[r][0] = (int)((unsigned)ab[ol] | (lin ? 0u : 255u));
+        D[r][1] = h2f_lo(d4.x); A[r][1] = (int)(t4 & 255u);
+        D[r][2] = h2f_hi(d4.x); A[r][2] = (int)((t4 >> 8) & 255u);
+        D[r][3] = h2f_lo(d4.y); A[r][3] = (int)((t4 >> 16) & 255u);
+        D[r][4] = h2f_hi(d4.y); A[r][4] = (int)(t4 >> 24);
     }
     auto hit = [&](int r, int k, int tap) { return A[r][k] == tap ? D[r][k] : 0.f; };
     float s[2][8];
@@ -1186,6 +1276,8 @@ int bwd_planes(const PoolGeom& g, int& tlo_max, size_t& lds) {
 static int pool_fwd(const int* geom, const int64_t* strides, const float* x, float* y, unsigned char* argtap,
                     unsigned char* signbits, void* stream, int io = 0) {
     if (!geom || !strides || !x || !y || !argtap) return OTAL_E_NULL;
+    const bool nonneg = (io & 4) != 0;      // the caller guarantees x >= +0 (a conv + ReLU output): ordered-key kernels
+    io &= 3;
     if (io != 0 && io != 1 && io != 3) return OTAL_E_UNSUPPORTED;
     PoolGeom g;
     if (int e = fill(g, geom, strides)) return e;
@@ -1199,8 +1291,12 @@ static int pool_fwd(const int* geom, const int64_t* strides, const float* x, flo
             (reinterpret_cast<uintptr_t>(argtap) & 3) == 0 && (!signbits || (reinterpret_cast<uintptr_t>(signbits) & 1) == 0) &&
             !OTAL_OPT("OTAL_POOL_NOW8", 0)) {           // eight input columns per thread
             const int n4 = g.To * g.Ho * (g.Wo / 4);
-            hipLaunchKernelGGL(maxpool133_s2_w8_fwd_kernel, dim3((n4 + 255) / 256, g.B * g.C), dim3(256), 0, st_, x, y, argtap, g,
-                               make_fastdiv((uint32_t)(g.Wo / 4)), signbits);
+            if (nonneg && !OTAL_OPT("OTAL_POOL_NOKEYS", 0))
+                hipLaunchKernelGGL(maxpool133_s2_w8_nn_fwd_kernel, dim3((n4 + 255) / 256, g.B * g.C), dim3(256), 0, st_, x, y, argtap, g,
+                                   make_fastdiv((uint32_t)(g.Wo / 4)), signbits);
+            else
+                hipLaunchKernelGGL(maxpool133_s2_w8_fwd_kernel, dim3((n4 + 255) / 256, g.B * g.C), dim3(256), 0, st_, x, y, argtap, g,
+                                   make_fastdiv((uint32_t)(g.Wo / 4)), signbits);
         } else if (io == 3) {   // bf16 in, bf16 out
             if (kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_fwd_kernel<1, true, true>), grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);
             else hipLaunchKernelGGL((maxpoolk33_s2_fwd_kernel<3, true, true>), grid, dim3(256), 0, st_, x, y, argtap, g, fW2, signbits);

@@ -164,3 +164,24 @@ def test_storage_conversion_of_channel_slices():
     assert torch.equal(big[:, 8:48], x.to(BF)) and float(big[:, :8].abs().max()) == 0 and float(big[:, 48:].abs().max()) == 0
     back = ops.convert_storage(big[:, 8:48], torch.float32)
     assert back.dtype == torch.float32 and torch.equal(back, x.to(BF).float())
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 6, 48, 48), (1, 8, 4, 24, 24), (1, 3, 2, 16, 8), (2, 4, 3, 48, 96)])
+def test_ordered_key_pool_equals_the_scanning_kernel_on_relu_outputs(shape):
+    """Round 5: for the output of a conv + ReLU -- what MaxPool3d_2a / 3a read -- the (1,3,3)/(1,2,2) pool
+    runs on ordered integer keys (io bit 2).  Values, winner bytes and sign bits must be those of the scanning kernel, ties
+    included (half of the inputs are exact zeros, the rest bf16 values with many equal neighbours), at plane borders (SAME
+    padding = a zero row / column that may tie with real zeros) and on channel slices."""
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape))
+    x = torch.relu(_t(rs, *shape)).to(BF)
+    x = (x * 4).round() / 4                                     # few distinct values: ties inside most windows
+    x = x.to(BF)
+    k, s = (1, 3, 3), (1, 2, 2)
+    y0, a0, b0 = ops.maxpool3d_forward(x, k, s, signbits=True, half_out=True)
+    xv = _sliced(x, 8, 8)
+    y1, a1, b1 = ops.maxpool3d_forward(xv, k, s, signbits=True, half_out=True, nonneg=True)
+    assert y1.dtype == BF and torch.equal(y1, y0) and torch.equal(a1, a0) and torch.equal(b1, b0)
+    assert int((a1 == 255).sum()) == 0                          # the padding never wins over a non-negative tap 0
+    ref = torch.nn.functional.max_pool3d(torch.nn.functional.pad(x.float(), (0, 1, 0, 1, 0, 0)), k, s)
+    assert torch.equal(y1.float(), ref)
