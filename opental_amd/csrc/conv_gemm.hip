@@ -1758,10 +1758,47 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
     const int64_t total = (int64_t)a.M * a.N;
     struct alignas(4 * V) vec_t { float f[V]; };
     for (int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V; base < total; base += (int64_t)gridDim.x * 256 * V) {
+        // ---- where the V results go and the epilogue operands they need -- issued BEFORE the slab loads and not touched until
+        // the sums exist: these launches are a few microseconds long, and an operand fetched where it is used (scale, shift,
+        // ReLU mask: up to three dependent loads per element behind the slab loads) is a memory round trip each
+        int mm[V], nn[V];
+        int64_t off[V];
+        float sc[V], sh[V];
+        unsigned mraw[V];
+        {
+            const int m0 = (int)(base / a.N);
+            int m = m0, n = (int)(base - (int64_t)m0 * a.N);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                mm[e] = m; nn[e] = n;
+                if (++n == a.N) { n = 0; ++m; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int m = mm[e], n = nn[e];
+            sc[e] = 1.f; sh[e] = 0.f; mraw[e] = 0u;
+            if (MODE == MODE_FWD) {
+                off[e] = conv_out_offset(g, dec_pos_fd(n, a.fd.To, a.fd.Ho, a.fd.Wo), m);
+                if (a.scale) sc[e] = a.scale[m];
+                if (a.shift) sh[e] = a.shift[m];
+            } else if (MODE == MODE_DGRAD) {
+                off[e] = conv_in_offset(g, dec_pos_fd(n, a.fd.Ti, a.fd.Hi, a.fd.Wi), m);
+                if (a.emask) {
+                    sc[e] = a.escale[m];
+                    if constexpr (H) mraw[e] = reinterpret_cast<const unsigned short*>(a.emask)[off[e]];
+                    else mraw[e] = __float_as_uint(a.emask[off[e]]);
+                }
+            } else if (a.flags & EPI_NPAD8) {
+                off[e] = (int64_t)m * ((a.N >> 3) * g.kw) + (n >> 3) * g.kw + (n & 7);
+            } else {
+                off[e] = base + e;
+            }
+        }
         float acc[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] = 0.f;
-        for (int s0 = 0; s0 < a.splits; s0 += 8) {
+        auto add8 = [&](int s0) __attribute__((always_inline)) {
             vec_t tmp[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1774,28 +1811,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < V; ++e) acc[e] += tmp[u].f[e];
                 }
-        }
+        };
+        add8(0);                                                     // peeled: no loop header (= full wait) between the operand loads and these
+        for (int s0 = 8; s0 < a.splits; s0 += 8) add8(s0);
+#pragma unroll
+        for (int e = 0; e < V; ++e) asm volatile("" : "+v"(sc[e]), "+v"(sh[e]), "+v"(mraw[e]));   // keeps the compiler from moving the operands' first use (a compare) up to the loads
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const int64_t idx = base + e;
-            const int m = (int)(idx / a.N), n = (int)(idx - (int64_t)m * a.N);
             float v = acc[e];
-            int64_t off;
             if (MODE == MODE_FWD) {
-                if (a.scale) v *= a.scale[m];
-                if (a.shift) v += a.shift[m];
+                if (a.scale) v *= sc[e];
+                if (a.shift) v += sh[e];
                 if (a.flags & EPI_RELU) v = fmaxf(v, 0.f);
-                off = conv_out_offset(g, dec_pos_fd(n, a.fd.To, a.fd.Ho, a.fd.Wo), m);
             } else if (MODE == MODE_DGRAD) {
-                off = conv_in_offset(g, dec_pos_fd(n, a.fd.Ti, a.fd.Hi, a.fd.Wi), m);
-                if (a.emask) v = relu_mask_at<H>(a, off) ? v * a.escale[m] : 0.f;
+                if (a.emask) {
+                    const bool pos = H ? bf16_pos((unsigned short)mraw[e]) : __uint_as_float(mraw[e]) > 0.f;
+                    v = pos ? v * sc[e] : 0.f;
+                }
             } else if (a.flags & EPI_NPAD8) {
-                if ((n & 7) >= g.kw) continue;
-                off = (int64_t)m * ((a.N >> 3) * g.kw) + (n >> 3) * g.kw + (n & 7);
-            } else {
-                off = idx;
+                if ((nn[e] & 7) >= g.kw) continue;
             }
-            reduce_store<H>(a, off, v);
+            reduce_store<H>(a, off[e], v);
         }
     }
 }
@@ -2737,7 +2773,39 @@ __global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const ConvArgs a, int
     const float* dyb = pdy + (int64_t)b * g.y_bs + t0;
     const float* xb = px + (int64_t)b * g.x_bs + t0;
     __syncthreads();            // the previous unit's operand reads are done
+    // halo: x[t0 - 1] at element 7, x[t0 + 128] at element 136 (pairs written whole: 6|7 and 136|137) -- fetched first (clamped
+    // address, masked at the store below) so that it travels with the tile loads instead of one more round trip behind them
+    unsigned halo_raw = 0u, halo_keep = 0u;
+    if (tid < 128) {
+        const int r = tid & 63, u = (tid >> 6) ? t0 + W1_TC : t0 - 1;
+        const bool ok = ci0 + r < g.Cin && u >= 0 && u < T;
+        halo_keep = ok ? ~0u : 0u;
+        halo_raw = __float_as_uint(px[(int64_t)b * g.x_bs + (int64_t)min(ci0 + r, g.Cin - 1) * g.x_cs + (ok ? u : 0)]);
+    }
     // ---- stage dy (64 rows x 128 positions) and x (+ 8 elements of left pad, of which the last is the halo x[t0 - 1])
+    if ((T & 1) == 0) {
+        // even T (every map of the models): a position pair is inside or outside as a whole.  All 32 loads of a thread are
+        // issued from CLAMPED addresses before the first value is touched and rows / pairs outside the tensors are masked
+        // afterwards -- with `if (inside) load` the compiler emitted a branch and a full s_waitcnt per load: 32 dependent
+        // memory round trips per workgroup, most of this kernel's ~28 us (tools/isa_loads.sh)
+        const int tl = (tid & 63) * 2, r0 = tid >> 6;
+        const bool in = t0 + tl < T;
+        const int tlc = in ? tl : 0;                         // (t0 < T: position t0 exists)
+        uint2 dv[16], xv[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = r0 + 4 * it;
+            dv[it] = *reinterpret_cast<const uint2*>(dyb + (int64_t)min(co0 + r, g.Cout - 1) * g.y_cs + tlc);
+            xv[it] = *reinterpret_cast<const uint2*>(xb + (int64_t)min(ci0 + r, g.Cin - 1) * g.x_cs + tlc);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = r0 + 4 * it;
+            const unsigned kd = (in && co0 + r < g.Cout) ? ~0u : 0u, kx = (in && ci0 + r < g.Cin) ? ~0u : 0u;
+            *reinterpret_cast<unsigned*>(sdy + r * W1_PITCH + tl * 2) = cvt_pk_bf16(__uint_as_float(dv[it].x & kd), __uint_as_float(dv[it].y & kd));
+            *reinterpret_cast<unsigned*>(sx + r * W1_PITCH + (8 + tl) * 2) = cvt_pk_bf16(__uint_as_float(xv[it].x & kx), __uint_as_float(xv[it].y & kx));
+        }
+    } else
     for (int idx = tid; idx < 64 * 64; idx += 256) {
         const int r = idx >> 6, tl = (idx & 63) * 2;
         const bool rowd = co0 + r < g.Cout, rowx = ci0 + r < g.Cin;
@@ -2750,11 +2818,9 @@ __global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const ConvArgs a, int
         *reinterpret_cast<unsigned*>(sdy + r * W1_PITCH + tl * 2) = cvt_pk_bf16(d.x, d.y);
         *reinterpret_cast<unsigned*>(sx + r * W1_PITCH + (8 + tl) * 2) = cvt_pk_bf16(v.x, v.y);
     }
-    if (tid < 128) {        // halo: x[t0 - 1] at element 7, x[t0 + 128] at element 136 (pairs written whole: 6|7 and 136|137)
+    if (tid < 128) {
         const int r = tid & 63, right = tid >> 6;
-        const int u = right ? t0 + W1_TC : t0 - 1;
-        const bool ok = ci0 + r < g.Cin && u >= 0 && u < T;
-        const float v = ok ? px[(int64_t)b * g.x_bs + (int64_t)(ci0 + r) * g.x_cs + u] : 0.f;
+        const float v = __uint_as_float(halo_raw & halo_keep);
         *reinterpret_cast<unsigned*>(sx + r * W1_PITCH + (right ? 136 : 6) * 2) = right ? cvt_pk_bf16(v, 0.f) : cvt_pk_bf16(0.f, v);
     }
     if (tid < W1_TC / 2) {  // a tap shifted by -1 is cut where t starts a level, one shifted by +1 where t ends one

@@ -47,6 +47,15 @@ __device__ __forceinline__ void for_level(int lane, int nlanes, int cpg, int len
     }
 }
 
+// global -> LDS copy of a group's map (n floats) by the whole workgroup: float4 pieces when the source is 16-byte aligned
+__device__ __forceinline__ void stage_map(float* dst, const float* __restrict__ src, int n, int tid) {
+    if (((reinterpret_cast<uintptr_t>(src) | (uintptr_t)(n * 4)) & 15) == 0) {
+        for (int i = tid; i < (n >> 2); i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    } else {
+        for (int i = tid; i < n; i += 256) dst[i] = src[i];
+    }
+}
+
 // x,y: (B,C,T); stats out: (B,G,nlev,2) = {mean, rstd}
 // (pair launches, otal_gn_relu_*_pair: grid.y = 2 and `alt` carries the second problem's tensors -- same shapes and options)
 struct GnFwdAlt { const float* x; const float* gamma; const float* beta; float* y; float* stats; };
@@ -65,8 +74,13 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
     float* bet = gam + cpg;
     const int64_t base = ((int64_t)b * C + (int64_t)g * cpg) * T;
     const int n = cpg * T;
-    if (tid < cpg) { gam[tid] = gamma[g * cpg + tid]; bet[tid] = beta[g * cpg + tid]; }
-    for (int i = tid; i < n; i += 256) buf[i] = x[base + i];
+    // (one workgroup per (sample, group), a few microseconds long: every dependent memory round trip counts.  The affine
+    //  parameters are fetched into registers and parked in LDS only AFTER the map's loads have been issued, and the map
+    //  travels as 16-byte pieces where its alignment allows)
+    float gv = 0.f, bv = 0.f;
+    if (tid < cpg) { gv = gamma[g * cpg + tid]; bv = beta[g * cpg + tid]; }
+    stage_map(buf, x + base, n, tid);
+    if (tid < cpg) { gam[tid] = gv; bet[tid] = bv; }
     __syncthreads();
     if (L.nlev == 1) {          // one level: the whole workgroup reduces it
         const int cnt = n;
@@ -122,33 +136,65 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ stats, float* __restrict__ dx,
                                                           float* __restrict__ partial, int C, int T, int G, int relu,
-                                                          GnLevels L, int64_t dy_bs, GnBwdAlt alt) {
+                                                          GnLevels L, int64_t dy_bs, int keep_dx, GnBwdAlt alt) {
     if (blockIdx.y) { dy = alt.dy; x = alt.x; gamma = alt.gamma; beta = alt.beta; stats = alt.stats; dx = alt.dx; partial = alt.partial; dy_bs = alt.dy_bs; }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int cpg = C / G;
     float* xb = reinterpret_cast<float*>(smem);          // x, later xhat
     float* gb = xb + (size_t)cpg * T;                    // dy masked (dyh), later dx
-    float* red = gb + (size_t)cpg * T;                   // 8 floats
+    // keep_dx: a third array holds dx for the channel sums at the end (the host sets it when the LDS allows; otherwise those
+    // sums re-read dx from global memory: four dependent round trips per wave at the tail of a latency-bound kernel)
+    float* dxl = gb + (size_t)cpg * T;
+    float* red = dxl + (keep_dx ? (size_t)cpg * T : 0);  // 8 floats
     float* gam = red + 8;                                // the group's affine parameters
     float* bet = gam + cpg;
     const int tid = threadIdx.x;
     const int b = blockIdx.x / G, g = blockIdx.x % G;
     const int64_t base = ((int64_t)b * C + (int64_t)g * cpg) * T;
     const int n = cpg * T;
-    if (tid < cpg) { gam[tid] = gamma[g * cpg + tid]; bet[tid] = beta[g * cpg + tid]; }
+    float gv = 0.f, bv = 0.f;                                               // (see the forward: registers first, LDS after the map loads)
+    if (tid < cpg) { gv = gamma[g * cpg + tid]; bv = beta[g * cpg + tid]; }
     const int64_t dbase = (int64_t)b * dy_bs + (int64_t)g * cpg * T;         // dy may be a channel slice of a wider map
-    for (int i = tid; i < n; i += 256) { xb[i] = x[base + i]; gb[i] = dy[dbase + i]; }
-    __syncthreads();
     // level l is handled by the whole workgroup when it is the only one, else by wave l % 4 on its own (see the forward)
     const bool solo = L.nlev == 1;
     const int wv = tid >> 6, ln = tid & 63;
     const int first = solo ? tid : ln, stride = solo ? 256 : 64;
+    // the statistics of this wave's levels (at most GN_LPW = 2 per wave for the six-level map; further ones are fetched in the
+    // loop): fetched together with the maps, not one dependent round trip per level behind the barrier
+    constexpr int GN_LPW = 2;
+    float2 st_pre[GN_LPW];
+#pragma unroll
+    for (int k = 0; k < GN_LPW; ++k) {
+        const int l = (solo ? 0 : wv) + k * (solo ? 1 : 4);
+        st_pre[k] = make_float2(0.f, 0.f);
+        if (l < L.nlev) {
+            st_pre[k].x = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 0];
+            st_pre[k].y = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 1];
+        }
+    }
+    if (((reinterpret_cast<uintptr_t>(x + base) | reinterpret_cast<uintptr_t>(dy + dbase) | (uintptr_t)(n * 4)) & 15) == 0) {
+        for (int i = tid; i < (n >> 2); i += 256) {          // both maps in one trip: their loads are in flight together
+            const float4 xv = reinterpret_cast<const float4*>(x + base)[i], dv = reinterpret_cast<const float4*>(dy + dbase)[i];
+            reinterpret_cast<float4*>(xb)[i] = xv;
+            reinterpret_cast<float4*>(gb)[i] = dv;
+        }
+    } else {
+        for (int i = tid; i < n; i += 256) { xb[i] = x[base + i]; gb[i] = dy[dbase + i]; }
+    }
+    if (tid < cpg) { gam[tid] = gv; bet[tid] = bv; }
+    __syncthreads();
+    int kl = 0;
 #pragma unroll 1
-    for (int l = solo ? 0 : wv; l < L.nlev; l += solo ? 1 : 4) {
+    for (int l = solo ? 0 : wv; l < L.nlev; l += solo ? 1 : 4, ++kl) {
         const int lo = L.lev[l], len = L.lev[l + 1] - lo;
         const int cnt = cpg * len;
-        const float mean = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 0];
-        const float rstd = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 1];
+        float mean, rstd;
+        if (kl == 0) { mean = st_pre[0].x; rstd = st_pre[0].y; }
+        else if (kl == 1) { mean = st_pre[1].x; rstd = st_pre[1].y; }
+        else {
+            mean = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 0];
+            rstd = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 1];
+        }
         float s1 = 0.f, s2 = 0.f;
         for_level(first, stride, cpg, len, [&](int c, int t) {
             const int p = c * T + lo + t;
@@ -174,6 +220,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
             const int p = c * T + lo + t;
             const float v = rstd * (gb[p] * gam[c] - m1 - xb[p] * m2);
             dx[base + (int64_t)c * T + lo + t] = v;
+            if (keep_dx) dxl[p] = v;
         });
     }
     __syncthreads();            // xb / gb of every level (and the dx stores the sums below re-read) are complete
@@ -186,7 +233,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
             const float d = gb[c * T + t], xh = xb[c * T + t];
             a0 += d * xh;
             a1 += d;
-            a2 += dx[base + (int64_t)c * T + t];
+            a2 += keep_dx ? dxl[c * T + t] : dx[base + (int64_t)c * T + t];
         }
         a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
         if (lane == 0) {
@@ -259,12 +306,14 @@ extern "C" int otal_gn_relu_bwd(const float* dy, int64_t dy_batch_stride, const 
     if (dy_batch_stride < (int64_t)C * T) return OTAL_E_SHAPE;
     GnLevels L;
     if (int e = fill_levels(L, T, nlev, lev)) return e;
-    const size_t lds = (size_t)(C / G) * T * 8 + 64 + (size_t)(C / G) * 8;
+    size_t lds = (size_t)(C / G) * T * 12 + 64 + (size_t)(C / G) * 8;
+    const int keep_dx = lds <= LDS_MAX;
+    if (!keep_dx) lds -= (size_t)(C / G) * T * 4;
     if (lds > LDS_MAX) return OTAL_E_UNSUPPORTED;
     static bool large_ok = false;
     if (int e = allow_large_lds(gn_relu_bwd_kernel, lds, large_ok)) return e;
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(256), lds, (hipStream_t)stream,
-                       dy, x, gamma, beta, stats, dx, partial, C, T, G, relu, L, dy_batch_stride, GnBwdAlt{});
+                       dy, x, gamma, beta, stats, dx, partial, C, T, G, relu, L, dy_batch_stride, keep_dx, GnBwdAlt{});
     return otal_launch_status();
 }
 
@@ -282,11 +331,13 @@ extern "C" int otal_gn_relu_bwd_pair(const float* const* dy, const int64_t* dy_b
     if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G) return OTAL_E_SHAPE;
     GnLevels L;
     if (int e = fill_levels(L, T, nlev, lev)) return e;
-    const size_t lds = (size_t)(C / G) * T * 8 + 64 + (size_t)(C / G) * 8;
+    size_t lds = (size_t)(C / G) * T * 12 + 64 + (size_t)(C / G) * 8;
+    const int keep_dx = lds <= 64 * 1024;
+    if (!keep_dx) lds -= (size_t)(C / G) * T * 4;
     if (lds > 64 * 1024) return OTAL_E_UNSUPPORTED;
     const GnBwdAlt alt = {dy[1], x[1], gamma[1], beta[1], stats[1], dx[1], partial[1], bs[1]};
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G, 2), dim3(256), lds, (hipStream_t)stream,
-                       dy[0], x[0], gamma[0], beta[0], stats[0], dx[0], partial[0], C, T, G, relu, L, bs[0], alt);
+                       dy[0], x[0], gamma[0], beta[0], stats[0], dx[0], partial[0], C, T, G, relu, L, bs[0], keep_dx, alt);
     return otal_launch_status();
 }
 

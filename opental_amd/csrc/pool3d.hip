@@ -59,33 +59,69 @@ __device__ __forceinline__ unsigned f2h_pair_rne(float lo, float hi) {        //
 }
 // a run of N (even) consecutive elements of a fp32 / bf16 tensor <-> registers; `base` is the tensor seen as float*,
 // `off` the ELEMENT offset of the run (a multiple of VW; the caller guarantees the alignment of VW elements)
+// `ok` false: the run reads as zeros.  The address must be VALID either way (callers clamp it): the load is unconditional and
+// the value is masked afterwards -- `ok ? load : 0` makes the compiler put every load into its own branch with a full
+// s_waitcnt behind it, one exposed memory round trip per piece (tools/isa_loads.sh shows it).
 template <int N, int VW, bool H>
 __device__ __forceinline__ void load_run(const float* base, int64_t off, bool ok, float (&a)[N]) {
     static_assert(VW == 4 || VW == 2, "vector width");
+    const unsigned keep = ok ? ~0u : 0u;
     if constexpr (H) {
         const unsigned short* src = reinterpret_cast<const unsigned short*>(base) + off;
 #pragma unroll
         for (int q = 0; q < N / VW; ++q) {
             if constexpr (VW == 4) {
-                const uint2 t = ok ? *reinterpret_cast<const uint2*>(src + 4 * q) : make_uint2(0u, 0u);
+                uint2 t = *reinterpret_cast<const uint2*>(src + 4 * q);
+                t.x &= keep; t.y &= keep;
                 a[4 * q] = h2f_lo(t.x); a[4 * q + 1] = h2f_hi(t.x); a[4 * q + 2] = h2f_lo(t.y); a[4 * q + 3] = h2f_hi(t.y);
             } else {
-                const unsigned t = ok ? *reinterpret_cast<const unsigned*>(src + 2 * q) : 0u;
+                const unsigned t = *reinterpret_cast<const unsigned*>(src + 2 * q) & keep;
                 a[2 * q] = h2f_lo(t); a[2 * q + 1] = h2f_hi(t);
             }
         }
     } else {
-        const float* src = base + off;
+        const unsigned* src = reinterpret_cast<const unsigned*>(base + off);
 #pragma unroll
         for (int q = 0; q < N / VW; ++q) {
             if constexpr (VW == 4) {
-                const float4 t4 = ok ? *reinterpret_cast<const float4*>(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                a[4 * q] = t4.x; a[4 * q + 1] = t4.y; a[4 * q + 2] = t4.z; a[4 * q + 3] = t4.w;
+                const uint4 t4 = *reinterpret_cast<const uint4*>(src + 4 * q);
+                a[4 * q] = __uint_as_float(t4.x & keep); a[4 * q + 1] = __uint_as_float(t4.y & keep);
+                a[4 * q + 2] = __uint_as_float(t4.z & keep); a[4 * q + 3] = __uint_as_float(t4.w & keep);
             } else {
-                const float2 t2 = ok ? *reinterpret_cast<const float2*>(src + 2 * q) : make_float2(0.f, 0.f);
-                a[2 * q] = t2.x; a[2 * q + 1] = t2.y;
+                const uint2 t2 = *reinterpret_cast<const uint2*>(src + 2 * q);
+                a[2 * q] = __uint_as_float(t2.x & keep); a[2 * q + 1] = __uint_as_float(t2.y & keep);
             }
         }
+    }
+}
+// the same run as RAW words: loaded now, unpacked where it is used -- any arithmetic on a loaded value (even the bf16 -> fp32
+// shift) inside a conditional block makes the compiler wait for the load at the end of that block
+template <int N, bool H>
+struct RawRun { unsigned w[H ? N / 2 : N]; };
+template <int N, int VW, bool H>
+__device__ __forceinline__ void load_raw(const float* base, int64_t off, RawRun<N, H>& r) {
+    constexpr int NW = H ? N / 2 : N, PW = H ? VW / 2 : VW;        // words in all / per piece
+    const unsigned* src = H ? reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(base) + off)
+                            : reinterpret_cast<const unsigned*>(base + off);
+#pragma unroll
+    for (int q = 0; q < NW / PW; ++q) {
+        if constexpr (PW == 4) {
+            const uint4 t = *reinterpret_cast<const uint4*>(src + 4 * q);
+            r.w[4 * q] = t.x; r.w[4 * q + 1] = t.y; r.w[4 * q + 2] = t.z; r.w[4 * q + 3] = t.w;
+        } else if constexpr (PW == 2) {
+            const uint2 t = *reinterpret_cast<const uint2*>(src + 2 * q);
+            r.w[2 * q] = t.x; r.w[2 * q + 1] = t.y;
+        } else {
+            r.w[q] = src[q];
+        }
+    }
+}
+template <int N, bool H>
+__device__ __forceinline__ void unpack_run(const RawRun<N, H>& r, float (&a)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if constexpr (H) a[i] = (i & 1) ? h2f_hi(r.w[i >> 1]) : h2f_lo(r.w[i >> 1]);
+        else a[i] = __uint_as_float(r.w[i]);
     }
 }
 template <int N, int VW, bool H, bool EXACT>
@@ -727,9 +763,9 @@ __global__ __launch_bounds__(256) void maxpool333_rows_bwd_kernel(const float* _
         }
     };
     // epilogue operands first: their latency hides behind the LDS stages
-    float mk[P], old[P];
-    load_run<P, VW, H>(emask, xoff, inside && emask != nullptr, mk);
-    load_run<P, VW, H>(dx, xoff, inside && accumulate, old);
+    RawRun<P, H> mkr = {}, oldr = {};                                  // (threads outside the tile never use them; xoff is clamped)
+    if (emask) load_raw<P, VW, H>(emask, xoff, mkr);                   // uniform conditions, unconditional loads, no use until the end
+    if (accumulate) load_raw<P, VW, H>(dx, xoff, oldr);
     {   // stage this thread's dy row and tap row
         float d[P];
         const bool in = act && (unsigned)to < (unsigned)g.To;
@@ -741,16 +777,12 @@ __global__ __launch_bounds__(256) void maxpool333_rows_bwd_kernel(const float* _
             if constexpr (P % 4 == 0) {
 #pragma unroll
                 for (int q = 0; q < P / 4; ++q)
-                    reinterpret_cast<unsigned*>(stp + r * TB)[q] = in ? reinterpret_cast<const unsigned*>(ab)[q] : 0xffffffffu;
+                    reinterpret_cast<unsigned*>(stp + r * TB)[q] = reinterpret_cast<const unsigned*>(ab)[q] | (in ? 0u : 0xffffffffu);
             } else {
-                unsigned lo = 0xffffffffu, hi = 0xffffffffu;
-                if (in) {
-                    const unsigned short* a16 = reinterpret_cast<const unsigned short*>(ab);
-                    lo = (unsigned)a16[0] | ((unsigned)a16[1] << 16);
-                    hi = (unsigned)a16[2] | 0xffff0000u;
-                }
-                reinterpret_cast<unsigned*>(stp + r * TB)[0] = lo;
-                reinterpret_cast<unsigned*>(stp + r * TB)[1] = hi;
+                const unsigned short* a16 = reinterpret_cast<const unsigned short*>(ab);    // (clamped address: always readable)
+                const unsigned none = in ? 0u : 0xffffffffu;
+                reinterpret_cast<unsigned*>(stp + r * TB)[0] = ((unsigned)a16[0] | ((unsigned)a16[1] << 16)) | none;
+                reinterpret_cast<unsigned*>(stp + r * TB)[1] = ((unsigned)a16[2] | 0xffff0000u) | none;
             }
         }
     }
@@ -793,7 +825,9 @@ __global__ __launch_bounds__(256) void maxpool333_rows_bwd_kernel(const float* _
         }
     }
     const float esc = emask ? escale[c] : 1.f;
-    float res[P];
+    float res[P], mk[P], old[P];
+    unpack_run<P, H>(mkr, mk);
+    unpack_run<P, H>(oldr, old);
 #pragma unroll
     for (int w = 0; w < P; ++w) {   // through the w stage: row-max cells w + 1 - dw of the same row
         float s_ = 0.f;
