@@ -405,7 +405,7 @@ class I3DFeaturesFunction(Function):
                 # backward pass does not re-read the 4-byte activations only for their sign
                 if chain:
                     # (cur_scale is not None: `cur` is a conv / Inception output behind its ReLU, so >= +0 everywhere)
-                    y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=True, half_out=True, nonneg=cur_scale is not None)
+                    y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=True, half_out=True, nonneg=ops.POOL_KEYS and cur_scale is not None)
                 elif cur_scale is not None:
                     y, arg, bits = ops.maxpool3d_forward(cur, k, s, signbits=True)
                 else:                                       # (a pool that is not behind a conv + ReLU: nothing to mask)

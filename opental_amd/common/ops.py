@@ -1064,6 +1064,11 @@ def _pool_geom(x5, k, s):
     return [B, C, Ti, Hi, Wi, *outs, *k, *s, *pads], tuple(outs)
 
 
+# OTAL_POOL_KEYS=1: the strided pools behind a conv + ReLU take the ordered-key (v_max3_u32) forward kernel.  Bit-identical
+# to the scanning kernel and within +-5 % of it either way once both were freed of their serialized loads: off.
+POOL_KEYS = os.environ.get("OTAL_POOL_KEYS", "0") == "1"
+
+
 def maxpool3d_forward(x, k, s, out=None, signbits=False, half_out=False, nonneg=False):
     """(y, winner bytes) -- with signbits=True (y, winner bytes, sign bits of x or None): the strided 3x3 pools can hand
     the ReLU mask of their input to the backward pass as one bit per element (maxpool3d_backward(out_signbits=...)).

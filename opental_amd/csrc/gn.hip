@@ -229,11 +229,20 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
     for (int c = wave; c < cpg; c += 4) {
         const int ch = g * cpg + c;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int t = lane; t < T; t += 64) {
-            const float d = gb[c * T + t], xh = xb[c * T + t];
-            a0 += d * xh;
-            a1 += d;
-            a2 += keep_dx ? dxl[c * T + t] : dx[base + (int64_t)c * T + t];
+        if (keep_dx) {                                       // (two loops: a pointer select would turn the read into a flat load)
+            for (int t = lane; t < T; t += 64) {
+                const float d = gb[c * T + t], xh = xb[c * T + t];
+                a0 += d * xh;
+                a1 += d;
+                a2 += dxl[c * T + t];
+            }
+        } else {
+            for (int t = lane; t < T; t += 64) {
+                const float d = gb[c * T + t], xh = xb[c * T + t];
+                a0 += d * xh;
+                a1 += d;
+                a2 += dx[base + (int64_t)c * T + t];
+            }
         }
         a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
         if (lane == 0) {

@@ -45,15 +45,28 @@ struct LossArgs {
 constexpr int SCR = 12;             // loc_t0, loc_t1, conf_t, prop_conf_t, iou, prop_loc_t0, prop_loc_t1, ghat, slot, binpos, per, used
 
 // ---- deterministic block reductions ---------------------------------------------------------------
+// The sum is the pairwise halving tree over the thread index (r[t] += r[t + s], s = 512 .. 1) -- the order the first version
+// of this kernel walked with one __syncthreads() per level.  This single-workgroup kernel is a chain of ~250 barriers of
+// sixteen waves (a third of a microsecond each: most of its 111 us), so the tree is now evaluated with THREE: the levels that
+// pair different waves (s >= 64) are summed by wave 0 from LDS in exactly that order, the levels inside a wave by DPP-free
+// shuffles (lane t adds lane t + s).  Bit-identical to the barrier-per-level form.
 __device__ float block_sum(float v, float* red) {
+    static_assert(LT == 1024, "the cross-wave tree below is written for sixteen waves");
     const int t = threadIdx.x;
     __syncthreads();
     red[t] = v;
     __syncthreads();
-    for (int s = LT / 2; s > 0; s >>= 1) {
-        if (t < s) red[t] += red[t + s];
-        __syncthreads();
+    if (t < 64) {
+        float y[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) y[w] = red[w * 64 + t] + red[(w + 8) * 64 + t];         // s = 512
+        const float z0 = y[0] + y[4], z1 = y[1] + y[5], z2 = y[2] + y[6], z3 = y[3] + y[7];  // s = 256
+        float r = (z0 + z2) + (z1 + z3);                                                     // s = 128, 64
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) r += __shfl_down(r, s, 64);                         // s = 32 .. 1 (lane t < s keeps the tree's value)
+        if (t == 0) red[0] = r;
     }
+    __syncthreads();
     const float r = red[0];
     __syncthreads();
     return r;
@@ -350,6 +363,10 @@ __global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
         }
         __syncthreads();
         if (top_m > 0) {
+            // a stage of distance j < 64 exchanges keys inside 64-aligned groups of indices = inside one WAVE (i = t mod LT):
+            // it needs the workgroup barrier only if its keys were written, or will next be read, across waves (the stage
+            // before / after has distance >= 64, or the sort ends); otherwise the wave's own LDS order (+ a wave barrier) is
+            // enough -- 14 workgroup barriers per sort of 1024 keys instead of 55
             for (int k = 2; k <= n2; k <<= 1)
                 for (int j = k >> 1; j > 0; j >>= 1) {
                     for (int i = t; i < n2; i += LT) {
@@ -360,7 +377,9 @@ __global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
                             if ((x > y) == up) { skey[i] = y; skey[ixj] = x; }
                         }
                     }
-                    __syncthreads();
+                    const int jn = j > 1 ? (j >> 1) : k;                 // distance of the next stage (k = the last stage's successor reads everything)
+                    if (j >= 64 || jn >= 64 || (k == n2 && j == 1)) __syncthreads();
+                    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
                 }
             for (int p_ = t; p_ < min(top_m, A); p_ += LT) {
                 const unsigned long long kv = skey[p_];
