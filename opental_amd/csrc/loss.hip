@@ -115,7 +115,14 @@ __device__ Edl edl_row(const float* z, int C, int y, int num_bins) {
     return e;
 }
 
+// ST (EvidenceLoss mode, A * C floats fit the dynamic LDS): the logits of a pass are copied to LDS with coalesced 16-byte loads,
+// every class loop reads them there, the gradient rows are written over them in place (with the IoU-calibration term of the
+// prop_conf pass folded in: same operands, same order of additions as the separate loop below) and leave with coalesced
+// stores.  One anchor per thread reads its C = 21 logits at an 84-byte stride: every one of the ~230 load / store
+// instructions per wave touched 64 different cache lines -- on ONE compute unit that was ~80 of the kernel's 107 us.
+template <bool ST>
 __global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float zl[];       // ST: A * C floats (logits, then gradients, of the current pass)
     __shared__ float red[LT];
     __shared__ float wacc[MAX_BINS];
     __shared__ int icnt[4];
@@ -210,11 +217,21 @@ __global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
             loss_cls[pass] = block_sum(part, red) / norm;
             continue;
         }
+        const bool staged = ST;
+        const int AC = A * C;
+        if constexpr (ST) {      // (16-byte pieces when the tensor allows, the tail and unaligned tensors element-wise)
+            __syncthreads();     // the previous pass's copy-out has read zl
+            const int n4 = (reinterpret_cast<uintptr_t>(logits) & 15) == 0 ? AC >> 2 : 0;
+            for (int q = t; q < n4; q += LT) reinterpret_cast<float4*>(zl)[q] = reinterpret_cast<const float4*>(logits)[q];
+            for (int q = 4 * n4 + t; q < AC; q += LT) zl[q] = logits[q];
+            __syncthreads();
+        }
+        const bool cal = ST && pass == 1 && a.iou_aware;
         for (int i = t; i < A; i += LT) {
             float* s = a.scratch + (size_t)i * SCR;
             const int tgt = (int)s[2 + pass];
             const int y = max(tgt - 1, 0);
-            const Edl e = edl_row(logits + (size_t)i * C, C, y, a.num_bins);
+            const Edl e = edl_row(staged ? zl + (size_t)i * C : logits + (size_t)i * C, C, y, a.num_bins);
             s[7] = e.ghat; s[8] = (float)e.slot; s[9] = (float)e.binpos; s[10] = e.per;
             s_val[i] = e.ghat; s_slot[i] = (unsigned char)e.slot; s_flag[i] = (tgt > 0 && e.binpos) ? 1 : 0;
         }
@@ -238,10 +255,41 @@ __global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
             }
             __syncthreads();
         }
-        float part = 0.f;
+        float part = 0.f, part_cal = 0.f;
         for (int i = t; i < A; i += LT) {
             const float* s = a.scratch + (size_t)i * SCR;
             const int tgt = (int)s[2 + pass];
+            if constexpr (ST) {
+                float* z = zl + (size_t)i * C;                  // logits in, gradient row out (in place: element k is read before it is written)
+                const float wgt = (tgt > 0 && a.ibm_active) ? wacc[(int)s[8]] : 1.f;
+                if (tgt > 0) part += wgt * s[10];
+                const int y = tgt - 1;
+                float S = 0.f, ay = 1.f;
+                if (tgt > 0 || cal) {
+                    for (int k = 0; k < C; ++k) {
+                        const float al = expf(fminf(fmaxf(z[k], -10.f), 10.f)) + 1.f;
+                        S += al;
+                        if (k == y) ay = al;
+                    }
+                }
+                float cg = 0.f;                                 // IoU calibration (the separate loop of the unstaged form, see there)
+                if (cal) {
+                    const int kk = i / a.B, bb = i - kk * a.B;
+                    float iou = a.scratch[(size_t)(bb * a.K + kk) * SCR + 4];
+                    if (iou < 0.f) iou = 1e-3f;
+                    const float u = (float)C / S;
+                    part_cal += -iou * logf(1.f - u) - (1.f - iou) * logf(u);
+                    const float dreg_du = iou / (1.f - u) - (1.f - iou) / u;
+                    cg = dreg_du * (-(float)C / (S * S));
+                }
+                for (int k = 0; k < C; ++k) {
+                    const float zk = z[k];
+                    const float da = (zk >= -10.f && zk <= 10.f) ? expf(zk) : 0.f;      // clamp backward is inclusive
+                    float gk = tgt > 0 ? wgt * (1.f / S - (k == y ? 1.f / ay : 0.f)) * da / norm : 0.f;
+                    if (cal) gk += cg * da / (float)A;
+                    z[k] = gk;
+                }
+            } else {
             const float* z = logits + (size_t)i * C;
             float* gz = gout + (size_t)i * C;
             if (tgt > 0) {
@@ -262,13 +310,21 @@ __global__ __launch_bounds__(LT) void detection_loss_kernel(const LossArgs a) {
             } else {
                 for (int k = 0; k < C; ++k) gz[k] = 0.f;
             }
+            }
+        }
+        if constexpr (ST) {
+            __syncthreads();
+            const int n4 = (reinterpret_cast<uintptr_t>(gout) & 15) == 0 ? AC >> 2 : 0;
+            for (int q = t; q < n4; q += LT) reinterpret_cast<float4*>(gout)[q] = reinterpret_cast<const float4*>(zl)[q];
+            for (int q = 4 * n4 + t; q < AC; q += LT) gout[q] = zl[q];
         }
         loss_cls[pass] = block_sum(part, red) / norm;
+        if (cal) loss_cls[1] += block_sum(part_cal, red) / (float)A;
     }
     if (t < a.num_bins) a.weight_accum[t] = wacc[t];
 
     // ---- IoU calibration on prop_conf (cls_loss.py:120-129; pairing quirk of multisegment_loss.py:234-236)
-    if (a.iou_aware) {
+    if (!ST && a.iou_aware) {
         float part = 0.f;
         for (int j = t; j < A; j += LT) {
             const int kk = j / a.B, bb = j - kk * a.B;                 // iou_pred.transpose(0,1).reshape(-1)[j]
@@ -769,7 +825,21 @@ extern "C" int otal_detection_loss(const float* loc, const float* conf, const fl
     a.B = B; a.K = K; a.C = C; a.G = G; a.clip = clip_length; a.overlap = overlap_thresh;
     a.ibm_active = cls_mode == 0 ? ibm_active : 0; a.num_bins = num_bins; a.iou_aware = cls_mode == 0 ? iou_aware : 0;
     a.momentum = momentum; a.cls_mode = cls_mode; a.focal_alpha = focal_alpha;
-    hipLaunchKernelGGL(detection_loss_kernel, dim3(1), dim3(LT), 0, (hipStream_t)stream, a);
+    // staged logits: EvidenceLoss mode and A * C floats within the dynamic LDS this kernel may add to its ~40 KB of static arrays
+    const size_t stage = (size_t)B * K * C * sizeof(float);
+    constexpr size_t STAGE_MAX = 96 * 1024;
+    static int staged_ok = -1;          // -1: not asked yet; the attribute is set once per process
+    if (cls_mode == 0 && stage <= STAGE_MAX && !OTAL_OPT("OTAL_LOSS_NOSTAGE", 0)) {
+        if (staged_ok < 0)
+            staged_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(detection_loss_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)STAGE_MAX) == hipSuccess ? 1 : 0;
+        if (staged_ok == 1) {
+            hipLaunchKernelGGL(detection_loss_kernel<true>, dim3(1), dim3(LT), stage, (hipStream_t)stream, a);
+            return otal_launch_status();
+        }
+        (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(detection_loss_kernel<false>, dim3(1), dim3(LT), 0, (hipStream_t)stream, a);
     return otal_launch_status();
 }
 

@@ -140,3 +140,33 @@ def test_hip_focal_dispatch_matches_cpu_oracle(B, n_gt):
         assert np.allclose([float(v.detach()) for v in l2], got, rtol=3e-5, atol=2e-6)
     finally:
         M.FUSED = True
+
+
+@pytest.mark.parametrize("B,n_gt,epoch", [(8, [1, 3, 2, 1, 4, 2, 3, 1], 12), (8, 3, 0), (3, 2, 12), (2, "between", 12)])
+def test_lds_staged_logits_change_no_bit(B, n_gt, epoch):
+    """The kernel that keeps a pass's logits / gradient rows in LDS (and folds the IoU calibration into the prop_conf pass)
+    against the one that reads and writes them in global memory (OTAL_LOSS_NOSTAGE): losses, every gradient and the IBM
+    state bit for bit -- same operands, same order of every addition."""
+    from opental_amd import _lib as L
+    from opental_amd.thumos14 import multisegment_loss as M
+    dev = torch.device("cuda", 0)
+    res = []
+    for nostage in (1, 0):
+        L.set_option("OTAL_LOSS_NOSTAGE", nostage)
+        try:
+            crit = M.MultiSegmentLoss(15, 0.5, 1.0, cls_loss_type='edl', edl_config=EDL, os_head=True, act_config=ACT).to(dev)
+            crit.cls_loss.epoch = epoch
+            crit.cls_loss.weight_accum.copy_(torch.linspace(0.5, 1.5, 50))
+            out, targets = _inputs(B, 31 + B, n_gt, dev)
+            losses = crit(out, targets)
+            w = [1.0, 10.0, 1.0, 10.0, 1.0, 1.0, 1.0]
+            sum(l * wi for l, wi in zip(losses, w)).backward()
+            res.append((torch.stack([l.detach() for l in losses]), {k: v.grad.clone() for k, v in out.items() if v.requires_grad},
+                        crit.cls_loss.weight_accum.clone()))
+        finally:
+            L.set_option("OTAL_LOSS_NOSTAGE", 0)
+    (l0, g0, w0), (l1, g1, w1) = res
+    assert torch.equal(l0, l1), (l0, l1)
+    assert torch.equal(w0, w1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k

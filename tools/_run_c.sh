@@ -1,7 +1,3 @@
-python -m pytest tests/test_ops_gpu.py tests/test_loss_gpu.py tests/test_model_gpu.py tests/test_determinism_gpu.py tests/test_train_gpu.py tests/test_conv1x1_stream_gpu.py tests/test_half_storage_gpu.py -q -m gpu -x 2>&1 | tail -8 > gpurun_out/r05d_tests.txt
-export TMPDIR=/tmp; repo=$(pwd)
-( cd /tmp && rm -rf /tmp/prof_c && OTAL_WGRAD_STREAM=0 OTAL_BRANCH_LANE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c -o b -- python $repo/bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-hbm-kernels --no-roofline --no-extras --graph off > /tmp/prof_c.log 2>&1 )
-cp $(find /tmp/prof_c -name "*kernel_stats.csv" | head -1) gpurun_out/r05d_kernel_stats.csv
-python tools/kstats.py gpurun_out/r05d_kernel_stats.csv 18 90 > gpurun_out/r05d_kernel_summary.txt
-python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-hbm-kernels --no-roofline --no-extras > gpurun_out/r05d_bench.json 2> gpurun_out/r05d_bench.err
-python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-hbm-kernels --no-roofline --no-extras > gpurun_out/r05d_bench2.json 2>> gpurun_out/r05d_bench.err
+python -m pytest tests/test_loss_gpu.py tests/test_ops_gpu.py tests/test_model_gpu.py tests/test_determinism_gpu.py tests/test_train_gpu.py -q -m gpu -x 2>&1 | tail -8 > gpurun_out/r05e_tests.txt
+bash tools/ab_lanes.sh "OTAL_LIB_PATH=ab/c774.so" "OTAL_LOSS_NOSTAGE=1" "-" "OTAL_LOSS_NOSTAGE=1" "-" > gpurun_out/r05e_ab.txt 2>&1
+bash tools/kernel_time.sh 40 -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-hbm-kernels --no-roofline --no-extras --graph off 2>&1 | grep -E "loss|boundary|bmp|heads|head_convs|proj" > gpurun_out/r05e_k.txt
