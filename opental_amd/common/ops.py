@@ -474,6 +474,7 @@ class PrologueCache:
         self.dev_starts = None
         self.dev_descs = None
         self.dirty = False
+        self.pending_join = False    # the refresh runs on the side lane and nobody has waited for it yet
 
     def region(self, mode, ga, sa, key, w, prec):
         if key in self.entries:
@@ -513,11 +514,23 @@ class PrologueCache:
             self.dev_starts = torch.tensor(starts, dtype=torch.int32).to(dev)
             self.total_blocks = starts[-1]
             self.dirty = False
-        L.check(L.lib().otal_conv_prologue_batch(len(self.descs), L.ptr(self.dev_descs), L.ptr(self.dev_starts),
-                                                 int(self.total_blocks), L.stream()), "otal_conv_prologue_batch")
+        def launch():
+            L.check(L.lib().otal_conv_prologue_batch(len(self.descs), L.ptr(self.dev_descs), L.ptr(self.dev_starts),
+                                                     int(self.total_blocks), L.stream()), "otal_conv_prologue_batch")
+        if LANES is not None and PREP_LANE:
+            # lane-graph step: the re-pack (0.54 GB of traffic, ~140 us) goes to the SIDE lane and the main lane starts with the
+            # first convolution, which packs its own weights (Conv3d_1a's tile kernel, matrix-bound: 380 us + the pool behind
+            # it); the main lane waits for the side lane in front of the first launch that reads a region (_prologue)
+            LANES.side_chunk(launch)
+            self.pending_join = True
+        else:
+            launch()
 
 
 PROLOGUES = None        # the active PrologueCache, or None (every launch builds its own prologue)
+# OTAL_PREP_LANE=1: in lane graphs the step's weight re-pack runs on the side lane beside Conv3d_1a's forward.  Measured +-0
+# (r05f timeline: the pack's 142 us disappear from the main lane and conv1a_tile_fwd_kernel stretches by 110 us): off.
+PREP_LANE = os.environ.get("OTAL_PREP_LANE", "0") == "1"
 
 
 def activate_prologues(cache):
@@ -529,6 +542,11 @@ def activate_prologues(cache):
 
 def deactivate_prologues():
     global PROLOGUES
+    c = PROLOGUES
+    if c is not None and c.pending_join:         # nobody consumed a region: the side lane is joined all the same
+        if LANES is not None:
+            LANES.cut(("join",))
+        c.pending_join = False
     PROLOGUES = None
 
 
@@ -544,7 +562,12 @@ def _prologue(mode, ga, sa, pkey, w, prec):
         if r is None or not (r[0] <= wp < r[1]):
             return None
     reg = c.region(mode, ga, sa, (wp, pkey, prec), w, prec)
-    return None if reg is None else L.ptr(reg)
+    if reg is None:
+        return None
+    if c.pending_join and LANES is not None:
+        LANES.cut(("join",))
+        c.pending_join = False
+    return L.ptr(reg)
 
 
 # ---- launch plans.  Everything about a convolution launch that depends only on shapes and strides -- the geometry record,
