@@ -1353,6 +1353,23 @@ class AnetDetectionLossFunction(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- head output tails
+HEAD_GRAD_SLOTS = "OTAL_NO_GRAD_SLOTS_HEADS" not in os.environ      # (A/B switch of the head bias / ScaleExp gradient slots)
+
+
+_SLOT_INDEX = {}        # arena offsets of a group of one-element gradient slots, as a device index tensor
+
+
+def _adjacent_view(ts):
+    """One (n,) view over n one-element fp32 tensors that lie next to each other in ONE storage, in order; else None."""
+    if not ts or any(t is None or t.numel() != 1 or t.dtype != torch.float32 for t in ts):
+        return None
+    base = ts[0]
+    st = base.untyped_storage().data_ptr()
+    if any(t.untyped_storage().data_ptr() != st or t.data_ptr() != base.data_ptr() + 4 * i for i, t in enumerate(ts)):
+        return None
+    return base.detach().as_strided((len(ts),), (1,), base.storage_offset())
+
+
 class HeadOutputsFunction(torch.autograd.Function):
     """permute / ScaleExp / Dirichlet uncertainty of all detection-head maps in one launch (csrc/heads.hip).
 
@@ -1364,7 +1381,10 @@ class HeadOutputsFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, levels, level_strides, modes, *tensors):
         nlev_ = len(levels) - 1
-        scales = torch.cat([t.detach().reshape(1) for t in tensors[:nlev_]])
+        ctx.scale_params = tensors[:nlev_]
+        scales = _adjacent_view(tensors[:nlev_])             # the parameters where they lie (the trainer's arena), or a packed copy
+        if scales is None:
+            scales = torch.cat([t.detach().reshape(1) for t in tensors[:nlev_]])
         raws = [r.contiguous() for r in tensors[nlev_:]]
         L.require_device(scales, *raws)
         B, _, N = raws[0].shape
@@ -1395,12 +1415,38 @@ class HeadOutputsFunction(torch.autograd.Function):
         douts = [None if g is None else g.contiguous() for g in grads[:n]]
         dunct = [None if g is None else g.contiguous() for g in dunct]
         draws = [torch.empty_like(r) for r in raws]
-        dscales = torch.zeros_like(scales)
         VP = ctypes.c_void_p * n
         arr = lambda ts: VP(*[None if t is None else t.data_ptr() for t in ts])
-        L.check(L.lib().otal_head_outputs_bwd(n, chans, modes_a, arr(raws), arr(outs), arr(uncts), arr(douts), arr(dunct), arr(draws),
-                                              L.ptr(scales), L.ptr(dscales), B, N, nlev, lev, strides, L.stream()),
-                "otal_head_outputs_bwd")
+
+        def launch(dscales):
+            L.check(L.lib().otal_head_outputs_bwd(n, chans, modes_a, arr(raws), arr(outs), arr(uncts), arr(douts), arr(dunct), arr(draws),
+                                                  L.ptr(scales), L.ptr(dscales), B, N, nlev, lev, strides, L.stream()),
+                    "otal_head_outputs_bwd")
+        # the nlev one-element gradients: written in place when the parameters' arena slots are adjacent (no packing, no copies:
+        # they were 6 of the 13 tiny gradient copies -- a hipMemcpyAsync node each -- of every step's bucket flushes)
+        want = HEAD_GRAD_SLOTS and all(ctx.needs_input_grad[3:3 + nlev])     # (the refined stage passes the scales detached)
+        slots = [grad_slot(p) if want else None for p in ctx.scale_params]
+        direct = _adjacent_view(slots) if all(sl is not None for sl in slots) else None
+        if direct is not None:
+            direct.zero_()
+            launch(direct)
+            return (None, None, None) + tuple(slots) + tuple(draws)
+        dscales = torch.zeros_like(scales)
+        launch(dscales)
+        if all(sl is not None for sl in slots):     # slots anywhere in the arena (e.g. in descending order): ONE scatter launch
+            key = tuple(sl.data_ptr() for sl in slots)
+            idx = _SLOT_INDEX.get(key)
+            if idx is None:
+                flat = GRAD_SLOTS.grad
+                idx = torch.tensor([(sl.data_ptr() - flat.data_ptr()) // 4 for sl in slots], dtype=torch.int64).to(flat.device)
+                if len(_SLOT_INDEX) > 64:
+                    _SLOT_INDEX.clear()
+                _SLOT_INDEX[key] = idx
+            GRAD_SLOTS.grad.index_copy_(0, idx, dscales)
+            return (None, None, None) + tuple(slots) + tuple(draws)
+        for p, sl in zip(ctx.scale_params, slots):
+            if sl is not None:
+                GRAD_SLOTS.release(p)
         aligned = torch.zeros((nlev, 4), dtype=dscales.dtype, device=dscales.device)
         aligned[:, 0] = dscales
         return (None, None, None) + tuple(aligned[l, :1] for l in range(nlev)) + tuple(draws)
@@ -1446,6 +1492,7 @@ class HeadConvsFunction(torch.autograd.Function):
         L.check(L.lib().otal_head_convs_fwd(*meta, VP(xs), VP(ws), VP(bs), VP(ys), B, C, N, nlev, lev, L.stream()),
                 "otal_head_convs_fwd")
         ctx.cfg = (meta, nlev, lev, n_inputs, nh, (B, C, N), [b is not None for b in bs])
+        ctx.bias_params = bs                # (leaf parameters: only their arena slots are looked up in backward)
         ctx.save_for_backward(*xs, *ws)
         return tuple(ys)
 
@@ -1460,7 +1507,12 @@ class HeadConvsFunction(torch.autograd.Function):
         for w in ws:
             slot = grad_slot(w)
             dws.append(slot if slot is not None else torch.empty_like(w))
-        dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if hb else None for w, hb in zip(ws, has_bias)]
+        # bias gradients go straight to their arena slots too (they were 7 of the 13 one-to-fifteen-element gradient copies --
+        # a hipMemcpyAsync node each -- that every step's bucket flushes issued)
+        dbs = []
+        for w, b in zip(ws, ctx.bias_params):
+            slot = grad_slot(b) if (b is not None and HEAD_GRAD_SLOTS) else None
+            dbs.append(slot if slot is not None else (torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if b is not None else None))
         VP = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
         L.check(L.lib().otal_head_convs_bwd(*meta, VP(xs), VP(ws), VP(dys), VP(dxs), VP(dws), VP(dbs), B, C, N, nlev, lev, L.stream()),
                 "otal_head_convs_bwd")
