@@ -151,11 +151,11 @@ def measure(batch=8):
     scc = torch.ones(288, device=dev)
     yc = ops.conv_forward(xc, wc, (1, 1, 1), (1, 1, 1), scale=scc, shift=scc, relu=True)
     add("conv1x1_3c_fwd_bf16", timed(lambda: ops.conv_forward(xc, wc, (1, 1, 1), (1, 1, 1), scale=scc, shift=scc, relu=True, out=yc), reps=50),
-        2 * (xc.numel() + yc.numel()) + 2 * wc.numel(), False, "otal_conv_fwd, bf16 tensors on both sides (precision bits 2 + 3)", "conv_gemm_bf16c_kernel")
+        2 * (xc.numel() + yc.numel()) + 2 * wc.numel(), False, "otal_conv_fwd, bf16 tensors on both sides (precision bits 2 + 3)", "conv1x1_stream_kernel|conv_gemm_bf16c_kernel")
     dxc = torch.empty_like(xc)
     sci = torch.ones(256, device=dev)
     add("conv1x1_3c_dgrad_bf16", timed(lambda: ops.conv_dgrad(yc, wc, xc.shape, (1, 1, 1), (1, 1, 1), out=dxc, out_mask=xc, out_scale=sci), reps=50),
-        2 * (2 * xc.numel() + yc.numel()) + 2 * wc.numel(), False, "otal_conv_dgrad with the bf16 activation as ReLU mask", "conv_gemm_bf16c_kernel")
+        2 * (2 * xc.numel() + yc.numel()) + 2 * wc.numel(), False, "otal_conv_dgrad with the bf16 activation as ReLU mask", "conv1x1_stream_kernel|conv_gemm_bf16c_kernel")
     del xc, yc, dxc
     # Adam over the flat arena: reads p, g, m, v; writes p, m, v -> 28 B / parameter
     n = 44_720_000
