@@ -1187,6 +1187,98 @@ __global__ __launch_bounds__(256) void maxpool133_s2_w8_nn_fwd_kernel(const floa
     }
 }
 
+// ---- MaxPool3d_4a ((3,3,3) / (2,2,2)) backward on bf16-STORED 12-wide planes, sign-bit mask: a thread owns input planes 2k
+// and 2k+1, rows 2a and 2a+1, all twelve columns, and reads the output rows that can point into them -- planes k (dt = 0 for
+// plane 2k, dt = 1 for plane 2k+1) and k-1 (dt = 2, plane 2k only), rows a and a-1, six columns each: 16 row loads + 6 sign
+// bytes for 96 bytes of dx, where the 2 x 4-block form issues 17 / 9 loads for 16 bytes.  Per input element the same hits are
+// added in the same (ascending tap) order as maxpoolk33_s2_bwd_kernel<3, true, true>: bit-identical
+// (tests/test_half_chain_gpu.py::test_strided_pools_on_bf16_tensors).  72 -> 56 us for the model's (8,480,128,12,12) map.
+// (The forward twin -- one output row per thread, nine 24-byte row loads -- was built too and is SLOWER than the two-output
+// form, 72.6 vs 62.9 us: a third of the load instructions, but a third of the threads as well.  Not kept.)
+// Wi == 12, Hi even, Ti even, To == Ti / 2.
+__global__ __launch_bounds__(256) void maxpool333_s2_w12_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                                    float* __restrict__ dx, PoolGeom g, const float* __restrict__ escale,
+                                                                    const unsigned char* __restrict__ signbits) {
+    const int H2 = g.Hi >> 1;
+    const int r = blockIdx.x * 256 + threadIdx.x;            // (k, a)
+    if (r >= g.To * H2) return;
+    const int bc = blockIdx.y;
+    const int b = bc / g.C, c = bc - b * g.C;
+    const int k = (int)fd_div(g.fHo, (uint32_t)r);           // Ho == Hi / 2
+    const int a = r - k * H2;
+    const unsigned short* dyh = reinterpret_cast<const unsigned short*>(dy) + (int64_t)b * g.y_bs + (int64_t)c * g.y_cs;
+    const unsigned char* ab = arg + (int64_t)bc * g.To * g.Ho * 6;
+    // raw rows [pl][rr]: pl 0 = output plane k, 1 = plane k-1; rr 0 = output row a-1, 1 = row a (clamped addresses, masked below)
+    uint2 d8[2][2];
+    unsigned d4[2][2], t4[2][2], t2[2][2];
+    unsigned sraw[2][3] = {};
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int o = (max(k - pl, 0) * g.Ho + max(a - 1 + rr, 0)) * 6;
+            d8[pl][rr] = *reinterpret_cast<const uint2*>(dyh + o);
+            d4[pl][rr] = *reinterpret_cast<const unsigned*>(dyh + o + 4);
+            t4[pl][rr] = *reinterpret_cast<const unsigned*>(ab + o);                 // (6-byte rows: 2-byte aligned -- global loads, any alignment)
+            t2[pl][rr] = *reinterpret_cast<const unsigned short*>(ab + o + 4);
+        }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                           // (no branch around these loads: without sign bits they read winner bytes nobody uses)
+        const unsigned char* sp = signbits ? signbits + (((int64_t)bc * g.Ti + 2 * k + q) * H2 + a) * 3 : ab;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) sraw[q][m] = sp[m];
+    }
+    __builtin_amdgcn_sched_barrier(0);                      // all loads issued before the first value is used
+    float D[2][2][6];
+    int A[2][2][6];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const bool in = (k - pl >= 0) && (a - 1 + rr >= 0);
+            const unsigned keep = in ? ~0u : 0u;
+            const unsigned w0 = d8[pl][rr].x & keep, w1 = d8[pl][rr].y & keep, w2 = d4[pl][rr] & keep;
+            const unsigned tl = t4[pl][rr] | ~keep, th = t2[pl][rr] | ~keep;
+            D[pl][rr][0] = h2f_lo(w0); D[pl][rr][1] = h2f_hi(w0); D[pl][rr][2] = h2f_lo(w1);
+            D[pl][rr][3] = h2f_hi(w1); D[pl][rr][4] = h2f_lo(w2); D[pl][rr][5] = h2f_hi(w2);
+            A[pl][rr][0] = (int)(tl & 255u); A[pl][rr][1] = (int)((tl >> 8) & 255u); A[pl][rr][2] = (int)((tl >> 16) & 255u);
+            A[pl][rr][3] = (int)((tl >> 24) & 255u); A[pl][rr][4] = (int)(th & 255u); A[pl][rr][5] = (int)((th >> 8) & 255u);
+        }
+    // hit(pl, rr, w, tap): output (plane k - pl, row a - 1 + rr, column w) chose `tap` (w = -1: the column left of the plane)
+    auto hit = [&](int pl, int rr, int w, int tap) __attribute__((always_inline)) -> float {
+        return (w >= 0 && A[pl][rr][w >= 0 ? w : 0] == tap) ? D[pl][rr][w >= 0 ? w : 0] : 0.f;
+    };
+    // contribution of one (output plane, dt) to input row i (0: row 2a, 1: row 2a+1), column j
+    auto contrib = [&](int pl, int base, int i, int j) __attribute__((always_inline)) -> float {
+        const int w = j >> 1;
+        if (i == 0) {
+            if ((j & 1) == 0) return ((hit(pl, 1, w, base + 0) + hit(pl, 1, w - 1, base + 2)) + hit(pl, 0, w, base + 6)) + hit(pl, 0, w - 1, base + 8);
+            return hit(pl, 1, w, base + 1) + hit(pl, 0, w, base + 7);
+        }
+        if ((j & 1) == 0) return hit(pl, 1, w, base + 3) + hit(pl, 1, w - 1, base + 5);
+        return hit(pl, 1, w, base + 4);
+    };
+    const float esc = signbits ? escale[c] : 1.f;
+    unsigned short* dh = reinterpret_cast<unsigned short*>(dx) + (int64_t)b * g.x_bs + (int64_t)c * g.x_cs + ((int64_t)(2 * k) * g.Hi + 2 * a) * 12;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)                             // input plane 2k + q
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float sv[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                float v;
+                if (q == 0) { v = 0.f + contrib(0, 0, i, j); v += contrib(1, 18, i, j); }      // dt = 0 from plane k, then dt = 2 from plane k-1
+                else v = 0.f + contrib(0, 9, i, j);                                             // dt = 1 from plane k
+                if (signbits) v = ((sraw[q][j >> 2] >> (i * 4 + (j & 3))) & 1u) ? v * esc : 0.f;
+                sv[j] = v;
+            }
+            unsigned short* row = dh + ((int64_t)q * g.Hi + i) * 12;
+            *reinterpret_cast<uint4*>(row) = make_uint4(f2h_pair_rne(sv[0], sv[1]), f2h_pair_rne(sv[2], sv[3]), f2h_pair_rne(sv[4], sv[5]), f2h_pair_rne(sv[6], sv[7]));
+            *reinterpret_cast<uint2*>(row + 8) = make_uint2(f2h_pair_rne(sv[8], sv[9]), f2h_pair_rne(sv[10], sv[11]));
+        }
+}
+
 __global__ __launch_bounds__(256) void maxpool133_s2_w8_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
                                                                    float* __restrict__ dx, PoolGeom g, const float* __restrict__ escale,
                                                                    FastDiv fW8, FastDiv fH2, const unsigned char* __restrict__ signbits) {
@@ -1420,6 +1512,8 @@ static int pool_bwd(const int* geom, const int64_t* strides, const float* dy, co
             hipLaunchKernelGGL(maxpool133_s2_w8_bwd_kernel, dim3((n8 + 255) / 256, g.B * g.C), dim3(256), 0, st_, dy, argtap, dx, g, out_scale,
                                make_fastdiv((uint32_t)(g.Wi / 8)), fH2, signbits);
         } else if (all_half && kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, true, true>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
+        else if (all_half && g.Wi == 12 && g.x_bs % 4 == 0 && g.x_cs % 4 == 0 && g.y_bs % 2 == 0 && g.y_cs % 2 == 0 && !OTAL_OPT("OTAL_POOL_NOW12", 0))
+            hipLaunchKernelGGL(maxpool333_s2_w12_bwd_kernel, dim3((g.To * (g.Hi / 2) + 255) / 256, g.B * g.C), dim3(256), 0, st_, dy, argtap, dx, g, out_scale, signbits);
         else if (all_half) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<3, true, true>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
         else if (io == 1) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, true>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
         else if (kind == 1) hipLaunchKernelGGL((maxpoolk33_s2_bwd_kernel<1, false>), grid, dim3(256), 0, st_, dy, argtap, dx, g, accumulate, out_mask, out_scale, fW4, fH2, signbits);
