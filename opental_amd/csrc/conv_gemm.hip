@@ -3150,7 +3150,11 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
         a.N = a.g.Cin * a.g.kt * a.g.kh * 8;
         a.flags |= EPI_NPAD8;
     }
-    const int BMsel = choose_bm(a.M, pair ? 0 : 2);
+    int BMsel = choose_bm(a.M, pair ? 0 : 2);
+    {   // (experiment knob: a smaller row block = a smaller register / LDS footprint per workgroup beside the main lane's kernels)
+        const int cap = OTAL_OPT("OTAL_WGRADV_MAXBM", 192);
+        while (BMsel > cap && BMsel > 32) BMsel = BMsel == 192 ? 128 : (BMsel == 128 ? 96 : (BMsel == 96 ? 64 : 32));
+    }
     const int tm = (a.M + BMsel - 1) / BMsel, tn = (a.N + 127) / 128;
     const size_t tb = ptab_bytes(a.g, cw);
     a.fd = make_conv_fastdiv(a.g);
