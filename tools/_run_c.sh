@@ -1,3 +1,2 @@
-python -m pytest tests/test_half_chain_gpu.py tests/test_ops_gpu.py -q -m gpu -k "pool" 2>&1 | tail -3 > gpurun_out/r05h_pooltests.txt
-python tools/micro_pool_half.py 2>&1 | grep -v amdgpu > gpurun_out/r05h_pool_new.txt
-OTAL_POOL_NOW12=1 python tools/micro_pool_half.py 2>&1 | grep -v amdgpu > gpurun_out/r05h_pool_old.txt
+OTAL_WDIRECT_BM=32 python -m pytest tests/test_ops_gpu.py tests/test_half_chain_gpu.py tests/test_bf16_layer_pin_gpu.py -q -m gpu -x 2>&1 | tail -3 > gpurun_out/r05i_wd32_tests.txt
+bash tools/ab_lanes.sh "-" "OTAL_WDIRECT_BM=32" "OTAL_WDIRECT_BM=32 OTAL_WDIRECT_BLOCKS=512" "-" "OTAL_WDIRECT_BM=32" > gpurun_out/r05i_wd32.txt 2>&1
