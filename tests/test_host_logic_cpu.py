@@ -101,3 +101,24 @@ def test_step_log_jsonl_sink_writes_the_reference_scalar_tags(tmp_path):
     assert [r['step'] for r in rows] == [2, 4, 6] == seen
     assert set(rows[0]) == {'step'} | {'Train/' + t for t in ('Total', 'loc', 'conf', 'prop_loc', 'prop_conf', 'IoU', 'start', 'end')}
     assert rows[1]['Train/Total'] == 4.0 and rows[1]['Train/end'] == 11.0
+
+
+def test_one_element_parameters_as_one_view_and_their_slot_index():
+    """Round 5: the six ScaleExp scales are read where they lie when they are adjacent IN ORDER in one storage (a packed copy
+    otherwise), and their gradients are scattered into the arena slots with one index_copy_ whatever the slots' order -- the
+    trainer's arena holds them in DESCENDING order."""
+    arena = torch.arange(32, dtype=torch.float32)
+    up = [arena[4 + i:5 + i] for i in range(6)]
+    v = ops._adjacent_view(up)
+    assert v is not None and v.shape == (6,) and v.data_ptr() == up[0].data_ptr() and torch.equal(v, arena[4:10])
+    down = [arena[20 - i:21 - i] for i in range(6)]
+    assert ops._adjacent_view(down) is None                       # adjacent, wrong direction
+    assert ops._adjacent_view([arena[0:1], arena[2:3]]) is None   # a gap
+    assert ops._adjacent_view([arena[0:1], torch.zeros(1)]) is None
+    assert ops._adjacent_view([arena[0:2]]) is None               # not one element
+    # the scatter HeadOutputsFunction.backward uses for slots in any order
+    grad = torch.zeros(32)
+    slots = [grad[20 - i:21 - i] for i in range(6)]
+    idx = torch.tensor([(s.data_ptr() - grad.data_ptr()) // 4 for s in slots])
+    grad.index_copy_(0, idx, torch.arange(1., 7.))
+    assert [float(s) for s in slots] == [1., 2., 3., 4., 5., 6.]
