@@ -45,7 +45,7 @@ namespace {
 
 constexpr int NT = 256;
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
-enum { EPI_RELU = 1, EPI_ACCUM = 2, DBG_NOLOAD = 4, DBG_NOSTORE = 8, DBG_NOBARRIER = 16, EPI_NPAD8 = 32 };   // DBG_*: ablation only (OTAL_CONV_DEBUG)
+enum { EPI_RELU = 1, EPI_ACCUM = 2, DBG_NOLOAD = 4, DBG_NOSTORE = 8, DBG_NOBARRIER = 16, EPI_NPAD8 = 32, EPI_PLAIN_GRID = 256 };   // DBG_*: ablation only (OTAL_CONV_DEBUG)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -2787,8 +2787,11 @@ __global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const ConvArgs a, int
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_co = (g.Cout + 63) / 64;
-    const bool second = (int)blockIdx.x >= tiles_co;        // pair launch: grid.x = 2 x the output-channel tiles
-    const int co0 = ((int)blockIdx.x - (second ? tiles_co : 0)) * 64, ci0 = blockIdx.y * 64, split = blockIdx.z;
+    // grid = (splits, input-channel tiles, output-channel tiles [x 2 for a pair launch]): the SPLIT (sample, chunk) is the fastest
+    // index, so the workgroups of one sample's chunk -- which all read the same 64 x 128 blocks of x and dy rows -- share an
+    // XCD's L2 (workgroups go to the XCDs round-robin by linear index; with the channel tile fastest every XCD fetched every sample)
+    const bool second = (int)blockIdx.z >= tiles_co;        // pair launch: grid.z = 2 x the output-channel tiles
+    const int co0 = ((int)blockIdx.z - (second ? tiles_co : 0)) * 64, ci0 = blockIdx.y * 64, split = blockIdx.x;
     const float* const pdy = second ? a.dy2 : a.dy;
     const float* const px = second ? a.x2 : a.x;
     const int T = g.Ti;
@@ -2925,7 +2928,7 @@ int launch_wgrad1d(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!ws || ws_bytes < need * (a.pair ? 2 : 1)) return OTAL_E_UNSUPPORTED;
     a.splits = splits; a.k_per_split = 0; a.slab = reinterpret_cast<float*>(ws);
     if (a.pair) a.slab2 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + need);
-    const dim3 grid(((a.g.Cout + 63) / 64) * (a.pair ? 2 : 1), a.g.Cin / 64, splits);
+    const dim3 grid(splits, a.g.Cin / 64, ((a.g.Cout + 63) / 64) * (a.pair ? 2 : 1));
     if (a.g.kt == 1) hipLaunchKernelGGL(conv_wgrad1d_kernel<1>, grid, dim3(256), 0, st, a, nchunks, units, upw);
     else hipLaunchKernelGGL(conv_wgrad1d_kernel<3>, grid, dim3(256), 0, st, a, nchunks, units, upw);
     if (int e = otal_launch_status()) return e;
