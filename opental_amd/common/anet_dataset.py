@@ -10,7 +10,9 @@ and the spliced ssl batch on the device.  Clips shorter than clip_length are pad
 (:226-229), i.e. exactly 0.0 after it: bit 1 of the clip record's `flip` word selects that padding in the kernel.
 """
 import json
+import concurrent.futures
 import math
+import threading
 import os
 import random
 
@@ -160,6 +162,11 @@ class ANET_Dataset:
         self._cache = {}                # name -> tensor, in least-recently-used order (dicts keep insertion order)
         self._cap = max(1, int(cache_videos))
         self._shapes = {}
+        # background reads (prefetch()): the reference hides the ~29 MB np.load per sample in DataLoader workers; here the epoch
+        # loop names the NEXT batch's videos while the current step runs and two reader threads bring them into the cache
+        self._lock = threading.Lock()
+        self._pending = {}              # name -> Future of the tensor
+        self._pool = None
         if not rgb_norm:
             raise NotImplementedError("the device kernel normalises (rgb_norm=True, the only setting the reference uses)")
 
@@ -177,17 +184,36 @@ class ANET_Dataset:
             del m
         return shp
 
+    def _read(self, name):
+        v = torch.from_numpy(np.load(os.path.join(self.video_dir, name + '.npy')))
+        if v.dtype != torch.uint8 or v.dim() != 4 or v.shape[3] != 3:
+            raise RuntimeError(f"{name}.npy: expected uint8 (T,H,W,3)")
+        if self._pin and torch.cuda.is_available():
+            v = v.pin_memory()
+        return v
+
+    def prefetch(self, names):
+        """Start reading the named videos in the background (at most cache_videos / 2 outstanding); video(name) then finds
+        them in the cache or waits for the read that is already under way.  Called by the epoch loop with the next batch's
+        names while the current step runs (thumos14.train.run_one_epoch)."""
+        with self._lock:
+            if self._pool is None:
+                self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=2, thread_name_prefix="anet-video")
+            for name in dict.fromkeys(names):
+                if name in self._cache or name in self._pending or len(self._pending) >= max(1, self._cap // 2):
+                    continue
+                self._pending[name] = self._pool.submit(self._read, name)
+
     def video(self, name):
-        v = self._cache.pop(name, None)
+        with self._lock:
+            v = self._cache.pop(name, None)
+            fut = self._pending.pop(name, None) if v is None else None
         if v is None:
-            v = torch.from_numpy(np.load(os.path.join(self.video_dir, name + '.npy')))
-            if v.dtype != torch.uint8 or v.dim() != 4 or v.shape[3] != 3:
-                raise RuntimeError(f"{name}.npy: expected uint8 (T,H,W,3)")
-            if self._pin and torch.cuda.is_available():
-                v = v.pin_memory()
+            v = fut.result() if fut is not None else self._read(name)       # (a failed background read raises here)
+        with self._lock:
             while len(self._cache) >= self._cap:            # evict the least recently used (the stager copies frames into
                 self._cache.pop(next(iter(self._cache)))    # its own pinned slots at submit time: nothing points here later)
-        self._cache[name] = v
+            self._cache[name] = v
         return v
 
     def decide(self, idx, rng=random):

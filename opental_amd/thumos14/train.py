@@ -1115,6 +1115,8 @@ def run_one_epoch(epoch, trainer, dataset, stager, batch_size, rank=0, world=1, 
         rec = stager.labels()
         if k + 1 < len(mine):
             stager.submit(mine[k + 1])                     # next batch crosses PCIe while this step runs
+        if k + 2 < len(mine) and hasattr(dataset, 'prefetch'):      # lazily loaded videos (ActivityNet): the batch after that is read
+            dataset.prefetch([s_['video'].name for s_ in mine[k + 2] if hasattr(s_['video'], 'name')])    # from disk in the background
         if rec is not None:
             targets, scores, ssl_targets = rec.targets, rec.scores, rec.ssl_targets() if use_ssl else None
         else:                                              # a stager without label records: ragged lists, eager steps

@@ -69,6 +69,28 @@ def test_deciding_an_epoch_loads_no_frames_and_the_video_cache_is_bounded(tmp_pa
     assert list(ds._cache) == list(dict.fromkeys(reversed(names)))[:2][::-1]      # the two most recently used, oldest first
 
 
+def test_background_prefetch_feeds_the_cache_and_a_failed_read_surfaces_at_the_consumer(tmp_path):
+    """with lazy videos every sample was a synchronous np.load on the training thread.  prefetch(names) reads
+    in the background; video(name) takes the finished read (or waits for it), the cache bound still holds, duplicates and
+    already cached names are skipped, and an unreadable file raises where the video is USED, not in the reader thread."""
+    from opental_amd.common import anet_dataset as MD
+    root = str(tmp_path)
+    videos = P.write_dataset(root, P.dataset_spec())
+    ds = MD.ANET_Dataset(os.path.join(root, "info.json"), os.path.join(root, "npy"), P.CLIP, P.CROP, P.STRIDE, cache_videos=4)
+    names = list(videos)[:3]
+    ds.prefetch(names + names[:1])
+    assert set(ds._pending) <= set(names) and len(ds._pending) <= 2            # at most cache_videos / 2 outstanding
+    for n in names:
+        assert torch.equal(ds.video(n), torch.from_numpy(videos[n]))
+    assert not ds._pending and list(ds._cache) == names
+    ds.prefetch(names)                                          # all cached: nothing to do
+    assert not ds._pending
+    ds.prefetch(["no_such_video"])
+    with pytest.raises(FileNotFoundError):
+        ds.video("no_such_video")
+    assert len(ds._cache) <= 4
+
+
 def test_slice_assignment_semantics_of_the_splice():
     """`new[:, a:b] = old[:, c:d]` as torch evaluates it: equal lengths copy, a one-frame source broadcasts, anything
     else is the RuntimeError the reference catches (anet_dataset.py:194-207) -> the splice is given up."""
