@@ -25,9 +25,27 @@ __global__ __launch_bounds__(256) void boundary_bce_kernel(const float* __restri
     const int half = C >> 1;
     const bool live = t < T;
     const float* xp = x + (int64_t)b * x_bs + (int64_t)h * half * x_cs + (live ? t : 0);
+    // A thread's channels (cg, cg + 16, ..: up to BCE_MAXI of them) are fetched in rounds of eight loads issued together and their
+    // tanh kept in registers for the gradient pass below.  (The plain loop -- load, tanh, add, one channel at a time, then the
+    // same again for the gradient -- was 2 x 32 dependent round trips per thread in a 19 us kernel; channels beyond the register
+    // budget fall back to it.)  Same values, same order of additions.
+    constexpr int BCE_MAXI = 32;
+    float th[BCE_MAXI];
+    const int nit = live ? (half - cg + 15) / 16 : 0;         // this thread's channel count
     float s = 0.f;
-    if (live)
-        for (int c = cg; c < half; c += 16) s += tanhf(xp[(int64_t)c * x_cs]);
+#pragma unroll
+    for (int i0 = 0; i0 < BCE_MAXI; i0 += 8) {
+        if (i0 >= nit) { for (int u = 0; u < 8; ++u) th[i0 + u] = 0.f; continue; }      // (uniform in practice: a whole round less)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[(int64_t)(cg + 16 * min(i0 + u, max(nit - 1, 0))) * x_cs];      // clamped: always readable
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            th[i0 + u] = tanhf(v[u]);
+            if (i0 + u < nit) s += th[i0 + u];
+        }
+    }
+    for (int i = BCE_MAXI; i < nit; ++i) s += tanhf(xp[(int64_t)(cg + 16 * i) * x_cs]);
     part[cg][tl] = s;
     __syncthreads();
     float tot = 0.f;
@@ -43,9 +61,12 @@ __global__ __launch_bounds__(256) void boundary_bce_kernel(const float* __restri
     // d mean-loss / d x = (m - y) / max(m (1 - m), 1e-12) / (B T) / half * (1 - tanh(x)^2)
     const float gm = (m - y) / fmaxf(m * (1.f - m), 1e-12f) / ((float)B * (float)T) / (float)half;
     float* dp = dx + ((int64_t)b * C + (int64_t)h * half) * T + t;
-    for (int c = cg; c < half; c += 16) {
-        const float th = tanhf(xp[(int64_t)c * x_cs]);
-        dp[(int64_t)c * T] = gm * (1.f - th * th);
+#pragma unroll
+    for (int i = 0; i < BCE_MAXI; ++i)
+        if (i < nit) dp[(int64_t)(cg + 16 * i) * T] = gm * (1.f - th[i] * th[i]);
+    for (int i = BCE_MAXI; i < nit; ++i) {
+        const float t1 = tanhf(xp[(int64_t)(cg + 16 * i) * x_cs]);
+        dp[(int64_t)(cg + 16 * i) * T] = gm * (1.f - t1 * t1);
     }
 }
 
@@ -59,26 +80,43 @@ constexpr int BL_MAX = 4;
 struct BlItems { int n; const float* terms[BL_MAX]; const float* dx[BL_MAX]; float* out[BL_MAX]; float weight[BL_MAX]; int T[BL_MAX]; int C[BL_MAX]; };
 
 __global__ __launch_bounds__(256) void boundary_finish_kernel(BlItems it, int B, float* __restrict__ out) {
+    // One workgroup, six sums (2 halves x up to 3 maps), each the pairwise halving tree over the 256 thread partials
+    // (r[t] += r[t + s], s = 128 .. 1) as in the first version -- which walked it with nine barriers per sum and fetched a
+    // thread's terms one dependent load at a time.  Here: eight loads per round, the cross-wave levels (s = 128, 64) summed by
+    // wave 0 from LDS and the in-wave levels by shuffles: three barriers per sum, the same additions in the same order.
     __shared__ float red[256];
+    const int t = threadIdx.x;
     for (int h = 0; h < 2; ++h) {
         float total = 0.f;
         for (int i = 0; i < it.n; ++i) {
             const int T = it.T[i], cnt = B * T;
+            const float* __restrict__ src = it.terms[i];
             float acc = 0.f;
-            for (int e = threadIdx.x; e < cnt; e += 256) {
-                const int b = e / T, t = e - b * T;
-                acc += it.terms[i][((size_t)b * 2 + h) * T + t];
+            for (int e0 = t; e0 < cnt; e0 += 8 * 256) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u * 256, cnt - 1);           // clamped: the surplus values are not added
+                    const int b = e / T, tt = e - b * T;
+                    v[u] = src[((size_t)b * 2 + h) * T + tt];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u * 256 < cnt) acc += v[u];
             }
-            red[threadIdx.x] = acc;
+            red[t] = acc;
             __syncthreads();
-            for (int s = 128; s > 0; s >>= 1) {
-                if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-                __syncthreads();
+            if (t < 64) {
+                float r = (red[t] + red[t + 128]) + (red[t + 64] + red[t + 192]);       // s = 128, then s = 64
+#pragma unroll
+                for (int s = 32; s > 0; s >>= 1) r += __shfl_down(r, s, 64);
+                if (t == 0) red[0] = r;
             }
+            __syncthreads();
             total += it.weight[i] * (red[0] / (float)cnt);
             __syncthreads();
         }
-        if (threadIdx.x == 0) out[h] = total;
+        if (t == 0) out[h] = total;
     }
 }
 
