@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTAL_LIB_PATH") or os.path.join(_HERE, "lib", "libopental_hip.so")   # override: A/B kernel builds
-ABI_VERSION = 23
+ABI_VERSION = 24
 F32, BF16, F16, F64 = 0, 1, 2, 3
 E_UNSUPPORTED = -7      # OTAL_E_UNSUPPORTED: no kernel for this call's geometry (pair launches: issue the two launches instead)
 

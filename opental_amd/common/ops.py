@@ -324,6 +324,8 @@ class SideWgrads:
 # one: common/i3d_backbone.py).  with lane: ... issues this library's launches on the lane's stream, with the lane's own
 # workspace; fork() / join() are one event each.
 BRANCH_LANE = os.environ.get("OTAL_BRANCH_LANE", "1") != "0"
+# the pyramid as two hand-scheduled autograd nodes (thumos14/pyramid_fused.py) instead of one node per block
+FUSED_PYRAMID = os.environ.get("OTAL_FUSED_PYRAMID", "1") != "0"
 _BRANCHES = {}
 
 
@@ -961,15 +963,26 @@ def conv_wgrad_pair(xs, dys, w_shape, k, s, levels=None, outs=(None, None)):
     return outs
 
 
-def gn_relu_forward_pair(xs, gammas, betas, groups=32, eps=1e-5, relu=True, levels=None):
-    """[(y0, stats0), (y1, stats1)] in one launch, or None."""
+def gn_relu_forward_pair(xs, gammas, betas, groups=32, eps=1e-5, relu=True, levels=None, outs=None):
+    """[(y0, stats0), (y1, stats1)] in one launch, or None.  outs: two destinations of ONE layout (see gn_relu_forward)."""
     if not PAIR_LAUNCHES or not _same_layout(xs[0], xs[1]) or not xs[0].is_contiguous():
         return None
     L.require_device(*xs, *gammas, *betas)
     B, C, T = xs[0].shape
     nlev, lev = _lev_arg(levels)
-    ys = [torch.empty_like(x) for x in xs]
     stats = [torch.empty((B, groups, nlev, 2), dtype=torch.float32, device=x.device) for x in xs]
+    if outs is not None:
+        st0, st1 = _dest_strides(outs[0], B, C, T), _dest_strides(outs[1], B, C, T)
+        if st0 != st1:
+            return None
+        rc = L.lib().otal_gn_relu_fwd_pair_to(_pp(*xs), _pp(*gammas), _pp(*betas), _pp(*outs), ctypes.c_int64(st0[0]),
+                                              ctypes.c_int64(st0[1]), _pp(*stats), B, C, T, groups, ctypes.c_float(eps), int(relu),
+                                              nlev, lev, L.stream())
+        if rc == L.E_UNSUPPORTED:
+            return None
+        L.check(rc, "otal_gn_relu_fwd_pair_to")
+        return list(zip(outs, stats))
+    ys = [torch.empty_like(x) for x in xs]
     rc = L.lib().otal_gn_relu_fwd_pair(_pp(*xs), _pp(*gammas), _pp(*betas), _pp(*ys), _pp(*stats), B, C, T, groups,
                                        ctypes.c_float(eps), int(relu), nlev, lev, L.stream())
     if rc == L.E_UNSUPPORTED:
@@ -985,15 +998,60 @@ def _lev_arg(levels):
     return len(levels) - 1, L.int_array(list(levels))
 
 
-def gn_relu_forward(x, gamma, beta, groups=32, eps=1e-5, relu=True, levels=None):
+def _dest_strides(out, B, C, T):
+    """(batch stride, channel stride) of a destination that may be a level / channel slice of a wider buffer."""
+    if tuple(out.shape) != (B, C, T) or out.dtype != torch.float32 or not out.is_cuda or (T > 1 and out.stride(2) != 1):
+        raise RuntimeError("gn_relu_forward: `out` must be a float32 (B,C,T) GPU tensor with dense positions")
+    cs = out.stride(1) if C > 1 else T
+    return (out.stride(0) if B > 1 else cs * C), cs
+
+
+def gn_relu_forward(x, gamma, beta, groups=32, eps=1e-5, relu=True, levels=None, out=None):
+    """out: write y there -- a level slice of a packed pyramid buffer, a channel slice of a concatenation buffer (the copy
+    of torch.cat disappears); its positions must be dense."""
     L.require_device(x, gamma, beta)
     B, C, T = x.shape
     nlev, lev = _lev_arg(levels)
-    y = torch.empty_like(x)
     stats = torch.empty((B, groups, nlev, 2), dtype=torch.float32, device=x.device)
+    if out is not None:
+        bs, cs = _dest_strides(out, B, C, T)
+        L.check(L.lib().otal_gn_relu_fwd_to(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(out), ctypes.c_int64(bs), ctypes.c_int64(cs),
+                                            L.ptr(stats), B, C, T, groups, ctypes.c_float(eps), int(relu), nlev, lev, L.stream()),
+                "otal_gn_relu_fwd_to")
+        return out, stats
+    y = torch.empty_like(x)
     L.check(L.lib().otal_gn_relu_fwd(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(stats), B, C, T, groups,
                                      ctypes.c_float(eps), int(relu), nlev, lev, L.stream()), "otal_gn_relu_fwd")
     return y, stats
+
+
+def pyramid_merge_forward(p0, p1, total, up):
+    """(packed, frame): packed (B,C,total) with level 0 = p0 + nearest-upsampled p1 and level 1 = p1 filled in (the other
+    levels are left for their producers), frame (B,C,t0*up) = nearest-upsampled level 0 (BDNet.py:310-326)."""
+    L.require_device(p0, p1)
+    B, C, t0 = p0.shape
+    if tuple(p1.shape) != (B, C, t0 // 2):
+        raise RuntimeError("pyramid_merge_forward: p1 must have half of p0's positions")
+    packed = torch.empty((B, C, total), dtype=torch.float32, device=p0.device)
+    frame = torch.empty((B, C, t0 * up), dtype=torch.float32, device=p0.device)
+    L.check(L.lib().otal_pyramid_merge_fwd(L.ptr(p0), L.ptr(p1), L.ptr(packed), L.ptr(frame), B, C, t0, total, up, L.stream()),
+            "otal_pyramid_merge_fwd")
+    return packed, frame
+
+
+def pyramid_merge_backward(da, db, dframe, dnext, t0, up):
+    """(dp0, dp1) from the gradients w.r.t. the packed buffer (da + db; db may be None), the frame-level input and the
+    stride-2 layer's data gradient at level 1 (may be None)."""
+    L.require_device(da, dframe)
+    B, C, T = da.shape
+    dp0 = torch.empty((B, C, t0), dtype=torch.float32, device=da.device)
+    dp1 = torch.empty((B, C, t0 // 2), dtype=torch.float32, device=da.device)
+    for t in (db, dnext):
+        if t is not None:
+            L.require_device(t)
+    L.check(L.lib().otal_pyramid_merge_bwd(L.ptr(da), _opt(db), L.ptr(dframe), _opt(dnext), L.ptr(dp0), L.ptr(dp1), B, C, t0, T, up,
+                                           L.stream()), "otal_pyramid_merge_bwd")
+    return dp0, dp1
 
 
 PENDING_SUMS = None     # the running trainer's list of deferred batch sums (DetectorTrainer.begin_backward), or None

@@ -62,7 +62,8 @@ struct GnFwdAlt { const float* x; const float* gamma; const float* beta; float* 
 __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y,
                                                           float* __restrict__ stats, int C, int T, int G,
-                                                          float eps, int relu, GnLevels L, GnFwdAlt alt) {
+                                                          float eps, int relu, GnLevels L, GnFwdAlt alt,
+                                                          int64_t y_bs, int64_t y_cs) {
     if (blockIdx.y) { x = alt.x; gamma = alt.gamma; beta = alt.beta; y = alt.y; stats = alt.stats; }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* buf = reinterpret_cast<float*>(smem);
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
     const int cpg = C / G;
     float* bet = gam + cpg;
     const int64_t base = ((int64_t)b * C + (int64_t)g * cpg) * T;
+    const int64_t ybase = (int64_t)b * y_bs + (int64_t)g * cpg * y_cs;      // the destination may be a slice of a wider buffer
     const int n = cpg * T;
     // (one workgroup per (sample, group), a few microseconds long: every dependent memory round trip counts.  The affine
     //  parameters are fetched into registers and parked in LDS only AFTER the map's loads have been issued, and the map
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
         for_level(tid, 256, cpg, T, [&](int c, int t) {
             float v = (buf[c * T + t] - mean) * rstd * gam[c] + bet[c];
             if (relu) v = fmaxf(v, 0.f);
-            y[base + (int64_t)c * T + t] = v;
+            y[ybase + (int64_t)c * y_cs + t] = v;
         });
         return;
     }
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
         for_level(lane, 64, cpg, len, [&](int c, int t) {
             float v = (buf[c * T + lo + t] - mean) * rstd * gam[c] + bet[c];
             if (relu) v = fmaxf(v, 0.f);
-            y[base + (int64_t)c * T + lo + t] = v;
+            y[ybase + (int64_t)c * y_cs + lo + t] = v;
         });
     }
 }
@@ -286,7 +288,23 @@ extern "C" int otal_gn_relu_fwd(const float* x, const float* gamma, const float*
     static bool large_ok = false;
     if (int e = allow_large_lds(gn_relu_fwd_kernel, lds, large_ok)) return e;
     hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G), dim3(256), lds, (hipStream_t)stream,
-                       x, gamma, beta, y, stats, C, T, G, eps, relu, L, GnFwdAlt{});
+                       x, gamma, beta, y, stats, C, T, G, eps, relu, L, GnFwdAlt{}, (int64_t)C * T, (int64_t)T);
+    return otal_launch_status();
+}
+
+extern "C" int otal_gn_relu_fwd_to(const float* x, const float* gamma, const float* beta, float* y, int64_t y_bs, int64_t y_cs,
+                                   float* stats, int B, int C, int T, int G, float eps, int relu, int nlev, const int* lev,
+                                   void* stream) {
+    if (!x || !gamma || !beta || !y || !stats) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G || y_cs < T || y_bs < 0) return OTAL_E_SHAPE;
+    GnLevels L;
+    if (int e = fill_levels(L, T, nlev, lev)) return e;
+    const size_t lds = (size_t)(C / G) * T * 4 + 64 + (size_t)(C / G) * 8;
+    if (lds > LDS_MAX) return OTAL_E_UNSUPPORTED;
+    static bool large_ok = false;
+    if (int e = allow_large_lds(gn_relu_fwd_kernel, lds, large_ok)) return e;
+    hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G), dim3(256), lds, (hipStream_t)stream,
+                       x, gamma, beta, y, stats, C, T, G, eps, relu, L, GnFwdAlt{}, y_bs, y_cs);
     return otal_launch_status();
 }
 
@@ -302,7 +320,23 @@ extern "C" int otal_gn_relu_fwd_pair(const float* const* x, const float* const* 
     if (lds > 64 * 1024) return OTAL_E_UNSUPPORTED;
     const GnFwdAlt alt = {x[1], gamma[1], beta[1], y[1], stats[1]};
     hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G, 2), dim3(256), lds, (hipStream_t)stream,
-                       x[0], gamma[0], beta[0], y[0], stats[0], C, T, G, eps, relu, L, alt);
+                       x[0], gamma[0], beta[0], y[0], stats[0], C, T, G, eps, relu, L, alt, (int64_t)C * T, (int64_t)T);
+    return otal_launch_status();
+}
+
+extern "C" int otal_gn_relu_fwd_pair_to(const float* const* x, const float* const* gamma, const float* const* beta,
+                                        float* const* y, int64_t y_bs, int64_t y_cs, float* const* stats, int B, int C, int T,
+                                        int G, float eps, int relu, int nlev, const int* lev, void* stream) {
+    if (!x || !gamma || !beta || !y || !stats) return OTAL_E_NULL;
+    for (int i = 0; i < 2; ++i) if (!x[i] || !gamma[i] || !beta[i] || !y[i] || !stats[i]) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G || y_cs < T || y_bs < 0) return OTAL_E_SHAPE;
+    GnLevels L;
+    if (int e = fill_levels(L, T, nlev, lev)) return e;
+    const size_t lds = (size_t)(C / G) * T * 4 + 64 + (size_t)(C / G) * 8;
+    if (lds > 64 * 1024) return OTAL_E_UNSUPPORTED;
+    const GnFwdAlt alt = {x[1], gamma[1], beta[1], y[1], stats[1]};
+    hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G, 2), dim3(256), lds, (hipStream_t)stream,
+                       x[0], gamma[0], beta[0], y[0], stats[0], C, T, G, eps, relu, L, alt, y_bs, y_cs);
     return otal_launch_status();
 }
 

@@ -244,3 +244,68 @@ extern "C" int otal_masked_scale_copy(const float* src, const int64_t* src_strid
     else hipLaunchKernelGGL(masked_scale_copy_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, src, ss, z, zs, scale, dst, ds, C, T, S, total, accumulate);
     return otal_launch_status();
 }
+
+// ---- pyramid merge (AFSD/thumos14/BDNet.py:310-326): the two projected maps p0 (B,C,t0) and p1 (B,C,t0/2) -> the first two
+// levels of the level-packed buffer, level 0 = p0 + nearest-upsampled p1 (F.interpolate(x, x0.size()[2:], mode='nearest'):
+// source index t / 2), level 1 = p1, and the frame-level input F.interpolate(level 0, [frame_num, 1]) (index t / up) --
+// one launch for what were upsample_nearest1d + add + the level copies of torch.cat + upsample_nearest2d.
+namespace {
+__global__ __launch_bounds__(256) void pyramid_merge_fwd_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                                float* __restrict__ packed, float* __restrict__ frame,
+                                                                int rows, int t0, int T, int up) {
+    const int t1 = t0 >> 1, F = t0 * up;
+    const int row = blockIdx.x;                              // (b, c)
+    if (row >= rows) return;
+    for (int t = threadIdx.x; t < F; t += 256) {
+        const int s = t / up;
+        const float v = p0[(size_t)row * t0 + s] + p1[(size_t)row * t1 + (s >> 1)];
+        frame[(size_t)row * F + t] = v;
+        if (t < t0) packed[(size_t)row * T + t] = p0[(size_t)row * t0 + t] + p1[(size_t)row * t1 + (t >> 1)];
+        if (t < t1) packed[(size_t)row * T + t0 + t] = p1[(size_t)row * t1 + t];
+    }
+}
+// backward: da, db (B,C,T) the two gradients w.r.t. the packed buffer (only their first two levels are read), dframe
+// (B,C,t0*up), dnext (B,C,t0/2) the data gradient of the stride-2 layer that reads level 1 (may be null):
+//   d level0[t] = da[t] + db[t] + sum_{j<up} dframe[up t + j];  dp0 = d level0;
+//   dp1[s] = da[t0+s] + db[t0+s] + dnext[s] + d level0[2s] + d level0[2s+1]        (fixed summation order)
+__global__ __launch_bounds__(256) void pyramid_merge_bwd_kernel(const float* __restrict__ da, const float* __restrict__ db,
+                                                                const float* __restrict__ dframe, const float* __restrict__ dnext,
+                                                                float* __restrict__ dp0, float* __restrict__ dp1,
+                                                                int rows, int t0, int T, int up) {
+    __shared__ float l0[1024];
+    const int t1 = t0 >> 1, F = t0 * up;
+    const int row = blockIdx.x;
+    if (row >= rows) return;
+    for (int t = threadIdx.x; t < t0; t += 256) {
+        float v = da[(size_t)row * T + t] + (db ? db[(size_t)row * T + t] : 0.f);
+        float f = 0.f;
+        for (int j = 0; j < up; ++j) f += dframe[(size_t)row * F + t * up + j];
+        v += f;
+        l0[t] = v;
+        dp0[(size_t)row * t0 + t] = v;
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < t1; s += 256) {
+        float v = da[(size_t)row * T + t0 + s] + (db ? db[(size_t)row * T + t0 + s] : 0.f);
+        if (dnext) v += dnext[(size_t)row * t1 + s];
+        v += l0[2 * s] + l0[2 * s + 1];
+        dp1[(size_t)row * t1 + s] = v;
+    }
+}
+}  // namespace
+
+extern "C" int otal_pyramid_merge_fwd(const float* p0, const float* p1, float* packed, float* frame, int B, int C, int t0,
+                                      int T, int up, void* stream) {
+    if (!p0 || !p1 || !packed || !frame) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0 || t0 <= 0 || (t0 & 1) || up <= 0 || T < t0 + t0 / 2) return OTAL_E_SHAPE;
+    hipLaunchKernelGGL(pyramid_merge_fwd_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, p0, p1, packed, frame, B * C, t0, T, up);
+    return otal_launch_status();
+}
+extern "C" int otal_pyramid_merge_bwd(const float* da, const float* db, const float* dframe, const float* dnext, float* dp0,
+                                      float* dp1, int B, int C, int t0, int T, int up, void* stream) {
+    if (!da || !dframe || !dp0 || !dp1) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0 || t0 <= 0 || (t0 & 1) || t0 > 1024 || up <= 0 || T < t0 + t0 / 2) return OTAL_E_SHAPE;
+    hipLaunchKernelGGL(pyramid_merge_bwd_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, da, db, dframe, dnext, dp0, dp1,
+                       B * C, t0, T, up);
+    return otal_launch_status();
+}

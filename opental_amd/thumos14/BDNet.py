@@ -242,19 +242,27 @@ class CoarsePyramid(nn.Module):
 
     def forward(self, feat_dict, ssl=False, get_feat=False):
         tr = lambda y: y.permute(0, 2, 1).contiguous()
-        feats, frame_level_feat = self._pyramid(feat_dict)
-        batch_num = feats[0].size(0)
-        if ssl:   # triplet branch: level 0 only (BDNet.py:392-398)
-            loc_feat = self.loc_tower[1](self.loc_tower[0](feats[0]))
-            conf_feat = self.conf_tower[1](self.conf_tower[0](feats[0]))
-            return [frame_level_feat, self.loc_proposal_branch.lr_conv(loc_feat),
-                    self.conf_proposal_branch.lr_conv(conf_feat)]
+        from . import pyramid_fused as PF
+        # the pyramid as two hand-scheduled autograd nodes (thumos14/pyramid_fused.py) where the layout is the THUMOS14 one;
+        # the module-by-module composition below otherwise (ActivityNet, the ssl branch, the compat-gradient mode)
+        fused = ops.FUSED_PYRAMID and not ssl and PF.eligible(self, feat_dict)
         lev = self.levels
-        packed = torch.cat(feats, dim=2)                                    # (B,512,126)
-        # the loc and the conf tower are siblings of one shape: each of their two stages is ONE set of launches for both
-        # (common/layers.py conv_gn_relu_pair; values as of the blocks on their own)
-        l0, c0 = conv_gn_relu_pair(self.loc_tower[0], self.conf_tower[0], packed, packed, lev)
-        loc_feat, conf_feat = conv_gn_relu_pair(self.loc_tower[1], self.conf_tower[1], l0, c0, lev)
+        if fused:
+            loc_feat, conf_feat, frame_level_feat = PF.trunk(self, feat_dict)
+            batch_num = loc_feat.size(0)
+        else:
+            feats, frame_level_feat = self._pyramid(feat_dict)
+            batch_num = feats[0].size(0)
+            if ssl:   # triplet branch: level 0 only (BDNet.py:392-398)
+                loc_feat = self.loc_tower[1](self.loc_tower[0](feats[0]))
+                conf_feat = self.conf_tower[1](self.conf_tower[0](feats[0]))
+                return [frame_level_feat, self.loc_proposal_branch.lr_conv(loc_feat),
+                        self.conf_proposal_branch.lr_conv(conf_feat)]
+            packed = torch.cat(feats, dim=2)                                    # (B,512,126)
+            # the loc and the conf tower are siblings of one shape: each of their two stages is ONE set of launches for both
+            # (common/layers.py conv_gn_relu_pair; values as of the blocks on their own)
+            l0, c0 = conv_gn_relu_pair(self.loc_tower[0], self.conf_tower[0], packed, packed, lev)
+            loc_feat, conf_feat = conv_gn_relu_pair(self.loc_tower[1], self.conf_tower[1], l0, c0, lev)
         # Head convolutions are level-batched GEMM launches; their tails -- ScaleExp (x fpn stride in the ActivityNet model),
         # the permute(0,2,1).contiguous() of every map and the Dirichlet uncertainty -- are one launch per stage
         # (csrc/heads.hip): the coarse stage here, the refined stage after the proposal branches.
@@ -277,20 +285,25 @@ class CoarsePyramid(nn.Module):
         from ..prop_pooling import boundary_pooling_op as _bp
         # compat-gradient mode keeps one pooling per branch: the reference's (buggy) backward runs once per branch, and
         # bwd(g1) + bwd(g2) is only bit-identical to bwd(g1 + g2) for the correct gradient up to fp32 rounding anyway
-        roi = None if _bp.COMPAT_REFERENCE_BWD else self.loc_proposal_branch.pool_frame_level(frame_level_feat, frame_segments, lev)
-        (loc_prop_feat, loc_lr), (conf_prop_feat, conf_lr) = self._proposal_branches(
-            loc_feat, conf_feat, frame_level_feat, segments, frame_segments, lev, roi)
+        t0 = self.level_lengths[0]
+        if fused:
+            loc_prop_feat, conf_prop_feat, loc_lr0, conf_lr0 = PF.branches(self, loc_feat, conf_feat, frame_level_feat,
+                                                                           segments, frame_segments)
+        else:
+            roi = None if _bp.COMPAT_REFERENCE_BWD else self.loc_proposal_branch.pool_frame_level(frame_level_feat, frame_segments, lev)
+            (loc_prop_feat, loc_lr), (conf_prop_feat, conf_lr) = self._proposal_branches(
+                loc_feat, conf_feat, frame_level_feat, segments, frame_segments, lev, roi)
+            loc_lr0, conf_lr0 = loc_lr[:, :, :t0], conf_lr[:, :, :t0]
         # The six boundary maps of the output dict are (B,T,C) VIEWS of the channel-major maps (the reference returns
         # permuted copies, BDNet.py:328-331,:392-396; same values): their only consumer, the start / end losses of the
         # training step, reads the channel-major maps in place (ops.BoundaryBCEFunction via OutputDict.boundary_maps).
         pv = lambda y: y.permute(0, 2, 1)
         half = frame_level_feat.size(1) // 2
         start, end = pv(frame_level_feat[:, :half]), pv(frame_level_feat[:, half:])
-        t0 = self.level_lengths[0]
-        ndim = loc_lr.size(1) // 2
-        start_loc_prop, end_loc_prop = pv(loc_lr[:, :ndim, :t0]), pv(loc_lr[:, ndim:, :t0])
-        start_conf_prop, end_conf_prop = pv(conf_lr[:, :ndim, :t0]), pv(conf_lr[:, ndim:, :t0])
-        boundary_maps = (frame_level_feat, loc_lr[:, :, :t0], conf_lr[:, :, :t0])
+        ndim = loc_lr0.size(1) // 2
+        start_loc_prop, end_loc_prop = pv(loc_lr0[:, :ndim]), pv(loc_lr0[:, ndim:])
+        start_conf_prop, end_conf_prop = pv(conf_lr0[:, :ndim]), pv(conf_lr0[:, ndim:])
+        boundary_maps = (frame_level_feat, loc_lr0, conf_lr0)
         stage = [(loc_prop_feat, self.prop_loc_head), (self._drop(conf_prop_feat), self.prop_conf_head), (loc_prop_feat, self.center_head)]
         if self.os_head:
             stage.append((conf_prop_feat, self.prop_actionness_head))

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.otal_abi_version() == 23
+    assert lib.otal_abi_version() == 24
     lib.otal_error_string.restype = ctypes.c_char_p
     assert b"batch" in lib.otal_error_string(-4)
     assert lib.otal_error_string(0) == b"success"
