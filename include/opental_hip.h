@@ -560,6 +560,13 @@ int otal_gn_relu_fwd_pair_to(const float* const* x, const float* const* gamma, c
                              int64_t y_bs, int64_t y_cs, float* const* stats, int B, int C, int T, int G, float eps, int relu,
                              int nlev, const int* lev, void* stream);
 
+/* otal_gn_relu_bwd whose output gradient is the SUM of n_terms (1..3) maps (B,C,dy_T[k] <= T) with their own batch / channel
+ * strides (positions >= dy_T[k] of term k add nothing; summation order = term order): the gradient adds autograd issues for a
+ * tensor with several consumers, done while the map is staged. */
+int otal_gn_relu_bwd_sum(int n_terms, const float* const* dy, const int64_t* dy_bs, const int64_t* dy_cs, const int* dy_T,
+                         const float* x, const float* gamma, const float* beta, const float* stats, float* dx, float* partial,
+                         int B, int C, int T, int G, int relu, int nlev, const int* lev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -504,7 +504,13 @@ class I3DFeaturesFunction(Function):
         in_slots = True
         dcur = None
         cloned = True               # False while dcur still aliases an incoming gradient tensor
+        # where only the stem's tail is left (no Inception module below this position): the trainer may start the optimizer
+        # step for every other parameter beside these last weight gradients (ops.late_mark)
+        mixed_pos = [p for p in range(1, len(tape) + 1) if tape[p - 1][0] == "mixed"]
+        tail_below = min(mixed_pos) if mixed_pos and not need_dx else 0
         for pos in range(len(tape), 0, -1):
+            if pos == tail_below - 1 and not any(pending.get(q) for q in range(1, pos + 1)):
+                ops.late_mark([weights[st[1]] for st in tape[:pos] if st[0] == "conv"])
             for g, z, zs in pending.pop(pos, ()):
                 dense = g.dim() == 5 and (g.shape[4] == 1 or g.stride(4) == 1) and (g.shape[3] == 1 or g.stride(3) == g.shape[4])
                 if zs is not None and not dense:

@@ -165,6 +165,7 @@ class LanePlan:
         self.cur = None
         self.side = side_stream
         self.keep = []
+        self.mark_event = None      # ("mark",) records it on the side stream, ("wait_mark",) makes the main stream wait for it
 
     def begin_main(self):
         g = torch.cuda.CUDAGraph()
@@ -212,6 +213,12 @@ class LanePlan:
                     e[1].replay()
             elif kind == "join":
                 L.check(lib.otal_stream_wait(main, side_raw), "otal_stream_wait")
+            elif kind == "mark":            # the side lane's position NOW: every chunk issued so far, none of the later ones
+                if self.mark_event is None:
+                    self.mark_event = torch.cuda.Event()
+                self.mark_event.record(self.side)
+            elif kind == "wait_mark":
+                torch.cuda.current_stream().wait_event(self.mark_event)
             else:
                 e[1]()
 
@@ -326,6 +333,7 @@ class SideWgrads:
 BRANCH_LANE = os.environ.get("OTAL_BRANCH_LANE", "1") != "0"
 # the pyramid as two hand-scheduled autograd nodes (thumos14/pyramid_fused.py) instead of one node per block
 FUSED_PYRAMID = os.environ.get("OTAL_FUSED_PYRAMID", "1") != "0"
+PYRAMID_LANE = os.environ.get("OTAL_PYRAMID_LANE", "1") != "0"        # ... with their independent chains on the branch lane
 _BRANCHES = {}
 
 
@@ -350,10 +358,17 @@ class BranchLane:
         global _WS_SIDE
         self._saved = (_WS_SIDE, L.STREAM_OVERRIDE)
         _WS_SIDE, L.STREAM_OVERRIDE = 2, self._raw.value
+        # the lane is also torch's current stream inside the block: tensors allocated here come from the LANE's pool of the
+        # caching allocator.  With the main stream current, a block the main lane had just freed (its last reader still
+        # queued there) could be handed to a lane tensor and overwritten by a lane kernel first -- two lanes, one pool
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
         return self
 
     def __exit__(self, *exc):
         global _WS_SIDE
+        self._ctx.__exit__(*exc)
+        self._ctx = None
         _WS_SIDE, L.STREAM_OVERRIDE = self._saved
         return False
 
@@ -372,6 +387,31 @@ def side_wgrads(device):
     if sd is None:
         sd = _SIDES[key] = SideWgrads(device)
     return sd
+
+
+# ---- the optimizer step beside the LAST weight gradients.  The stem's weight gradients (Conv3d_2c, 2b, 1a: ~0.75 ms on the
+# side lane) are the step's tail: the main lane has nothing left but Adam, which needs every gradient -- except that an
+# elementwise optimizer can update all OTHER parameters as soon as THEIR gradients are final.  The backbone's backward
+# calls late_mark() where only its stem tail is left; in a lane-graph capture that closes the side lane's chunk and records a
+# ("mark",) entry, and the trainer (DetectorTrainer.end_backward) runs Adam over everything but LATE_WEIGHTS behind the mark,
+# beside the tail's weight gradients, and Adam over the tail's few parameters after the final join.
+EARLY_ADAM = os.environ.get("OTAL_EARLY_ADAM", "1") != "0"
+LATE_WEIGHTS = None
+
+
+def late_mark(weights):
+    global LATE_WEIGHTS
+    if LANES is None or not EARLY_ADAM or LATE_WEIGHTS is not None:
+        return
+    side_issue()
+    LANES.cut(("mark",))
+    LATE_WEIGHTS = list(weights)
+
+
+def take_late_weights():
+    global LATE_WEIGHTS
+    w, LATE_WEIGHTS = LATE_WEIGHTS, None
+    return w
 
 
 def side_join():

@@ -134,11 +134,15 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
 // dx: (B,C,T); partial: (B,3,C) = {sum dyh*xhat, sum dyh, sum dx} (channel-contiguous rows: summing over b leaves
 // d_gamma, d_beta and the bias gradient as three contiguous vectors)
 struct GnBwdAlt { const float* dy; const float* x; const float* gamma; const float* beta; const float* stats; float* dx; float* partial; int64_t dy_bs; };
+// otal_gn_relu_bwd_sum: the output gradient is the SUM of up to three terms, each a (B,C,T_i <= T) map with its own batch /
+// channel strides (a level slice of a packed buffer, a map that covers only the first level): what autograd used to add with
+// one elementwise launch per term, read here while the map is staged (term order = summation order).
+struct GnTerms { int n; int Tn[3]; const float* p[3]; int64_t bs[3]; int64_t cs[3]; };
 __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ stats, float* __restrict__ dx,
                                                           float* __restrict__ partial, int C, int T, int G, int relu,
-                                                          GnLevels L, int64_t dy_bs, int keep_dx, GnBwdAlt alt) {
+                                                          GnLevels L, int64_t dy_bs, int keep_dx, GnBwdAlt alt, GnTerms terms) {
     if (blockIdx.y) { dy = alt.dy; x = alt.x; gamma = alt.gamma; beta = alt.beta; stats = alt.stats; dx = alt.dx; partial = alt.partial; dy_bs = alt.dy_bs; }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int cpg = C / G;
@@ -174,7 +178,31 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
             st_pre[k].y = stats[(((int64_t)b * G + g) * L.nlev + l) * 2 + 1];
         }
     }
-    if (((reinterpret_cast<uintptr_t>(x + base) | reinterpret_cast<uintptr_t>(dy + dbase) | (uintptr_t)(n * 4)) & 15) == 0) {
+    if (terms.n > 0) {          // summed terms: rows of the group wave by wave, lanes along the positions; all loads of a trip together
+        for (int c = wv; c < cpg; c += 4)
+            for (int t0 = ln; t0 < T; t0 += 128) {
+                float v[2][3], xv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = t0 + 64 * u;
+                    const int tc = t < T ? t : T - 1;
+                    xv[u] = x[base + (int64_t)c * T + tc];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const bool ok = k < terms.n && t < terms.Tn[k];
+                        const int tk = k < terms.n ? (tc < terms.Tn[k] ? tc : terms.Tn[k] - 1) : 0;
+                        const float* q = k < terms.n ? terms.p[k] + (int64_t)b * terms.bs[k] + (int64_t)(g * cpg + c) * terms.cs[k] + tk : x + base;
+                        const float w = *q;
+                        v[u][k] = ok ? w : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = t0 + 64 * u;
+                    if (t < T) { xb[c * T + t] = xv[u]; gb[c * T + t] = (v[u][0] + v[u][1]) + v[u][2]; }
+                }
+            }
+    } else if (((reinterpret_cast<uintptr_t>(x + base) | reinterpret_cast<uintptr_t>(dy + dbase) | (uintptr_t)(n * 4)) & 15) == 0) {
         for (int i = tid; i < (n >> 2); i += 256) {          // both maps in one trip: their loads are in flight together
             const float4 xv = reinterpret_cast<const float4*>(x + base)[i], dv = reinterpret_cast<const float4*>(dy + dbase)[i];
             reinterpret_cast<float4*>(xb)[i] = xv;
@@ -356,7 +384,32 @@ extern "C" int otal_gn_relu_bwd(const float* dy, int64_t dy_batch_stride, const 
     static bool large_ok = false;
     if (int e = allow_large_lds(gn_relu_bwd_kernel, lds, large_ok)) return e;
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(256), lds, (hipStream_t)stream,
-                       dy, x, gamma, beta, stats, dx, partial, C, T, G, relu, L, dy_batch_stride, keep_dx, GnBwdAlt{});
+                       dy, x, gamma, beta, stats, dx, partial, C, T, G, relu, L, dy_batch_stride, keep_dx, GnBwdAlt{}, GnTerms{});
+    return otal_launch_status();
+}
+
+extern "C" int otal_gn_relu_bwd_sum(int n_terms, const float* const* dy, const int64_t* dy_bs, const int64_t* dy_cs, const int* dy_T,
+                                    const float* x, const float* gamma, const float* beta, const float* stats, float* dx,
+                                    float* partial, int B, int C, int T, int G, int relu, int nlev, const int* lev, void* stream) {
+    if (!dy || !dy_bs || !dy_cs || !dy_T || !x || !gamma || !beta || !stats || !dx || !partial) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G || n_terms < 1 || n_terms > 3) return OTAL_E_SHAPE;
+    GnTerms tm = {};
+    tm.n = n_terms;
+    for (int k = 0; k < n_terms; ++k) {
+        if (!dy[k]) return OTAL_E_NULL;
+        if (dy_T[k] <= 0 || dy_T[k] > T || dy_cs[k] < dy_T[k] || dy_bs[k] < 0) return OTAL_E_SHAPE;
+        tm.p[k] = dy[k]; tm.bs[k] = dy_bs[k]; tm.cs[k] = dy_cs[k]; tm.Tn[k] = dy_T[k];
+    }
+    GnLevels L;
+    if (int e = fill_levels(L, T, nlev, lev)) return e;
+    size_t lds = (size_t)(C / G) * T * 12 + 64 + (size_t)(C / G) * 8;
+    const int keep_dx = lds <= LDS_MAX;
+    if (!keep_dx) lds -= (size_t)(C / G) * T * 4;
+    if (lds > LDS_MAX) return OTAL_E_UNSUPPORTED;
+    static bool large_ok = false;
+    if (int e = allow_large_lds(gn_relu_bwd_kernel, lds, large_ok)) return e;
+    hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(256), lds, (hipStream_t)stream,
+                       dy[0], x, gamma, beta, stats, dx, partial, C, T, G, relu, L, (int64_t)C * T, keep_dx, GnBwdAlt{}, tm);
     return otal_launch_status();
 }
 
@@ -380,7 +433,7 @@ extern "C" int otal_gn_relu_bwd_pair(const float* const* dy, const int64_t* dy_b
     if (lds > 64 * 1024) return OTAL_E_UNSUPPORTED;
     const GnBwdAlt alt = {dy[1], x[1], gamma[1], beta[1], stats[1], dx[1], partial[1], bs[1]};
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G, 2), dim3(256), lds, (hipStream_t)stream,
-                       dy[0], x[0], gamma[0], beta[0], stats[0], dx[0], partial[0], C, T, G, relu, L, bs[0], keep_dx, alt);
+                       dy[0], x[0], gamma[0], beta[0], stats[0], dx[0], partial[0], C, T, G, relu, L, bs[0], keep_dx, alt, GnTerms{});
     return otal_launch_status();
 }
 

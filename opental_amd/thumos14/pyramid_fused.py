@@ -47,14 +47,19 @@ def _gn_bwd_raw(dy, c, gamma, beta, stats, groups, levels):
 
 def _gn_bwd_adds(adds, c, gamma, beta, stats, groups, levels):
     """GroupNorm + ReLU backward of a block whose output gradient is the SUM of `adds` [(tensor, positions or None)]: the
-    sum happens inside the launch (otal_b1d_launch, no GEMM segment).  -> (dc, partial)."""
+    sum happens while the launch stages the map (otal_gn_relu_bwd_sum).  -> (dc, partial)."""
     B, C, T = c.shape
+    n = len(adds)
     dc = torch.empty_like(c)
     partial = torch.empty((B, 3, C), dtype=torch.float32, device=c.device)
-    P = B1.problem(B1.BWD, B, C, T, [], dc, c=c, stats=stats, gamma=gamma, beta=beta, adds=adds, partial=partial,
-                   levels=levels, groups=groups)
-    if not B1.launch([P]):
-        raise RuntimeError("pyramid_fused: otal_b1d_launch has no kernel for this GroupNorm backward")
+    nlev, lev = ops._lev_arg(levels)
+    strides = [B1._bs_cs(t) for t, _ in adds]
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in adds])
+    I64 = ctypes.c_int64 * n
+    L.check(L.lib().otal_gn_relu_bwd_sum(n, ptrs, I64(*[s[0] for s in strides]), I64(*[s[1] for s in strides]),
+                                         (ctypes.c_int * n)(*[t.shape[2] if Ta is None else Ta for t, Ta in adds]),
+                                         L.ptr(c), L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.ptr(dc), L.ptr(partial),
+                                         B, C, T, groups, 1, nlev, lev, L.stream()), "otal_gn_relu_bwd_sum")
     return dc, partial
 
 
@@ -138,7 +143,7 @@ class TrunkFunction(Function):
         tape["proj"] = (c0, st0, c1, st1)
         # the frame-level deconv (BDNet.py:324-326) on the branch lane, beside the stride-2 levels and the towers
         lane = ops.branch_lane(x1.device)
-        use_lane = lane.on
+        use_lane = lane.on and ops.PYRAMID_LANE
         dtape = []
 
         def deconv():
@@ -193,7 +198,7 @@ class TrunkFunction(Function):
         def put(i, dw):
             grads[4 * i] = dw
         lane = ops.branch_lane(dev)
-        use_lane = lane.on and d_frame is not None
+        use_lane = lane.on and ops.PYRAMID_LANE and d_frame is not None
         d_loc, d_conf = d_loc.contiguous(), d_conf.contiguous()
         if d_frame is not None:
             d_frame = d_frame.contiguous()
@@ -201,6 +206,9 @@ class TrunkFunction(Function):
 
         lane_wgrads = []                    # recorded on the lane, handed to the side lane only after the join: the side lane
                                             # waits for the MAIN lane's position, which does not cover the branch lane's work
+
+        hold = []                           # every tensor a lane kernel reads stays alive until the join: the caching allocator
+                                            # believes the main stream owns it and would hand a freed block to the next request
 
         def deconv_bwd():
             dy = d_frame
@@ -210,6 +218,7 @@ class TrunkFunction(Function):
                 sums.append((6 + i, part, B))
                 lane_wgrads.append((6 + i, x, dc, dec[i][0], k))
                 dy = ops.conv_dgrad(dc, dec[i][0], x.shape, k, ONE)
+                hold.append(dy)
             return dy
         if use_lane:
             lane.fork()
@@ -284,7 +293,7 @@ class BranchesFunction(Function):
         dev = loc_feat.device
         cat = [torch.empty((B, 4 * Cp, T), dtype=torch.float32, device=dev) for _ in range(2)]      # [roi | pooled | short]
         lane = ops.branch_lane(dev)
-        use_lane = lane.on
+        use_lane = lane.on and ops.PYRAMID_LANE
 
         def roi_path():
             pooled = bp.bmp_forward(frame, frame_segments)                                          # BDNet.py:109 (shared)
@@ -339,14 +348,16 @@ class BranchesFunction(Function):
         put(3, WG.pair(cat, (r[0][0], r[1][0]), (prop[0][0], prop[1][0]), K1, ONE, lev))
         dcat = _dgrad_pair((r[0][0], r[1][0]), (prop[0][0], prop[1][0]), cat[0].shape, K1, lev)
         lane = ops.branch_lane(dev)
-        use_lane = lane.on
+        use_lane = lane.on and ops.PYRAMID_LANE
         d_frame = None
+        hold = []
 
         def roi_bwd():
             rr = _gn_bwd_pair((dcat[0][:, :Cp], dcat[1][:, :Cp]), (c_roi[0][0], c_roi[1][0]), roi, (c_roi[0][1], c_roi[1][1]), G, lev)
             # the two branches' gradients w.r.t. the shared pooled map: the second data gradient adds to the first
             dpool = ops.conv_dgrad(rr[0][0], roi[0][0], pooled_roi.shape, K1, ONE, levels=lev)
             ops.conv_dgrad(rr[1][0], roi[1][0], pooled_roi.shape, K1, ONE, levels=lev, out=dpool, accumulate=True)
+            hold.append(dpool)              # (read by a lane kernel: alive until the join, see TrunkFunction.backward)
             return rr, bp.bmp_backward(dpool, frame, frame_segments)
         if use_lane:
             lane.fork()

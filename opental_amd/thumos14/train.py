@@ -410,6 +410,20 @@ class DetectorTrainer:
         """Call after cost.backward(): flush the buckets that did not complete (unused parameters), wait for the
         all-reduces, and leave every .grad aliasing its arena slice."""
         self._drain(force=True)
+        self._adam_left = None
+        late = ops.take_late_weights()
+        if late and ops.LANES is not None and self._capturing and not self.collectives and not self._skipped:
+            # lane capture, one process: Adam for everything but the stem tail's weights runs NOW on the main lane -- behind the
+            # mark the backbone left on the side lane (ops.late_mark), beside the tail's weight gradients -- and only the
+            # tail's parameters wait for the final join (_graph_body)
+            span = self._late_range(late)
+            if span is not None:
+                ops.side_issue()                        # the tail's chunk (its fork sits in front of the optimizer launches)
+                ops.flush_pending_sums()                # GroupNorm batch sums: main-lane launches into the arena
+                ops.LANES.cut(("wait_mark",))
+                self._adam_captured(0, span[0])
+                self._adam_captured(span[1], self.arena.numel)
+                self._adam_left = span
         ops.side_join()                                 # the weight gradients' stream: everything after this reads them
         ops.SIDE_DEFER_JOIN = False
         ops.defer_reduces(False)                        # flushes what is still recorded
@@ -577,14 +591,32 @@ class DetectorTrainer:
             ops.PENDING_SUMS = None
             ops.SIDE_DEFER_JOIN = False
             ops.defer_reduces(False)
-        a = self.arena
         keep = self._stash_skipped()
+        span = getattr(self, "_adam_left", None) or (0, self.arena.numel)       # (what end_backward's early launches left)
+        self._adam_captured(span[0], span[1])
+        self._adam_left = None
+        self._restore_skipped(keep)
+        return cost.detach(), _detached(losses)
+
+    def _adam_captured(self, start, stop):
+        """Adam over the arena range [start, stop) (graph-replayable: bias corrections in device memory), group by group."""
+        a = self.arena
         for lo, hi, g_lr in self._group_ranges:
+            lo, hi = max(lo, start), min(hi, stop)
+            if lo >= hi:
+                continue
             g_lr = g_lr * (self.lr / self._base_lr) if self._base_lr else g_lr
             ops.adam_flat_dev(a.flat[lo:hi], a.grad[lo:hi], a.m[lo:hi], a.v[lo:hi], self._bias_corr, g_lr,
                               self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
-        self._restore_skipped(keep)
-        return cost.detach(), _detached(losses)
+
+    def _late_range(self, weights):
+        """[lo, hi) of the arena when the stem tail's weights are neighbours there (the backbone's parameters sit in reverse
+        registration order: its first layers end its block), else None."""
+        a = self.arena
+        idx = sorted(self._index_of.get(w.data_ptr(), -1) for w in weights)
+        if not idx or idx[0] < 0 or idx != list(range(idx[0], idx[-1] + 1)):
+            return None
+        return a.offsets[idx[0]], a.offsets[idx[-1]] + a.params[idx[-1]].numel()
 
     def capture_step(self, clips, targets, scores, warmup=2, split=False, lanes=False):
         """Capture forward + losses + backward (+ gradient all-reduce) + Adam for inputs of these shapes.
