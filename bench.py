@@ -723,6 +723,25 @@ def main():
                   f"({100 * frac:.1f} % > 10 %) -- the collectives are NOT hidden under the backward pass at N = {world}\n" + "!" * 100,
                   file=sys.stderr, flush=True)
     replicas_ok = replica_check("after the timed steps") and replicas_ok
+    # one more step with the all-reduce trace on: per rank, where on the step's timeline every bucket's all-reduce is issued
+    # (HIP event on the issuing lane, ms after the step's first launch) and where the step waits for them -- the first N > 1
+    # hardware run is then diagnosable from this line alone (which bucket is late, which lane issued it, how long the wait is)
+    allreduce_timeline = None
+    if multi:
+        try:
+            trainer.bucket_trace = []
+            step()
+            torch.cuda.synchronize()
+            rec, trainer.bucket_trace = trainer.bucket_trace, None
+            t_host, ev0 = rec[0][3], rec[0][4]
+            mine = [{"what": k, "bucket": b, "MB": None if nb is None else round(nb / 1e6, 2),
+                     "gpu_ms": round(ev0.elapsed_time(ev), 3), "host_ms": round((th - t_host) * 1e3, 3)} for k, b, nb, th, ev in rec]
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            allreduce_timeline = {f"rank{r}": g for r, g in enumerate(gathered)}
+        except Exception as e:                      # noqa: BLE001 -- a diagnostic must never take the headline down
+            trainer.bucket_trace = None
+            allreduce_timeline = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
 
     nbuckets = len(trainer.arena.buckets)
     infer_n = None
@@ -851,6 +870,7 @@ def main():
                                          "the backward pass (the backbone hands its finished layers over while it runs); "
                                          "exposed = compute-stream wait for the collectives after backward" % nbuckets,
                        "allreduce_exposed_ms": None if exposed_ms is None else round(exposed_ms, 3),
+                       "allreduce_timeline": allreduce_timeline,
                        "allreduce_check": allreduce_check,
                        "ms_per_step_per_rank": per_rank_ms,
                        "rank_spread_ms": None if not per_rank_ms else round(max(per_rank_ms) - min(per_rank_ms), 3),

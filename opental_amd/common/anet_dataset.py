@@ -144,6 +144,10 @@ class LazyVideo:
         return self._ds.video(self.name)[idx]
 
 
+# set by DetectorTrainer while it captures a step (thumos14/train.py): background readers do not pin host memory meanwhile
+CAPTURE_IN_PROGRESS = [False]
+
+
 class ANET_Dataset:
     """Same constructor arguments as the reference's Dataset (anet_dataset.py:129-153).  `decide(idx)` is `__getitem__`
     up to the pixels.  Videos are read from <video_dir>/<name>.npy (uint8, (T,H,W,3)) when a batch is SUBMITTED and kept in a
@@ -188,7 +192,12 @@ class ANET_Dataset:
         v = torch.from_numpy(np.load(os.path.join(self.video_dir, name + '.npy')))
         if v.dtype != torch.uint8 or v.dim() != 4 or v.shape[3] != 3:
             raise RuntimeError(f"{name}.npy: expected uint8 (T,H,W,3)")
-        if self._pin and torch.cuda.is_available():
+        # (pinning = hipHostMalloc: done by the thread that reads -- the main thread when it waits in video(), a reader thread
+        #  otherwise -- but never while the main thread captures the step: hipHostMalloc is not legal during a stream capture
+        #  in relaxed mode on every runtime, so background readers hand over pageable frames then and the stager's own pinned
+        #  slots, which every frame is copied into at submit time anyway, carry the upload)
+        if self._pin and torch.cuda.is_available() and not (threading.current_thread() is not threading.main_thread()
+                                                            and CAPTURE_IN_PROGRESS[0]):
             v = v.pin_memory()
         return v
 
@@ -199,6 +208,15 @@ class ANET_Dataset:
         with self._lock:
             if self._pool is None:
                 self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=2, thread_name_prefix="anet-video")
+            # finished reads nobody came for (the epoch ended, --max_steps cut the loop) and that this request does not name:
+            # their pinned frames would be held for good and count against the cap until prefetching stops silently.  A read
+            # that FAILED is reported here -- video() would only have raised it had somebody asked for that video
+            want = set(names)
+            for old_name in [n for n, f in self._pending.items() if n not in want and f.done()]:
+                fut = self._pending.pop(old_name)
+                if fut.exception() is not None:
+                    import warnings
+                    warnings.warn(f"background read of {old_name}.npy failed: {fut.exception()!r}")
             for name in dict.fromkeys(names):
                 if name in self._cache or name in self._pending or len(self._pending) >= max(1, self._cap // 2):
                     continue

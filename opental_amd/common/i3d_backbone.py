@@ -368,8 +368,11 @@ class I3DFeaturesFunction(Function):
             # or a geometry the chain's kernels do not cover): the pool's bf16-in / fp32-out kernel reads it as it is
             # (ops.maxpool3d_forward on a bfloat16 input) -- no conversion pass, no "cvt" seam, the gradient convention of
             # the tape entry below (half_grads) decides how the pool's backward stores dx
+            # (... where that kernel exists: the sign-bit form needs even H and W % 4 == 0, as _pool_half_ok states it -- any other
+            # plane takes the conversion seam like every geometry without bf16-tensor kernels)
             pool_io1 = (cur.dtype == BF and not chain and kind == "pool" and cur_scale is not None
-                        and tuple(step[1]) == (1, 3, 3) and tuple(step[2]) == (1, 2, 2))
+                        and tuple(step[1]) == (1, 3, 3) and tuple(step[2]) == (1, 2, 2)
+                        and cur.shape[3] % 2 == 0 and cur.shape[4] % 4 == 0)
             if cur.dtype == BF and not chain and not pool_io1:
                 leave_half()
             if kind == "conv" and chain:

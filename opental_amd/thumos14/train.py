@@ -258,6 +258,7 @@ class DetectorTrainer:
         self._used_work, self._used_global = None, None
         self._early = True          # the backbone may hand finished weight gradients over from inside its backward
         self.measure_exposed = False    # bench.py: record HIP events around the wait for the all-reduces
+        self.bucket_trace = None        # bench.py: a list -> (kind, bucket, bytes, host clock, HIP event) per all-reduce issue / wait
         self.exposed_events = []
         self._ibm_work = None
         self._slots = ops.GradSlots(self.arena.flat, self.arena.grad, self.arena.offsets, [p.numel() for p in self.arena.params])
@@ -358,14 +359,27 @@ class DetectorTrainer:
             # right behind it, from the side stream
             ops.LANES.cut(("call", lambda b=b: self._issue_allreduce(b, side=True)))
 
+    def _trace(self, kind, b=None, stream=None):
+        """bench.py --gpus N: where on the lane timeline a bucket's all-reduce is issued and where the step waits for them --
+        a HIP event on the issuing stream + the host clock, one record per call (`bucket_trace` is a list while tracing)."""
+        if self.bucket_trace is None or self._capturing:
+            return
+        import time
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream if stream is not None else torch.cuda.current_stream())
+        nbytes = None if b is None else 4 * (self.arena.buckets[b][1] - self.arena.buckets[b][0])
+        self.bucket_trace.append((kind, b, nbytes, time.perf_counter(), ev))
+
     def _issue_allreduce(self, b, side=False):
         lo, hi = self.arena.buckets[b]
         if side:        # behind everything both lanes have been given: RCCL's stream then waits for the side stream only
             sd = ops.side_wgrads(self.arena.grad.device)
             ops.L.check(ops.L.lib().otal_stream_wait(sd._raw, ops.L.stream()), "otal_stream_wait")
             with torch.cuda.stream(sd.side):
+                self._trace("issue(side lane)", b)
                 self._works.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
+        self._trace("issue(main lane)", b)
         self._works.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def begin_backward(self, early=True):
@@ -459,6 +473,7 @@ class DetectorTrainer:
         if not self.collectives or self._capturing:
             return
         self._issue_used_mask()
+        self._trace("wait begin")
         ev = None
         if self.measure_exposed:
             ev = torch.cuda.Event(enable_timing=True)
@@ -473,6 +488,7 @@ class DetectorTrainer:
             self._ibm_work.wait()
             self._ibm_work = None
             self._ibm_state().div_(self.world)
+        self._trace("wait end")
         if ev is not None:
             end = torch.cuda.Event(enable_timing=True)
             end.record()
@@ -488,6 +504,7 @@ class DetectorTrainer:
         return cost, losses
 
     def step(self, clips, targets, scores, ssl_clips=None, ssl_targets=None):
+        self._trace("step begin")
         stale = False
         if self._graph is not None and ssl_clips is None:
             if self._graph_key == self._capture_key():
@@ -501,9 +518,10 @@ class DetectorTrainer:
             # launch plan exists -- the second one is captured (a capture executes nothing) and replayed.
             shapes = tuple(tuple(t.shape) for t in _flatten_inputs(clips, targets, scores))
             if self._eager_shapes == shapes:
-                self.capture_step(clips, targets, scores, warmup=0, lanes=True)
-                return self._replay(clips, targets, scores)
-            self._eager_shapes = shapes
+                if self._try_capture_lanes(clips, targets, scores):
+                    return self._replay(clips, targets, scores)
+            else:
+                self._eager_shapes = shapes
         # an eager step next to a captured graph (ssl branch) must not touch the descriptor buffers the graph replays
         # from: it works on its own prologue cache
         cache = self._prologues if self._graph is None else self._eager_prologues()
@@ -525,6 +543,40 @@ class DetectorTrainer:
         if stale:
             self.capture_step(clips, targets, scores, warmup=0, split=was_split, lanes=was_lanes)
         return cost.detach(), _detached(losses)
+
+    def _try_capture_lanes(self, clips, targets, scores):
+        """The drivers' in-step capture.  A capture that cannot be had -- a parameter without a gradient (an unused head:
+        torch.optim.Adam leaves it alone, a captured Adam cannot), a HIP capture error -- must not end the training run at
+        its second step: everything the aborted capture touched is put back, the trainer stays on eager launches for good
+        and says so once."""
+        try:
+            self.capture_step(clips, targets, scores, warmup=0, lanes=True)
+            return True
+        except RuntimeError as err:
+            import warnings
+            dev = clips.device
+            ops.LANES = None
+            self._capturing = False
+            self._graph = None
+            self._graph_key = None
+            self._pending = None
+            self._adam_left = None
+            ops.take_late_weights()
+            ops.deactivate_prologues()
+            ops.GRAD_SLOTS = ops.GRAD_READY = ops.PENDING_SUMS = None
+            ops.SIDE_DEFER_JOIN = False
+            try:
+                ops.defer_reduces(False)
+            except RuntimeError:
+                pass
+            for sd in ops._SIDES.values():          # launches the aborted capture recorded for the side lane: never issued
+                sd.pending.clear()
+                sd.keep.clear()
+            torch.cuda.synchronize(dev)
+            self.launch = 'eager'
+            self._eager_shapes = None
+            warnings.warn(f"lane-graph capture of the training step failed ({err}); continuing with eager launches")
+            return False
 
     def _eager_prologues(self):
         c = getattr(self, '_prologues_eager', None)
@@ -691,6 +743,8 @@ class DetectorTrainer:
         self._set_bias(self.step_count + 1)
         self._capturing = True
         ops.LANES = plan
+        from ..common import anet_dataset as _ad
+        _ad.CAPTURE_IN_PROGRESS[0] = True           # background video readers must not call hipHostMalloc meanwhile
         try:
             # the capture of a main graph ends and the next begins INSIDE the backward pass: autograd has to run it on this
             # thread (a stream capture is ended by the thread that began it)
@@ -704,6 +758,7 @@ class DetectorTrainer:
             ops.LANES = None
             self._capturing = False
             self._pending = None
+            _ad.CAPTURE_IN_PROGRESS[0] = False
         if self._skipped:
             raise RuntimeError("capture_step(lanes=True): a parameter received no gradient; use eager launches")
         self._graph = ("lanes", plan, static, out)

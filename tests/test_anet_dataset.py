@@ -91,6 +91,30 @@ def test_background_prefetch_feeds_the_cache_and_a_failed_read_surfaces_at_the_c
     assert len(ds._cache) <= 4
 
 
+def test_prefetched_videos_nobody_asks_for_are_dropped_and_failed_reads_are_reported(tmp_path):
+    """a name that was prefetched but never consumed (epoch end, a --max_steps cut) kept its frames for good
+    and counted against the outstanding-read limit, so prefetching stopped silently; a failed read was never surfaced.  The
+    next prefetch() drops finished reads its request does not name and warns about the failed ones."""
+    import time
+    import warnings
+    from opental_amd.common import anet_dataset as MD
+    root = str(tmp_path)
+    videos = P.write_dataset(root, P.dataset_spec())
+    ds = MD.ANET_Dataset(os.path.join(root, "info.json"), os.path.join(root, "npy"), P.CLIP, P.CROP, P.STRIDE, cache_videos=4)
+    names = list(videos)
+    ds.prefetch([names[0], "no_such_video"])                    # two outstanding reads = the limit (cache_videos / 2)
+    for f in list(ds._pending.values()):
+        while not f.done():
+            time.sleep(0.01)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        ds.prefetch(names[1:3])                                 # the epoch moved on: the two old reads are nobody's
+    assert set(ds._pending) == set(names[1:3])                  # ... and prefetching goes on
+    assert any("no_such_video" in str(w.message) for w in caught)
+    for n in names[1:3]:
+        assert torch.equal(ds.video(n), torch.from_numpy(videos[n]))
+
+
 def test_slice_assignment_semantics_of_the_splice():
     """`new[:, a:b] = old[:, c:d]` as torch evaluates it: equal lengths copy, a one-frame source broadcasts, anything
     else is the RuntimeError the reference catches (anet_dataset.py:194-207) -> the splice is given up."""

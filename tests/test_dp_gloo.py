@@ -552,3 +552,93 @@ def test_anet_criterion_without_ibm_state_steps_under_data_parallelism():
             p.kill()
     assert res is not None and all(p.exitcode == 0 for p in procs)
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+def _anet_norm_worker(rank, world, port, q):
+    """One rank's shard of a global batch through the ActivityNet criterion: (7-tuple, d cost / d theta) all-reduced as the
+    trainer does (SUM of gradients, then 1 / world in the optimizer launch)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from test_anet_loss_cpu import EDL, KEYS, predictions
+        from test_dp_gloo import _anet_global_batch, _anet_cost
+        preds, targets = _anet_global_batch()
+        per = len(targets) // world
+        sl = slice(rank * per, (rank + 1) * per)
+        theta = torch.ones(3, requires_grad=True)
+        terms, cost = _anet_cost({k: (v if k == "priors" else v[sl]) for k, v in preds.items()}, targets[sl], theta, EDL, KEYS)
+        cost.backward()
+        g = theta.grad.clone()
+        t7 = torch.stack([t.detach() for t in terms])
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t7, op=dist.ReduceOp.SUM)
+        q.put((rank, g / world, t7 / world))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _anet_global_batch():
+    """Four samples with UNEQUAL target counts -- rank 0 of a two-rank run gets 1 + 3 targets, rank 1 gets 2 and a sample whose
+    only target matches no anchor (no positive at all)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_anet_loss_cpu import predictions
+    preds = predictions(11, 4)
+    rs = np.random.RandomState(5)
+
+    def segs(n):
+        s = np.sort(rs.uniform(0.05, 0.95, (n, 2)), axis=1)
+        s[:, 1] = np.maximum(s[:, 1], s[:, 0] + 0.08)
+        return torch.from_numpy(np.concatenate([s, rs.randint(1, 150, (n, 1))], 1).astype(np.float32))
+    targets = [segs(1), segs(3), segs(2), torch.tensor([[0.5, 0.5 + 2.0 / 768, 7.0]])]
+    return preds, targets
+
+
+def _anet_cost(preds, targets, theta, edl, keys):
+    from opental_amd.anet.multisegment_loss import MultiSegmentLoss
+    crit = MultiSegmentLoss(150, 0.6, 1.0, cls_loss_type='edl', edl_config=edl, os_head=True)
+    crit.cls_loss.epoch = 12                        # past ibm_start: the closed-form influence-balanced weight is active
+    scaled = dict(preds)
+    scaled["loc"], scaled["conf"], scaled["prop_conf"] = preds["loc"] * theta[0], preds["conf"] * theta[1], preds["prop_conf"] * theta[2]
+    terms = crit([scaled[k] for k in keys], targets)
+    return terms, sum(w * t for w, t in zip((1.0, 10.0, 1.0, 10.0, 1.0, 1.0, 1.0), terms))
+
+
+def test_anet_per_sample_normalisation_equals_the_global_batch_at_world_two():
+    """every term of the ActivityNet criterion (AFSD/anet/multisegment_loss.py:87-301) is normalised per
+    SAMPLE and averaged over the batch, so with equal per-rank batch sizes the average of the ranks' gradients IS the gradient
+    of the single-process criterion on the global batch -- whatever the target counts per rank are (unlike the THUMOS14
+    criterion, whose normalisers count the batch's positives).  Two gloo ranks, unequal target counts, one sample without a
+    positive: the all-reduced 7-tuple and parameter gradient equal the single-process ones to fp32 summation order."""
+    import queue
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_anet_loss_cpu import EDL, KEYS
+    preds, targets = _anet_global_batch()
+    theta = torch.ones(3, requires_grad=True)
+    terms, cost = _anet_cost(preds, targets, theta, EDL, KEYS)
+    cost.backward()
+    want_g, want_t = theta.grad.clone(), torch.stack([t.detach() for t in terms])
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_anet_norm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    except queue.Empty:
+        res = None
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert res is not None and all(p.exitcode == 0 for p in procs)
+    for _, g, t7 in res:
+        assert torch.allclose(g, want_g, rtol=2e-5, atol=1e-6), (g, want_g)
+        assert torch.allclose(t7, want_t, rtol=2e-5, atol=1e-6), (t7, want_t)
+    assert float(want_g.abs().min()) > 0            # every scaled prediction reaches the cost

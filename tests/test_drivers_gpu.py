@@ -161,3 +161,33 @@ def test_epoch_loop_replays_the_captured_step_on_ragged_targets(tmp_path, monkey
         assert torch.equal(getattr(tr_l.arena, name), getattr(tr_e.arena, name)), name
     assert torch.equal(tr_l.criterion.cls_loss.weight_accum, tr_e.criterion.cls_loss.weight_accum)
     assert hist_l == hist_e
+
+
+def test_in_step_capture_failure_falls_back_to_eager_launches(tmp_path, monkeypatch):
+    """the drivers default to `--launch lanes`, and step() captures the second plain step of a shape.
+    A capture that cannot be had -- here a parameter that never receives a gradient, which `capture_step(lanes=True)`
+    refuses -- must not end the run at step 2: the trainer warns once, stays on eager launches and trains on, with the
+    same parameters as a run that was eager from the start (torch.optim.Adam leaves the unused parameter alone)."""
+    import warnings
+    from make_synthetic_thumos import make
+    from opental_amd.thumos14 import train as R
+    from opental_amd.thumos14.BDNet import BDNet
+    yaml_path = make(str(tmp_path / "data"), videos=3, frames=520, size=100, uniform=2)
+    common = [yaml_path] + FLAGS + ['--random_init', '--max_steps', '6', '--max_epoch', '1']
+    init = BDNet.__init__
+
+    def with_unused_head(self, *a, **k):
+        init(self, *a, **k)
+        self.unused_head = torch.nn.Parameter(torch.full((8,), 0.5))
+    monkeypatch.setattr(BDNet, "__init__", with_unused_head)
+    tr_e, hist_e = R.main(common + ['--launch', 'eager', '--checkpoint_path', str(tmp_path / "run_e")])
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        tr_l, hist_l = R.main(common + ['--checkpoint_path', str(tmp_path / "run_l")])          # default: lanes
+    assert any("continuing with eager launches" in str(w.message) for w in caught)
+    assert tr_l.launch == 'eager' and tr_l._graph is None and tr_l.replayed_steps == 0
+    assert tr_l.step_count == tr_e.step_count == 6
+    for name in ("flat", "m", "v"):
+        assert torch.equal(getattr(tr_l.arena, name), getattr(tr_e.arena, name)), name
+    assert torch.equal(tr_l.net.unused_head.detach().cpu(), torch.full((8,), 0.5))
+    assert hist_l == hist_e

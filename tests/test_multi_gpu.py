@@ -60,3 +60,13 @@ def test_two_rank_control_flow_on_one_gpu_with_gloo():
     assert d["n_gpus"] == 2 and cfg["ranks"] == 2 and cfg["rccl_ranks"] == 0 and cfg["backend"] == "gloo"
     assert cfg["replicas_bit_identical"] is True
     assert cfg["launch_probe"]["allreduce_exposed_ms_eager"] is not None
+    # the line carries, per rank, where every bucket's all-reduce is issued and where the step waits
+    tl = cfg["allreduce_timeline"]
+    assert sorted(tl) == ["rank0", "rank1"], tl
+    for recs in tl.values():
+        kinds = [r["what"] for r in recs]
+        assert kinds[0] == "step begin" and "wait begin" in kinds and "wait end" in kinds
+        issued = [r for r in recs if r["what"].startswith("issue")]
+        assert len(issued) == cfg["arena_buckets"] and sorted(r["bucket"] for r in issued) == list(range(cfg["arena_buckets"]))
+        assert all(r["MB"] > 0 and r["gpu_ms"] >= 0 for r in issued)
+        assert recs[kinds.index("wait end")]["gpu_ms"] >= max(r["gpu_ms"] for r in issued)
