@@ -239,7 +239,6 @@ __global__ __launch_bounds__(256) void block1d_kernel(const Launch L) {
             const unsigned char* X = smem + buf * XB;
             const unsigned char* A = smem + 2 * XB + buf * AB + col * f_AP;
             const int steps = f_kt * kc >> 5;                // k32 steps of the chunk
-#pragma unroll 2
             for (int s = 0; s < steps; ++s) {
                 const int q8 = 4 * s + kb;                   // this lane's k8 group: (channel block q8 / kt, tap q8 % kt)
                 const int cb = f_kt == 3 ? q8 / 3 : q8, tap = q8 - cb * f_kt;

@@ -41,6 +41,10 @@ struct PoolShape {
     __device__ __forceinline__ static int st(const PoolGeom& g) { return KT ? ST : g.st; }
     __device__ __forceinline__ static int sh(const PoolGeom& g) { return KT ? SH : g.sh; }
     __device__ __forceinline__ static int sw(const PoolGeom& g) { return KT ? SW : g.sw; }
+    // unroll factors of the window loops: the window itself, or 1 for the run-time-sized instance (nothing to unroll there:
+    // a bare `#pragma unroll` on a loop with a run-time trip count only earns a -Wpass-failed warning)
+    static constexpr int UT = KT ? KT : 1, UH = KT ? KH : 1, UW = KT ? KW : 1;
+    static constexpr int UCT = KT ? (KT + ST - 1) / ST : 1, UCH = KT ? (KH + SH - 1) / SH : 1, UCW = KT ? (KW + SW - 1) / SW : 1;
 };
 
 // ---- bf16-STORED pool tensors (template flag H of the row-per-thread and strided kernels; ops.HALF_STORAGE).  A max-pool
@@ -168,13 +172,13 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(const float* __restr
     float best = 0.f;
     int win = 255;
     bool first = true;
-#pragma unroll
+#pragma unroll S::UT
     for (int dt = 0; dt < kt; ++dt) {
         const int ti = to * S::st(g) + dt - g.pt;
-#pragma unroll
+#pragma unroll S::UH
         for (int dh = 0; dh < kh; ++dh) {
             const int hi = ho * S::sh(g) + dh - g.ph;
-#pragma unroll
+#pragma unroll S::UW
             for (int dw = 0; dw < kw; ++dw) {
                 const int wi = wo * S::sw(g) + dw - g.pw;
                 const bool in = (unsigned)ti < (unsigned)g.Ti && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
@@ -223,17 +227,17 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restr
     const int ct = KT ? CT : (kt + st - 1) / st, ch = KT ? CH : (kh + sh - 1) / sh, cw = KT ? CW : (kw + sw - 1) / sw;
     const int to0 = tn / st, ho0 = hn / sh, wo0 = wn / sw;
     float acc = 0.f;
-#pragma unroll
+#pragma unroll S::UCT
     for (int a_ = 0; a_ < ct; ++a_) {
         const int to = to0 - a_, dt = tn - to * st;
         const bool okt = to >= 0 && to < g.To && dt < kt;
         const int toc = min(max(to, 0), g.To - 1);
-#pragma unroll
+#pragma unroll S::UCH
         for (int b_ = 0; b_ < ch; ++b_) {
             const int ho = ho0 - b_, dh = hn - ho * sh;
             const bool okh = okt && ho >= 0 && ho < g.Ho && dh < kh;
             const int hoc = min(max(ho, 0), g.Ho - 1);
-#pragma unroll
+#pragma unroll S::UCW
             for (int c_ = 0; c_ < cw; ++c_) {
                 const int wo = wo0 - c_, dw = wn - wo * sw;
                 const bool ok = okh && wo >= 0 && wo < g.Wo && dw < kw;
@@ -290,11 +294,11 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_lds_kernel(const float* __r
         float best = 0.f;
         int win = 0;
         bool first = true;
-#pragma unroll
+#pragma unroll S::UT
         for (int dt = 0; dt < kt; ++dt)
-#pragma unroll
+#pragma unroll S::UH
             for (int dh = 0; dh < kh; ++dh)
-#pragma unroll
+#pragma unroll S::UW
                 for (int dw = 0; dw < kw; ++dw) {
                     const float v = base[(dt * g.HL + dh) * g.WL + dw];
                     if (first || v > best || v != v) {
@@ -362,13 +366,13 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_lds_kernel(const float* __r
         const int tn = ti0 + (int)tq + g.pt, hn = (int)hi + g.ph, wn = wi + g.pw;
         const int to0 = tn / st, ho0 = hn / sh, wo0 = wn / sw;
         float acc = 0.f;
-#pragma unroll
+#pragma unroll S::UCT
         for (int a_ = 0; a_ < ct; ++a_) {
             const int to = to0 - a_, dt = tn - to * st;
-#pragma unroll
+#pragma unroll S::UCH
             for (int b_ = 0; b_ < ch; ++b_) {
                 const int ho = ho0 - b_, dh = hn - ho * sh;
-#pragma unroll
+#pragma unroll S::UCW
                 for (int c_ = 0; c_ < cw; ++c_) {
                     const int wo = wo0 - c_, dw = wn - wo * sw;
                     const int idx = ((to - toA) * g.HLo + (ho - g.ho_min)) * g.WLo + (wo - g.wo_min);

@@ -92,7 +92,7 @@ def test_conv1a_weight_gradient_from_a_bf16_gradient(shape, cout):
     assert torch.equal(dw, dw_ref)          # same bf16 operands, same summation order
 
 
-OUTSIDE_REL_BOUND = 1.0      # set from the measurement below
+OUTSIDE_REL_BOUND, OUTSIDE_REL_MEDIAN = 0.4, 0.2
 
 
 def test_model_forward_is_unchanged_and_only_backbone_gradients_move(golden_dir):
@@ -182,6 +182,11 @@ def test_model_forward_is_unchanged_and_only_backbone_gradients_move(golden_dir)
     print("outside the region, largest relative gradient differences:", sorted(out_rel.items(), key=lambda kv: -kv[1])[:4])
     print("bf16-stored vs fp32-stored gradients, lowest cosines: chunked", sorted(worst2.items(), key=lambda kv: kv[1])[:3],
           "default", sorted(worst.items(), key=lambda kv: kv[1])[:3])
+    med = float(np.median(list(out_rel.values())))
+    print("outside the region: median relative gradient difference", med, "of", len(out_rel), "tensors")
+    # measured (b = 1): median 0.09 (= cosine 0.996), largest 0.19 (the t = 2 pyramid level and Mixed_5c's narrow branch: few anchors, one
+    # proposal window that rounds to the neighbouring frame moves them) -- bounds at about twice that
+    assert med < OUTSIDE_REL_MEDIAN, med
     for k, r in out_rel.items():
         assert r < OUTSIDE_REL_BOUND, (k, r)
     for k, cos in worst.items():
