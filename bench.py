@@ -333,7 +333,8 @@ def extras(device, batch):
         ops.CONV_PRECISION = 1
         rs = np.random.RandomState(1)
         vids = [torch.from_numpy(rs.randint(0, 256, (1200, 112, 112, 3)).astype(np.uint8)).pin_memory() for _ in range(4)]
-        st = D.ClipStager(batch, 256, 112, 112, 96, device=device, max_targets=8, score_rows=2)
+        st = D.ClipStager(batch, 256, 112, 112, 96, device=device, max_targets=8, score_rows=2,
+                          copy_stream=ops.side_wgrads(device).side)     # as the drivers build it (thumos14.train.main)
 
         def samples(k):
             r = np.random.RandomState(k)

@@ -137,7 +137,8 @@ def main(argv=None):
         raise SystemExit("no training videos found under " + str(ds['video_mp4_path']))
     any_shape = dataset.video_shape(dataset.training_list[0]['video_name'])
     stager = ClipStager(tr['batch_size'], ds['clip_length'], int(any_shape[1]), int(any_shape[2]), ds['crop_size'],
-                        device=dev, max_targets=max_target_count(dataset), score_rows=3)
+                        device=dev, max_targets=max_target_count(dataset), score_rows=3,
+                        copy_stream=ops.side_wgrads(dev).side)
     if extra['launch'] not in ('lanes', 'eager'):
         raise SystemExit("--launch takes lanes or eager")
     trainer.launch = extra['launch']

@@ -381,6 +381,21 @@ def branch_lane(device):
     return b
 
 
+_CAPTURE_STREAMS = {}
+
+
+def capture_stream(device):
+    """ONE stream per device for every capture / warm-up of every trainer: a fresh torch.cuda.Stream() per capture is a
+    fresh HIP stream that keeps a share of one of the runtime's four hardware queues for the life of the process -- enough
+    of them and a lane of a later step lands on the queue of another (measured with tools/probe_fed.py: the same replayed
+    step at 981 or 854 clips/s depending on how many streams existed before its lanes were created)."""
+    key = (device.type, device.index)
+    st = _CAPTURE_STREAMS.get(key)
+    if st is None:
+        st = _CAPTURE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def side_wgrads(device):
     key = (device.type, device.index)
     sd = _SIDES.get(key)

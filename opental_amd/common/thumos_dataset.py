@@ -206,7 +206,7 @@ class ClipStager:
     otherwise pair batch k's frames with batch k+2's decisions.  That wait is over long before it is reached unless
     the host really is that far ahead."""
 
-    def __init__(self, batch, clip_length, H, W, crop, device="cuda", max_targets=None, score_rows=2):
+    def __init__(self, batch, clip_length, H, W, crop, device="cuda", max_targets=None, score_rows=2, copy_stream=None):
         """`max_targets` (input_pipeline.max_target_count(dataset)): the batch's labels -- targets padded to that row count,
         boundary masks, ssl segments -- travel with the frames as ONE fixed-shape record per slot (LabelRecord): one pinned
         buffer, one asynchronous copy; `labels()` hands out the device record of the batch collected last."""
@@ -223,7 +223,13 @@ class ClipStager:
         self.maps_host = [torch.empty(batch * clip_length, dtype=torch.int32).pin_memory() for _ in range(2)]
         self.params_dev = [torch.empty_like(p, device=self.device) for p in self.params_host]
         self.maps_dev = [torch.empty(batch * clip_length, dtype=torch.int32, device=self.device) for _ in range(2)]
-        self.copy_stream = torch.cuda.Stream(device=self.device)
+        # Which stream carries the copies matters more than it should: HIP hands its few hardware queues (4) to streams in
+        # creation order, and a copy stream of its own can land on the queue of the step's main or weight-gradient lane --
+        # that lane's launches then queue behind 77 MB of DMA per step (measured by moving the creation order: 948 -> 812
+        # clips/s fed, the resident step unchanged; a high-priority stream only moves the collision).  `copy_stream`: the
+        # caller's choice -- the training drivers pass the weight-gradient lane's stream, which is idle during the forward
+        # pass: the next batch's copies, issued in front of the step's replay, run there and no fifth stream exists.
+        self.copy_stream = copy_stream if copy_stream is not None else torch.cuda.Stream(device=self.device)
         self.ready = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [torch.cuda.Event() for _ in range(2)]
         self.slot = 0

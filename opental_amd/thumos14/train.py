@@ -693,7 +693,7 @@ class DetectorTrainer:
         static = _clone_inputs(clips, targets, scores)
         # (the warm-up steps run on a side stream on purpose: the AccumulateGrad stream-mismatch warning is noise here)
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        side = torch.cuda.Stream(device=dev)
+        side = ops.capture_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(warmup):
@@ -728,7 +728,7 @@ class DetectorTrainer:
         self._bias_corr = torch.zeros(2, dtype=torch.float32, device=dev)
         static = _clone_inputs(clips, targets, scores)
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        cap = torch.cuda.Stream(device=dev)
+        cap = ops.capture_stream(dev)
         cap.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(cap):
             for _ in range(warmup):                 # eager steps (real ones): regions, workspaces and plans exist afterwards
@@ -797,7 +797,7 @@ class DetectorTrainer:
         self._bias_corr = torch.zeros(2, dtype=torch.float32, device=dev)
         static = _clone_inputs(clips, targets, scores)
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        side = torch.cuda.Stream(device=dev)
+        side = ops.capture_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(max(warmup, 0 if already_split else 1)):     # eager data-parallel steps in the two-node form (real steps)
@@ -1284,7 +1284,9 @@ def main(argv=None):
                                stride=ds_cfg['clip_stride'])
     any_video = next(iter(data.values()))
     stager = D.ClipStager(tr['batch_size'], ds_cfg['clip_length'], int(any_video.shape[1]), int(any_video.shape[2]),
-                          ds_cfg['crop_size'], device=dev, max_targets=D.max_target_count(dataset), score_rows=2)
+                          ds_cfg['crop_size'], device=dev, max_targets=D.max_target_count(dataset), score_rows=2,
+                          copy_stream=ops.side_wgrads(dev).side)       # the next batch crosses PCIe on the weight-gradient
+                                                                        # lane's stream, idle during the forward pass (ClipStager)
     trainer.launch = extra['launch']
     checkpoint_path = tr['checkpoint_path']
     train_state_path = os.path.join(checkpoint_path, 'training')

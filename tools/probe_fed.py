@@ -20,7 +20,14 @@ def main():
     ops.CONV_PRECISION = 1
     rs = np.random.RandomState(1)
     vids = [torch.from_numpy(rs.randint(0, 256, (1200, 112, 112, 3)).astype(np.uint8)).pin_memory() for _ in range(4)]
-    st = D.ClipStager(batch, 256, 112, 112, 96, device=dev, max_targets=8, score_rows=2)
+    # OTAL_PROBE_DUMMY_STREAMS=n: n streams created (and used once) first -- HIP hands its few hardware queues to streams in
+    # creation order, so this moves the stager's copy stream onto another hardware queue
+    dummies = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("OTAL_PROBE_DUMMY_STREAMS", "0")))]
+    for d_ in dummies:
+        with torch.cuda.stream(d_):
+            torch.zeros(8, device=dev)
+    side = ops.side_wgrads(dev).side if os.environ.get('OTAL_PROBE_COPY_ON_SIDE', '1') != '0' else None
+    st = D.ClipStager(batch, 256, 112, 112, 96, device=dev, max_targets=8, score_rows=2, copy_stream=side)
 
     def samples(k):
         r = np.random.RandomState(k)
