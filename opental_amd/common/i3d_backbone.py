@@ -464,6 +464,9 @@ class I3DFeaturesFunction(Function):
                         found[name] = (ops.convert_storage(cur, torch.float32), len(tape))
                 else:
                     found[name] = (cur, len(tape))
+                hook = ops.ENDPOINT_HOOKS.get(name) if ops.ENDPOINT_HOOKS else None
+                if hook is not None:                        # a consumer that can start on this endpoint now (ops.early_lane)
+                    hook(found[name][0])
         missing = [e for e in endpoints if e not in found]
         if missing:
             raise RuntimeError(f"unknown endpoints {missing}")
@@ -515,6 +518,7 @@ class I3DFeaturesFunction(Function):
             if pos == tail_below - 1 and not any(pending.get(q) for q in range(1, pos + 1)):
                 ops.late_mark([weights[st[1]] for st in tape[:pos] if st[0] == "conv"])
             for g, z, zs in pending.pop(pos, ()):
+                ops.join_pending(g)                         # (a gradient its producer still writes on another lane)
                 dense = g.dim() == 5 and (g.shape[4] == 1 or g.stride(4) == 1) and (g.shape[3] == 1 or g.stride(3) == g.shape[4])
                 if zs is not None and not dense:
                     g = g.contiguous()

@@ -77,7 +77,7 @@ def workspace(device, side=False):
 # (_DEFER_OWNER: (side workspace?, torch stream or None = the current one)); a weight gradient issued on the other stream
 # flushes them first.
 _DEFER = False
-_WS_CURSOR = [0, 0, 0]      # main / weight-gradient side / branch lane workspace
+_WS_CURSOR = [0, 0, 0, 0]   # main / weight-gradient side / branch lane / early lane workspace
 _WS_SIDE = 0                # 1 while SideWgrads issues a launch on its stream, 2 inside a BranchLane block
 _SIDE_NOW = None            # ... and that torch stream
 _DEFER_OWNER = None
@@ -338,10 +338,11 @@ _BRANCHES = {}
 
 
 class BranchLane:
-    def __init__(self, device):
+    def __init__(self, device, ws_index=2):
         self.stream = torch.cuda.Stream(device=device)
         self._raw = ctypes.c_void_p(self.stream.cuda_stream)
         self._saved = None
+        self._ws = ws_index         # the lane's own split-K workspace (launches of two lanes run side by side)
 
     @property
     def on(self):
@@ -357,7 +358,7 @@ class BranchLane:
     def __enter__(self):
         global _WS_SIDE
         self._saved = (_WS_SIDE, L.STREAM_OVERRIDE)
-        _WS_SIDE, L.STREAM_OVERRIDE = 2, self._raw.value
+        _WS_SIDE, L.STREAM_OVERRIDE = self._ws, self._raw.value
         # the lane is also torch's current stream inside the block: tensors allocated here come from the LANE's pool of the
         # caching allocator.  With the main stream current, a block the main lane had just freed (its last reader still
         # queued there) could be handed to a lane tensor and overwritten by a lane kernel first -- two lanes, one pool
@@ -379,6 +380,35 @@ def branch_lane(device):
     if b is None:
         b = _BRANCHES[key] = BranchLane(device)
     return b
+
+
+# ---- the early lane: the Mixed_4f projection of the pyramid (Unit3D [1,6,6], AFSD/thumos14/BDNet.py:129-139,:310-313) needs
+# only Mixed_4f, which the backbone finishes ~280 us before Mixed_5c -- five small-plane launches that leave most of the chip
+# idle.  The backbone calls ENDPOINT_HOOKS[name](tensor) where an endpoint is final; the pyramid's hook runs the projection
+# on this lane (its own stream and split-K workspace: the branch lane forks and joins inside Mixed_5b / 5c meanwhile) and
+# parks the result in EARLY_RESULTS for TrunkFunction.forward (thumos14/pyramid_fused.py), which joins the lane.  Backward,
+# mirrored: the projection's data gradient (the gradient of Mixed_4f) runs on the lane while the main lane already walks
+# Mixed_5c / 5b; the backbone joins (join_pending) where it picks that gradient up.
+EARLY_PROJ = os.environ.get("OTAL_EARLY_PROJ", "1") != "0"
+ENDPOINT_HOOKS = None
+EARLY_RESULTS = {}
+PENDING_JOINS = {}
+_EARLY = {}
+
+
+def early_lane(device):
+    key = (device.type, device.index)
+    b = _EARLY.get(key)
+    if b is None:
+        b = _EARLY[key] = BranchLane(device, ws_index=3)
+    return b
+
+
+def join_pending(t):
+    """The main lane waits for the lane that still writes `t` (a gradient handed over without a join)."""
+    lane = PENDING_JOINS.pop(t.data_ptr(), None) if PENDING_JOINS else None
+    if lane is not None:
+        lane.join()
 
 
 _CAPTURE_STREAMS = {}

@@ -386,7 +386,13 @@ class BDNet(nn.Module):
             self.weight_init(m)
 
     def forward(self, x, proposals=None, ssl=False, get_feat=False):
-        feat_dict = self.backbone(x)
+        if not ssl and x.is_cuda:
+            from . import pyramid_fused as PF
+            ops.ENDPOINT_HOOKS = PF.early_projection_hooks(self.coarse_pyramid_detection)
+        try:
+            feat_dict = self.backbone(x)
+        finally:
+            ops.ENDPOINT_HOOKS = None
         if ssl:
             top_feat = self.coarse_pyramid_detection(feat_dict, ssl)
             d = proposals[0].unsqueeze(0)

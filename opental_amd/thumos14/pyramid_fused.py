@@ -134,11 +134,16 @@ class TrunkFunction(Function):
         C = pyr[0][0].shape[0]
         t0, total = lev[1], lev[-1]
         tape = {}
-        # projections (BDNet.py:310-319)
-        c0 = ops.conv_forward(x1, pyr[0][0], cfg["k0"], ONE, shift=pyr[0][1], spatial_valid=True).view(B, C, t0)
-        p0, st0 = ops.gn_relu_forward(c0, pyr[0][2], pyr[0][3], G, eps, True, None)
+        # projections (BDNet.py:310-319); the Mixed_4f one may already be running on the early lane (ops.early_lane)
+        early = ops.EARLY_RESULTS.pop(x1.data_ptr(), None)
+        if early is None:
+            c0 = ops.conv_forward(x1, pyr[0][0], cfg["k0"], ONE, shift=pyr[0][1], spatial_valid=True).view(B, C, t0)
+            p0, st0 = ops.gn_relu_forward(c0, pyr[0][2], pyr[0][3], G, eps, True, None)
         c1 = ops.conv_forward(x2, pyr[1][0], cfg["k1"], ONE, shift=pyr[1][1], spatial_valid=True).view(B, C, t0 // 2)
         p1, st1 = ops.gn_relu_forward(c1, pyr[1][2], pyr[1][3], G, eps, True, None)
+        if early is not None:
+            c0, p0, st0, elane = early
+            elane.join()
         packed, frame_in = ops.pyramid_merge_forward(p0, p1, total, up)
         tape["proj"] = (c0, st0, c1, st1)
         # the frame-level deconv (BDNet.py:324-326) on the branch lane, beside the stride-2 levels and the towers
@@ -260,14 +265,27 @@ class TrunkFunction(Function):
         WG.side.flush()
         # projections: the small one first (its data gradient is what the backbone's backward starts from)
         dxs = [None, None]
+        elane = ops.early_lane(dev)
         for i, (x, c, st, k, dp) in ((1, (x2, c1, st1, cfg["k1"], dp1)), (0, (x1, c0, st0, cfg["k0"], dp0))):
             dc, part = _gn_bwd_raw(dp, c, pyr[i][2], pyr[i][3], st, G, None)
             sums.append((i, part, B))
             dc5 = dc.view(B, C, dc.shape[2], 1, 1)
             put(i, WG.one(x, dc5, pyr[i][0], k, ONE, sv=True))
             if ctx.needs_input_grad[1 + i]:
-                dxs[i] = (ops.conv_dgrad_collapse(dc5, pyr[i][0], x.shape) if ops.is_full_collapse(x.shape, k, ONE, True)
-                          else ops.conv_dgrad(dc5, pyr[i][0], x.shape, k, ONE, spatial_valid=True))
+                dgrad = lambda: (ops.conv_dgrad_collapse(dc5, pyr[i][0], x.shape) if ops.is_full_collapse(x.shape, k, ONE, True)
+                                 else ops.conv_dgrad(dc5, pyr[i][0], x.shape, k, ONE, spatial_valid=True))
+                if i == 0 and ops.EARLY_PROJ and elane.on and ops.PYRAMID_LANE and ctx.needs_input_grad[2] and ops.LANES is None:
+                    # the gradient of Mixed_4f is needed only after Mixed_5c / 5b / MaxPool3d_5a have been walked back:
+                    # its GEMM runs on the early lane beside them, the backbone joins where it picks the gradient up.
+                    # (Eager launches only: a lane-graph capture is CUT where the weight-gradient lane takes a chunk, and a
+                    #  capture cannot end while a forked stream has not rejoined it.)
+                    elane.fork()
+                    with elane:
+                        dxs[0] = dgrad()
+                    ops.PENDING_JOINS[dxs[0].data_ptr()] = elane
+                    ctx.early_keep = (dc5, dxs[0])
+                else:
+                    dxs[i] = dgrad()
         for i, part, nb in sums:            # d_gamma, d_beta, d_bias: deferred into the arena, or summed now
             dg, dbe, dbi = ops._gn_sums(part, P[i][2], P[i][3], P[i][1], C, nb)
             grads[4 * i + 1], grads[4 * i + 2], grads[4 * i + 3] = dbi, dg, dbe
@@ -444,3 +462,35 @@ def branches(pyramid, loc_feat, conf_feat, frame, segments, frame_segments):
             params += _block_params(b)
     cfg = dict(levels=tuple(p.levels), groups=32, eps=p.pyramids[0][1].eps)
     return BranchesFunction.apply(cfg, loc_feat, conf_feat, frame, segments, frame_segments, *params)
+
+
+def eligible_static(pyramid):
+    """eligible() for what is known before the backbone runs."""
+    lv = pyramid.level_lengths
+    return (len(pyramid.projection_inputs) == 2 and pyramid.fpn_strides is None and not bp.COMPAT_REFERENCE_BWD
+            and all(lv[i] == 2 * lv[i + 1] for i in range(len(lv) - 1)) and len(lv) >= 3 and lv[0] <= 256
+            and pyramid.frame_num % lv[0] == 0 and pyramid.frame_num <= 256)
+
+
+def early_projection_hooks(pyramid):
+    """{endpoint: hook} for ops.ENDPOINT_HOOKS: the Mixed_4f projection starts on the early lane the moment the backbone has
+    the endpoint (TrunkFunction.forward picks the result up)."""
+    p = pyramid
+    if not (ops.FUSED_PYRAMID and ops.EARLY_PROJ and ops.PYRAMID_LANE and eligible_static(p)):
+        return None
+    w, b, gamma, beta = _block_params(p.pyramids[0])
+    k0, eps = tuple(p.pyramids[0][0]._kernel_shape), p.pyramids[0][1].eps
+    t0 = p.level_lengths[0]
+
+    def hook(x1):
+        lane = ops.early_lane(x1.device)
+        if not lane.on or not x1.is_cuda or x1.dtype != torch.float32:
+            return
+        ops.EARLY_RESULTS.clear()                       # (a forward pass whose pyramid never ran leaves nothing behind)
+        lane.fork()
+        with lane, torch.no_grad():
+            B = x1.shape[0]
+            c0 = ops.conv_forward(x1, w, k0, ONE, shift=b, spatial_valid=True).view(B, w.shape[0], t0)
+            p0, st0 = ops.gn_relu_forward(c0, gamma, beta, 32, eps, True, None)
+        ops.EARLY_RESULTS[x1.data_ptr()] = (c0, p0, st0, lane)
+    return {p.projection_inputs[0]: hook}
