@@ -567,6 +567,14 @@ int otal_gn_relu_bwd_sum(int n_terms, const float* const* dy, const int64_t* dy_
                          const float* x, const float* gamma, const float* beta, const float* stats, float* dx, float* partial,
                          int B, int C, int T, int G, int relu, int nlev, const int* lev, void* stream);
 
+/* otal_bmp_fwd_levels / otal_bmp_bwd_levels (fp32) with the pooled tensor (out resp. grad_out) a channel slice of a wider
+ * (B,Ctot,N) buffer: pooled_bs = elements between samples (>= C*N).  The torch.cat of AFSD/thumos14/BDNet.py:111 and the
+ * slice of its gradient, without copies. */
+int otal_bmp_fwd_levels_to(const float* in, const float* seg, float* out, int64_t pooled_bs, int B, int C, int nlev,
+                           const int* t_start, const int* n_start, void* stream);
+int otal_bmp_bwd_levels_from(const float* grad_out, int64_t pooled_bs, const float* in, const float* seg, float* grad_in, int B,
+                             int C, int nlev, const int* t_start, const int* n_start, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,7 +116,7 @@ __device__ __forceinline__ void stage_windows(int* win, const float* seg, int N,
 template <typename T, int ROWS>
 __global__ __launch_bounds__(256) void bmp_fwd_kernel(const T* __restrict__ in, const float* __restrict__ seg,
                                                       T* __restrict__ out, int C, int Tt, int Nt,
-                                                      LevelTab lt, int lxT, int lxN, int off_win) {
+                                                      LevelTab lt, int lxT, int lxN, int off_win, int64_t out_bs) {
     typedef typename StageOf<T>::type S;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     S* rows = reinterpret_cast<S*>(smem);
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void bmp_fwd_kernel(const T* __restrict__ in, 
         for (int k = kx; k < Nt; k += (1 << lxN)) {
             const int l = win[k * 4 + which], rr = win[k * 4 + which + 1];
             int a;
-            st_as<S>(out, (size_t)(row0 + r) * Nt + k, window_max(row, l, rr, a));
+            st_as<S>(out, (size_t)n * out_bs + (size_t)(c0 + r) * Nt + k, window_max(row, l, rr, a));     // (out may be a channel slice)
         }
     }
 }
@@ -145,7 +145,7 @@ template <typename T, int ROWS>
 __global__ __launch_bounds__(256) void bmp_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ in,
                                                       const float* __restrict__ seg, T* __restrict__ gin,
                                                       int C, int Tt, int Nt, LevelTab lt, int lxT, int lxN,
-                                                      int off_win, int off_g, int off_arg) {
+                                                      int off_win, int off_g, int off_arg, int64_t gout_bs) {
     typedef typename StageOf<T>::type S;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     S* rows = reinterpret_cast<S*>(smem);
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void bmp_bwd_kernel(const T* __restrict__ gout
     const int n = row0 / C, c0 = row0 - n * C;
     const int Tp = Tt | 1, Np = Nt | 1;
     stage_rows(rows, in + (size_t)row0 * Tt, ROWS, Tt, Tp, lxT, tid);
-    stage_rows(g, gout + (size_t)row0 * Nt, ROWS, Nt, Np, lxN, tid);
+    stage_rows(g, gout + (size_t)n * gout_bs + (size_t)c0 * Nt, ROWS, Nt, Np, lxN, tid);     // (grad_out may be a channel slice)
     stage_windows(win, seg + (size_t)n * Nt * 4, Nt, lt, tid);
     __syncthreads();
     {   // phase 1: arg-max per (row, proposal)
@@ -202,7 +202,9 @@ __global__ __launch_bounds__(256) void bmp_bwd_kernel(const T* __restrict__ gout
 }
 
 template <typename T>
-int launch_fwd(const T* in, const float* seg, T* out, int B, int C, int Tt, int Nt, const LevelTab& lt, hipStream_t s) {
+int launch_fwd(const T* in, const float* seg, T* out, int B, int C, int Tt, int Nt, const LevelTab& lt, hipStream_t s,
+               int64_t out_bs = 0) {
+    if (out_bs == 0) out_bs = (int64_t)C * Nt;
     const int lxT = ilog2_ceil(Tt < 256 ? Tt : 256), lxN = ilog2_ceil(Nt < 256 ? Nt : 256);
     const int cand[4] = {16, 8, 4, 2};
     for (int ci = 0; ci < 4; ++ci) {
@@ -212,7 +214,7 @@ int launch_fwd(const T* in, const float* seg, T* out, int B, int C, int Tt, int 
         if (cv.total > 48 * 1024 && R > 2) continue;
         if (cv.total > 64 * 1024) return OTAL_E_UNSUPPORTED;
         const dim3 grid((unsigned)((size_t)B * C / R));
-#define OTAL_FWD(RR) hipLaunchKernelGGL((bmp_fwd_kernel<T, RR>), grid, dim3(256), cv.total, s, in, seg, out, C, Tt, Nt, lt, lxT, lxN, cv.win)
+#define OTAL_FWD(RR) hipLaunchKernelGGL((bmp_fwd_kernel<T, RR>), grid, dim3(256), cv.total, s, in, seg, out, C, Tt, Nt, lt, lxT, lxN, cv.win, out_bs)
         if (R == 16) OTAL_FWD(16); else if (R == 8) OTAL_FWD(8); else if (R == 4) OTAL_FWD(4); else OTAL_FWD(2);
 #undef OTAL_FWD
         return otal_launch_status();
@@ -222,7 +224,8 @@ int launch_fwd(const T* in, const float* seg, T* out, int B, int C, int Tt, int 
 
 template <typename T>
 int launch_bwd(const T* gout, const T* in, const float* seg, T* gin, int B, int C, int Tt, int Nt,
-               const LevelTab& lt, hipStream_t s) {
+               const LevelTab& lt, hipStream_t s, int64_t gout_bs = 0) {
+    if (gout_bs == 0) gout_bs = (int64_t)C * Nt;
     const int lxT = ilog2_ceil(Tt < 256 ? Tt : 256), lxN = ilog2_ceil(Nt < 256 ? Nt : 256);
     const int cand[4] = {16, 8, 4, 2};
     for (int ci = 0; ci < 4; ++ci) {
@@ -232,7 +235,7 @@ int launch_bwd(const T* gout, const T* in, const float* seg, T* gin, int B, int 
         if (cv.total > 48 * 1024 && R > 2) continue;
         if (cv.total > 64 * 1024) return OTAL_E_UNSUPPORTED;
         const dim3 grid((unsigned)((size_t)B * C / R));
-#define OTAL_BWD(RR) hipLaunchKernelGGL((bmp_bwd_kernel<T, RR>), grid, dim3(256), cv.total, s, gout, in, seg, gin, C, Tt, Nt, lt, lxT, lxN, cv.win, cv.g, cv.arg)
+#define OTAL_BWD(RR) hipLaunchKernelGGL((bmp_bwd_kernel<T, RR>), grid, dim3(256), cv.total, s, gout, in, seg, gin, C, Tt, Nt, lt, lxT, lxN, cv.win, cv.g, cv.arg, gout_bs)
         if (R == 16) OTAL_BWD(16); else if (R == 8) OTAL_BWD(8); else if (R == 4) OTAL_BWD(4); else OTAL_BWD(2);
 #undef OTAL_BWD
         return otal_launch_status();
@@ -284,6 +287,32 @@ extern "C" int otal_bmp_bwd_levels(const void* gout, const void* in, const float
     if (dtype == OTAL_F16) return launch_bwd<f16_t>((const f16_t*)gout, (const f16_t*)in, seg, (f16_t*)gin, B, C, Tt, Nt, lt, s);
     if (dtype == OTAL_F64) return launch_bwd<double>((const double*)gout, (const double*)in, seg, (double*)gin, B, C, Tt, Nt, lt, s);
     return OTAL_E_DTYPE;
+}
+
+// The level-batched calls with the POOLED tensor as a channel slice of a wider (B,Ctot,N) buffer (pooled_bs = Ctot * N
+// elements between samples): the ProposalBranch concatenation torch.cat([roi, pooled, short], 1) (AFSD/thumos14/BDNet.py:111)
+// is written in place going forward and its gradient read in place going backward -- no copy either way.  fp32.
+extern "C" int otal_bmp_fwd_levels_to(const float* in, const float* seg, float* out, int64_t pooled_bs, int B, int C, int nlev,
+                                      const int* t_start, const int* n_start, void* stream) {
+    if (!in || !seg || !out) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0) return OTAL_E_SHAPE;
+    if (C & 1) return OTAL_E_ODD_C;
+    LevelTab lt;
+    if (int e = check_levels(nlev, t_start, n_start, lt)) return e;
+    const int Tt = lt.ts[nlev], Nt = lt.ns[nlev];
+    if (pooled_bs < (int64_t)C * Nt) return OTAL_E_SHAPE;
+    return launch_fwd<float>(in, seg, out, B, C, Tt, Nt, lt, (hipStream_t)stream, pooled_bs);
+}
+extern "C" int otal_bmp_bwd_levels_from(const float* gout, int64_t pooled_bs, const float* in, const float* seg, float* gin, int B,
+                                        int C, int nlev, const int* t_start, const int* n_start, void* stream) {
+    if (!gout || !in || !seg || !gin) return OTAL_E_NULL;
+    if (B <= 0 || C <= 0) return OTAL_E_SHAPE;
+    if (C & 1) return OTAL_E_ODD_C;
+    LevelTab lt;
+    if (int e = check_levels(nlev, t_start, n_start, lt)) return e;
+    const int Tt = lt.ts[nlev], Nt = lt.ns[nlev];
+    if (pooled_bs < (int64_t)C * Nt) return OTAL_E_SHAPE;
+    return launch_bwd<float>(gout, in, seg, gin, B, C, Tt, Nt, lt, (hipStream_t)stream, pooled_bs);
 }
 
 extern "C" int otal_bmp_fwd(const void* in, const float* seg, void* out, int B, int C, int T, int N,

@@ -88,6 +88,38 @@ def bmp_backward_levels(grad_output, input, segments, t_start, n_start):
     return grad_input
 
 
+def _slice_stride(t, B, C, N):
+    """Batch stride of a (B,C,N) fp32 tensor that may be a channel slice of a wider buffer (rows dense)."""
+    if tuple(t.shape) != (B, C, N) or t.dtype != torch.float32 or not t.is_cuda or t.stride(2) != 1 or t.stride(1) != N:
+        raise RuntimeError("BoundaryMaxPooling: the pooled tensor must be fp32 (B,C,N) with dense rows")
+    return t.stride(0) if B > 1 else C * N
+
+
+def bmp_forward_levels_to(input, segments, t_start, n_start, out):
+    """bmp_forward_levels writing into `out`, a channel slice of a concatenation buffer."""
+    import ctypes
+    L.require_device(input, segments)
+    B, C, Tt = input.shape
+    N = n_start[-1]
+    L.check(L.lib().otal_bmp_fwd_levels_to(L.ptr(input), L.ptr(segments), L.ptr(out), ctypes.c_int64(_slice_stride(out, B, C, N)),
+                                           B, C, len(t_start) - 1, L.int_array(t_start), L.int_array(n_start), L.stream()),
+            "otal_bmp_fwd_levels_to")
+    return out
+
+
+def bmp_backward_levels_from(grad_output, input, segments, t_start, n_start):
+    """bmp_backward_levels reading `grad_output` in place where it is a channel slice of a wider gradient buffer."""
+    import ctypes
+    L.require_device(input, segments)
+    B, C, _ = input.shape
+    N = n_start[-1]
+    grad_input = torch.empty_like(input)
+    L.check(L.lib().otal_bmp_bwd_levels_from(L.ptr(grad_output), ctypes.c_int64(_slice_stride(grad_output, B, C, N)), L.ptr(input),
+                                             L.ptr(segments), L.ptr(grad_input), B, C, len(t_start) - 1, L.int_array(t_start),
+                                             L.int_array(n_start), L.stream()), "otal_bmp_bwd_levels_from")
+    return grad_input
+
+
 class BoundaryMaxPoolingLevelsFunction(Function):
     """All pyramid levels in one launch: input (B,C,sum t_l), segments (B,sum n_l,4) in
     level-local coordinates.  Equivalent to the per-level calls of BDNet.py:386-389."""

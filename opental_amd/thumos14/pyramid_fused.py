@@ -322,13 +322,12 @@ class BranchesFunction(Function):
                 pooled_roi, r_roi = roi_path()
         r_cur = _conv_gn_pair((loc_feat, conf_feat), cur, K1, lev, G, eps, outs=(cat[0][:, 3 * Cp:], cat[1][:, 3 * Cp:]))
         r_lr = _conv_gn_pair((loc_feat, conf_feat), lr, K1, lev, G, eps)
-        pools = [bp.bmp_forward_levels(r_lr[i][1], segments, lev, lev) for i in range(2)]
+        for i in range(2):                                  # pooled rows straight into their slice of the concatenation
+            bp.bmp_forward_levels_to(r_lr[i][1], segments, lev, lev, cat[i][:, Cp:3 * Cp])
         if use_lane:
             lane.join()
         else:
             pooled_roi, r_roi = roi_path()
-        for i in range(2):
-            cat[i][:, Cp:3 * Cp].copy_(pools[i])
         r_prop = _conv_gn_pair(cat, prop, K1, lev, G, eps)
         t0 = lev[1]
         lr_l, lr_c = r_lr[0][1], r_lr[1][1]
@@ -384,7 +383,7 @@ class BranchesFunction(Function):
         # pooled rows -> the lr maps; their level-0 columns also receive the boundary losses' gradients
         dlr = []
         for i, d_l0 in enumerate((d_lr_l0, d_lr_c0)):
-            dpool = bp.bmp_backward_levels(dcat[i][:, Cp:3 * Cp].contiguous(), (lr_l, lr_c)[i], segments, lev, lev)
+            dpool = bp.bmp_backward_levels_from(dcat[i][:, Cp:3 * Cp], (lr_l, lr_c)[i], segments, lev, lev)
             adds = [(dpool, None)]
             if d_l0 is not None:
                 adds.append((d_l0.contiguous(), t0))
