@@ -3452,6 +3452,10 @@ int launch_mode(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
             if (e != OTAL_E_UNSUPPORTED || a.half) return e;
         }
         if (a.half) return OTAL_E_UNSUPPORTED;              // bf16-stored dy: the kernels above only
+        if (proj_wgrad_eligible(a.g, a.prec, a.x, a.dy)) {  // the pyramid projections: short K, no split (proj_gemm.inc)
+            const int e = launch_proj_wgrad(a, st);
+            if (e != OTAL_E_UNSUPPORTED) return e;
+        }
         if (wgrad_direct_eligible(a.g, a.prec, a.x, a.dy)) {
             const int e = launch_wgrad_direct(a, ws, ws_bytes, st);
             if (e != OTAL_E_UNSUPPORTED) return e;          // slabs do not fit: the vector kernel below

@@ -732,6 +732,44 @@ def test_projection_gemm_forward(shape, cout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,k,cout,accumulate", [((2, 832, 64, 6, 6), (1, 6, 6), 512, False), ((2, 1024, 32, 3, 3), (1, 3, 3), 512, False),
+                                                     ((1, 40, 32, 6, 6), (1, 6, 6), 72, True), ((3, 20, 96, 3, 3), (1, 3, 3), 200, True),
+                                                     ((2, 16, 64, 2, 2), (1, 2, 2), 130, False)])
+def test_projection_weight_gradient(shape, k, cout, accumulate):
+    """proj_wgrad_kernel (csrc/proj_gemm.inc): the weight gradient of the spatial_valid pyramid projections
+    (AFSD/thumos14/BDNet.py:129-155) as one 128 x 128-tile GEMM over the whole K = B * T, no split-K, straight into the
+    gradient -- equal to the fp32 conv3d weight gradient on bf16-rounded operands (1e-4 of scale) and to the tiled gather
+    kernel it replaces; both model shapes (6 x 6: 16-byte column quads; 3 x 3: per-element loads), ragged M / N tiles,
+    channel-sliced x, accumulate."""
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    rs = np.random.RandomState(sum(shape) + cout)
+    B, cin, T, H, W = shape
+    xb = torch.from_numpy(rs.randn(B, cin + 8, T, H, W).astype(np.float32)).cuda()
+    x = xb[:, 4:4 + cin]
+    dc = torch.from_numpy(rs.randn(B, cout, T, 1, 1).astype(np.float32)).cuda()
+    base = torch.from_numpy(rs.randn(cout, cin, *k).astype(np.float32)).cuda()
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        dw = ops.conv_wgrad(x, dc, (cout, cin) + k, k, (1, 1, 1), spatial_valid=True, out=base.clone() if accumulate else None,
+                            accumulate=accumulate)
+        L.set_option("OTAL_CONV_NOPROJW", 1)
+        dw_old = ops.conv_wgrad(x, dc, (cout, cin) + k, k, (1, 1, 1), spatial_valid=True, out=base.clone() if accumulate else None,
+                                accumulate=accumulate)
+    finally:
+        L.set_option("OTAL_CONV_NOPROJW", 0)
+        ops.CONV_PRECISION = old
+    xr, dr = _bf16_round(x.cpu()).double(), _bf16_round(dc.cpu()).double()
+    ref = torch.einsum("bot,bcthw->ochw", dr.view(B, cout, T), xr).view(cout, cin, *k)
+    if accumulate:
+        ref = ref + base.cpu().double()
+    close(dw, ref.float())
+    close(dw_old, ref.float())
+    assert float((dw - dw_old).abs().max()) <= 3e-5 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape,cout,accumulate", [((2, 256, 4, 12, 12), 288, False), ((1, 192, 2, 24, 24), 176, True), ((3, 832, 8, 6, 6), 624, False),
                                                    ((2, 40, 32, 3, 3), 24, False), ((1, 480, 8, 6, 6), 304, False), ((1, 64, 1, 8, 4), 448, False)])
 def test_wide_1x1_wgrad_matches_reference_and_vector_kernel(shape, cout, accumulate):
