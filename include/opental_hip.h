@@ -470,78 +470,7 @@ int otal_prepare_clips_map(const unsigned char* frames, const void* params, cons
  * and 4-byte aligned videos (else OTAL_E_UNSUPPORTED). */
 int otal_prepare_windows(const void* params, float* out, int B, int C, int T, int H, int W, void* stream);
 
-/* ------------------------------------------------------------------ fused 1-D blocks (ABI 24) ----
- * One launch = up to OTAL_B1D_MAX_PROB independent PROBLEMS; a problem is one Unit1D + GroupNorm(32, C) + ReLU block of
- * the pyramid (AFSD/thumos14/BDNet.py:67-103,:129-203,:274-284; Unit1D = AFSD/common/layers.py:178-214) going forward,
- * or that block's GroupNorm / ReLU backward fed by the data gradients of the layers that consume its output, going
- * backward -- conv launch + GroupNorm launch (+ the torch.cat / upsample / add glue between them) become ONE launch.
- *
- * A workgroup owns (sample, GroupNorm group, range of whole pyramid levels): it computes that group's cpg (16 or 32)
- * rows of the GEMM  acc[cpg][positions] = sum over K segments of  A_seg[rows][K_seg] * gather_seg[K_seg][positions]
- * on the matrix cores (bf16 operands, fp32 accumulation), so the statistics of the group never leave the workgroup:
- *   epilogue OTAL_B1D_FWD    c = acc + bias -> GroupNorm statistics per level -> y = relu(xhat*gamma + beta);
- *                            writes c (kept for backward), y, stats (B,G,nlev,2) {mean, rstd}
- *   epilogue OTAL_B1D_BWD    dy = acc + sum add_j -> ReLU mask recomputed from c -> GroupNorm backward; writes dc (the
- *                            gradient w.r.t. the convolution output) and partial (B*nrange,3,M) {sum dyh*xhat, sum dyh,
- *                            sum dc} per channel (batch sums by otal_sum_partials)
- *   epilogue OTAL_B1D_PLAIN  out = acc + sum add_j   (a data gradient that feeds no GroupNorm, e.g. the pooled rows)
- * K segment: a (B,C,Ts) fp32 channel-major source (rounded to bf16 while it is staged, exactly as otal_conv_* do in the
- * bf16-operand mode) and the bf16 operand pack of its weights (otal_b1d_pack: row r at wp + r*wp_pitch, element
- * ((c/8)*kt + tap)*8 + c%8).  Tap `tp` of output position n reads virtual position q = n*mul + off + sgn*tp, valid when
- * lo <= q < up (the bounds of n's level when use_levels, else [0,Tv)) and (q & par) == 0; source position q >> shr:
- *   forward stride 1 (SAME)        mul 1, off -pad, sgn +1, shr 0, par 0     forward stride 2     mul 2, off -pad
- *   forward on a x4-upsampled map  mul 1, off -1,  sgn +1, shr 2            data gradient s1     mul 1, off +pad, sgn -1
- *   data gradient of a stride-2 layer   mul 1, off +pad, sgn -1, shr 1, par 1 (Tv = 2*To)
- * Requirements (else OTAL_E_UNSUPPORTED): C % kc == 0, kc in {64,128}, cpg in {16,32}, every range <= 256 positions,
- * 8-byte aligned source rows.  Everything is deterministic (fixed summation orders). */
-#define OTAL_B1D_MAX_SEG   4
-#define OTAL_B1D_MAX_ADD   3
-#define OTAL_B1D_MAX_PROB  6
-#define OTAL_B1D_MAX_RANGE 4
-#define OTAL_B1D_FWD   0
-#define OTAL_B1D_BWD   1
-#define OTAL_B1D_PLAIN 2
-typedef struct otal_b1d_seg {
-    const float* src;               /* (B,C,Ts) */
-    const unsigned short* wp;       /* bf16 operand pack; row 0 = this problem's first row */
-    int64_t src_bs, src_cs;         /* batch / channel stride of src, elements */
-    int64_t src_elems;              /* elements readable from src (buffer bound) */
-    int64_t wp_elems;               /* elements readable from wp */
-    int wp_pitch;                   /* elements per pack row */
-    int C, kt;                      /* channels of the segment; taps (1 or 3) */
-    int mul, off, sgn, shr, par;    /* position map, see above */
-    int Tv;                         /* virtual extent when !use_levels */
-    int use_levels;
-} otal_b1d_seg;
-typedef struct otal_b1d_add {       /* fp32 (B,M,Ta) term added to the accumulator; positions >= Ta add nothing */
-    const float* p; int64_t bs, cs; int Ta; int pad_;
-} otal_b1d_add;
-typedef struct otal_b1d_problem {
-    otal_b1d_seg seg[OTAL_B1D_MAX_SEG];
-    otal_b1d_add add[OTAL_B1D_MAX_ADD];
-    int nseg, nadd;
-    int B, M, cpg, T;               /* samples, rows (output channels), rows per group, positions per sample */
-    int kc;                         /* channels per K chunk: 64 or 128 */
-    int epilogue;                   /* OTAL_B1D_* */
-    int nlev; int lev[OTAL_MAX_LEVELS + 1];         /* level table over [0,T) (nlev 1: one level) */
-    int nrange; int range_lev[OTAL_B1D_MAX_RANGE + 1];  /* workgroup r of a (sample, group) owns levels [range_lev[r], range_lev[r+1]) */
-    float eps; int relu;
-    const float* bias;              /* FWD: (M) or null;  BWD: the block's conv bias is not needed */
-    const float* gamma; const float* beta;          /* (M) */
-    float* c; int64_t c_bs, c_cs;   /* FWD out / BWD in: convolution output (B,M,T) */
-    float* y; int64_t y_bs, y_cs;   /* FWD out: relu(GN(c));  BWD / PLAIN out: dc resp. acc + adds */
-    float* stats;                   /* FWD out / BWD in: (B,G,nlev,2) */
-    float* partial;                 /* BWD out: (B*nrange,3,M) */
-} otal_b1d_problem;
-/* mode: the epilogue of every problem of the launch (problems of one launch share it). */
-int otal_b1d_launch(const otal_b1d_problem* problems, int n_problems, void* stream);
-size_t otal_b1d_problem_bytes(void);
-/* Operand packs of many layers in one launch.  Item i: w (Cout,Cin,kt) fp32 -> fwd (Cout rows, pitch Cin*kt) when fwd[i]
- * is non-null, and -> dgrad (Cin rows, pitch Cout*kt; element (ci, ((co/8)*kt + tap)*8 + co%8) = w[co][ci][tap]) when
- * dgrad[i] is non-null.  items: DEVICE array of n records {const float* w; unsigned short* fwd; unsigned short* dgrad;
- * int Cout, Cin, kt, first_block} (40 bytes; first_block = prefix sum of ceil(Cout*Cin*kt / 8 / 256) over the items
- * before i); total_blocks = that sum over all items.  Cout % 8 == 0 and Cin % 8 == 0. */
-int otal_b1d_pack(const void* items, int n_items, int total_blocks, void* stream);
+/* ------------------------------------------------------------------ pyramid glue (ABI 24) ---- */
 
 /* Pyramid merge (AFSD/thumos14/BDNet.py:310-326) in one launch: p0 (B,C,t0), p1 (B,C,t0/2) -> packed[:, :, :t0] = p0 +
  * nearest-upsampled p1 (source index t/2), packed[:, :, t0:t0+t0/2] = p1 (packed has T positions per row), and

@@ -11,7 +11,7 @@ BoundaryMaxPooling); what the explicit tapes buy:
   * no tensor-library glue: upsample + add + cat + upsample become ONE launch (`ops.pyramid_merge_forward`), stride-2 blocks
     write their level of the packed buffer in place, the ProposalBranch concatenation is written in place by its three
     producers, gradients that meet in one tensor are added inside the GroupNorm-backward launch that consumes them
-    (`otal_b1d_launch` with no GEMM segment) instead of by autograd's accumulation kernels;
+    (`otal_gn_relu_bwd_sum`) instead of by autograd's accumulation kernels;
   * independent chains run side by side on the branch lane (`ops.branch_lane`): the frame-level deconv beside the stride-2
     pyramid + towers, the roi path beside the level path -- forward AND backward (autograd's engine serialises nodes; inside
     one node the order and the streams are ours);
@@ -24,12 +24,20 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib as L
-from ..common import block1d as B1
 from ..common import ops
 from ..prop_pooling import boundary_pooling_op as bp
 
 ONE = (1, 1, 1)
 K3, K1, S2 = (3, 1, 1), (1, 1, 1), (2, 1, 1)
+
+
+def _bs_cs(t):
+    """(batch stride, channel stride) of a (B,C,T) tensor whose positions are dense (a level / channel slice included)."""
+    B, C, T = t.shape
+    if T > 1 and t.stride(2) != 1:
+        raise RuntimeError("pyramid_fused: positions must be dense")
+    cs = t.stride(1) if C > 1 else T
+    return (t.stride(0) if B > 1 else cs * C), cs
 
 
 def _gn_bwd_raw(dy, c, gamma, beta, stats, groups, levels):
@@ -53,7 +61,7 @@ def _gn_bwd_adds(adds, c, gamma, beta, stats, groups, levels):
     dc = torch.empty_like(c)
     partial = torch.empty((B, 3, C), dtype=torch.float32, device=c.device)
     nlev, lev = ops._lev_arg(levels)
-    strides = [B1._bs_cs(t) for t, _ in adds]
+    strides = [_bs_cs(t) for t, _ in adds]
     ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in adds])
     I64 = ctypes.c_int64 * n
     L.check(L.lib().otal_gn_relu_bwd_sum(n, ptrs, I64(*[s[0] for s in strides]), I64(*[s[1] for s in strides]),
