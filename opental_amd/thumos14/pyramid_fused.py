@@ -248,7 +248,8 @@ class TrunkFunction(Function):
         dws = WG.pair((packed, packed), (r[0][0], r[1][0]), (lt[0][0], ct[0][0]), K3, ONE, lev)
         put(9, dws[0]); put(11, dws[1])
         da, db = _dgrad_pair((r[0][0], r[1][0]), (lt[0][0], ct[0][0]), packed.shape, K3, lev)
-        WG.side.flush()
+        if not use_lane:                    # (never while the branch lane is forked: a flush may CUT the lane-graph capture, and a
+            WG.side.flush()                 #  capture cannot end before a forked stream has rejoined it -- found with OTAL_WGRAD_CHUNK=5)
         # stride-2 levels from the top: the level's gradient = the towers' two + the data gradient of the level above
         dnext = None
         for l in range(len(lev) - 2, 1, -1):

@@ -80,3 +80,35 @@ def test_fused_pyramid_nodes_equal_the_module_by_module_path(golden_dir, prec):
             worst = (n, err / scale)
         assert err <= 2e-5 * max(scale, 1e-12), (n, err, scale)
     print("worst gradient difference:", worst)
+
+
+@pytest.mark.parametrize("chunk", [3, 5, 6])
+def test_lane_graph_capture_survives_any_weight_gradient_chunk_size(chunk):
+    """A lane-graph capture is CUT wherever the weight-gradient lane takes a chunk (ops.SideWgrads.flush), and a capture
+    cannot end while a forked stream has not rejoined it: the fused nodes must not flush between a branch-lane fork and its
+    join.  With the default chunk (4) the counts happened to work out; 5 and 6 crashed hipStreamEndCapture.  Every chunk size
+    must capture, and the replayed steps must leave the parameters of eager steps."""
+    import bench
+    from opental_amd.common import ops
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda", 0)
+    old = (ops.CONV_PRECISION, ops.SideWgrads.CHUNK)
+    ops.CONV_PRECISION = 1
+    try:
+        batch = bench.synth_batch(2, 1000, dev)
+        ops.SideWgrads.CHUNK = 4
+        ref = bench.build_trainer(dev, seed=21)
+        for _ in range(3):
+            ref.step(*batch)
+        ops.SideWgrads.CHUNK = chunk
+        tr = bench.build_trainer(dev, seed=21)
+        tr.step(*batch)
+        tr.capture_step(*batch, warmup=0, lanes=True)
+        for _ in range(2):
+            tr.step(*batch)
+        torch.cuda.synchronize()
+        assert tr.replayed_steps == 2
+        assert torch.equal(tr.arena.flat, ref.arena.flat) and torch.equal(tr.arena.m, ref.arena.m)
+    finally:
+        ops.CONV_PRECISION, ops.SideWgrads.CHUNK = old
