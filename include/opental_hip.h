@@ -375,6 +375,11 @@ int otal_head_convs_fwd(int n_heads, int n_inputs, const int* in_idx, const int*
 int otal_head_convs_bwd(int n_heads, int n_inputs, const int* in_idx, const int* cout, const int* ksize,
                         const float* const* x, const float* const* w, const float* const* dy, float* const* dx,
                         float* const* dw, float* const* db, int B, int C, int N, int nlev, const int* lev, void* stream);
+/* The same with the two launches selectable: parts bit 0 = data gradients, bit 1 = weight / bias gradients (independent:
+ * a caller may put them on different streams). */
+int otal_head_convs_bwd_parts(int n_heads, int n_inputs, const int* in_idx, const int* cout, const int* ksize,
+                        const float* const* x, const float* const* w, const float* const* dy, float* const* dx,
+                        float* const* dw, float* const* db, int B, int C, int N, int nlev, const int* lev, int parts, void* stream);
 
 /* ------------------------------------------------------------------ gradient hand-over to the backbone ----
  * dst[b][c][t][s] (+)= (z[b][c][t][s] > 0 ? scale[c] : 0) * src[b][c][t][s]   (scale NULL: 1; accumulate != 0: +=).

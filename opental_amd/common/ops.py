@@ -1496,6 +1496,7 @@ class AnetDetectionLossFunction(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- head output tails
+HEAD_WGRAD_SIDE = os.environ.get("OTAL_HEAD_WGRAD_SIDE", "1") != "0"     # the fused heads' weight gradients on the weight-gradient lane
 HEAD_GRAD_SLOTS = "OTAL_NO_GRAD_SLOTS_HEADS" not in os.environ      # (A/B switch of the head bias / ScaleExp gradient slots)
 
 
@@ -1646,19 +1647,35 @@ class HeadConvsFunction(torch.autograd.Function):
         xs, ws = list(saved[:n_inputs]), list(saved[n_inputs:])
         dys = [None if g is None else g.contiguous() for g in dys]
         dxs = [torch.empty_like(x) if ctx.needs_input_grad[3 + j] else None for j, x in enumerate(xs)]
-        dws = []
+        dws, slots_w, slots_b = [], [], []
         for w in ws:
             slot = grad_slot(w)
+            slots_w.append(slot)
             dws.append(slot if slot is not None else torch.empty_like(w))
         # bias gradients go straight to their arena slots too (they were 7 of the 13 one-to-fifteen-element gradient copies --
         # a hipMemcpyAsync node each -- that every step's bucket flushes issued)
         dbs = []
         for w, b in zip(ws, ctx.bias_params):
             slot = grad_slot(b) if (b is not None and HEAD_GRAD_SLOTS) else None
+            slots_b.append(slot)
             dbs.append(slot if slot is not None else (torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if b is not None else None))
         VP = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
-        L.check(L.lib().otal_head_convs_bwd(*meta, VP(xs), VP(ws), VP(dys), VP(dxs), VP(dws), VP(dbs), B, C, N, nlev, lev, L.stream()),
-                "otal_head_convs_bwd")
+        in_slots = all(s_ is not None for s_ in slots_w) and all(s_ is not None for s_, b in zip(slots_b, ctx.bias_params) if b is not None)
+        side = side_wgrads(xs[0].device)
+        if HEAD_WGRAD_SIDE and side.on and in_slots and SIDE_DEFER_JOIN:
+            # the data gradients on the chain that waits for them, the weight / bias gradients on the weight-gradient lane (they
+            # land in arena slots nobody reads before the trainer's join): 29 + 39 us off the serial middle of the step
+            L.check(L.lib().otal_head_convs_bwd_parts(*meta, VP(xs), VP(ws), VP(dys), VP(dxs), VP(dws), VP(dbs), B, C, N, nlev, lev, 1,
+                                                      L.stream()), "otal_head_convs_bwd_parts")
+            dst_w, dst_b = [t.detach() for t in dws], [None if t is None else t.detach() for t in dbs]
+            side.pending.append(lambda: L.check(L.lib().otal_head_convs_bwd_parts(
+                *meta, VP(xs), VP(ws), VP(dys), VP([None] * len(xs)), VP(dst_w), VP(dst_b), B, C, N, nlev, lev, 2, L.stream()),
+                "otal_head_convs_bwd_parts"))
+            side.keep.append((xs, dys, ws))
+            side.node_end(True)
+        else:
+            L.check(L.lib().otal_head_convs_bwd(*meta, VP(xs), VP(ws), VP(dys), VP(dxs), VP(dws), VP(dbs), B, C, N, nlev, lev, L.stream()),
+                    "otal_head_convs_bwd")
         return (None, None, None) + tuple(dxs) + tuple(dws) + tuple(dbs)
 
 

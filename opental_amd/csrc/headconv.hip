@@ -404,10 +404,24 @@ extern "C" int otal_head_convs_fwd(int n_heads, int n_inputs, const int* in_idx,
     return otal_launch_status();
 }
 
+// parts: bit 0 = the data gradients (dx), bit 1 = the weight / bias gradients (dw, db).  The two launches are independent
+// (both read x, w, dy only), so a caller may issue them on different streams -- the data gradient on the chain that needs
+// it, the weight gradients on its weight-gradient lane.
+extern "C" int otal_head_convs_bwd_parts(int n_heads, int n_inputs, const int* in_idx, const int* cout, const int* ksize,
+                                         const float* const* x, const float* const* w, const float* const* dy, float* const* dx,
+                                         float* const* dw, float* const* db, int B, int C, int N, int nlev, const int* lev,
+                                         int parts, void* stream);
 extern "C" int otal_head_convs_bwd(int n_heads, int n_inputs, const int* in_idx, const int* cout, const int* ksize,
                                    const float* const* x, const float* const* w, const float* const* dy, float* const* dx,
                                    float* const* dw, float* const* db, int B, int C, int N, int nlev, const int* lev, void* stream) {
+    return otal_head_convs_bwd_parts(n_heads, n_inputs, in_idx, cout, ksize, x, w, dy, dx, dw, db, B, C, N, nlev, lev, 3, stream);
+}
+extern "C" int otal_head_convs_bwd_parts(int n_heads, int n_inputs, const int* in_idx, const int* cout, const int* ksize,
+                                         const float* const* x, const float* const* w, const float* const* dy, float* const* dx,
+                                         float* const* dw, float* const* db, int B, int C, int N, int nlev, const int* lev,
+                                         int parts, void* stream) {
     if (!x || !w || !dy || !dx || !dw || !db) return OTAL_E_NULL;
+    if (parts < 1 || parts > 3) return OTAL_E_SHAPE;
     HcArgs a;
     if (int e = fill(a, n_heads, n_inputs, in_idx, cout, ksize, B, C, N, nlev, lev)) return e;
     bool any_dx = false;
@@ -422,13 +436,14 @@ extern "C" int otal_head_convs_bwd(int n_heads, int n_inputs, const int* in_idx,
         if (!w[h] || !dw[h]) return OTAL_E_NULL;
         a.w[h] = w[h]; a.dy[h] = dy[h]; a.dw[h] = dw[h]; a.db[h] = db[h];
     }
-    if (any_dx) {
+    if (any_dx && (parts & 1)) {
         const size_t lds = ((size_t)maxrows * (N + 2) + (size_t)maxrows * 48) * 4;
         if (lds > HC_LDS_MAX) return OTAL_E_UNSUPPORTED;
         if (int e = allow_lds(head_convs_dgrad_kernel, lds)) return e;
         hipLaunchKernelGGL(head_convs_dgrad_kernel, dim3(C / 16, B, n_inputs), dim3(256), lds, (hipStream_t)stream, a);
         if (int e = otal_launch_status()) return e;
     }
+    if (!(parts & 2)) return 0;
     const size_t lds = wgrad_lds(a);
     if (lds > HC_LDS_MAX) return OTAL_E_UNSUPPORTED;
     if (int e = allow_lds(head_convs_wgrad_kernel, lds)) return e;
