@@ -11,7 +11,7 @@ import os
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LAUNCH_PATH = ("opental_amd/common/ops.py", "opental_amd/common/layers.py", "opental_amd/common/i3d_backbone.py",
                "opental_amd/thumos14/BDNet.py", "opental_amd/thumos14/train.py", "opental_amd/thumos14/multisegment_loss.py",
-               "opental_amd/prop_pooling/boundary_pooling_op.py")
+               "opental_amd/prop_pooling/boundary_pooling_op.py", "opental_amd/thumos14/pyramid_fused.py")
 
 
 def source_stamp():
