@@ -3221,8 +3221,16 @@ int launch_wgrad_vector(ConvArgs& a, int cw, void* ws, size_t ws_bytes, hipStrea
 }
 
 // ---- direct 3x3x3 path: eligibility and launch
-static inline int direct_bm(int M) {
+static inline int direct_bm(const ConvGeom& g, int M) {
     if (M % 96 == 0) return 96;
+    // one workgroup per CU and launch round: where 64-row tiles of 256 positions need a second, nearly empty round (the 6x6
+    // planes of Mixed_4b..4d b1b forward: 4 x 72 = 288 workgroups) and 96-row tiles do not (3 x 72 = 216), the padded rows
+    // are cheaper than the round -- forward 43 / 68 / 76 us on 64-row tiles against 56 us for Mixed_4e's 216 tiles of 96
+    if (M > 96 && !OTAL_OPT("OTAL_CONV_DIRECT_NOROUNDS", 0)) {
+        const int64_t nt = (int64_t)g.B * conv_out_positions(g) / 256;
+        const int64_t w64 = (M + 63) / 64 * nt, w96 = (M + 95) / 96 * nt;
+        if (w64 <= 512 && (w96 + 255) / 256 * 96 < (w64 + 255) / 256 * 64) return 96;
+    }
     if (M % 64 == 0) return 64;
     // 16 .. 32 rows (data gradient of the Inception b2b layers: M = Cin = 16 / 24 / 32; forward of Mixed_3b.b2b): one 32-row
     // MFMA tile per wave.  LDS-read-bound (9 weight + 9 position fragments per 9 MFMAs), but these layers are tiny and ran
@@ -3234,7 +3242,7 @@ static inline int direct_bm(int M) {
 // positions per workgroup: 256 (8 waves), or 128 (4 waves) when 256 would leave the chip half empty (the 6x6 planes of
 // Mixed_4x: 72 position tiles); 0 = too few tiles either way (no split-K on this path)
 static inline int direct_bnp(const ConvGeom& g, int M) {
-    const int BM = direct_bm(M);
+    const int BM = direct_bm(g, M);
     if (!BM) return 0;
     const int64_t tm = (M + BM - 1) / BM, NP = (int64_t)g.B * conv_out_positions(g);
     // (140: the 144 tiles of a one-M-tile layer on the 6x6 planes still take the 128-position form -- Mixed_4b / 4e b2b forward
@@ -3260,8 +3268,8 @@ static inline bool direct_eligible(const ConvGeom& g, int mode, int prec, int M)
     const int64_t ext = gather_extent_bytes(g, mode);
     return ext > 0 && ext < (1LL << 31);
 }
-static inline size_t direct_wp_bytes(int M, int C) {
-    const int BM = direct_bm(M);
+static inline size_t direct_wp_bytes(const ConvGeom& g, int M, int C) {
+    const int BM = direct_bm(g, M);
     return align256((size_t)((M + BM - 1) / BM * BM) * C * 27 * 2 + 1024);
 }
 
@@ -3313,9 +3321,9 @@ template <int MODE, bool H = false>
 int launch_direct(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     if (H && ((a.g.Wi & 1) || (a.flags & EPI_ACCUM))) return OTAL_E_UNSUPPORTED;       // (4-byte aligned loads need an even row length)
     const int C = MODE == MODE_FWD ? a.g.Cin : a.g.Cout;
-    const int BM = direct_bm(a.M);
+    const int BM = direct_bm(a.g, a.M);
     const int tm = (a.M + BM - 1) / BM, Mpad = tm * BM;
-    const size_t wb = direct_wp_bytes(a.M, C);
+    const size_t wb = direct_wp_bytes(a.g, a.M, C);
     if (a.pre) {            // packed earlier into a caller-owned region (otal_conv_prologue[_batch]): nothing to do per launch
         ws = const_cast<void*>(a.pre);
     } else {
@@ -3605,7 +3613,7 @@ extern "C" size_t otal_conv_workspace_bytes(const int* geom, int mode) {
         const int Kc = mode == MODE_FWD && g.Cin * g.kt * g.kh * 8 > K ? g.Cin * g.kt * g.kh * 8 : (int)K;   // kw-vector mode pads kw to 8
         size_t cf = chunk_tab_bytes(Kc) + chunk_wp_bytes((int)M, BMsel, Kc);
         if (M % 192 == 0) { const size_t ct = chunk_tab_bytes(Kc) + chunk_wp_bytes((int)M, 192, Kc); if (ct > cf) cf = ct; }
-        if (direct_eligible(g, mode, 1, (int)M)) { const size_t dd = direct_wp_bytes((int)M, mode == MODE_FWD ? g.Cin : g.Cout); if (dd > cf) cf = dd; }
+        if (direct_eligible(g, mode, 1, (int)M)) { const size_t dd = direct_wp_bytes(g, (int)M, mode == MODE_FWD ? g.Cin : g.Cout); if (dd > cf) cf = dd; }
         if (cf > front) front = cf;
     }
     if (mode == MODE_DGRAD) front += align256((size_t)g.Cin * g.Cout * kvol * sizeof(float));    // natural-layout weights on the generic path
@@ -3795,7 +3803,7 @@ extern "C" size_t otal_conv_prologue_bytes(const int* geom, const int64_t* strid
         return chunk_tab_bytes(a.K) + chunk_wp_bytes(a.M, choose_bm(a.M, kwv ? 0 : 1), a.K);
     }
     if (kind == 2) return ptab_bytes(a.g, a.g.sw == 2 ? 8 : wgrad_vector_width(a.g, a.prec));
-    if (kind == 3) return direct_wp_bytes(a.M, mode == MODE_FWD ? a.g.Cin : a.g.Cout);
+    if (kind == 3) return direct_wp_bytes(a.g, a.M, mode == MODE_FWD ? a.g.Cin : a.g.Cout);
     return 0;
 }
 
@@ -3824,7 +3832,7 @@ extern "C" int otal_conv_prologue(const int* geom, const int64_t* strides, int m
     PrepDesc d;
     if (kind == 3) {
         d = PrepDesc{};
-        const int BM = direct_bm(a.M);
+        const int BM = direct_bm(a.g, a.M);
         d.wp = reinterpret_cast<unsigned*>(region); d.wsrc = w; d.g = a.g; d.M = a.M; d.Mpad = (a.M + BM - 1) / BM * BM;
         d.C = mode == MODE_FWD ? a.g.Cin : a.g.Cout; d.natural = a.w_natural; d.mode = mode; d.direct = 1;
         d.fh = make_fastdiv((uint32_t)(d.C * 27 / 2));

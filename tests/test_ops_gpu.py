@@ -584,10 +584,13 @@ def test_wgrad_1d_kernel_matches_torch(B, Cin, Cout, T, k, lev, monkeypatch):
                                                ((2, 80, 5, 12, 12), 64, True),       # Cin not a multiple of the 32-channel block
                                                ((3, 128, 8, 12, 12), 192, False),
                                                ((2, 96, 16, 6, 6), 208, False),      # 6x6 planes: four planes per K step, ring of 16 slabs
-                                               ((3, 144, 8, 6, 6), 96, True), ((1, 64, 4, 6, 6), 64, False), ((2, 70, 40, 6, 6), 130, True)])
+                                               ((3, 144, 8, 6, 6), 96, True), ((1, 64, 4, 6, 6), 64, False), ((2, 70, 40, 6, 6), 130, True),
+                                               ((2, 48, 32, 3, 3), 128, False),      # 3x3 planes: sixteen planes per K step, two slabs
+                                               ((3, 160, 16, 3, 3), 96, True), ((2, 64, 32, 3, 3), 130, True),
+                                               ((1, 34, 48, 3, 3), 70, False)])      # Cin % 4 != 0: the epilogue's 4-byte row stores
 def test_direct_wgrad_3x3x3_matches_reference_and_vector_kernel(shape, cout, slices):
     """conv3_wgrad_direct_kernel (LDS-staged receptive field, transposed LDS reads; csrc/conv_wgrad_direct.inc) on the
-    backbone's 24x24 / 12x12 / 6x6 layer shapes: equal to an fp32 convolution's weight gradient on the bf16-ROUNDED operands
+    backbone's 24x24 / 12x12 / 6x6 / 3x3 layer shapes: equal to an fp32 convolution's weight gradient on the bf16-ROUNDED operands
     (1e-4 of scale), equal to the vector kernel it replaces (same products, other summation order), with x / dy taken as
     channel slices of larger buffers (Inception concat layout), several samples / planes (zero borders in t and h), and
     split-K over the positions."""
@@ -622,6 +625,33 @@ def test_direct_wgrad_3x3x3_matches_reference_and_vector_kernel(shape, cout, sli
     close(dw_vec, w.grad)
     scale = float(w.grad.abs().max())
     assert float((dw - dw_vec).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout", [((2, 64, 2, 24, 24), 96), ((1, 96, 4, 12, 12), 64), ((2, 64, 8, 6, 6), 80), ((2, 40, 16, 3, 3), 64)])
+def test_direct_wgrad_accumulates_into_dw_without_a_split(shape, cout):
+    """One workgroup per tile (OTAL_WDIRECT_BLOCKS=1: no split-K): the direct kernels' row epilogue adds to the dW it finds
+    (accumulate=True) -- equal to dW0 + the weight gradient, as the split-K reduction does it."""
+    from opental_amd import _lib as L
+    from opental_amd.common import ops
+    rs = np.random.RandomState(7)
+    B, Cin, T, H, W = shape
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rs.randn(B, cout, T, H, W).astype(np.float32)).cuda()
+    dw0 = torch.from_numpy(rs.randn(cout, Cin, 3, 3, 3).astype(np.float32)).cuda()
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = 1
+    try:
+        plain = ops.conv_wgrad(x, dy, tuple(dw0.shape), (3, 3, 3), (1, 1, 1))
+        L.set_option("OTAL_WDIRECT_BLOCKS", 1)
+        one = ops.conv_wgrad(x, dy, tuple(dw0.shape), (3, 3, 3), (1, 1, 1))
+        acc = ops.conv_wgrad(x, dy, tuple(dw0.shape), (3, 3, 3), (1, 1, 1), out=dw0.clone(), accumulate=True)
+    finally:
+        L.set_option("OTAL_WDIRECT_BLOCKS", 0)
+        ops.CONV_PRECISION = old
+    scale = float(plain.abs().max())
+    assert float((one - plain).abs().max()) <= 2e-5 * scale
+    assert torch.equal(acc, dw0 + one)
 
 
 LEV126 = (0, 64, 96, 112, 120, 124, 126)

@@ -9,6 +9,10 @@ LAYERS = {
     "1a": ((8, 3, 256, 96, 96), 64, (7, 7, 7), (2, 2, 2)),   # dgrad unused by the model (input needs no gradient)
     "3c_b1b": ((8, 128, 128, 12, 12), 192, (3, 3, 3), (1, 1, 1)),
     "4f_b1b": ((8, 160, 64, 6, 6), 320, (3, 3, 3), (1, 1, 1)),
+    "4b_b1b": ((8, 96, 64, 6, 6), 208, (3, 3, 3), (1, 1, 1)),
+    "4c_b1b": ((8, 112, 64, 6, 6), 224, (3, 3, 3), (1, 1, 1)),
+    "4d_b1b": ((8, 128, 64, 6, 6), 256, (3, 3, 3), (1, 1, 1)),
+    "4e_b1b": ((8, 144, 64, 6, 6), 288, (3, 3, 3), (1, 1, 1)),
     "3b_b0": ((8, 192, 128, 12, 12), 64, (1, 1, 1), (1, 1, 1)),
     "2b": ((8, 64, 128, 24, 24), 64, (1, 1, 1), (1, 1, 1)),
     "3c_1x1": ((8, 256, 128, 12, 12), 288, (1, 1, 1), (1, 1, 1)),     # Mixed_3c: the fused [b1a | b2a | b0] launch
