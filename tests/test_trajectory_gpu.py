@@ -25,10 +25,11 @@ pytestmark = pytest.mark.gpu
 import os
 STEPS, NB, B = 200, 16, 8
 SEED = int(os.environ.get('OTAL_TRAJ_SEED', '21'))
-# measured on MI355X, seed 21 (the printed table), two runs of two trees that differ in summation order only:
-# window means within 18-21 % (bf16) / 10-14 % (nochain) of fp32, tails 1.5-8 % / 0.7-5.6 %; displacement cosines 0.96 / 0.96,
-# lengths 0.996-0.998 / 1.012-1.013, weight_accum 8.5-14 % / 6.4-8 %.  Bands at about 1.5 x (a chaotic sample: see the docstring).
-WINDOW_BAND, TAIL_BAND, COS_MIN, LEN_BAND, ACCUM_BAND = 0.32, 0.15, 0.90, 0.05, 0.22
+# measured on MI355X, seed 21 (the printed table), THREE trees that differ in the summation order of some weight
+# gradients only: window means within 17-21 % (bf16) / 10-15 % (nochain) of fp32, tails 1.5-15.6 % / 0.7-10.8 %; displacement cosines
+# 0.96 / 0.96, lengths 0.996-1.001 / 1.010-1.013, weight_accum 8.5-14 % / 6.1-8 %.  The tail moved from 8 % to 15.6 % when nothing but
+# a split-K reduction's summation tree changed: a chaotic sample (see the docstring) -- bands at about twice the spread seen.
+WINDOW_BAND, TAIL_BAND, COS_MIN, LEN_BAND, ACCUM_BAND = 0.40, 0.30, 0.90, 0.05, 0.25
 
 
 def _run(mode, batches, ring):
