@@ -1937,7 +1937,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_tall_kernel(const ConvArgs 
 namespace otal_conv {
 constexpr int DEFER_MAX = 24;
 struct DeferItem { const float* slab; float* out; int64_t total; int splits, flags, N, kw; };
-struct DeferBatch { DeferItem it[DEFER_MAX]; };
+struct DeferBatch { DeferItem it[DEFER_MAX]; int start[DEFER_MAX + 1]; };    // start[i]: first workgroup of item i (1-D grid: no empty workgroups)
 // (the record is process-wide: calls that touch it are serialised by `mu`, so a binding that issues from several host threads
 //  cannot corrupt it -- but it stays ONE list: defer / flush belong to one logical issuer at a time, see the header)
 struct DeferState { bool on = false; int n = 0; DeferBatch batch; uintptr_t last_end = 0; std::recursive_mutex mu; };
@@ -1954,10 +1954,13 @@ using otal_conv::g_defer;
 
 __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const DeferBatch b) {
     __shared__ float4 part[3][64];
-    const DeferItem& d = b.it[blockIdx.y];
+    int item = 0;
+#pragma unroll 1
+    while (item + 1 < DEFER_MAX && b.start[item + 1] <= (int)blockIdx.x) ++item;     // (uniform; start[] is non-decreasing, unused tail = grid size)
+    const DeferItem& d = b.it[item];
+    const int wg = (int)blockIdx.x - b.start[item];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t base = ((int64_t)blockIdx.x * 64 + lane) * 4;
-    if ((int64_t)blockIdx.x * 256 >= d.total) return;              // workgroup beyond this item (uniform)
+    const int64_t base = ((int64_t)wg * 64 + lane) * 4;
     const bool live = base < d.total;
     const int per = (d.splits + 3) / 4;
     const int s_lo = q * per, s_hi = min(d.splits, s_lo + per);
@@ -1998,9 +2001,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const DeferBat
 static int flush_deferred(hipStream_t st) {
     std::lock_guard<std::recursive_mutex> lock(g_defer.mu);
     if (g_defer.n == 0) return 0;
-    int64_t most = 0;
-    for (int i = 0; i < g_defer.n; ++i) most = g_defer.batch.it[i].total > most ? g_defer.batch.it[i].total : most;
-    hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3((unsigned)((most + 255) / 256), g_defer.n), dim3(256), 0, st, g_defer.batch);
+    int blocks = 0;
+    for (int i = 0; i <= DEFER_MAX; ++i) {
+        g_defer.batch.start[i] = blocks;
+        if (i < g_defer.n) blocks += (int)((g_defer.batch.it[i].total + 255) / 256);
+    }
+    hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g_defer.batch);
     g_defer.n = 0;
     return otal_launch_status();
 }
