@@ -1593,6 +1593,8 @@ typedef __attribute__((address_space(1))) float GlobalF32;
 typedef __attribute__((address_space(1))) unsigned GlobalU32;
 typedef __attribute__((address_space(1))) unsigned long long GlobalU64;
 constexpr int PREP_U = 4;       // packed pairs per thread and trip of the pack loops
+constexpr int PREP_T_KVOL = 3;  // data-gradient packs from the natural W with kvol <= 3: transposed through LDS (prep_chunks_body)
+constexpr int PREP_T_PITCH = 256 * 2 + 4;   // bytes of a tile row in LDS: 129 words, the 32 rows of a 2-byte column write on 32 banks
 
 template <int MODE>
 __device__ __forceinline__ void prep_chunks_body(const PrepDesc& d, unsigned bid, unsigned nblk) {
@@ -1646,6 +1648,52 @@ __device__ __forceinline__ void prep_chunks_body(const PrepDesc& d, unsigned bid
             e.y = (1 << dt) | (1 << (8 + dh)) | (1 << (16 + dw));
         }
         ctab[gid] = (unsigned long long)(unsigned)e.x | ((unsigned long long)(unsigned)e.y << 32);
+    }
+    if (MODE == MODE_DGRAD && natural && kvol <= PREP_T_KVOL) {
+        // The data gradient's operand rows are the INPUT channels of W (Cout, Cin, kvol) taken as it lies: A[m = ci][k <-> (co, tap)].
+        // Walking k along a packed row, as the loop below does, reads W with a stride of Cin * kvol floats -- one 64-byte sector
+        // per 4-byte element for the 1x1x1 and 1-D layers (16 M parameters per step: the pack launch fetched 774 MB for 179 MB of
+        // weights).  Here a workgroup takes a 32-row x 256-k tile: 32 consecutive m of one (co, tap) are 32 * kvol contiguous
+        // floats (lanes along m), the tile is transposed in LDS and leaves as 512-byte runs of the packed rows.
+        __shared__ __attribute__((aligned(16))) unsigned char tl[32 * PREP_T_PITCH];
+        const int tk = (Kp + 255) / 256, tiles = (Mpad / 32) * tk;
+        const int l = threadIdx.x & 31, kq = threadIdx.x >> 5;
+        const FastDiv fk = d.fk;
+        for (int t = (int)bid; t < tiles; t += (int)nblk) {
+            const int m0 = (t / tk) * 32, k0 = (t - (t / tk) * tk) * 256;
+            const int m = m0 + l;
+#pragma unroll
+            for (int i0 = 0; i0 < 32; i0 += 8) {
+                unsigned raw[8];
+                bool ok[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = k0 + kq + 8 * (i0 + u);
+                    const int j = kk >> 3, cb = (int)fd_div(fk, (unsigned)j), tap = j - cb * kvol, c = cb * 8 + (kk & 7);
+                    ok[u] = m < M && kk < K;
+                    raw[u] = __float_as_uint(wsrc[ok[u] ? ((int64_t)c * M + m) * kvol + tap : 0]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned pk = cvt_pk_bf16(__uint_as_float(ok[u] ? raw[u] : 0u), 0.f);
+                    *reinterpret_cast<unsigned short*>(tl + l * PREP_T_PITCH + (kq + 8 * (i0 + u)) * 2) = (unsigned short)pk;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int r = ps * 8 + (threadIdx.x >> 5), seg = threadIdx.x & 31;
+                const unsigned* src = reinterpret_cast<const unsigned*>(tl + r * PREP_T_PITCH + seg * 16);
+                const unsigned w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+                const int kk = k0 + seg * 8;
+                if (kk < Kp) {
+                    GlobalU32* dst = wp + ((int64_t)(m0 + r) * Kp + kk) / 2;
+                    dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
+                }
+            }
+            __syncthreads();
+        }
+        return;
     }
     const unsigned half = (unsigned)Kp / 2;
     const unsigned pairs = (unsigned)Mpad * half;
@@ -3011,6 +3059,7 @@ static inline unsigned prep_blocks(const PrepDesc& d) {
     const int64_t pairs = (int64_t)d.Mpad * (d.Kp / 2);
     if (pairs >= (1LL << 31)) return 0;
     int64_t blocks = (pairs + 256 * PREP_U - 1) / (256 * PREP_U);
+    if (d.mode == MODE_DGRAD && d.natural && d.kvol <= PREP_T_KVOL && !d.kwv) blocks = (int64_t)(d.Mpad / 32) * ((d.Kp + 255) / 256);   // tiles
     if (blocks < (d.nchunk + 255) / 256) blocks = (d.nchunk + 255) / 256;
     return (unsigned)(blocks > 2048 ? 2048 : blocks);
 }
