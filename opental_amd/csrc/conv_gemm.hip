@@ -2975,7 +2975,11 @@ int launch_wgrad1d(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
     const int upw_env = OTAL_OPT("OTAL_W1D_UPW", 0);
     const int nchunks = wgrad1d_chunks(a.g), units = a.g.B * nchunks;
     const int tiles = ((a.g.Cout + 63) / 64) * (a.g.Cin / 64);
-    const int upw = upw_env > 0 ? upw_env : 1;      // units per workgroup: measured 1 -> 478.4, 2 -> 475.8, 4 -> 465.7 clips/s
+    // units per workgroup = (sample, chunk) units folded into one split-K slab.  Round 2 (every reduction its own launch behind
+    // its GEMM, one lane): 1 -> 478.4, 2 -> 475.8, 4 -> 465.7 clips/s.  Round 6 (reductions batched on the weight-gradient lane, whose
+    // slab traffic is what these eight launches cost -- 328 MB written, 328 MB read back per step): 1 / 2 / 4 / 8 -> 8.09 / 8.03 /
+    // 8.02 / 8.02 ms.  Four where there are eight units or more (two slabs at b = 8), two from four units on.
+    const int upw = upw_env > 0 ? upw_env : (units >= 8 ? 4 : units >= 4 ? 2 : 1);
     (void)tiles;
     const int splits = (units + upw - 1) / upw;
     const size_t need = ((size_t)splits * a.M * a.N * sizeof(float) + 255) & ~(size_t)255;
