@@ -13,7 +13,7 @@ done
 python - "$out" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
-GROUPS = [("conv gemm", ("conv_gemm", "conv_wgrad", "conv3_direct", "conv1a_direct", "conv1a_tile", "conv3_wgrad_direct", "conv1d_tile", "conv1a_wgrad", "wgrad1x1_wide", "conv3_wgrad_planes6", "proj_fwd")), ("split-K reduce", ("splitk_reduce",)),
+GROUPS = [("conv gemm", ("conv_gemm", "conv_wgrad", "conv3_direct", "conv1a_direct", "conv1a_tile", "conv3_wgrad_direct", "conv1d_tile", "conv1a_wgrad", "wgrad1x1_wide", "conv3_wgrad_planes", "proj_fwd", "proj_wgrad", "conv1x1_stream")), ("split-K reduce", ("splitk_reduce",)),
           ("conv prologue", ("prep_chunks", "pack_wt", "pack_direct", "pack_conv1a", "build_")), ("max-pool", ("maxpool",)),
           ("groupnorm", ("gn_relu",)), ("adam", ("adam_flat",)), ("bmp", ("bmp_",)), ("other", ())]
 tot = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
