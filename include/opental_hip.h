@@ -187,8 +187,8 @@ int otal_conv_prologue_batch(int n, const void* device_descs, const int* device_
  * the plain fixed-order slab sum leave their slabs in the workspace and record the reduction instead of launching it;
  * otal_conv_deferred_end() != 0 then is the address one past those slabs -- the caller must hand every later launch workspace
  * BEHIND it until otal_conv_flush_reduces(stream) has run all recorded reductions (up to 24; more flush by themselves) as
- * ONE launch.  Launches with a transposing reduce (direct 3x3x3 kernels) or unaligned slabs reduce at once as before
- * (deferred_end() == 0).  otal_conv_defer_reduces(0) needs an empty record.  The summation order is the one of the
+ * ONE launch.  Launches with unaligned slabs reduce at once as before (deferred_end() == 0); the direct 3x3x3 kernels, whose
+ * slabs needed a transposing reduce until round 6, now write slabs in dW's own layout and are recorded like the others.  otal_conv_defer_reduces(0) needs an empty record.  The summation order is the one of the
  * immediate reduce for >= 16 slabs (quarter sums in slab order, (q0+q1)+(q2+q3)); deterministic.  Process-wide record behind a
  * mutex: one logical issuer at a time (see the preamble).  Replaces nothing in the reference (autograd of nn.Conv1d / nn.Conv3d, i3d_backbone.py:33-43,
  * layers.py:187-192, has no split-K); it removes ~40 of this library's own launches per training step. */
