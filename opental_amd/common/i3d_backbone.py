@@ -551,7 +551,13 @@ class I3DFeaturesFunction(Function):
                 _, wi, k, s, xin, y, in_scale, _ = step
                 slot = ops.grad_slot(weights[wi])
                 in_slots = in_slots and slot is not None
-                dws[wi] = side.wgrad(xin, dcur, weights[wi].shape, k, s, out=slot)
+                if first and not need_dx and ops.LAST_WGRAD_MAIN:
+                    # the walk's LAST weight gradient (Conv3d_1a: its input needs no gradient, nothing follows on this lane) runs
+                    # HERE, beside what the weight-gradient lane still holds (the Mixed_3 backlog, Conv3d_2c, 2b) -- ops.LAST_WGRAD_MAIN
+                    side.issue()
+                    dws[wi] = ops.conv_wgrad(xin, dcur, weights[wi].shape, k, s, out=slot)
+                else:
+                    dws[wi] = side.wgrad(xin, dcur, weights[wi].shape, k, s, out=slot)
                 if first and not need_dx:
                     dcur = None
                 else:

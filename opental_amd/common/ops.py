@@ -441,6 +441,12 @@ def side_wgrads(device):
 # ("mark",) entry, and the trainer (DetectorTrainer.end_backward) runs Adam over everything but LATE_WEIGHTS behind the mark,
 # beside the tail's weight gradients, and Adam over the tail's few parameters after the final join.
 EARLY_ADAM = os.environ.get("OTAL_EARLY_ADAM", "1") != "0"
+# The backbone's last weight gradient (Conv3d_1a, 0.44 ms) on the MAIN lane, which has nothing left when it reaches it, while
+# the weight-gradient lane works off what it still holds (~0.5 ms: the end of Mixed_3, Conv3d_2c, 2b).  Measured +-0 in the
+# first session of round 6 (8.217 vs 8.228 ms: the kernel then kept three workgroups per CU resident and the two lanes'
+# kernels took turns); with the second session's kernel (two per CU, 220 registers) 8.07 -> 7.99 ms, 8.25 -> 8.13 on a slower box.
+# Also moving Conv3d_2b's or 2c's behind it: no further gain (8.02-8.07).
+LAST_WGRAD_MAIN = os.environ.get("OTAL_LAST_WGRAD_MAIN", "1") != "0"
 LATE_WEIGHTS = None
 
 
